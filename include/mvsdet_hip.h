@@ -1,0 +1,166 @@
+/*
+ * mvsdet_hip.h -- C ABI of the MI355X (gfx950) plane-sweep hot path of MVSDet.
+ *
+ * This is the drop-in boundary.  The reference has no FFI on this path: it
+ * is Python calling PyTorch operators.  Each entry point below replaces a
+ * block of reference Python (file:line relative to projects/NeRF-Det/nerfdet/ of Pixie8888/MVSDet)
+ * and is what a maintainer would bind from that Python with ctypes (INTEGRATION.md shows the
+ * stub).  mvsdet_amd/_lib.py is exactly such a binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.cuda tensor storage) unless marked HOST;
+ *   - tensors are fp32, dense row-major in the stated shape unless a stride array is given
+ *     (strides are in ELEMENTS, HOST arrays of 4 int64);
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work: no allocation, no
+ *     host synchronisation, so they can be captured in a hipGraph;
+ *   - return 0 on success, an MVSDET_ERR_* code otherwise; mvsdet_last_error() (HOST, thread-local)
+ *     describes the failure.  Nothing is launched when an argument check fails.
+ */
+#ifndef MVSDET_HIP_H
+#define MVSDET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSDET_OK 0
+#define MVSDET_ERR_INVALID_ARG 1 /* bad shape / NULL pointer / unsupported size */
+#define MVSDET_ERR_WORKSPACE 2   /* workspace too small */
+#define MVSDET_ERR_HIP 3         /* a HIP runtime call failed (launch error) */
+
+#define MVSDET_MAX_NEIGHBORS 4 /* k source views per reference view (reference: k = min(2, N-1)) */
+#define MVSDET_MAX_TOPK 8      /* depth candidates per pixel (reference: topk = 3) */
+#define MVSDET_MAX_DEPTH 512   /* depth planes (reference: 12) */
+
+typedef void* mvsdet_stream_t; /* hipStream_t */
+
+/* ABI version: major*1000 + minor. */
+int mvsdet_version(void);
+/* HOST, thread-local message of the last failing call on this thread ("" if none). */
+const char* mvsdet_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Packed feature maps.
+ * The sweep and the fused voxel lifting read 2-D features channel-last so that one bilinear tap /
+ * one voxel sample is a single contiguous run of all channels.  Packed layout:
+ *     packed[n][y][x][q],  q in [0, 4*G),  G = ceil(C/4),  q = 4*g + i  <->  channel c = i*G + g
+ * (zero where c >= C).  mvsdet_packed_bytes() = N*H*W*4*G*sizeof(float).
+ * mvsdet_pack_features_f32 reads element (n,c,y,x) at feat[n*fs[0] + c*fs[1] + y*fs[2] + x*fs[3]],
+ * so the reference's non-contiguous crop feature[:, :, :h, :w] (mvsdet.py:499) needs no copy.
+ * ------------------------------------------------------------------------------------------- */
+size_t mvsdet_packed_bytes(int N, int C, int H, int W);
+int mvsdet_pack_features_f32(const float* feat, const int64_t* feat_strides /*HOST[4]*/, float* packed,
+                             int N, int C, int H, int W, mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3  homo_warping -- mvs_models/module.py:105-146.
+ *   src  (B,C,H,W)   source-view features
+ *   proj (B,4,4)     src_proj @ inverse(ref_proj)  (module.py:116; computed by the caller with the
+ *                    same torch ops as the reference -- see DESIGN.md "geometry stays on the host")
+ *   depth(B,D)       plane depths
+ *   out  (B,C,D,H,W) warped features: bilinear, zero padding, align_corners=False sampling of a grid
+ *                    normalised with the align_corners=True formula (module.py:137-143), no z>0 test.
+ * ------------------------------------------------------------------------------------------- */
+int mvsdet_homo_warp_f32(const float* src, const float* proj, const float* depth, float* out,
+                         int B, int C, int D, int H, int W, mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3+a4  plane-sweep variance cost volume -- mvsdet.py:439-467 (k calls of homo_warping fused with
+ * the running sum / sum of squares and the variance).
+ *   packed (see above) features of all N views; nbr (N,K) int64 neighbour view ids (mvsdet.py:434);
+ *   proj (N,K,4,4) = nei_proj[n][j] @ inverse(ref_proj[n]);  depth (N,D);
+ *   var (N,C,D,H,W) = sum_sq/(K+1) - (sum/(K+1))^2 over {ref, warped_1..K}  (mvsdet.py:467).
+ * The _f32 form packs `feat` (N,C,H,W dense) into `workspace` first
+ * (workspace_bytes >= mvsdet_packed_bytes(N,C,H,W)).
+ * ------------------------------------------------------------------------------------------- */
+int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
+                                           const float* depth, float* var, int N, int K, int C, int D,
+                                           int H, int W, mvsdet_stream_t stream);
+int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,
+                                    const float* depth, float* var, void* workspace, size_t workspace_bytes,
+                                    int N, int K, int C, int D, int H, int W, mvsdet_stream_t stream);
+/* backward of the above w.r.t. feat (the sampling grid carries no gradient, module.py:115).
+ *   g (N,C,D,H,W) = dL/dvar;  gfeat (N,C,H,W) is OVERWRITTEN with dL/dfeat.
+ *   workspace_bytes >= 2*mvsdet_packed_bytes(N,C,H,W)  (packed features + packed gradient). */
+int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, const float* proj,
+                                        const float* depth, const float* g, float* gfeat, void* workspace,
+                                        size_t workspace_bytes, int N, int K, int C, int D, int H, int W,
+                                        mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a5-a7  depth probability, top-k plane selection, depth expectation --
+ * mvsdet.py:470-475 (softmax / sigmoid), :266-283 (sample_depth_prob), :298-317 (compute_avg_depth).
+ *   cost_reg, off_logit (N,D,H,W)  the two output channels of CostRegNet_3DGS
+ *   prob, off (N,D,H,W)            softmax over D / sigmoid
+ *   est_depth, est_dens (N,topk,H,W) the topk most probable planes, descending; depth =
+ *                                  idx*interval + near + off[idx]*interval; dens = prob[idx] (raw)
+ *   est_idx (N,topk,H,W) int32     chosen plane indices (may be NULL); ties -> lower index
+ *   avg_depth (N,H,W)              sum_d prob_d * (d*interval + near + off_d*interval)
+ * ------------------------------------------------------------------------------------------- */
+int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* off_logit, float* prob, float* off,
+                               float* est_depth, float* est_dens, int32_t* est_idx, float* avg_depth,
+                               int N, int D, int H, int W, int topk, float near, float interval,
+                               mvsdet_stream_t stream);
+/* a6+a7 only, for callers that already hold prob = softmax(cost_reg) and off = sigmoid(off_logit)
+ * (signature-level parity with MVSDet.sample_depth_prob / compute_avg_depth, mvsdet.py:266,298). */
+int mvsdet_sample_depth_prob_f32(const float* prob, const float* off, float* est_depth, float* est_dens,
+                                 int32_t* est_idx, float* avg_depth, int N, int D, int H, int W, int topk,
+                                 float near, float interval, mvsdet_stream_t stream);
+/* backward: any of g_prob (N,D,H,W), g_depth, g_dens (N,topk,H,W), g_avg (N,H,W) may be NULL. */
+int mvsdet_depth_prob_topk_bwd_f32(const float* prob, const float* off, const int32_t* est_idx,
+                                   const float* g_prob, const float* g_depth, const float* g_dens,
+                                   const float* g_avg, float* g_cost, float* g_offlogit, int N, int D,
+                                   int H, int W, int topk, float near, float interval, mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a9  backproject_Weigh -- mvsdet.py:1372-1492 (gt_depth=None).
+ *   feat + feat_strides: (N,C,h,w) view of the 2-D features (crop allowed, see pack above)
+ *   points (3,V) voxel coordinates from get_points (mvsdet.py:1316); projection (N,3,4)
+ *   depth, dens + dd_strides: candidate j of pixel (y,x) of view i at
+ *       ptr[i*s[0] + j*s[1] + y*s[2] + x*s[3]]   (the reference's (N,h*w,1,J) tensors are views of this)
+ *   vz = voxel_size[-1]
+ *   volume (N,C,V) fp32; valid (N,V) uint8 (1 = voxel is in view i's frustum AND inside the depth
+ *   window of at least one candidate).  xi, yi (N,V) int32 rounded pixel coordinates may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int mvsdet_backproject_weigh_f32(const float* feat, const int64_t* feat_strides /*HOST[4]*/, const float* points,
+                                 const float* projection, const float* depth, const float* dens,
+                                 const int64_t* dd_strides /*HOST[4]*/, float* volume, uint8_t* valid,
+                                 int32_t* xi, int32_t* yi, int N, int C, int h, int w, int V, int J, float vz,
+                                 mvsdet_stream_t stream);
+/* a9+a10 fused: per-voxel mean over views, mvsdet.py:511-515.
+ *   packed: packed features of the FULL (N,C,H,W) maps; only pixels y<h, x<w are addressed.
+ *   mean (C,V) fp32 = sum_i volume_i / (count + 1e-8), 0 where count == 0; count (V) int32. */
+int mvsdet_backproject_weigh_mean_packed_f32(const float* packed, const float* points, const float* projection,
+                                             const float* depth, const float* dens,
+                                             const int64_t* dd_strides /*HOST[4]*/, float* mean, int32_t* count,
+                                             int N, int C, int H, int W, int h, int w, int V, int J, float vz,
+                                             mvsdet_stream_t stream);
+/* backward of a9 w.r.t. features and dens (depth carries no gradient).
+ *   g (N,C,V); gfeat (N,C,h,w) dense and gdens (N,J,h,w) dense are OVERWRITTEN. */
+int mvsdet_backproject_weigh_bwd_f32(const float* feat, const int64_t* feat_strides /*HOST[4]*/, const float* points,
+                                     const float* projection, const float* depth, const float* dens,
+                                     const int64_t* dd_strides /*HOST[4]*/, const float* g, float* gfeat,
+                                     float* gdens, int N, int C, int h, int w, int V, int J, float vz,
+                                     mvsdet_stream_t stream);
+/* backward of a9+a10 (fused mean): g (C,V) = dL/dmean. */
+int mvsdet_backproject_weigh_mean_bwd_f32(const float* feat, const int64_t* feat_strides /*HOST[4]*/,
+                                          const float* points, const float* projection, const float* depth,
+                                          const float* dens, const int64_t* dd_strides /*HOST[4]*/,
+                                          const int32_t* count, const float* g, float* gfeat, float* gdens,
+                                          int N, int C, int h, int w, int V, int J, float vz,
+                                          mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement helper for bench.py: runs `fn`-independent HIP-event timing is done by the caller;
+ * this only exposes a device-to-device float4 copy so the achievable HBM ceiling can be calibrated
+ * on the same box (SURVEY.md section 8d "Roofline").
+ * ------------------------------------------------------------------------------------------- */
+int mvsdet_copy_f32(const float* src, float* dst, size_t n_floats, mvsdet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSDET_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libmvsdet_hip.so (include/mvsdet_hip.h) -- the stub a maintainer of the reference
+would add to call the HIP path from Python.
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvsdet_hip.so")
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+# name -> argtypes (all return int unless listed in _RESTYPE); mirrors include/mvsdet_hip.h one to one
+SIGNATURES = {
+    "mvsdet_version": [],
+    "mvsdet_last_error": [],
+    "mvsdet_packed_bytes": [_i, _i, _i, _i],
+    "mvsdet_pack_features_f32": [_vp, _i64p, _vp, _i, _i, _i, _i, _vp],
+    "mvsdet_homo_warp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_variance_packed_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_variance_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_variance_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_depth_prob_topk_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "mvsdet_sample_depth_prob_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "mvsdet_depth_prob_topk_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "mvsdet_backproject_weigh_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp,
+                                     _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvsdet_backproject_weigh_mean_packed_f32": [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp,
+                                                 _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvsdet_backproject_weigh_bwd_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp,
+                                         _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvsdet_backproject_weigh_mean_bwd_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp,
+                                              _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvsdet_copy_f32": [_vp, _vp, _sz, _vp],
+}
+_RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_packed_bytes": ctypes.c_size_t}
+
+
+def build(verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every kernel into mvsdet_amd/libmvsdet_hip.so (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load the HIP library; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C mvsdet_amd/csrc`). mvsdet_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mvsdet_last_error().decode("utf-8", "replace")
+        kinds = {1: ValueError, 2: RuntimeError, 3: RuntimeError}
+        raise kinds.get(rc, RuntimeError)(f"{what} failed (code {rc}): {msg}")
+
+
+def strides4(t) -> ctypes.Array:
+    """HOST int64[4] with the element strides of a 4-D tensor."""
+    assert t.dim() == 4
+    return (ctypes.c_int64 * 4)(*[int(s) for s in t.stride()])
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device) -> ctypes.c_void_p:
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,48 @@
+// Library-level entry points: version, error string, HBM-ceiling copy kernel.
+#include "common.h"
+
+#include <cstring>
+
+namespace mvsdet {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// float4 grid-stride copy: the achievable-HBM yardstick of bench.py (MI355X_MICROARCH: 6.29 TB/s measured).
+__global__ __launch_bounds__(kThreads) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ void copy_tail_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t begin, size_t n) {
+    const size_t i = begin + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+}  // namespace mvsdet
+
+using namespace mvsdet;
+
+extern "C" int mvsdet_version(void) { return 1000; }
+
+extern "C" const char* mvsdet_last_error(void) { return g_err; }
+
+extern "C" int mvsdet_copy_f32(const float* src, float* dst, size_t n, mvsdet_stream_t stream) {
+    MVS_REQUIRE(src && dst, "copy: NULL pointer");
+    MVS_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "copy: pointers must be 16-byte aligned");
+    const size_t n4 = n / 4;
+    if (n4) {
+        const size_t want = (n4 + kThreads - 1) / kThreads;
+        const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+        hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n4);
+    }
+    if (n % 4) hipLaunchKernelGGL(copy_tail_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, src, dst, n4 * 4, n);
+    MVS_LAUNCH_CHECK("copy");
+    return MVSDET_OK;
+}

@@ -1,0 +1,135 @@
+// Shared helpers of the mvsdet_hip library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mvsdet_hip.h"
+
+namespace mvsdet {
+
+void set_error(const char* fmt, ...);
+
+constexpr int kWave = 64;       // CDNA wavefront
+constexpr int kThreads = 256;   // 4 waves, one per SIMD
+constexpr int kXcds = 8;        // MI355X: 8 XCDs, blocks are dealt round-robin over them
+
+#define MVS_REQUIRE(cond, ...)              \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::mvsdet::set_error(__VA_ARGS__); \
+            return MVSDET_ERR_INVALID_ARG;  \
+        }                                   \
+    } while (0)
+
+#define MVS_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            ::mvsdet::set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return MVSDET_ERR_HIP;                                                    \
+        }                                                                             \
+    } while (0)
+
+// Blocks b and b+8 share an XCD (and its 4 MiB L2).  Map the hardware block id to a logical id so
+// that every XCD walks ONE contiguous range of logical ids: neighbouring tiles of a view then find
+// the source rows they share in their own L2.  Bijective for any nblocks (speed only, never
+// correctness: MI355X_MICROARCH "Workgroup dispatch").
+__device__ __forceinline__ int xcd_contiguous_id(int b, int nblocks) {
+    const int q = nblocks / kXcds, r = nblocks % kXcds;
+    const int xcd = b % kXcds, idx = b / kXcds;
+    return (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampling taps of one (reference pixel, depth plane, source view): mvs_models/module.py:116-143 +
+// ATen grid_sample(bilinear, zeros, align_corners=False).  Same rounding points as
+// oracle/planesweep_oracle.c:orc_compute_taps (the library is compiled with -ffp-contract=off, so
+// a fused multiply-add happens exactly where fmaf() is written).
+//   P      proj = src_proj @ inverse(ref_proj), row-major 4x4
+//   scale  element stride of one pixel in the sampled map (1 for NCHW planes, 4*G for packed maps)
+//   off    element offsets of taps nw, ne, sw, se (0 for a tap outside the map)
+//   w      bilinear weights (an outside tap carries weight*0, so Inf/NaN positions give NaN as ATen-CPU)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void compute_taps(const float* __restrict__ P, float x, float y, float d, int H, int W,
+                                             int scale, int4& off, float4& w) {
+    const float rx = fmaf(P[1], y, P[0] * x) + P[2];
+    const float ry = fmaf(P[5], y, P[4] * x) + P[6];
+    const float rz = fmaf(P[9], y, P[8] * x) + P[10];
+    const float X = rx * d + P[3];
+    const float Y = ry * d + P[7];
+    const float Z = rz * d + P[11];
+    const float px = X / Z;
+    const float py = Y / Z;
+    const float gx = px / ((float)(W - 1) * 0.5f) - 1.0f;
+    const float gy = py / ((float)(H - 1) * 0.5f) - 1.0f;
+    const float ix = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);
+    const float iy = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float wx = ix - x0, wy = iy - y0;
+    const float ex = 1.0f - wx, sy = 1.0f - wy;
+    const bool x0in = (x0 >= 0.0f) && (x0 <= (float)(W - 1));
+    const bool x1in = (x0 >= -1.0f) && (x0 <= (float)(W - 2));
+    const bool y0in = (y0 >= 0.0f) && (y0 <= (float)(H - 1));
+    const bool y1in = (y0 >= -1.0f) && (y0 <= (float)(H - 2));
+    const int xi = (x0in || x1in) ? (int)x0 : 0;
+    const int yi = (y0in || y1in) ? (int)y0 : 0;
+    const float wnw = sy * ex, wne = sy * wx, wsw = wy * ex, wse = wy * wx;
+    const int base = yi * W + xi;
+    off.x = (x0in && y0in) ? base * scale : 0;
+    off.y = (x1in && y0in) ? (base + 1) * scale : 0;
+    off.z = (x0in && y1in) ? (base + W) * scale : 0;
+    off.w = (x1in && y1in) ? (base + W + 1) * scale : 0;
+    w.x = (x0in && y0in) ? wnw : wnw * 0.0f;
+    w.y = (x1in && y0in) ? wne : wne * 0.0f;
+    w.z = (x0in && y1in) ? wsw : wsw * 0.0f;
+    w.w = (x1in && y1in) ? wse : wse * 0.0f;
+}
+
+// Voxel -> pixel projection of backproject_Weigh (mvsdet.py:1383-1391): q = P @ [p;1] summed in k
+// order with fused multiply-adds (oracle: orc_project), x = round_half_even(q0/q2), valid test.
+__device__ __forceinline__ bool project_voxel(const float* __restrict__ P, float px, float py, float pz, int h, int w,
+                                              float& xr, float& yr, float& z) {
+    const float q0 = fmaf(P[2], pz, fmaf(P[1], py, P[0] * px)) + P[3];
+    const float q1 = fmaf(P[6], pz, fmaf(P[5], py, P[4] * px)) + P[7];
+    const float q2 = fmaf(P[10], pz, fmaf(P[9], py, P[8] * px)) + P[11];
+    xr = rintf(q0 / q2);
+    yr = rintf(q1 / q2);
+    z = q2;
+    return (xr >= 0.0f) && (yr >= 0.0f) && (xr < (float)w) && (yr < (float)h) && (q2 > 0.0f);
+}
+
+// Depth window + weight of one (view, voxel) pair: mvsdet.py:1393-1428 (oracle: orc_depth_window).
+// depth/dens point at view i; candidate j of pixel (yi,xi) is at [j*s1 + yi*s2 + xi*s3].
+// Returns valid' and the weight max_j(m_j ? prob_norm_j : 0); *arg = index of the first maximal
+// matching candidate (-1 if none has positive weight) for the backward pass.
+__device__ __forceinline__ bool depth_window(const float* __restrict__ depth, const float* __restrict__ dens,
+                                             int64_t s1, int64_t s2, int64_t s3, int J, int yi, int xi, float z,
+                                             float vz, float& weight, float& psum_out, int& arg) {
+    const int64_t base = (int64_t)yi * s2 + (int64_t)xi * s3;
+    float psum = 0.0f;
+    for (int j = 0; j < J; ++j) psum = psum + dens[base + j * s1];
+    float wmax = 0.0f;
+    bool any = false;
+    int a = -1;
+    for (int j = 0; j < J; ++j) {
+        const float dj = depth[base + j * s1];
+        const bool m = (z > dj - vz) && (z < dj + vz);
+        const float pn = dens[base + j * s1] / psum;
+        const float cand = m ? pn : 0.0f;
+        if (cand > wmax) {
+            wmax = cand;
+            a = j;
+        }
+        if (cand != cand) wmax = cand;
+        any = any || m;
+    }
+    weight = wmax;
+    psum_out = psum;
+    arg = a;
+    return any;
+}
+
+}  // namespace mvsdet

@@ -1,0 +1,117 @@
+"""Host-side mirror of the reference's Python interface for the hot path.
+
+Same names, argument order, shapes and return arity as projects/NeRF-Det/nerfdet/ of Pixie8888/MVSDet
+(mvs_models/module.py and mvsdet.py; file:line cited per function), so the reference's call sites -- and
+tests written against them -- read the same.  Heavy tensors go to the HIP operators in ops.py.
+
+Geometry stays on the host.  The camera matrices of a scene are a few hundred floats that arrive as numpy
+arrays in img_meta (mvsdet.py:419-420).  The sampling positions are sensitive to the rounding of the 4x4
+inverse at the 1e-4 px level (DESIGN.md "tolerance budget"), so `relative_projection` evaluates
+`src_proj @ inverse(ref_proj)` with the very ATen-CPU ops the reference uses (module.py:116) and ships the
+result to the device; nothing per-pixel ever runs on the CPU.
+"""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------- geometry (host)
+def relative_projection(src_proj: Tensor, ref_proj: Tensor) -> Tensor:
+    """module.py:116  proj = src_proj @ inverse(ref_proj), fp32, evaluated with ATen-CPU; result on CPU."""
+    return torch.matmul(src_proj.detach().float().cpu(), torch.inverse(ref_proj.detach().float().cpu()))
+
+
+def knn(x: Tensor, ref: Tensor, k: int, maskself: bool = False) -> Tensor:
+    """mvsdet.py:43-64.  x (B,3,Ns), ref (B,3,Nr) -> indices (B,Ns,k) of the k nearest `ref` columns
+    (largest negative squared distance first)."""
+    cross = -2 * torch.matmul(x.transpose(2, 1), ref)
+    x_sq = torch.sum(x ** 2, dim=1, keepdim=True)
+    r_sq = torch.sum(ref ** 2, dim=1, keepdim=True)
+    neg_dist = -r_sq - cross - x_sq.transpose(2, 1)
+    if maskself:
+        if x.shape != ref.shape:
+            raise AssertionError("maskself needs x and ref of the same shape")
+        diag = torch.arange(x_sq.shape[2])
+        neg_dist[:, diag, diag] = -100000
+    return neg_dist.topk(k=k, dim=-1)[1]
+
+
+def get_nearest_pose_ids(tar_pose: Tensor, ref_poses: Tensor, num_select: int, maskself: bool = False,
+                         angular_dist_method: str = "dist", scene_center=(0, 0, 0)) -> Tensor:
+    """mvsdet.py:67-104 ('dist' method, the only one the detector uses).  c2w poses (N,4,4) -> (N,k) int64."""
+    if angular_dist_method != "dist":
+        raise NotImplementedError("only angular_dist_method='dist' is on the MVSDet path (mvsdet.py:434)")
+    num_select = min(num_select, len(ref_poses) - 1)
+    tar = tar_pose[:, :3, 3].unsqueeze(0).transpose(2, 1)
+    ref = ref_poses[:, :3, 3].unsqueeze(0).transpose(2, 1)
+    return knn(tar, ref, k=num_select, maskself=maskself)[0]
+
+
+def collect_proj(w2c: Tensor, intr: Tensor, neighbor_ids: Tensor):
+    """MVSDet.collect_proj, mvsdet.py:249-264 -> (proj (N,4,4), tuple of k (N,4,4) neighbour projections)."""
+    if intr.dim() == 2:
+        intr = intr.unsqueeze(0).repeat(w2c.shape[0], 1, 1)
+    proj = torch.matmul(intr, w2c)
+    n, k = neighbor_ids.shape
+    nei = proj[neighbor_ids.reshape(-1)].view(n, k, 4, 4)
+    return proj, torch.unbind(nei, dim=1)
+
+
+def get_points(n_voxels: Tensor, voxel_size: Tensor, origin: Tensor) -> Tensor:
+    """mvsdet.py:1316-1327 -> voxel corner coordinates (3,X,Y,Z)."""
+    with torch.no_grad():
+        grid = torch.stack(torch.meshgrid([torch.arange(int(n_voxels[0])), torch.arange(int(n_voxels[1])),
+                                           torch.arange(int(n_voxels[2]))], indexing="ij"))
+        new_origin = origin - n_voxels / 2. * voxel_size
+        return grid * voxel_size.view(3, 1, 1, 1) + new_origin.view(3, 1, 1, 1)
+
+
+def compute_projection(img_meta: dict, stride: int, angles=None) -> Tensor:
+    """MVSDet._compute_projection, mvsdet.py:1124-1156 (angles=None) -> (N,3,4) voxel->feature-pixel matrices."""
+    if angles is not None:
+        raise NotImplementedError("predicted-angle extrinsics (SUNRGBDTotal) are outside the MVSDet configs")
+    ratio = img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
+    extr = torch.tensor(np.array(img_meta["lidar2img"]["extrinsic"]))
+    intr = torch.tensor(np.array(img_meta["lidar2img"]["intrinsic"]))
+    if intr.dim() == 2:  # ScanNet: one K per scene
+        K = intr[:3, :3].clone()
+        K[:2] /= ratio
+        return torch.stack([K @ e[:3] for e in extr])
+    K = intr[:, :3, :3].clone()  # ARKitScenes: one K per view
+    K[:, :2] /= ratio
+    return torch.stack([K[i] @ extr[i][:3] for i in range(len(extr))])
+
+
+# ------------------------------------------------------------------------------------------- a3
+def homo_warping(src_fea: Tensor, src_proj: Tensor, ref_proj: Tensor, depth_values: Tensor) -> Tensor:
+    """mvs_models/module.py:105-146.  src_fea (B,C,H,W), src_proj/ref_proj (B,4,4), depth_values (B,D)
+    -> warped (B,C,D,H,W)."""
+    if depth_values.dim() != 2:
+        raise NotImplementedError("per-pixel depth_values (B,D,H,W) (module.py:130-133) is unused by MVSDet")
+    proj = relative_projection(src_proj, ref_proj).to(src_fea.device)
+    return ops.homo_warp(src_fea, proj, depth_values.to(src_fea.device))
+
+
+# ------------------------------------------------------------------------------------------- a9
+def backproject_Weigh(features: Tensor, points: Tensor, projection: Tensor, depth: Tensor, voxel_size: Sequence[float],
+                      prob: Tensor, gt_depth=None, save_dir=None, img_meta=None, depth_mean=None):
+    """mvsdet.py:1372-1492.  features (N,C,h,w); points (3,X,Y,Z); projection (N,3,4);
+    depth, prob (N, h*w, 1, J) -> (volume (N,C,X,Y,Z), valid (N,1,X,Y,Z) bool, gap_all, rmse)."""
+    if gt_depth is not None:
+        raise NotImplementedError("the gt_depth debug branch (mvsdet.py:1435-1481) is outside the hot path")
+    n, c, h, w = features.shape
+    nx, ny, nz = points.shape[-3:]
+    j = depth.shape[-1] * depth.shape[-2]
+    # (N, h*w, 1, J) is a view of (N,J,h,w): hand the kernel that view, no copy (mvsdet.py:1393-1395)
+    est_depth = depth.reshape(n, h, w, j).permute(0, 3, 1, 2)
+    est_dens = prob.reshape(n, h, w, j).permute(0, 3, 1, 2)
+    volume, valid = ops.backproject_weigh(features, points, projection, est_depth, est_dens, float(voxel_size[-1]))
+    volume = volume.view(n, c, nx, ny, nz)
+    valid = valid.view(n, 1, nx, ny, nz)
+    return volume, valid, torch.tensor(1.), torch.tensor(1.)

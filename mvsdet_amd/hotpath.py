@@ -1,0 +1,143 @@
+"""Scene-level driver of the hot path: what MVSDet.extract_feat does between the 2-D neck and the 3-D neck
+(mvsdet.py:404-515 of Pixie8888/MVSDet), on the HIP operators.
+
+    features (N,C,Hf,Wf) + img_meta  ->  volume_mean (C,X,Y,Z), valid count (1,X,Y,Z)
+                                         (+ prob_volume, depth_coding, est_depth, est_densities for the NVS branch)
+
+Per scene the host does only the camera algebra on N 4x4 matrices (`prepare_scene`, ATen-CPU like the
+reference); everything proportional to pixels or voxels runs in five kernel launches:
+pack -> plane-sweep variance -> [cost regularisation network, not ours] -> depth_prob_topk -> backproject mean.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import functional as F_
+from . import ops
+
+
+@dataclass
+class SceneGeometry:
+    """Device-resident camera data of one scene (all tiny)."""
+    neighbor_ids: Tensor   # (N,k) int64   mvsdet.py:434
+    proj_rel: Tensor       # (N,k,4,4)     nei_proj @ inverse(ref_proj), module.py:116
+    depth_values: Tensor   # (N,D)         mvsdet.py:450
+    projection: Tensor     # (N,3,4)       mvsdet.py:407
+    points: Tensor         # (3,X,Y,Z)     mvsdet.py:409
+    height: int            # un-padded feature rows (img_shape[0] // stride)
+    width: int
+
+
+class MVSDetHotPath:
+    """Holds the hyper-parameters MVSDet.__init__ keeps for this path (mvsdet.py:165-230)."""
+
+    def __init__(self, n_voxels: Sequence[int], voxel_size: Sequence[float], near_far_range: Sequence[float],
+                 num_monocular_samples: int, topk: int = 3,
+                 cost_regularization: Optional[Callable[[Tensor], Tensor]] = None, stride: int = 4):
+        self.n_voxels = list(n_voxels)
+        self.voxel_size = list(voxel_size)
+        self.near_far_range = list(near_far_range)
+        self.num_depth = int(num_monocular_samples)
+        self.topk = int(topk)
+        self.stride = int(stride)
+        # mvsdet.py:221-225
+        self.depth_interval = (self.near_far_range[1] - self.near_far_range[0]) / self.num_depth
+        self.depth_values = np.arange(self.near_far_range[0], self.near_far_range[1], self.depth_interval,
+                                      dtype=np.float32)
+        assert len(self.depth_values) == self.num_depth
+        self.cost_regularization = cost_regularization
+
+    # ---- reference-named methods (mvsdet.py:249, 266, 298) -------------------------------------------
+    def collect_proj(self, w2c, intr, neighbor_ids):
+        return F_.collect_proj(w2c, intr, neighbor_ids)
+
+    def sample_depth_prob(self, prob_volume: Tensor, off_pred: Tensor, topk: int = 3):
+        """mvsdet.py:266-283 -> (est_depth (N,k,H,W), est_density (N,k,H,W))."""
+        est_depth, est_dens, _, _ = ops.sample_depth_prob(prob_volume, off_pred, float(self.near_far_range[0]),
+                                                          float(self.depth_interval), int(topk))
+        return est_depth, est_dens
+
+    def compute_avg_depth(self, prob_volume: Tensor, off_pred: Tensor):
+        """mvsdet.py:298-317 -> depth expectation (N,H,W)."""
+        return ops.sample_depth_prob(prob_volume, off_pred, float(self.near_far_range[0]),
+                                     float(self.depth_interval), min(self.topk, prob_volume.shape[1]))[3]
+
+    # ---- host-side camera algebra -----------------------------------------------------------------------
+    def prepare_scene(self, img_meta: dict, device) -> SceneGeometry:
+        """mvsdet.py:407-450 for one scene, evaluated with ATen-CPU exactly as the reference does, then uploaded."""
+        stride = self.stride
+        projection = F_.compute_projection(img_meta, stride)
+        points = F_.get_points(n_voxels=torch.tensor(self.n_voxels), voxel_size=torch.tensor(self.voxel_size),
+                               origin=torch.tensor(img_meta["lidar2img"]["origin"]))
+        height = img_meta["img_shape"][0] // stride
+        width = img_meta["img_shape"][1] // stride
+        w2c = torch.tensor(np.array(img_meta["lidar2img"]["extrinsic"]))
+        K = torch.tensor(np.array(img_meta["lidar2img"]["intrinsic"]))
+        ratio = img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
+        K_feat = K.clone()
+        if K_feat.dim() == 2:
+            K_feat[:2] /= ratio
+        else:
+            K_feat[:, :2] /= ratio
+        n = w2c.shape[0]
+        k = min(2, n - 1)  # mvsdet.py:432
+        c2w = w2c.inverse()
+        nbr = F_.get_nearest_pose_ids(c2w, c2w, k, maskself=True)
+        ref_proj, nei_projs = F_.collect_proj(w2c, K_feat, nbr)
+        inv_ref = torch.inverse(ref_proj)
+        if k > 0:
+            proj_rel = torch.stack([torch.matmul(p, inv_ref) for p in nei_projs], dim=1)
+        else:
+            proj_rel = torch.zeros((n, 0, 4, 4))
+        depth_values = torch.tensor(self.depth_values).unsqueeze(0).repeat(n, 1)
+        to = dict(device=device, non_blocking=True)
+        return SceneGeometry(nbr.to(**to), proj_rel.to(**to), depth_values.to(**to), projection.to(**to),
+                             points.to(**to), int(height), int(width))
+
+    # ---- the hot path -------------------------------------------------------------------------------------
+    def cost_volume(self, feature: Tensor, geo: SceneGeometry, packed: Optional[Tensor] = None) -> Tensor:
+        """a3+a4, mvsdet.py:439-467 -> variance (N,C,D,Hf,Wf)."""
+        if packed is not None and not (feature.requires_grad and torch.is_grad_enabled()):
+            n, c, h, w = feature.shape
+            return ops.plane_sweep_variance_packed(packed, geo.neighbor_ids, geo.proj_rel, geo.depth_values, c, h, w)
+        return ops.plane_sweep_variance(feature, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+
+    def depth_distribution(self, cost_logits: Tensor):
+        """a5-a7 on the (N,2,D,H,W) output of the cost regularisation network (mvsdet.py:470-482)."""
+        cost_reg, off_logit = cost_logits[:, 0], cost_logits[:, 1]
+        return ops.depth_prob_topk(cost_reg, off_logit, float(self.near_far_range[0]), float(self.depth_interval),
+                                   self.topk)
+
+    def lift(self, feature: Tensor, packed: Tensor, geo: SceneGeometry, est_depth: Tensor, est_dens: Tensor):
+        """a9+a10, mvsdet.py:499-515 -> volume_mean (C,X,Y,Z), valid count (1,X,Y,Z) int64."""
+        n, c, hf, wf = feature.shape
+        h, w = geo.height, geo.width
+        mean, count = ops.backproject_weigh_mean(feature[:, :, :h, :w], packed, geo.points, geo.projection,
+                                                 est_depth[:, :, :h, :w], est_dens[:, :, :h, :w], hf, wf,
+                                                 float(self.voxel_size[-1]))
+        nx, ny, nz = self.n_voxels
+        return mean.view(c, nx, ny, nz), count.view(1, nx, ny, nz).long()
+
+    def forward_scene(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor] = None,
+                      geo: Optional[SceneGeometry] = None) -> dict:
+        """One scene through a1..a10.  `cost_logits` (N,2,D,Hf,Wf) stands in for the cost regularisation
+        network's output when `self.cost_regularization` is None (benchmarks / parity tests)."""
+        if geo is None:
+            geo = self.prepare_scene(img_meta, feature.device)
+        packed = ops.pack_features(feature.detach())
+        variance = self.cost_volume(feature, geo, packed)
+        if self.cost_regularization is not None:
+            cost_logits = self.cost_regularization(variance)
+        elif cost_logits is None:
+            raise ValueError("forward_scene needs `cost_logits` when no cost_regularization module is set")
+        prob, off, est_depth, est_dens, est_idx, avg_depth = self.depth_distribution(cost_logits)
+        volume_mean, valid = self.lift(feature, packed, geo, est_depth, est_dens)
+        h, w = geo.height, geo.width
+        return dict(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
+                    est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
+                    depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo)

@@ -1,0 +1,471 @@
+"""PyTorch-ROCm custom operators over the C ABI (torch.ops.mvsdet_amd.*).
+
+Every operator enqueues hand-written gfx950 kernels of libmvsdet_hip.so on the current HIP stream
+through ctypes; torch supplies device memory, streams and autograd plumbing only.  Operators raise if
+their inputs are not float32 tensors on a ROCm device -- there is no CPU implementation here.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+_NS = "mvsdet_amd"
+
+
+def _req(t: Tensor, name: str, dtype=torch.float32, dim=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"mvsdet_amd: `{name}` must live on a ROCm device (got {t.device}); "
+                           "this package has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"mvsdet_amd: `{name}` must be {dtype} (got {t.dtype})")
+    if dim is not None and t.dim() != dim:
+        raise ValueError(f"mvsdet_amd: `{name}` must be {dim}-D (got shape {tuple(t.shape)})")
+
+
+def _stream(t: Tensor):
+    return _lib.current_stream(t.device)
+
+
+# ------------------------------------------------------------------------------------------- pack
+@torch.library.custom_op(f"{_NS}::pack_features", mutates_args=(), device_types="cuda")
+def pack_features(feat: Tensor) -> Tensor:
+    """(N,C,H,W) (any strides) -> packed channel-last maps, flat float32 (see include/mvsdet_hip.h)."""
+    _req(feat, "feat", dim=4)
+    N, C, H, W = feat.shape
+    lib = _lib.load()
+    out = torch.empty(lib.mvsdet_packed_bytes(N, C, H, W) // 4, dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        _lib.check(lib.mvsdet_pack_features_f32(_lib.ptr(feat), _lib.strides4(feat), _lib.ptr(out), N, C, H, W,
+                                                _stream(feat)), "pack_features")
+    return out
+
+
+@pack_features.register_fake
+def _(feat):
+    N, C, H, W = feat.shape
+    return feat.new_empty(N * H * W * 4 * ((C + 3) // 4))
+
+
+# ------------------------------------------------------------------------------------------- a3
+@torch.library.custom_op(f"{_NS}::homo_warp", mutates_args=(), device_types="cuda")
+def homo_warp(src: Tensor, proj: Tensor, depth: Tensor) -> Tensor:
+    """a3 (mvs_models/module.py:105): src (B,C,H,W), proj (B,4,4) = src_proj @ inv(ref_proj), depth (B,D)."""
+    _req(src, "src", dim=4)
+    _req(proj, "proj", dim=3)
+    _req(depth, "depth", dim=2)
+    B, C, H, W = src.shape
+    D = depth.shape[1]
+    if proj.shape != (B, 4, 4) or depth.shape[0] != B:
+        raise ValueError(f"homo_warp: proj {tuple(proj.shape)} / depth {tuple(depth.shape)} do not match B={B}")
+    src, proj, depth = src.contiguous(), proj.contiguous(), depth.contiguous()
+    out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().mvsdet_homo_warp_f32(_lib.ptr(src), _lib.ptr(proj), _lib.ptr(depth), _lib.ptr(out),
+                                                    B, C, D, H, W, _stream(src)), "homo_warp")
+    return out
+
+
+@homo_warp.register_fake
+def _(src, proj, depth):
+    B, C, H, W = src.shape
+    return src.new_empty((B, C, depth.shape[1], H, W))
+
+
+# ------------------------------------------------------------------------------------------- a3+a4
+def _check_sweep(feat, nbr, proj, depth):
+    _req(feat, "feat", dim=4)
+    _req(nbr, "nbr", dtype=torch.int64, dim=2)
+    _req(proj, "proj", dim=4)
+    _req(depth, "depth", dim=2)
+    N, C, H, W = feat.shape
+    K = nbr.shape[1]
+    if nbr.shape[0] != N or proj.shape != (N, K, 4, 4) or depth.shape[0] != N:
+        raise ValueError(f"plane_sweep_variance: nbr {tuple(nbr.shape)}, proj {tuple(proj.shape)}, depth "
+                         f"{tuple(depth.shape)} do not match N={N}")
+    return N, K, C, depth.shape[1], H, W
+
+
+@torch.library.custom_op(f"{_NS}::plane_sweep_variance_packed", mutates_args=(), device_types="cuda")
+def plane_sweep_variance_packed(packed: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor, C: int, H: int,
+                                W: int) -> Tensor:
+    """a3+a4 on already packed maps (mvsdet.py:439-467) -> (N,C,D,H,W)."""
+    _req(packed, "packed", dim=1)
+    _req(nbr, "nbr", dtype=torch.int64, dim=2)
+    _req(proj, "proj", dim=4)
+    _req(depth, "depth", dim=2)
+    N, K = nbr.shape
+    D = depth.shape[1]
+    lib = _lib.load()
+    if packed.numel() * 4 != lib.mvsdet_packed_bytes(N, C, H, W):
+        raise ValueError("plane_sweep_variance_packed: packed buffer does not match (N,C,H,W)")
+    if proj.shape != (N, K, 4, 4) or depth.shape[0] != N:
+        raise ValueError("plane_sweep_variance_packed: proj/depth shape mismatch")
+    nbr, proj, depth = nbr.contiguous(), proj.contiguous(), depth.contiguous()
+    out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=packed.device)
+    with torch.cuda.device(packed.device):
+        _lib.check(lib.mvsdet_plane_sweep_variance_packed_f32(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(proj),
+                                                              _lib.ptr(depth), _lib.ptr(out), N, K, C, D, H, W,
+                                                              _stream(packed)), "plane_sweep_variance_packed")
+    return out
+
+
+@plane_sweep_variance_packed.register_fake
+def _(packed, nbr, proj, depth, C, H, W):
+    return packed.new_empty((nbr.shape[0], C, depth.shape[1], H, W))
+
+
+@torch.library.custom_op(f"{_NS}::plane_sweep_variance", mutates_args=(), device_types="cuda")
+def plane_sweep_variance(feat: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor) -> Tensor:
+    """a3+a4 (mvsdet.py:439-467): feat (N,C,H,W), nbr (N,K) int64, proj (N,K,4,4), depth (N,D) -> (N,C,D,H,W)."""
+    N, K, C, D, H, W = _check_sweep(feat, nbr, proj, depth)
+    packed = pack_features(feat)
+    return plane_sweep_variance_packed(packed, nbr, proj, depth, C, H, W)
+
+
+@plane_sweep_variance.register_fake
+def _(feat, nbr, proj, depth):
+    N, C, H, W = feat.shape
+    return feat.new_empty((N, C, depth.shape[1], H, W))
+
+
+@torch.library.custom_op(f"{_NS}::plane_sweep_variance_backward", mutates_args=(), device_types="cuda")
+def plane_sweep_variance_backward(feat: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor, grad: Tensor) -> Tensor:
+    N, K, C, D, H, W = _check_sweep(feat, nbr, proj, depth)
+    _req(grad, "grad", dim=5)
+    if grad.shape != (N, C, D, H, W):
+        raise ValueError("plane_sweep_variance_backward: grad shape mismatch")
+    feat, nbr, proj, depth, grad = feat.contiguous(), nbr.contiguous(), proj.contiguous(), depth.contiguous(), grad.contiguous()
+    lib = _lib.load()
+    wbytes = 2 * lib.mvsdet_packed_bytes(N, C, H, W)
+    ws = torch.empty(wbytes // 4, dtype=torch.float32, device=feat.device)
+    gfeat = torch.empty_like(feat)
+    with torch.cuda.device(feat.device):
+        _lib.check(lib.mvsdet_plane_sweep_variance_bwd_f32(_lib.ptr(feat), _lib.ptr(nbr), _lib.ptr(proj), _lib.ptr(depth),
+                                                           _lib.ptr(grad), _lib.ptr(gfeat), _lib.ptr(ws), wbytes, N, K, C,
+                                                           D, H, W, _stream(feat)), "plane_sweep_variance_backward")
+    return gfeat
+
+
+@plane_sweep_variance_backward.register_fake
+def _(feat, nbr, proj, depth, grad):
+    return torch.empty_like(feat)
+
+
+def _sweep_setup(ctx, inputs, output):
+    feat, nbr, proj, depth = inputs
+    ctx.save_for_backward(feat, nbr, proj, depth)
+
+
+def _sweep_bwd(ctx, grad):
+    feat, nbr, proj, depth = ctx.saved_tensors
+    return plane_sweep_variance_backward(feat, nbr, proj, depth, grad), None, None, None
+
+
+plane_sweep_variance.register_autograd(_sweep_bwd, setup_context=_sweep_setup)
+
+
+# ------------------------------------------------------------------------------------------- a5-a7
+@torch.library.custom_op(f"{_NS}::depth_prob_topk", mutates_args=(), device_types="cuda")
+def depth_prob_topk(cost_reg: Tensor, off_logit: Tensor, near: float, interval: float,
+                    topk: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """a5-a7 (mvsdet.py:470-475, 266-283, 298-317) -> prob, off (N,D,H,W); est_depth, est_dens (N,topk,H,W);
+    est_idx (N,topk,H,W) int32; avg_depth (N,H,W)."""
+    _req(cost_reg, "cost_reg", dim=4)
+    _req(off_logit, "off_logit", dim=4)
+    if cost_reg.shape != off_logit.shape:
+        raise ValueError("depth_prob_topk: cost_reg / off_logit shape mismatch")
+    N, D, H, W = cost_reg.shape
+    cost_reg, off_logit = cost_reg.contiguous(), off_logit.contiguous()
+    dev = cost_reg.device
+    prob = torch.empty_like(cost_reg)
+    off = torch.empty_like(cost_reg)
+    est_depth = torch.empty((N, topk, H, W), dtype=torch.float32, device=dev)
+    est_dens = torch.empty((N, topk, H, W), dtype=torch.float32, device=dev)
+    est_idx = torch.empty((N, topk, H, W), dtype=torch.int32, device=dev)
+    avg = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mvsdet_depth_prob_topk_f32(_lib.ptr(cost_reg), _lib.ptr(off_logit), _lib.ptr(prob),
+                                                          _lib.ptr(off), _lib.ptr(est_depth), _lib.ptr(est_dens),
+                                                          _lib.ptr(est_idx), _lib.ptr(avg), N, D, H, W, topk, near,
+                                                          interval, _stream(cost_reg)), "depth_prob_topk")
+    return prob, off, est_depth, est_dens, est_idx, avg
+
+
+@depth_prob_topk.register_fake
+def _(cost_reg, off_logit, near, interval, topk):
+    N, D, H, W = cost_reg.shape
+    e = cost_reg.new_empty
+    return (e((N, D, H, W)), e((N, D, H, W)), e((N, topk, H, W)), e((N, topk, H, W)),
+            cost_reg.new_empty((N, topk, H, W), dtype=torch.int32), e((N, H, W)))
+
+
+@torch.library.custom_op(f"{_NS}::sample_depth_prob", mutates_args=(), device_types="cuda")
+def sample_depth_prob(prob: Tensor, off: Tensor, near: float, interval: float,
+                      topk: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """a6+a7 on ready-made probabilities (mvsdet.py:266-283, 298-317) -> est_depth, est_dens (N,topk,H,W),
+    est_idx int32, avg_depth (N,H,W)."""
+    _req(prob, "prob", dim=4)
+    _req(off, "off", dim=4)
+    if prob.shape != off.shape:
+        raise ValueError("sample_depth_prob: prob / off shape mismatch")
+    N, D, H, W = prob.shape
+    prob, off = prob.contiguous(), off.contiguous()
+    dev = prob.device
+    est_depth = torch.empty((N, topk, H, W), dtype=torch.float32, device=dev)
+    est_dens = torch.empty((N, topk, H, W), dtype=torch.float32, device=dev)
+    est_idx = torch.empty((N, topk, H, W), dtype=torch.int32, device=dev)
+    avg = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mvsdet_sample_depth_prob_f32(_lib.ptr(prob), _lib.ptr(off), _lib.ptr(est_depth),
+                                                            _lib.ptr(est_dens), _lib.ptr(est_idx), _lib.ptr(avg), N, D, H,
+                                                            W, topk, near, interval, _stream(prob)), "sample_depth_prob")
+    return est_depth, est_dens, est_idx, avg
+
+
+@sample_depth_prob.register_fake
+def _(prob, off, near, interval, topk):
+    N, D, H, W = prob.shape
+    e = prob.new_empty
+    return e((N, topk, H, W)), e((N, topk, H, W)), prob.new_empty((N, topk, H, W), dtype=torch.int32), e((N, H, W))
+
+
+def _sdp_setup(ctx, inputs, output):
+    prob, off, near, interval, topk = inputs
+    ctx.save_for_backward(prob, off, output[2])
+    ctx.near, ctx.interval = near, interval
+
+
+def _sdp_bwd(ctx, g_depth, g_dens, g_idx, g_avg):
+    # gradients w.r.t. prob and off directly (no softmax / sigmoid Jacobian), in plain tensor ops:
+    # est_dens = prob[idx]; est_depth = idx*iv + near + off[idx]*iv; avg = sum_d prob_d * depth_d
+    prob, off, est_idx = ctx.saved_tensors
+    iv, near = ctx.interval, ctx.near
+    idx = est_idx.long()
+    gp = torch.zeros_like(prob)
+    go = torch.zeros_like(prob)
+    if g_dens is not None:
+        gp.scatter_add_(1, idx, g_dens)
+    if g_depth is not None:
+        go.scatter_add_(1, idx, g_depth * iv)
+    if g_avg is not None:
+        d = torch.arange(prob.shape[1], device=prob.device, dtype=torch.float32).view(1, -1, 1, 1)
+        gp += g_avg.unsqueeze(1) * ((d * iv + near) + off * iv)
+        go += g_avg.unsqueeze(1) * prob * iv
+    return gp, go, None, None, None
+
+
+sample_depth_prob.register_autograd(_sdp_bwd, setup_context=_sdp_setup)
+
+
+@torch.library.custom_op(f"{_NS}::depth_prob_topk_backward", mutates_args=(), device_types="cuda")
+def depth_prob_topk_backward(prob: Tensor, off: Tensor, est_idx: Tensor, g_prob: Tensor, g_depth: Tensor,
+                             g_dens: Tensor, g_avg: Tensor, near: float, interval: float) -> Tuple[Tensor, Tensor]:
+    N, D, H, W = prob.shape
+    topk = est_idx.shape[1]
+    g_cost = torch.empty_like(prob)
+    g_off = torch.empty_like(prob)
+    g_prob, g_depth, g_dens, g_avg = g_prob.contiguous(), g_depth.contiguous(), g_dens.contiguous(), g_avg.contiguous()
+    with torch.cuda.device(prob.device):
+        _lib.check(_lib.load().mvsdet_depth_prob_topk_bwd_f32(
+            _lib.ptr(prob), _lib.ptr(off), _lib.ptr(est_idx), _lib.ptr(g_prob), _lib.ptr(g_depth), _lib.ptr(g_dens),
+            _lib.ptr(g_avg), _lib.ptr(g_cost), _lib.ptr(g_off), N, D, H, W, topk, near, interval, _stream(prob)),
+            "depth_prob_topk_backward")
+    return g_cost, g_off
+
+
+@depth_prob_topk_backward.register_fake
+def _(prob, off, est_idx, g_prob, g_depth, g_dens, g_avg, near, interval):
+    return torch.empty_like(prob), torch.empty_like(prob)
+
+
+def _dp_setup(ctx, inputs, output):
+    cost_reg, off_logit, near, interval, topk = inputs
+    prob, off, est_depth, est_dens, est_idx, avg = output
+    ctx.save_for_backward(prob, off, est_idx)
+    ctx.near, ctx.interval = near, interval
+
+
+def _dp_bwd(ctx, g_prob, g_off, g_depth, g_dens, g_idx, g_avg):
+    prob, off, est_idx = ctx.saved_tensors
+
+    def z(g, like_shape):
+        return torch.zeros(like_shape, dtype=torch.float32, device=prob.device) if g is None else g
+
+    N, D, H, W = prob.shape
+    k = est_idx.shape[1]
+    g_cost, g_offl = depth_prob_topk_backward(prob, off, est_idx, z(g_prob, prob.shape), z(g_depth, (N, k, H, W)),
+                                              z(g_dens, (N, k, H, W)), z(g_avg, (N, H, W)), ctx.near, ctx.interval)
+    if g_off is not None:  # direct gradient on the sigmoid output
+        g_offl = g_offl + g_off * off * (1.0 - off)
+    return g_cost, g_offl, None, None, None
+
+
+depth_prob_topk.register_autograd(_dp_bwd, setup_context=_dp_setup)
+
+
+# ------------------------------------------------------------------------------------------- a9
+def _check_stage3(features, points, projection, est_depth, est_dens):
+    _req(features, "features", dim=4)
+    _req(points, "points")
+    _req(projection, "projection", dim=3)
+    _req(est_depth, "est_depth", dim=4)
+    _req(est_dens, "est_dens", dim=4)
+    N, C, h, w = features.shape
+    if points.shape[0] != 3:
+        raise ValueError("backproject_weigh: points must be (3, ...)")
+    V = points.numel() // 3
+    J = est_depth.shape[1]
+    if projection.shape != (N, 3, 4):
+        raise ValueError(f"backproject_weigh: projection {tuple(projection.shape)} != ({N},3,4)")
+    if est_depth.shape != (N, J, h, w) or est_dens.shape != (N, J, h, w):
+        raise ValueError(f"backproject_weigh: est_depth/est_dens must be ({N},J,{h},{w}), got "
+                         f"{tuple(est_depth.shape)} / {tuple(est_dens.shape)}")
+    if est_depth.stride() != est_dens.stride():
+        est_dens = est_dens.contiguous()
+        est_depth = est_depth.contiguous()
+    return N, C, h, w, V, J, est_depth, est_dens
+
+
+@torch.library.custom_op(f"{_NS}::backproject_weigh", mutates_args=(), device_types="cuda")
+def backproject_weigh(features: Tensor, points: Tensor, projection: Tensor, est_depth: Tensor, est_dens: Tensor,
+                      vz: float) -> Tuple[Tensor, Tensor]:
+    """a9 (mvsdet.py:1372): features (N,C,h,w) any strides; points (3,X,Y,Z); projection (N,3,4);
+    est_depth/est_dens (N,J,h,w) any strides -> volume (N,C,V) fp32, valid (N,V) bool."""
+    N, C, h, w, V, J, est_depth, est_dens = _check_stage3(features, points, projection, est_depth, est_dens)
+    points, projection = points.contiguous(), projection.contiguous()
+    dev = features.device
+    volume = torch.empty((N, C, V), dtype=torch.float32, device=dev)
+    valid = torch.empty((N, V), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mvsdet_backproject_weigh_f32(
+            _lib.ptr(features), _lib.strides4(features), _lib.ptr(points), _lib.ptr(projection), _lib.ptr(est_depth),
+            _lib.ptr(est_dens), _lib.strides4(est_depth), _lib.ptr(volume), _lib.ptr(valid), None, None,
+            N, C, h, w, V, J, vz, _stream(features)), "backproject_weigh")
+    return volume, valid.bool()
+
+
+@backproject_weigh.register_fake
+def _(features, points, projection, est_depth, est_dens, vz):
+    N, C = features.shape[:2]
+    V = points.numel() // 3
+    return features.new_empty((N, C, V)), features.new_empty((N, V), dtype=torch.bool)
+
+
+@torch.library.custom_op(f"{_NS}::backproject_weigh_backward", mutates_args=(), device_types="cuda")
+def backproject_weigh_backward(features: Tensor, points: Tensor, projection: Tensor, est_depth: Tensor,
+                               est_dens: Tensor, vz: float, grad: Tensor) -> Tuple[Tensor, Tensor]:
+    N, C, h, w, V, J, est_depth, est_dens = _check_stage3(features, points, projection, est_depth, est_dens)
+    points, projection, grad = points.contiguous(), projection.contiguous(), grad.contiguous()
+    dev = features.device
+    gfeat = torch.empty((N, C, h, w), dtype=torch.float32, device=dev)
+    gdens = torch.empty((N, J, h, w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mvsdet_backproject_weigh_bwd_f32(
+            _lib.ptr(features), _lib.strides4(features), _lib.ptr(points), _lib.ptr(projection), _lib.ptr(est_depth),
+            _lib.ptr(est_dens), _lib.strides4(est_depth), _lib.ptr(grad), _lib.ptr(gfeat), _lib.ptr(gdens),
+            N, C, h, w, V, J, vz, _stream(features)), "backproject_weigh_backward")
+    return gfeat, gdens
+
+
+@backproject_weigh_backward.register_fake
+def _(features, points, projection, est_depth, est_dens, vz, grad):
+    N, C, h, w = features.shape
+    return features.new_empty((N, C, h, w)), features.new_empty((N, est_depth.shape[1], h, w))
+
+
+def _bp_setup(ctx, inputs, output):
+    features, points, projection, est_depth, est_dens, vz = inputs
+    ctx.save_for_backward(features, points, projection, est_depth, est_dens)
+    ctx.vz = vz
+
+
+def _bp_bwd(ctx, g_volume, g_valid):
+    features, points, projection, est_depth, est_dens = ctx.saved_tensors
+    gfeat, gdens = backproject_weigh_backward(features, points, projection, est_depth, est_dens, ctx.vz, g_volume)
+    return gfeat, None, None, None, gdens, None
+
+
+backproject_weigh.register_autograd(_bp_bwd, setup_context=_bp_setup)
+
+
+# ------------------------------------------------------------------------------------------- a9+a10
+@torch.library.custom_op(f"{_NS}::backproject_weigh_mean", mutates_args=(), device_types="cuda")
+def backproject_weigh_mean(features: Tensor, packed: Tensor, points: Tensor, projection: Tensor, est_depth: Tensor,
+                           est_dens: Tensor, H: int, W: int, vz: float) -> Tuple[Tensor, Tensor]:
+    """a9+a10 fused (mvsdet.py:1372 + 511-515).  `features` is the (N,C,h,w) crop view (used for shapes and by
+    the backward pass), `packed` = pack_features(full (N,C,H,W) maps).  -> mean (C,V) fp32, count (V) int32."""
+    N, C, h, w, V, J, est_depth, est_dens = _check_stage3(features, points, projection, est_depth, est_dens)
+    _req(packed, "packed", dim=1)
+    lib = _lib.load()
+    if packed.numel() * 4 != lib.mvsdet_packed_bytes(N, C, H, W):
+        raise ValueError("backproject_weigh_mean: packed buffer does not match (N,C,H,W)")
+    points, projection = points.contiguous(), projection.contiguous()
+    dev = features.device
+    mean = torch.empty((C, V), dtype=torch.float32, device=dev)
+    count = torch.empty((V,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mvsdet_backproject_weigh_mean_packed_f32(
+            _lib.ptr(packed), _lib.ptr(points), _lib.ptr(projection), _lib.ptr(est_depth), _lib.ptr(est_dens),
+            _lib.strides4(est_depth), _lib.ptr(mean), _lib.ptr(count), N, C, H, W, h, w, V, J, vz, _stream(features)),
+            "backproject_weigh_mean")
+    return mean, count
+
+
+@backproject_weigh_mean.register_fake
+def _(features, packed, points, projection, est_depth, est_dens, H, W, vz):
+    C = features.shape[1]
+    V = points.numel() // 3
+    return features.new_empty((C, V)), features.new_empty((V,), dtype=torch.int32)
+
+
+@torch.library.custom_op(f"{_NS}::backproject_weigh_mean_backward", mutates_args=(), device_types="cuda")
+def backproject_weigh_mean_backward(features: Tensor, points: Tensor, projection: Tensor, est_depth: Tensor,
+                                    est_dens: Tensor, count: Tensor, vz: float, grad: Tensor) -> Tuple[Tensor, Tensor]:
+    N, C, h, w, V, J, est_depth, est_dens = _check_stage3(features, points, projection, est_depth, est_dens)
+    points, projection, grad = points.contiguous(), projection.contiguous(), grad.contiguous()
+    dev = features.device
+    gfeat = torch.empty((N, C, h, w), dtype=torch.float32, device=dev)
+    gdens = torch.empty((N, J, h, w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mvsdet_backproject_weigh_mean_bwd_f32(
+            _lib.ptr(features), _lib.strides4(features), _lib.ptr(points), _lib.ptr(projection), _lib.ptr(est_depth),
+            _lib.ptr(est_dens), _lib.strides4(est_depth), _lib.ptr(count), _lib.ptr(grad), _lib.ptr(gfeat),
+            _lib.ptr(gdens), N, C, h, w, V, J, vz, _stream(features)), "backproject_weigh_mean_backward")
+    return gfeat, gdens
+
+
+@backproject_weigh_mean_backward.register_fake
+def _(features, points, projection, est_depth, est_dens, count, vz, grad):
+    N, C, h, w = features.shape
+    return features.new_empty((N, C, h, w)), features.new_empty((N, est_depth.shape[1], h, w))
+
+
+def _bpm_setup(ctx, inputs, output):
+    features, packed, points, projection, est_depth, est_dens, H, W, vz = inputs
+    mean, count = output
+    ctx.save_for_backward(features, points, projection, est_depth, est_dens, count)
+    ctx.vz = vz
+
+
+def _bpm_bwd(ctx, g_mean, g_count):
+    features, points, projection, est_depth, est_dens, count = ctx.saved_tensors
+    gfeat, gdens = backproject_weigh_mean_backward(features, points, projection, est_depth, est_dens, count, ctx.vz,
+                                                   g_mean)
+    return gfeat, None, None, None, None, gdens, None, None, None
+
+
+backproject_weigh_mean.register_autograd(_bpm_bwd, setup_context=_bpm_setup)
+
+
+# ------------------------------------------------------------------------------------------- misc
+def device_copy(src: Tensor, dst: Tensor):
+    """float4 device-to-device copy kernel (bench.py's achievable-HBM yardstick)."""
+    _req(src, "src")
+    _req(dst, "dst")
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().mvsdet_copy_f32(_lib.ptr(src), _lib.ptr(dst), src.numel(), _stream(src)), "copy")

@@ -1,0 +1,372 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_goldens.py
+
+Every array written here is data: seeded inputs plus the outputs the reference
+functions returned for them on PyTorch-CPU (torch version recorded in each file).
+Functions called (reference file:line, relative to projects/NeRF-Det/nerfdet/):
+
+    mvs_models/module.py:105  homo_warping
+    mvsdet.py:43,67           knn, get_nearest_pose_ids
+    mvsdet.py:249             MVSDet.collect_proj           (unbound, SimpleNamespace self)
+    mvsdet.py:266,298         MVSDet.sample_depth_prob, MVSDet.compute_avg_depth
+    mvsdet.py:1124            MVSDet._compute_projection    (static)
+    mvsdet.py:1316            get_points
+    mvsdet.py:1372            backproject_Weigh
+
+The variance block (mvsdet.py:439-467) and the view mean (mvsdet.py:511-515) are
+inline statements of ``extract_feat`` rather than functions; this script applies the
+same tensor statements around the imported ``homo_warping`` / ``backproject_Weigh``
+outputs (flagged ``inline_restated=1`` in the fixtures that contain them).
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from _ref_loader import load_reference  # noqa: E402
+from mvsdet_amd import synthetic  # noqa: E402
+
+torch.set_num_threads(4)
+ref, ref_module = load_reference()
+MVSDet = ref.MVSDet
+META = dict(torch_version=np.array(torch.__version__), generator=np.array("tests/golden/make_goldens.py"))
+
+
+def ns_self(near, far, D):
+    return SimpleNamespace(depth_interval=(far - near) / D, near_far_range=[near, far],
+                           gs_cfg=SimpleNamespace(num_monocular_samples=D))
+
+
+def depth_planes(near, far, D):
+    # mvsdet.py:221-225
+    interval = (far - near) / D
+    dv = np.arange(near, far, interval, dtype=np.float32)
+    assert len(dv) == D
+    return dv
+
+
+def feat_level_proj(meta, stride=4):
+    """mvsdet.py:416-428 + collect_proj(:249) ingredients: (w2c, K_feat)."""
+    w2c = torch.tensor(np.array(meta["lidar2img"]["extrinsic"]))
+    K = torch.tensor(np.array(meta["lidar2img"]["intrinsic"]))
+    is_list = isinstance(meta["lidar2img"]["intrinsic"], list)
+    ratio = meta["ori_shape"][0] / (meta["img_shape"][0] / stride)
+    Kf = K.clone()
+    if not is_list:
+        Kf[:2] /= ratio
+    else:
+        Kf[:, :2] /= ratio
+    return w2c, Kf
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    out.update(META)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+# --------------------------------------------------------------------------- G1
+def g1_homo_warping():
+    """homo_warping on 5 camera pairs: translation only, rotation+translation, frustum partly
+    behind the source camera (negative z, finite), identity (documents the align_corners
+    quirk), large displacement (most taps out of bounds)."""
+    C, D, H, W = 4, 8, 24, 32
+    g = torch.Generator().manual_seed(11)
+    src = torch.randn(5, C, H, W, generator=g)
+    # ramp in channel 0 of the identity case so the quirk is visible in the data
+    src[3, 0] = torch.arange(W, dtype=torch.float32)[None, :].repeat(H, 1)
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 28.0
+    K[0, 2], K[1, 2] = 15.5, 11.5
+
+    def pose(rx=0., ry=0., rz=0., t=(0., 0., 0.)):
+        cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        E = np.eye(4)
+        E[:3, :3] = Rz @ Ry @ Rx
+        E[:3, 3] = t
+        return torch.tensor(E, dtype=torch.float32)
+
+    ref_E = [pose(), pose(0.02, -0.03, 0.01, (0.1, 0.0, 0.0)), pose(), pose(0.01, 0.02, 0.0, (0.2, 0.1, 0.0)), pose()]
+    src_E = [pose(t=(0.15, -0.05, 0.02)), pose(-0.05, 0.12, 0.06, (-0.2, 0.1, 0.05)),
+             pose(0.0, 2.2, 0.0, (0.3, 0.0, 0.9)), pose(0.01, 0.02, 0.0, (0.2, 0.1, 0.0)),
+             pose(0.3, -0.9, 0.4, (1.5, -0.7, 0.2))]
+    ref_proj = torch.stack([K @ e for e in ref_E])
+    src_proj = torch.stack([K @ e for e in src_E])
+    dv = torch.tensor(depth_planes(0.2, 5.0, D)).unsqueeze(0).repeat(5, 1)
+    out = ref_module.homo_warping(src, src_proj, ref_proj, dv)
+    # module.py:116, the same ATen-CPU calls: stored so kernel parity can be tested in isolation from
+    # the LAPACK build of the machine that runs the test (sample positions move ~1e-4 px per ulp of it)
+    proj_rel = torch.matmul(src_proj, torch.inverse(ref_proj))
+    # sanity on the quirk: identity pair does not reproduce the ramp
+    assert not torch.allclose(out[3, 0, 0], src[3, 0])
+    assert torch.isfinite(out).all()
+    save("g1_homo_warping", src_fea=src, src_proj=src_proj, ref_proj=ref_proj, depth_values=dv, proj_rel=proj_rel,
+         warped=out)
+
+
+# --------------------------------------------------------------------------- G2 / G3
+def variance_path(feature, meta, D, near_far):
+    """mvsdet.py:416-467 restated around the imported functions (inline_restated)."""
+    N = feature.shape[0]
+    w2c, Kf = feat_level_proj(meta)
+    k = min(2, N - 1)
+    c2w = w2c.inverse()
+    nbr = ref.get_nearest_pose_ids(c2w, c2w, k, maskself=True)
+    ref_proj, nei_projs = MVSDet.collect_proj(None, w2c, Kf, nbr)
+    dv = torch.tensor(depth_planes(*near_far, D)).unsqueeze(0).repeat(N, 1)
+    ref_volume = feature.unsqueeze(2).repeat(1, 1, D, 1, 1)
+    volume_sum = ref_volume
+    volume_sq_sum = ref_volume ** 2
+    nei_features = torch.unbind(feature[nbr.view(-1)].view(N, k, *feature.shape[1:]), dim=1)
+    for nei_fea, nei_proj in zip(nei_features, nei_projs):
+        warped = ref_module.homo_warping(nei_fea, nei_proj, ref_proj, dv)
+        volume_sum = volume_sum + warped
+        volume_sq_sum = volume_sq_sum + warped ** 2
+    var = volume_sq_sum.div_(k + 1).sub_(volume_sum.div_(k + 1).pow_(2))
+    # module.py:116 evaluated per neighbour (see g1 note)
+    proj_rel = torch.stack([torch.matmul(p, torch.inverse(ref_proj)) for p in nei_projs], 1)
+    return dict(w2c=w2c, K_feat=Kf, c2w=c2w, neighbor_ids=nbr, ref_proj=ref_proj, proj_rel=proj_rel,
+                nei_projs=torch.stack(list(nei_projs), 1), depth_values=dv, variance=var)
+
+
+def g2_variance():
+    for tag, N, C, D, hw, nf, pvi in [("n3_d8", 3, 32, 8, (48, 64), (0.2, 5.0), False),
+                                      ("n2_k1", 2, 8, 8, (24, 32), (0.2, 5.0), False),
+                                      ("n6_d12_arkit", 6, 8, 12, (16, 20), (0.5, 5.5), True)]:
+        meta = synthetic.make_img_meta(N, hw, seed=21, per_view_intrinsics=pvi)
+        feat = synthetic.make_features(N, C, hw, seed=21)
+        r = variance_path(feat, meta, D, nf)
+        assert torch.isfinite(r["variance"]).all()
+        # keep fixtures small: config-1 shape stores every 4th channel of the variance
+        cs = 4 if C > 8 else 1
+        r["variance"] = r["variance"][:, ::cs].contiguous()
+        save("g2_variance_" + tag, variance_channel_stride=cs, feature=feat, near_far=np.array(nf, dtype=np.float64), inline_restated=1,
+             extrinsic=np.array(meta["lidar2img"]["extrinsic"]), intrinsic=np.array(meta["lidar2img"]["intrinsic"]),
+             img_shape=np.array(meta["img_shape"]), ori_shape=np.array(meta["ori_shape"]),
+             per_view_intrinsics=int(pvi), **r)
+
+
+def g3_knn():
+    out = {}
+    for N in (2, 3, 40):
+        w2c, _ = synthetic.make_cameras(N, seed=31 + N)
+        c2w = torch.tensor(w2c).inverse()
+        k = min(2, N - 1)
+        out[f"c2w_{N}"] = c2w
+        out[f"ids_{N}"] = ref.get_nearest_pose_ids(c2w, c2w, k, maskself=True)
+    # duplicated camera position (views 1 and 3 coincide): tie between equal distances
+    w2c, _ = synthetic.make_cameras(5, seed=77)
+    c2w = torch.tensor(w2c).inverse()
+    c2w[3, :3, 3] = c2w[1, :3, 3]
+    out["c2w_dup"] = c2w
+    out["ids_dup"] = ref.get_nearest_pose_ids(c2w, c2w, 2, maskself=True)
+    # NVS-style call (num_select=3, maskself=False, mvsdet.py:532)
+    out["ids_40_k3_noself"] = ref.get_nearest_pose_ids(out["c2w_40"], out["c2w_40"], 3, maskself=False)
+    save("g3_knn", **out)
+
+
+# --------------------------------------------------------------------------- G4
+def g4_depth_prob():
+    out = {}
+    for tag, D, near, far in [("d8", 8, 0.2, 5.0), ("d12", 12, 0.2, 5.0), ("d12_arkit", 12, 0.5, 5.5)]:
+        logits = synthetic.make_cost_logits(3, D, (12, 16), seed=41 + D)
+        cost_reg, off_logit = logits[:, 0], logits[:, 1]
+        prob = F.softmax(cost_reg, dim=1)            # mvsdet.py:472
+        off = torch.sigmoid(off_logit)               # mvsdet.py:475
+        s = ns_self(near, far, D)
+        est_depth, est_dens = MVSDet.sample_depth_prob(s, prob, off, topk=3)
+        avg = MVSDet.compute_avg_depth(s, prob, off)
+        # fixtures must not contain top-k ties (torch.topk tie order is unspecified)
+        srt = prob.sort(dim=1, descending=True)[0]
+        assert (srt[:, :3] - srt[:, 1:4]).min() > 1e-6
+        out.update({f"cost_reg_{tag}": cost_reg, f"off_logit_{tag}": off_logit, f"prob_{tag}": prob,
+                    f"off_{tag}": off, f"est_depth_{tag}": est_depth, f"est_dens_{tag}": est_dens,
+                    f"avg_depth_{tag}": avg, f"near_far_{tag}": np.array([near, far], dtype=np.float64)})
+    save("g4_depth_prob", **out)
+
+
+# --------------------------------------------------------------------------- G5
+def stage3_inputs(N, C, hw, D, near_far, seed, pvi):
+    hf, wf = hw
+    meta = synthetic.make_img_meta(N, hw, seed=seed, per_view_intrinsics=pvi)
+    feat = synthetic.make_features(N, C, hw, seed=seed)
+    logits = synthetic.make_cost_logits(N, D, hw, seed=seed, sharp=2.0)
+    prob = F.softmax(logits[:, 0], dim=1)
+    off = torch.sigmoid(logits[:, 1])
+    s = ns_self(*near_far, D)
+    height, width = meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+    est_depth, est_dens = MVSDet.sample_depth_prob(s, prob, off, topk=3)
+    est_depth = est_depth[:, :, :height, :width]
+    est_dens = est_dens[:, :, :height, :width]
+    # mvsdet.py:484,495
+    est_depth_r = est_depth.reshape(*est_depth.shape[:2], -1).transpose(2, 1).unsqueeze(2)
+    est_dens_r = est_dens.reshape(*est_dens.shape[:2], -1).transpose(2, 1).unsqueeze(2)
+    return meta, feat, est_depth, est_dens, est_depth_r, est_dens_r, height, width
+
+
+def g5_backproject():
+    n_voxels, voxel_size = [40, 40, 16], [0.16, 0.16, 0.2]
+    for tag, N, C, pvi, nf in [("scannet", 6, 8, False, (0.2, 5.0)), ("arkit", 4, 4, True, (0.5, 5.5))]:
+        meta, feat, est_depth, est_dens, ed_r, en_r, height, width = stage3_inputs(N, C, (60, 80), 12, nf, 51, pvi)
+        projection = MVSDet._compute_projection(meta, 4, None)
+        points = ref.get_points(n_voxels=torch.tensor(n_voxels), voxel_size=torch.tensor(voxel_size),
+                                origin=torch.tensor(meta["lidar2img"]["origin"]))
+        features = feat[:, :, :height, :width]
+        volume, valid, gap, rmse = ref.backproject_Weigh(features, points, projection, ed_r, voxel_size, en_r)
+        # intermediates (mvsdet.py:1383-1391) for the bit-exact index test, plus fp64 tie distance
+        pts = points.view(1, 3, -1).expand(N, 3, -1)
+        pts = torch.cat((pts, torch.ones_like(pts[:, :1])), dim=1)
+        p23 = torch.bmm(projection, pts)
+        x = (p23[:, 0] / p23[:, 2]).round().long()
+        y = (p23[:, 1] / p23[:, 2]).round().long()
+        z = p23[:, 2]
+        valid0 = (x >= 0) & (y >= 0) & (x < width) & (y < height) & (z > 0)
+        p64 = torch.bmm(projection.double(), pts.double())
+        qx, qy = p64[:, 0] / p64[:, 2], p64[:, 1] / p64[:, 2]
+        tie = torch.minimum((qx - torch.floor(qx) - 0.5).abs(), (qy - torch.floor(qy) - 0.5).abs())
+        # mvsdet.py:511-515
+        vs = volume.sum(dim=0)
+        cnt = valid.sum(dim=0)
+        mean = vs / (cnt + 1e-8)
+        mean[:, cnt[0] == 0] = .0
+        print(tag, "in-frustum", int(valid0.sum()), "pass depth window", int(valid.sum()),
+              "non-empty voxels", int((cnt[0] > 0).sum()), "min tie dist", float(tie[valid0].min()))
+        save("g5_backproject_" + tag, feature=feat, est_depth=est_depth, est_dens=est_dens,
+             extrinsic=np.array(meta["lidar2img"]["extrinsic"]), intrinsic=np.array(meta["lidar2img"]["intrinsic"]),
+             origin=meta["lidar2img"]["origin"], img_shape=np.array(meta["img_shape"]),
+             ori_shape=np.array(meta["ori_shape"]), per_view_intrinsics=int(pvi),
+             n_voxels=np.array(n_voxels), voxel_size=np.array(voxel_size, dtype=np.float64),
+             projection=projection, points=points, x=x.int(), y=y.int(), z=z, valid_frustum=valid0,
+             tie_dist=tie.float(), volume=volume, valid=valid,
+             gap_all=gap, rmse=rmse, volume_mean=mean, valid_count=cnt, inline_restated=1)
+
+
+# --------------------------------------------------------------------------- G6
+def g6_backward():
+    # stage 1: d(sum(var * R)) / d feature
+    N, C, D, hw = 3, 4, 8, (12, 16)
+    meta = synthetic.make_img_meta(N, hw, seed=61)
+    feat = synthetic.make_features(N, C, hw, seed=61).requires_grad_(True)
+    r = variance_path(feat, meta, D, (0.2, 5.0))
+    g = torch.Generator().manual_seed(62)
+    R1 = torch.randn(r["variance"].shape, generator=g)
+    (r["variance"] * R1).sum().backward()
+    out = dict(s1_feature=feat.detach(), s1_R=R1, s1_grad_feature=feat.grad.clone(),
+               s1_extrinsic=np.array(meta["lidar2img"]["extrinsic"]),
+               s1_intrinsic=np.array(meta["lidar2img"]["intrinsic"]),
+               s1_img_shape=np.array(meta["img_shape"]), s1_ori_shape=np.array(meta["ori_shape"]),
+               s1_variance=r["variance"].detach(), s1_neighbor_ids=r["neighbor_ids"],
+               s1_proj_rel=r["proj_rel"], s1_depth_values=r["depth_values"])
+    # stage 2: d(sum(est_dens*R + est_depth*R' + avg*R'')) / d{cost_reg, off_logit}
+    logits = synthetic.make_cost_logits(2, 12, (6, 8), seed=63).requires_grad_(True)
+    prob = F.softmax(logits[:, 0], dim=1)
+    off = torch.sigmoid(logits[:, 1])
+    s = ns_self(0.2, 5.0, 12)
+    ed, en = MVSDet.sample_depth_prob(s, prob, off, topk=3)
+    avg = MVSDet.compute_avg_depth(s, prob, off)
+    Ra, Rb, Rc, Rd = (torch.randn(t.shape, generator=g) for t in (ed, en, avg, prob))
+    ((ed * Ra).sum() + (en * Rb).sum() + (avg * Rc).sum() + (prob * Rd).sum()).backward()
+    out.update(s2_logits=logits.detach(), s2_R_depth=Ra, s2_R_dens=Rb, s2_R_avg=Rc, s2_R_prob=Rd,
+               s2_grad_logits=logits.grad.clone())
+    # stage 3: d(sum(volume * R)) / d{features, prob}; and through the view mean
+    n_voxels, voxel_size = [16, 16, 8], [0.4, 0.4, 0.4]
+    meta, feat, est_depth, est_dens, ed_r, en_r, height, width = stage3_inputs(4, 4, (60, 80), 12, (0.2, 5.0), 64, False)
+    feat = feat.requires_grad_(True)
+    est_dens = est_dens.clone().requires_grad_(True)
+    en_r = est_dens.reshape(*est_dens.shape[:2], -1).transpose(2, 1).unsqueeze(2)
+    projection = MVSDet._compute_projection(meta, 4, None)
+    points = ref.get_points(n_voxels=torch.tensor(n_voxels), voxel_size=torch.tensor(voxel_size),
+                            origin=torch.tensor(meta["lidar2img"]["origin"]))
+    volume, valid, _, _ = ref.backproject_Weigh(feat[:, :, :height, :width], points, projection, ed_r, voxel_size, en_r)
+    R3 = torch.randn(volume.shape, generator=g)
+    (volume * R3).sum().backward(retain_graph=True)
+    g_feat, g_dens = feat.grad.clone(), est_dens.grad.clone()
+    feat.grad = None
+    est_dens.grad = None
+    cnt = valid.sum(dim=0)
+    mean = volume.sum(dim=0) / (cnt + 1e-8)
+    mean = mean.clone()
+    mean[:, cnt[0] == 0] = .0
+    R3m = torch.randn(mean.shape, generator=g)
+    (mean * R3m).sum().backward()
+    print("stage3 grad: valid pairs", int(valid.sum()))
+    out.update(s3_feature=feat.detach(), s3_est_depth=est_depth, s3_est_dens=est_dens.detach(),
+               s3_extrinsic=np.array(meta["lidar2img"]["extrinsic"]), s3_intrinsic=np.array(meta["lidar2img"]["intrinsic"]),
+               s3_origin=meta["lidar2img"]["origin"], s3_img_shape=np.array(meta["img_shape"]),
+               s3_ori_shape=np.array(meta["ori_shape"]), s3_n_voxels=np.array(n_voxels),
+               s3_voxel_size=np.array(voxel_size, dtype=np.float64), s3_R=R3, s3_grad_feature=g_feat,
+               s3_grad_dens=g_dens, s3_Rmean=R3m, s3_grad_feature_mean=feat.grad.clone(),
+               s3_grad_dens_mean=est_dens.grad.clone(), s3_volume=volume.detach(), s3_valid=valid)
+    save("g6_backward", **out)
+
+
+# --------------------------------------------------------------------------- G7
+def g7_end_to_end():
+    """Tiny scene through a1..a10 with a fixed random stand-in for CostRegNet_3DGS output."""
+    N, C, D, hw, nf = 5, 8, 12, (60, 80), (0.2, 5.0)
+    n_voxels, voxel_size = [40, 40, 16], [0.16, 0.16, 0.2]
+    meta = synthetic.make_img_meta(N, hw, seed=71)
+    feat = synthetic.make_features(N, C, hw, seed=71)
+    r = variance_path(feat, meta, D, nf)
+    # stand-in network: logits are a fixed function of the variance so the stages stay chained
+    g = torch.Generator().manual_seed(72)
+    Wc = torch.randn(2, C, generator=g) * 1.5
+    logits = torch.einsum("oc,ncdhw->nodhw", Wc, r["variance"])
+    # planes whose neighbours both fall outside the source images have identical variance ->
+    # identical logits -> exact top-k ties (order unspecified in torch.topk); a small monotone
+    # ramp over d keeps this fixture tie-free.  Stored logits include the ramp.
+    logits[:, 0] += torch.linspace(0, 0.6, D).view(1, D, 1, 1)
+    prob = F.softmax(logits[:, 0], dim=1)
+    off = torch.sigmoid(logits[:, 1])
+    s = ns_self(*nf, D)
+    height, width = meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+    est_depth, est_dens = MVSDet.sample_depth_prob(s, prob, off, topk=3)
+    est_depth, est_dens = est_depth[:, :, :height, :width], est_dens[:, :, :height, :width]
+    depth_coding = MVSDet.compute_avg_depth(s, prob, off)[:, :height, :width].unsqueeze(1)
+    ed_r = est_depth.reshape(*est_depth.shape[:2], -1).transpose(2, 1).unsqueeze(2)
+    en_r = est_dens.reshape(*est_dens.shape[:2], -1).transpose(2, 1).unsqueeze(2)
+    projection = MVSDet._compute_projection(meta, 4, None)
+    points = ref.get_points(n_voxels=torch.tensor(n_voxels), voxel_size=torch.tensor(voxel_size),
+                            origin=torch.tensor(meta["lidar2img"]["origin"]))
+    volume, valid, _, _ = ref.backproject_Weigh(feat[:, :, :height, :width], points, projection, ed_r, voxel_size, en_r)
+    cnt = valid.sum(dim=0)
+    mean = volume.sum(dim=0) / (cnt + 1e-8)
+    mean[:, cnt[0] == 0] = .0
+    srt = prob.sort(dim=1, descending=True)[0]
+    print("g7 min top-k gap", float((srt[:, :3] - srt[:, 1:4]).min()), "non-empty voxels", int((cnt[0] > 0).sum()))
+    save("g7_end_to_end", feature=feat, extrinsic=np.array(meta["lidar2img"]["extrinsic"]),
+         intrinsic=np.array(meta["lidar2img"]["intrinsic"]), origin=meta["lidar2img"]["origin"],
+         img_shape=np.array(meta["img_shape"]), ori_shape=np.array(meta["ori_shape"]),
+         near_far=np.array(nf, dtype=np.float64), n_voxels=np.array(n_voxels),
+         voxel_size=np.array(voxel_size, dtype=np.float64), Wc=Wc, neighbor_ids=r["neighbor_ids"],
+         proj_rel=r["proj_rel"], depth_values=r["depth_values"], projection=projection,
+         variance_sample=r["variance"][:, :, :, ::6, ::8], logits=logits, prob=prob, est_depth=est_depth,
+         est_dens=est_dens, depth_coding=depth_coding, volume_mean=mean, valid_count=cnt, inline_restated=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    fns = dict(g1=g1_homo_warping, g2=g2_variance, g3=g3_knn, g4=g4_depth_prob, g5=g5_backproject,
+               g6=g6_backward, g7=g7_end_to_end)
+    for w in which:
+        fns[w]()

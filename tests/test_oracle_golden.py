@@ -1,0 +1,164 @@
+"""The CPU oracle (oracle/) against the golden vectors produced by running the reference
+(tests/golden/make_goldens.py).  This is what pins the oracle; the GPU tests then compare the HIP kernels
+with the oracle.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def test_homo_warp_bit_exact(oracle):
+    g = load_golden("g1_homo_warping")
+    out = oracle.homo_warp(g["src_fea"], g["proj_rel"], g["depth_values"])
+    # same rounding points as torch.matmul + ATen-CPU grid_sample: identical bits on the generating host
+    np.testing.assert_allclose(out, g["warped"], rtol=0, atol=2e-6)
+    assert (out == g["warped"]).mean() > 0.99
+    # the identity pair (case 3) does not reproduce its input
+    assert not np.allclose(out[3, 0, 0], g["src_fea"][3, 0])
+    # behind-camera case (2) stays finite
+    assert np.isfinite(out).all()
+
+
+@pytest.mark.parametrize("tag", ["n3_d8", "n2_k1", "n6_d12_arkit"])
+def test_plane_sweep_variance(oracle, tag):
+    g = load_golden("g2_variance_" + tag)
+    cs = int(g["variance_channel_stride"])
+    for mode, tol in ((0, 1e-5), (1, 1e-5)):
+        var = oracle.plane_sweep_variance(g["feature"], g["neighbor_ids"], g["proj_rel"], g["depth_values"], mode)
+        np.testing.assert_allclose(var[:, ::cs], g["variance"], rtol=0, atol=tol)
+    # eager-rounding mode reproduces most elements bit for bit
+    var0 = oracle.plane_sweep_variance(g["feature"], g["neighbor_ids"], g["proj_rel"], g["depth_values"], 0)
+    assert (var0[:, ::cs] == g["variance"]).mean() > 0.8
+
+
+@pytest.mark.parametrize("tag", ["n3_d8", "n2_k1", "n6_d12_arkit"])
+def test_host_geometry_numpy(oracle, tag):
+    g = load_golden("g2_variance_" + tag)
+    k = g["neighbor_ids"].shape[1]
+    nbr = oracle.knn_neighbors(g["c2w"], k)
+    np.testing.assert_array_equal(nbr, g["neighbor_ids"])
+    Kf = oracle.feat_intrinsics(g["intrinsic"], g["img_shape"], g["ori_shape"])
+    np.testing.assert_array_equal(Kf, g["K_feat"])
+    proj_rel, ref_proj = oracle.relative_projections(g["extrinsic"], Kf, nbr)
+    np.testing.assert_allclose(ref_proj, g["ref_proj"], rtol=1e-6, atol=1e-5)
+    # numpy's fp32 inverse (gesv) and torch's (getrf+getri) round differently: equal to ~1e-5 only
+    np.testing.assert_allclose(proj_rel, g["proj_rel"], rtol=1e-4, atol=1e-4)
+
+
+def test_knn(oracle):
+    g = load_golden("g3_knn")
+    for n in (2, 3, 40):
+        np.testing.assert_array_equal(oracle.knn_neighbors(g[f"c2w_{n}"], 2), g[f"ids_{n}"])
+    np.testing.assert_array_equal(oracle.knn_neighbors(g["c2w_dup"], 2), g["ids_dup"])
+    np.testing.assert_array_equal(oracle.knn_neighbors(g["c2w_40"], 3, maskself=False), g["ids_40_k3_noself"])
+
+
+@pytest.mark.parametrize("tag", ["d8", "d12", "d12_arkit"])
+def test_depth_prob_topk(oracle, tag):
+    g = load_golden("g4_depth_prob")
+    near, far = g[f"near_far_{tag}"]
+    D = g[f"cost_reg_{tag}"].shape[1]
+    r = oracle.depth_prob_topk(g[f"cost_reg_{tag}"], g[f"off_logit_{tag}"], near, (far - near) / D, 3)
+    np.testing.assert_allclose(r["prob"], g[f"prob_{tag}"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(r["off"], g[f"off_{tag}"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(r["est_dens"], g[f"est_dens_{tag}"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(r["est_depth"], g[f"est_depth_{tag}"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["avg_depth"], g[f"avg_depth_{tag}"], rtol=0, atol=5e-6)
+    # the restated a6/a7 arithmetic is exact when fed the reference's own prob/off
+    idx = r["est_idx"].astype(np.int64)
+    iv = np.float32((far - near) / D)
+    dep = (idx.astype(np.float32) * iv + np.float32(near)) + np.take_along_axis(g[f"off_{tag}"], idx, 1) * iv
+    ref_idx = np.argsort(-g[f"prob_{tag}"], axis=1, kind="stable")[:, :3]
+    same = (ref_idx == idx)
+    np.testing.assert_array_equal(dep[same], g[f"est_depth_{tag}"][same])
+
+
+@pytest.mark.parametrize("tag", ["scannet", "arkit"])
+def test_backproject_weigh_bit_exact(oracle, tag):
+    g = load_golden("g5_backproject_" + tag)
+    h, w = g["img_shape"][0] // 4, g["img_shape"][1] // 4
+    np.testing.assert_array_equal(oracle.compute_projection(g["extrinsic"], g["intrinsic"], g["img_shape"], g["ori_shape"]),
+                                  g["projection"])
+    np.testing.assert_array_equal(oracle.get_points(g["n_voxels"], g["voxel_size"], g["origin"]), g["points"])
+    feat = g["feature"][:, :, :h, :w]  # non-contiguous crop, as the reference passes it
+    r = oracle.backproject_weigh(feat, g["points"], g["projection"], g["est_depth"], g["est_dens"],
+                                 g["voxel_size"][-1], want_index=True)
+    vf = g["valid_frustum"]
+    # voxel indices bit-exact (north_star); z is the raw bmm output
+    np.testing.assert_array_equal(r["z"], g["z"])
+    np.testing.assert_array_equal(r["x"][vf], g["x"][vf])
+    np.testing.assert_array_equal(r["y"][vf], g["y"][vf])
+    N, C = feat.shape[:2]
+    np.testing.assert_array_equal(r["valid"], g["valid"].reshape(N, -1))
+    np.testing.assert_array_equal(r["volume"], g["volume"].reshape(N, C, -1))
+    m = oracle.backproject_weigh_mean(feat, g["points"], g["projection"], g["est_depth"], g["est_dens"], g["voxel_size"][-1])
+    np.testing.assert_array_equal(m["valid_count"], g["valid_count"].reshape(-1))
+    np.testing.assert_array_equal(m["volume_mean"], g["volume_mean"].reshape(C, -1))
+
+
+def test_backward_stage1(oracle):
+    g = load_golden("g6_backward")
+    gf = oracle.plane_sweep_variance_bwd(g["s1_feature"], g["s1_neighbor_ids"], g["s1_proj_rel"], g["s1_depth_values"], g["s1_R"])
+    np.testing.assert_allclose(gf, g["s1_grad_feature"], rtol=1e-4, atol=1e-4)
+
+
+def test_backward_stage2(oracle):
+    g = load_golden("g6_backward")
+    logits = g["s2_logits"]
+    D = logits.shape[2]
+    near, iv = 0.2, (5.0 - 0.2) / D
+    r = oracle.depth_prob_topk(logits[:, 0], logits[:, 1], near, iv, 3)
+    gc, go = oracle.depth_prob_topk_bwd(r["prob"], r["off"], r["est_idx"], g["s2_R_prob"], g["s2_R_depth"], g["s2_R_dens"],
+                                        g["s2_R_avg"], near, iv)
+    np.testing.assert_allclose(gc, g["s2_grad_logits"][:, 0], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(go, g["s2_grad_logits"][:, 1], rtol=1e-4, atol=2e-6)
+
+
+def test_backward_stage3(oracle):
+    g = load_golden("g6_backward")
+    h, w = g["s3_img_shape"][0] // 4, g["s3_img_shape"][1] // 4
+    feat = g["s3_feature"][:, :, :h, :w]
+    proj = oracle.compute_projection(g["s3_extrinsic"], g["s3_intrinsic"], g["s3_img_shape"], g["s3_ori_shape"])
+    pts = oracle.get_points(g["s3_n_voxels"], g["s3_voxel_size"], g["s3_origin"])
+    vz = g["s3_voxel_size"][-1]
+    N, C = feat.shape[:2]
+    gfeat, gdens = oracle.backproject_weigh_bwd(feat, pts, proj, g["s3_est_depth"], g["s3_est_dens"], vz, g["s3_R"].reshape(N, C, -1))
+    np.testing.assert_allclose(gfeat, g["s3_grad_feature"][:, :, :h, :w], rtol=1e-5, atol=1e-6)
+    assert np.abs(g["s3_grad_feature"][:, :, h:, :]).max() == 0
+    np.testing.assert_allclose(gdens, g["s3_grad_dens"], rtol=1e-4, atol=1e-5)
+    # through the view mean: dL/dvolume_i = dL/dmean / (count + 1e-8) on valid pairs
+    m = oracle.backproject_weigh_mean(feat, pts, proj, g["s3_est_depth"], g["s3_est_dens"], vz)
+    gv = g["s3_Rmean"].reshape(C, -1) / (m["valid_count"].astype(np.float32) + np.float32(1e-8))
+    gv[:, m["valid_count"] == 0] = 0
+    gfeat, gdens = oracle.backproject_weigh_bwd(feat, pts, proj, g["s3_est_depth"], g["s3_est_dens"], vz,
+                                                np.broadcast_to(gv, (N,) + gv.shape).copy())
+    np.testing.assert_allclose(gfeat, g["s3_grad_feature_mean"][:, :, :h, :w], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gdens, g["s3_grad_dens_mean"], rtol=1e-4, atol=1e-5)
+
+
+def test_end_to_end_chain(oracle):
+    """a1..a10 chained on the oracle alone, compared with the chained reference (G7)."""
+    g = load_golden("g7_end_to_end")
+    feat = g["feature"]
+    N, C = feat.shape[:2]
+    near, far = g["near_far"]
+    D = g["depth_values"].shape[1]
+    var = oracle.plane_sweep_variance(feat, g["neighbor_ids"], g["proj_rel"], g["depth_values"], 0)
+    np.testing.assert_allclose(var[:, :, :, ::6, ::8], g["variance_sample"], rtol=0, atol=1e-5)
+    logits = np.einsum("oc,ncdhw->nodhw", g["Wc"], var).astype(np.float32)
+    logits[:, 0] += np.linspace(0, 0.6, D, dtype=np.float32).reshape(1, D, 1, 1)
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-4)
+    # feed the reference's logits onward so stage 2/3 are compared on identical inputs
+    r = oracle.depth_prob_topk(g["logits"][:, 0], g["logits"][:, 1], near, (far - near) / D, 3)
+    h, w = g["img_shape"][0] // 4, g["img_shape"][1] // 4
+    srt = np.sort(g["prob"], axis=1)[:, ::-1]
+    clear = ((srt[:, :3] - srt[:, 1:4]).min(axis=1) > 1e-6)[:, :h, :w]  # pixels whose top-3 order is unambiguous
+    assert clear.mean() > 0.99
+    m3 = np.broadcast_to(clear[:, None], (N, 3, h, w))
+    np.testing.assert_allclose(r["est_depth"][:, :, :h, :w][m3], g["est_depth"][m3], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["est_dens"][:, :, :h, :w], g["est_dens"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(r["avg_depth"][:, :h, :w], g["depth_coding"][:, 0], rtol=0, atol=5e-6)
+    pts = oracle.get_points(g["n_voxels"], g["voxel_size"], g["origin"])
+    m = oracle.backproject_weigh_mean(feat[:, :, :h, :w], pts, g["projection"], g["est_depth"], g["est_dens"], g["voxel_size"][-1])
+    np.testing.assert_array_equal(m["valid_count"], g["valid_count"].reshape(-1))
+    np.testing.assert_array_equal(m["volume_mean"], g["volume_mean"].reshape(C, -1))
