@@ -162,3 +162,18 @@ def test_end_to_end_chain(oracle):
     m = oracle.backproject_weigh_mean(feat[:, :, :h, :w], pts, g["projection"], g["est_depth"], g["est_dens"], g["voxel_size"][-1])
     np.testing.assert_array_equal(m["valid_count"], g["valid_count"].reshape(-1))
     np.testing.assert_array_equal(m["volume_mean"], g["volume_mean"].reshape(C, -1))
+
+
+@pytest.mark.parametrize("tag", ["n3_d8", "n2_k1", "n6_d12_arkit"])
+def test_torch_restatement(tag):
+    """oracle/torch_restatement.py (the ATen-ops CPU baseline of bench.py) against the goldens."""
+    import torch
+    from oracle import torch_restatement as T
+    g = load_golden("g2_variance_" + tag)
+    cs = int(g["variance_channel_stride"])
+    var = T.plane_sweep_variance(torch.tensor(g["feature"]), torch.tensor(g["neighbor_ids"]), torch.tensor(g["proj_rel"]),
+                                 torch.tensor(g["depth_values"]), view_chunk=2).numpy()
+    np.testing.assert_allclose(var[:, ::cs], g["variance"], rtol=0, atol=1e-5)
+    g1 = load_golden("g1_homo_warping")
+    w = T.homo_warp(torch.tensor(g1["src_fea"]), torch.tensor(g1["proj_rel"]), torch.tensor(g1["depth_values"])).numpy()
+    np.testing.assert_allclose(w, g1["warped"], rtol=0, atol=1e-6)
