@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kThreads) void homo_warp_kernel(const float* __rest
 // Arithmetic (device rounding, oracle mode 1): warped = fma chain over the 4 taps; S = f + w1 + ..;
 // Q = fma(w,w,Q); var = fma(-m, m, Q*r) with m = S*r, r = 1/(K+1).
 // ---------------------------------------------------------------------------------------------
-template <int K, int TP>
+template <int K, int TP, bool NT>
 __global__ __launch_bounds__(kThreads) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
     const float* __restrict__ depth, float* __restrict__ var, int N, int C, int G, int D, int H, int W, int tiles,
@@ -160,8 +160,13 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_kernel(
                 for (int r = wave * RPI + rsub; r < rows; r += 4 * RPI) {
                     const int i = r / rg, gg = r - i * rg;
                     const int c = i * G + ci * 64 + gg;
-                    if (c < C && pvalid)
-                        var[(((size_t)n * C + c) * D + d) * HW + pix0 + pp] = s_tile[r * (TP + 1) + pp];
+                    if (c < C && pvalid) {
+                        float* dst = var + (((size_t)n * C + c) * D + d) * HW + pix0 + pp;
+                        // the cost volume is written once and not re-read by this kernel: a non-temporal store
+                        // keeps the output stream from evicting the source maps out of L2 / Infinity Cache
+                        if (NT) __builtin_nontemporal_store(s_tile[r * (TP + 1) + pp], dst);
+                        else *dst = s_tile[r * (TP + 1) + pp];
+                    }
                 }
             }
             __syncthreads();
@@ -214,7 +219,7 @@ extern "C" int mvsdet_homo_warp_f32(const float* src, const float* proj, const f
 namespace {
 int g_tile_pixels = 0;  // 0 = heuristic; set through MVSDET_SWEEP_TILE for tuning runs
 
-template <int TP>
+template <int TP, bool NT>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var, int N,
                  int K, int C, int D, int H, int W, hipStream_t stream) {
     const int G = (C + 3) / 4;
@@ -236,7 +241,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
 #define MVS_SWEEP_CASE(KV)                                                                                           \
     case KV:                                                                                                         \
-        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TP>), grid, dim3(kThreads), 0, stream, packed, nbr, proj, \
+        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TP, NT>), grid, dim3(kThreads), 0, stream, packed, nbr, proj, \
                            depth, var, N, C, G, D, H, W, tiles, d_per_block, lp_log2);                                \
         break;
     switch (K) {
@@ -262,13 +267,18 @@ extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "plane_sweep_variance: K=%d outside [0,%d]", K, MVSDET_MAX_NEIGHBORS);
     MVS_REQUIRE(D <= 65535, "plane_sweep_variance: D > 65535");
     MVS_REQUIRE((size_t)H * W * 4 * ((C + 3) / 4) < (size_t)INT32_MAX, "plane_sweep_variance: one view exceeds 2^31 elements");
-    if (g_tile_pixels == 0) {
+    {  // tuning knobs, read per call so A/B runs can flip them inside one process
         const char* e = getenv("MVSDET_SWEEP_TILE");
         g_tile_pixels = e ? atoi(e) : -1;
     }
-    const int tp = (g_tile_pixels == 32 || g_tile_pixels == 64) ? g_tile_pixels : 64;
-    if (tp == 32) return launch_sweep<32>(packed, nbr, proj, depth, var, N, K, C, D, H, W, (hipStream_t)stream);
-    return launch_sweep<64>(packed, nbr, proj, depth, var, N, K, C, D, H, W, (hipStream_t)stream);
+    const int tp = (g_tile_pixels == 32 || g_tile_pixels == 64) ? g_tile_pixels : 32;
+    const char* ent = getenv("MVSDET_SWEEP_NT");
+    const bool nt = ent ? atoi(ent) != 0 : true;
+    hipStream_t st = (hipStream_t)stream;
+    if (tp == 32) return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
+                            : launch_sweep<32, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
+    return nt ? launch_sweep<64, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
+              : launch_sweep<64, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,

@@ -39,9 +39,9 @@ class MVSDetHotPath:
     def __init__(self, n_voxels: Sequence[int], voxel_size: Sequence[float], near_far_range: Sequence[float],
                  num_monocular_samples: int, topk: int = 3,
                  cost_regularization: Optional[Callable[[Tensor], Tensor]] = None, stride: int = 4):
-        self.n_voxels = list(n_voxels)
-        self.voxel_size = list(voxel_size)
-        self.near_far_range = list(near_far_range)
+        self.n_voxels = [int(v) for v in n_voxels]
+        self.voxel_size = [float(v) for v in voxel_size]      # python floats -> torch.tensor(...) is fp32, as in the reference
+        self.near_far_range = [float(v) for v in near_far_range]
         self.num_depth = int(num_monocular_samples)
         self.topk = int(topk)
         self.stride = int(stride)

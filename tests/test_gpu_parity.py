@@ -275,7 +275,8 @@ def test_end_to_end_scene_vs_reference_chain(gpu, oracle):
     geo = out["geometry"]
     np.testing.assert_array_equal(geo.neighbor_ids.cpu().numpy(), g["neighbor_ids"])
     np.testing.assert_allclose(geo.proj_rel.cpu().numpy(), g["proj_rel"], rtol=1e-5, atol=1e-4)
-    np.testing.assert_array_equal(geo.projection.cpu().numpy(), g["projection"])
+    # host BLAS (3x3 @ 3x4) may round differently on this machine than on the golden-generating one
+    np.testing.assert_allclose(geo.projection.cpu().numpy(), g["projection"], rtol=2e-6, atol=1e-5)
     np.testing.assert_allclose(out["variance"].cpu().numpy()[:, :, :, ::6, ::8], g["variance_sample"], rtol=0, atol=TOL)
     np.testing.assert_allclose(out["prob_volume"].cpu().numpy(), g["prob"], rtol=0, atol=TOL)
     np.testing.assert_allclose(out["est_densities"].cpu().numpy(), g["est_dens"], rtol=0, atol=TOL)

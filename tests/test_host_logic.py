@@ -38,9 +38,10 @@ def test_collect_proj_and_relative_projection(tag):
     g = load_golden("g2_variance_" + tag)
     nbr = torch.tensor(g["neighbor_ids"])
     proj, nei = F_.collect_proj(torch.tensor(g["w2c"]), torch.tensor(g["K_feat"]), nbr)
-    np.testing.assert_array_equal(proj.numpy(), g["ref_proj"])
+    # matmul results: bit-identical on the golden-generating host, last-bit BLAS differences elsewhere
+    np.testing.assert_allclose(proj.numpy(), g["ref_proj"], rtol=2e-6, atol=1e-5)
     assert isinstance(nei, tuple) and len(nei) == nbr.shape[1]
-    np.testing.assert_array_equal(torch.stack(nei, 1).numpy(), g["nei_projs"])
+    np.testing.assert_allclose(torch.stack(nei, 1).numpy(), g["nei_projs"], rtol=2e-6, atol=1e-5)
     rel = torch.stack([F_.relative_projection(p, proj) for p in nei], 1)
     # same ATen-CPU ops as the reference; LAPACK builds may differ in the last bits between machines
     np.testing.assert_allclose(rel.numpy(), g["proj_rel"], rtol=1e-5, atol=1e-4)
@@ -51,7 +52,7 @@ def test_projection_and_points(tag):
     from mvsdet_amd import functional as F_
     g = load_golden("g5_backproject_" + tag)
     meta = meta_from(g)
-    np.testing.assert_array_equal(F_.compute_projection(meta, 4).numpy(), g["projection"])
+    np.testing.assert_allclose(F_.compute_projection(meta, 4).numpy(), g["projection"], rtol=2e-6, atol=1e-5)
     pts = F_.get_points(torch.tensor(g["n_voxels"]), torch.tensor(g["voxel_size"], dtype=torch.float32), torch.tensor(g["origin"]))
     assert pts.shape == (3, 40, 40, 16)
     np.testing.assert_array_equal(pts.numpy(), g["points"])
