@@ -46,8 +46,10 @@ const char* mvsdet_last_error(void);
  * Packed feature maps.
  * The sweep and the fused voxel lifting read 2-D features channel-last so that one bilinear tap /
  * one voxel sample is a single contiguous run of all channels.  Packed layout:
- *     packed[n][y][x][q],  q in [0, 4*G),  G = ceil(C/4),  q = 4*g + i  <->  channel c = i*G + g
- * (zero where c >= C).  mvsdet_packed_bytes() = N*H*W*4*G*sizeof(float).
+ *     packed[n][s][y][x][q],  s in [0, S), S = ceil(C/32) channel slabs,  q in [0, 32),
+ *     q = 4*g + i  <->  channel c = 32*s + 8*i + g      (g in [0,8), i in [0,4))
+ * (zero where c >= C): one texel of one slab is one 128-byte line, and every slab of a view is a
+ * contiguous H*W*128-byte image.  mvsdet_packed_bytes() = N*S*H*W*32*sizeof(float).
  * mvsdet_pack_features_f32 reads element (n,c,y,x) at feat[n*fs[0] + c*fs[1] + y*fs[2] + x*fs[3]],
  * so the reference's non-contiguous crop feature[:, :, :h, :w] (mvsdet.py:499) needs no copy.
  * ------------------------------------------------------------------------------------------- */

@@ -6,6 +6,7 @@
 // Roofline: HBM.  Per-view form writes N*C*V*4 B (mostly zeros); the fused mean writes C*V*4 B and reads
 // one packed feature column (C*4 B, contiguous) per valid (view, voxel) pair.
 #include "common.h"
+#include "pack.h"
 
 namespace mvsdet {
 
@@ -79,14 +80,16 @@ __global__ __launch_bounds__(kThreads) void backproject_mean_kernel(
     const int LP = 1 << lp_log2, PPI = 64 >> lp_log2;
     const int gl = lane & (LP - 1), ps = lane >> lp_log2;
     const int steps = PW / PPI;
-    const int G4 = 4 * G;
-    const size_t view_stride = (size_t)H * W * G4;
+    // packed layout (pack.h): [view][slab][pixel][32]; channel group gg = 8*slab + g
+    const size_t slab_stride = (size_t)H * W * kSlab;
+    const size_t view_stride = slab_stride * (size_t)(G / 8);
     const int chunks = (G + 63) / 64;
 
     for (int ci = 0; ci < chunks; ++ci) {
         const int rg = min(64, G - ci * 64);
         const bool gvalid = gl < rg;
-        const int g = ci * 64 + (gvalid ? gl : 0);
+        const int gg_ = ci * 64 + (gvalid ? gl : 0);
+        const size_t goff = (size_t)(gg_ >> 3) * slab_stride + 4 * (gg_ & 7);
         float acc[MAXSTEPS][4];
         int cnt[MAXSTEPS];
 #pragma unroll
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void backproject_mean_kernel(
                         ok = depth_window(depth + (int64_t)i * ds0, dens + (int64_t)i * ds0, ds1, ds2, ds3, J, yi, xi, z,
                                           vz, wgt, psum, arg);
                         if (ok) {
-                            s_off[il][p] = (yi * W + xi) * G4;
+                            s_off[il][p] = (yi * W + xi) * kSlab;
                             s_wt[il][p] = wgt;
                             atomicOr(&s_mask[p], 1ull << il);
                         }
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void backproject_mean_kernel(
                         m &= m - 1;
                         const float wt = s_wt[il][p];
                         const float4 f = *reinterpret_cast<const float4*>(packed + (size_t)(vc + il) * view_stride +
-                                                                          s_off[il][p] + 4 * g);
+                                                                          s_off[il][p] + goff);
                         // mvsdet.py:1459-1460 then :511  (feature * weight, then summed over views)
                         acc[s][0] = acc[s][0] + f.x * wt;
                         acc[s][1] = acc[s][1] + f.y * wt;
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(kThreads) void backproject_mean_kernel(
             const bool pvalid = v0 + pp < V;
             for (int r = wave * RPI + rsub; r < rows; r += 4 * RPI) {
                 const int i = r / rg, gg = r - i * rg;
-                const int c = i * G + ci * 64 + gg;
+                const int gq = ci * 64 + gg;
+                const int c = (gq >> 3) * kSlab + 8 * i + (gq & 7);
                 if (c < C && pvalid) mean[(size_t)c * V + v0 + pp] = s_tile[r * (TP + 1) + pp];
             }
         }
@@ -256,9 +260,9 @@ extern "C" int mvsdet_backproject_weigh_mean_packed_f32(const float* packed, con
     MVS_REQUIRE(packed && points && projection && depth && dens && ds && mean && count, "backproject_weigh_mean: NULL pointer");
     if (int rc = check_stage3("backproject_weigh_mean", N, C, h, w, V, J)) return rc;
     MVS_REQUIRE(h <= H && w <= W, "backproject_weigh_mean: crop %dx%d exceeds map %dx%d", h, w, H, W);
-    MVS_REQUIRE((size_t)H * W * 4 * ((C + 3) / 4) < (size_t)INT32_MAX, "backproject_weigh_mean: one view exceeds 2^31 elements");
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "backproject_weigh_mean: one slab image exceeds 2^31 elements");
     constexpr int TP = 32;
-    const int G = (C + 3) / 4;
+    const int G = 8 * num_slabs(C);  // channel groups of 4, slab padding included
     int lp_log2 = 0;
     while ((1 << lp_log2) < (G < 64 ? G : 64)) ++lp_log2;
     while ((64 >> lp_log2) > TP / 4) ++lp_log2;

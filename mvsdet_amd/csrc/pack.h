@@ -1,68 +1,79 @@
 // Channel-last "packed" feature layout (include/mvsdet_hip.h) <-> (N,C,H,W).
+//
+//   packed[n][s][pix][q]   s = channel slab (32 channels), pix = y*W + x, q in [0,32)
+//   q = 4*g + i  <->  channel c = 32*s + 8*i + g        (g in [0,8): lane of a texel, i in [0,4): float4 slot)
+//
+// One texel of one slab is 128 B = one cache line = 8 lanes x float4.  Slab-major order gives every slab
+// of a view a contiguous H*W*128-byte image: a slab's share of the source maps of one reference view
+// (K * H*W*128 B, 4.9 MB at 120x160, K=2) is what has to stay resident in ONE XCD's 4 MiB L2 while that
+// XCD sweeps its slab (planesweep.hip).  The i-major channel permutation makes the LDS transposes of the
+// sweep / lifting kernels bank-conflict free (lane g writes rows 8*i+g).
+//
 // Kernels are static: each translation unit that launches them carries its own copy (no -fgpu-rdc).
 #pragma once
 #include "common.h"
 
 namespace mvsdet {
 
-// ---------------------------------------------------------------------------------------------
-// pack: (N,C,H,W) strided -> packed[n][pix][4*g+i] = feat[n][i*G+g][pix]
-// One block = 64 pixels x 16 channel groups (64 channels).  Reads are coalesced along W, writes are
-// 256-byte runs along the packed channel axis.
-// ---------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(kThreads) void pack_features_kernel(const float* __restrict__ feat, int64_t s0, int64_t s1,
-                                                                  int64_t s2, int64_t s3, float* __restrict__ packed,
-                                                                  int C, int G, int H, int W) {
-    __shared__ float tile[64][65];
+constexpr int kSlab = 32;  // channels per slab
+
+__host__ __device__ __forceinline__ int num_slabs(int C) { return (C + kSlab - 1) / kSlab; }
+
+// One block = 64 pixels x one slab.  Reads are coalesced along W (256 B per channel row), writes are
+// 128-byte texels, 8 KiB contiguous per block.
+static __global__ __launch_bounds__(kThreads) void pack_features_kernel(const float* __restrict__ feat, int64_t s0,
+                                                                         int64_t s1, int64_t s2, int64_t s3,
+                                                                         float* __restrict__ packed, int C, int S,
+                                                                         int H, int W) {
+    __shared__ float tile[kSlab][65];
     const int HW = H * W;
-    const int pix0 = blockIdx.x * 64, g0 = blockIdx.y * 16, n = blockIdx.z;
+    const int pix0 = blockIdx.x * 64, s = blockIdx.y, n = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         const int pix = pix0 + lane;
         const int y = pix / W, x = pix - y * W;
         const float* src = feat + (int64_t)n * s0 + (int64_t)y * s2 + (int64_t)x * s3;
-        for (int r = wave; r < 64; r += 4) {
-            const int g = g0 + (r & 15), c = (r >> 4) * G + g;
+        for (int r = wave; r < kSlab; r += 4) {
+            const int c = s * kSlab + r;
             float v = 0.0f;
-            if (pix < HW && g < G && c < C) v = src[(int64_t)c * s1];
+            if (pix < HW && c < C) v = src[(int64_t)c * s1];
             tile[r][lane] = v;
         }
     }
     __syncthreads();
-    const int gg = threadIdx.x & 15;
-    for (int p = threadIdx.x >> 4; p < 64; p += 16) {
+    const int g = threadIdx.x & 7;
+    for (int p = threadIdx.x >> 3; p < 64; p += 32) {
         const int pix = pix0 + p;
-        if (pix < HW && g0 + gg < G) {
-            float4 v = make_float4(tile[gg][p], tile[16 + gg][p], tile[32 + gg][p], tile[48 + gg][p]);
-            *reinterpret_cast<float4*>(packed + ((size_t)n * HW + pix) * (size_t)(4 * G) + 4 * (g0 + gg)) = v;
+        if (pix < HW) {
+            const float4 v = make_float4(tile[g][p], tile[8 + g][p], tile[16 + g][p], tile[24 + g][p]);
+            *reinterpret_cast<float4*>(packed + (((size_t)n * S + s) * HW + pix) * kSlab + 4 * g) = v;
         }
     }
 }
 
-// unpack-add: gfeat[n][c][pix] = gpacked[n][pix][4g+i]  (used by the backward pass)
+// unpack: feat[n][c][pix] = packed[n][s][pix][4g+i]  (dense NCHW output; used by the backward pass)
 static __global__ __launch_bounds__(kThreads) void unpack_features_kernel(const float* __restrict__ packed,
-                                                                    float* __restrict__ feat, int C, int G, int H,
-                                                                    int W) {
-    __shared__ float tile[64][65];
+                                                                           float* __restrict__ feat, int C, int S, int H,
+                                                                           int W) {
+    __shared__ float tile[kSlab][65];
     const int HW = H * W;
-    const int pix0 = blockIdx.x * 64, g0 = blockIdx.y * 16, n = blockIdx.z;
+    const int pix0 = blockIdx.x * 64, s = blockIdx.y, n = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gg = threadIdx.x & 15;
-    for (int p = threadIdx.x >> 4; p < 64; p += 16) {
+    const int g = threadIdx.x & 7;
+    for (int p = threadIdx.x >> 3; p < 64; p += 32) {
         const int pix = pix0 + p;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pix < HW && g0 + gg < G)
-            v = *reinterpret_cast<const float4*>(packed + ((size_t)n * HW + pix) * (size_t)(4 * G) + 4 * (g0 + gg));
-        tile[gg][p] = v.x;
-        tile[16 + gg][p] = v.y;
-        tile[32 + gg][p] = v.z;
-        tile[48 + gg][p] = v.w;
+        if (pix < HW) v = *reinterpret_cast<const float4*>(packed + (((size_t)n * S + s) * HW + pix) * kSlab + 4 * g);
+        tile[g][p] = v.x;
+        tile[8 + g][p] = v.y;
+        tile[16 + g][p] = v.z;
+        tile[24 + g][p] = v.w;
     }
     __syncthreads();
     const int pix = pix0 + lane;
-    for (int r = wave; r < 64; r += 4) {
-        const int g = g0 + (r & 15), c = (r >> 4) * G + g;
-        if (pix < HW && g < G && c < C) feat[((size_t)n * C + c) * HW + pix] = tile[r][lane];
+    for (int r = wave; r < kSlab; r += 4) {
+        const int c = s * kSlab + r;
+        if (pix < HW && c < C) feat[((size_t)n * C + c) * HW + pix] = tile[r][lane];
     }
 }
 

@@ -2,15 +2,28 @@
 // plane-sweep variance cost volume (a3+a4).  Reference: mvs_models/module.py:105-146 and
 // mvsdet.py:439-467 of Pixie8888/MVSDet (projects/NeRF-Det/nerfdet/).
 //
-// Roofline: HBM.  Per cost volume the kernel must write C*D*H*W*4 B and read (K+1)*C*H*W*4 B; there
-// is no dense contraction, so MFMA does not apply.  The design problem is the gather:
-// 4*K bilinear taps per output element.  Reading them from NCHW planes costs one uncoalesced dword
-// load per tap per channel; instead the maps are re-laid channel-last ("packed", include/mvsdet_hip.h)
-// so that ONE 16-byte-per-lane wave load fetches a tap for 256 channels as a contiguous 1 KiB run,
-// and the results are transposed through LDS so the (N,C,D,H,W) output is still written as full
-// 256-byte rows along W.
+// Roofline: HBM.  Per cost volume the kernel must write C*D*H*W*4 B and read (K+1)*C*H*W*4 B; there is
+// no dense contraction, so MFMA does not apply.  The design problem is the gather: 4*K
+// bilinear taps per output element, i.e. 8x more bytes through the load path than are written.
+//
+// v1 of this kernel (git history; profiles/r01_v1_*) gathered the taps straight from a channel-last copy
+// of the maps with every block covering all 256 channels.  rocprofv3 showed it saturating the fabric
+// (2*FETCH_SIZE + WRITE_SIZE = 183 GB for 52.7 GB algorithmic, 6.3 TB/s) at a 43 % L2 hit rate: the 64
+// blocks resident on an XCD touched ~8 MB of source rows at once, twice its L2.  This version
+//   (1) splits the channels into 32-channel slabs and deals slab s to XCD s (8 slabs = 8 XCDs at C=256),
+//       so an XCD only ever reads ONE 128-byte slab of each source texel and its live working set
+//       (2 source images x 128 B/texel x the rows in flight) fits its 4 MiB L2;
+//   (2) uses 2-D pixel tiles (32x4 / 16x8) and stages the bounding box of a tile's sampling footprint in
+//       LDS with fully coalesced row reads, so each source texel is fetched once per (tile, plane) instead
+//       of once per tap (about 1.3-2 texels per output pixel and neighbour instead of 4), and the taps
+//       become ds_read_b128;
+//   (3) keeps the LDS transpose so the (N,C,D,H,W) output is written as whole 128-byte rows, with
+//       non-temporal stores so the write-once stream does not evict the source images.
+// A footprint that does not fit the LDS box (extreme roll / scale, or planes behind the camera) falls back
+// to direct global gathers for that (tile, plane, neighbour) -- same arithmetic, same result.
 #include "common.h"
 #include "pack.h"
+#include "sweep_kernel.h"
 
 namespace mvsdet {
 
@@ -44,162 +57,25 @@ __global__ __launch_bounds__(kThreads) void homo_warp_kernel(const float* __rest
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// a3+a4 fused: plane-sweep variance.
-//
-// Work decomposition
-//   block  = (reference view n, tile of TP consecutive pixels of the flattened H*W plane, depth chunk)
-//            -- out[n,c,d,:,:] is contiguous over (h,w), so a tile is one contiguous run per (c,d)
-//   per depth plane:
-//     phase 1  K*TP threads build the tap table (4 offsets + 4 weights per pixel and neighbour) in LDS
-//     phase 2  each wave walks its TP/4 pixels; lane = (pixel slot, channel group g): 1 + 4K
-//              16-byte loads per pixel and lane, each wave-instruction reading contiguous runs of
-//              4*LP floats of the packed maps; variance for 4 channels -> LDS tile [channel][pixel]
-//     phase 3  LDS rows -> global: one 4*TP-byte contiguous run per (channel, plane)
-//   LP (lanes per pixel) = min(64, pow2ceil(G)), so C=256 -> one pixel per wave-instruction.
-//
-// Arithmetic (device rounding, oracle mode 1): warped = fma chain over the 4 taps; S = f + w1 + ..;
-// Q = fma(w,w,Q); var = fma(-m, m, Q*r) with m = S*r, r = 1/(K+1).
-// ---------------------------------------------------------------------------------------------
-template <int K, int TP, bool NT>
-__global__ __launch_bounds__(kThreads) void plane_sweep_variance_kernel(
-    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
-    const float* __restrict__ depth, float* __restrict__ var, int N, int C, int G, int D, int H, int W, int tiles,
-    int d_per_block, int lp_log2) {
-    constexpr int KK = K > 0 ? K : 1;
-    constexpr int PW = TP / 4;  // pixels per wave
-    __shared__ float s_tile[256 * (TP + 1)];
-    __shared__ int4 s_off[KK][TP];
-    __shared__ float4 s_w[KK][TP];
-
-    const int HW = H * W;
-    const int L = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int n = L / tiles, tile = L - n * tiles;
-    const int pix0 = tile * TP;
-    const int d_begin = blockIdx.y * d_per_block;
-    const int d_end = min(D, d_begin + d_per_block);
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int LP = 1 << lp_log2, PPI = 64 >> lp_log2;
-    const int gl = lane & (LP - 1), ps = lane >> lp_log2;
-    const int G4 = 4 * G;
-    const size_t view_stride = (size_t)HW * G4;
-    const float* ref_base = packed + (size_t)n * view_stride;
-    const float* nb_base[KK];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        int64_t v = nbr[(size_t)n * K + j];
-        v = v < 0 ? 0 : (v >= N ? N - 1 : v);  // never read outside the packed maps
-        nb_base[j] = packed + (size_t)v * view_stride;
-    }
-    const float rcp = 1.0f / (float)(K + 1);
-    const int chunks = (G + 63) / 64;
-
-    for (int d = d_begin; d < d_end; ++d) {
-        // ---- phase 1: tap table
-        if (K > 0) {
-            const float dval = depth[(size_t)n * D + d];
-            for (int idx = threadIdx.x; idx < K * TP; idx += kThreads) {
-                const int j = idx / TP, p = idx - j * TP;
-                const int pix = pix0 + p;
-                int4 o = make_int4(0, 0, 0, 0);
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pix < HW) {
-                    const int y = pix / W, x = pix - y * W;
-                    compute_taps(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W, G4, o, w);
-                }
-                s_off[j][p] = o;
-                s_w[j][p] = w;
-            }
-        }
-        __syncthreads();
-        for (int ci = 0; ci < chunks; ++ci) {
-            const int rg = min(64, G - ci * 64);  // channel groups in this chunk
-            const bool gvalid = gl < rg;
-            const int g = ci * 64 + (gvalid ? gl : 0);
-            // ---- phase 2: gather + variance -> LDS tile
-#pragma unroll 2
-            for (int s = 0; s < PW / PPI; ++s) {
-                const int p = wave * PW + s * PPI + ps;
-                const int pix = min(pix0 + p, HW - 1);
-                const float4 f = *reinterpret_cast<const float4*>(ref_base + (size_t)pix * G4 + 4 * g);
-                float S0 = f.x, S1 = f.y, S2 = f.z, S3 = f.w;
-                float Q0 = f.x * f.x, Q1 = f.y * f.y, Q2 = f.z * f.z, Q3 = f.w * f.w;
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int4 o = s_off[j][p];
-                    const float4 w = s_w[j][p];
-                    const float* b = nb_base[j] + 4 * g;
-                    const float4 t0 = *reinterpret_cast<const float4*>(b + o.x);
-                    const float4 t1 = *reinterpret_cast<const float4*>(b + o.y);
-                    const float4 t2 = *reinterpret_cast<const float4*>(b + o.z);
-                    const float4 t3 = *reinterpret_cast<const float4*>(b + o.w);
-                    float v0 = t0.x * w.x, v1 = t0.y * w.x, v2 = t0.z * w.x, v3 = t0.w * w.x;
-                    v0 = fmaf(t1.x, w.y, v0); v1 = fmaf(t1.y, w.y, v1); v2 = fmaf(t1.z, w.y, v2); v3 = fmaf(t1.w, w.y, v3);
-                    v0 = fmaf(t2.x, w.z, v0); v1 = fmaf(t2.y, w.z, v1); v2 = fmaf(t2.z, w.z, v2); v3 = fmaf(t2.w, w.z, v3);
-                    v0 = fmaf(t3.x, w.w, v0); v1 = fmaf(t3.y, w.w, v1); v2 = fmaf(t3.z, w.w, v2); v3 = fmaf(t3.w, w.w, v3);
-                    S0 = S0 + v0; S1 = S1 + v1; S2 = S2 + v2; S3 = S3 + v3;
-                    Q0 = fmaf(v0, v0, Q0); Q1 = fmaf(v1, v1, Q1); Q2 = fmaf(v2, v2, Q2); Q3 = fmaf(v3, v3, Q3);
-                }
-                const float m0 = S0 * rcp, m1 = S1 * rcp, m2 = S2 * rcp, m3 = S3 * rcp;
-                if (gvalid) {
-                    float* t = s_tile + gl * (TP + 1) + p;
-                    t[0] = fmaf(-m0, m0, Q0 * rcp);
-                    t[rg * (TP + 1)] = fmaf(-m1, m1, Q1 * rcp);
-                    t[2 * rg * (TP + 1)] = fmaf(-m2, m2, Q2 * rcp);
-                    t[3 * rg * (TP + 1)] = fmaf(-m3, m3, Q3 * rcp);
-                }
-            }
-            __syncthreads();
-            // ---- phase 3: rows of the tile -> (N,C,D,H,W)
-            {
-                constexpr int RPI = 64 / TP;  // rows per wave-instruction
-                const int pp = lane % TP, rsub = lane / TP;
-                const int rows = 4 * rg;
-                const bool pvalid = pix0 + pp < HW;
-                for (int r = wave * RPI + rsub; r < rows; r += 4 * RPI) {
-                    const int i = r / rg, gg = r - i * rg;
-                    const int c = i * G + ci * 64 + gg;
-                    if (c < C && pvalid) {
-                        float* dst = var + (((size_t)n * C + c) * D + d) * HW + pix0 + pp;
-                        // the cost volume is written once and not re-read by this kernel: a non-temporal store
-                        // keeps the output stream from evicting the source maps out of L2 / Infinity Cache
-                        if (NT) __builtin_nontemporal_store(s_tile[r * (TP + 1) + pp], dst);
-                        else *dst = s_tile[r * (TP + 1) + pp];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 }  // namespace mvsdet
 
 using namespace mvsdet;
 
-static int pow2ceil_log2(int v) {
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
-}
-
 extern "C" size_t mvsdet_packed_bytes(int N, int C, int H, int W) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t G = (size_t)(C + 3) / 4;
-    return (size_t)N * H * W * 4 * G * sizeof(float);
+    return (size_t)N * num_slabs(C) * H * W * kSlab * sizeof(float);
 }
 
 extern "C" int mvsdet_pack_features_f32(const float* feat, const int64_t* fs, float* packed, int N, int C, int H, int W,
                                         mvsdet_stream_t stream) {
     MVS_REQUIRE(feat && fs && packed, "pack_features: NULL pointer");
     MVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "pack_features: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
-    MVS_REQUIRE((size_t)H * W * 4 * ((C + 3) / 4) < (size_t)INT32_MAX, "pack_features: one view exceeds 2^31 elements");
-    MVS_REQUIRE(N <= 65535, "pack_features: N > 65535");
-    const int G = (C + 3) / 4;
-    dim3 grid((H * W + 63) / 64, (G + 15) / 16, N);
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "pack_features: one slab image exceeds 2^31 elements");
+    MVS_REQUIRE(N <= 65535 && num_slabs(C) <= 65535, "pack_features: N or C too large");
+    const int S = num_slabs(C);
+    dim3 grid((H * W + 63) / 64, S, N);
     hipLaunchKernelGGL(pack_features_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, feat, fs[0], fs[1], fs[2],
-                       fs[3], packed, C, G, H, W);
+                       fs[3], packed, C, S, H, W);
     MVS_LAUNCH_CHECK("pack_features");
     return MVSDET_OK;
 }
@@ -217,32 +93,28 @@ extern "C" int mvsdet_homo_warp_f32(const float* src, const float* proj, const f
 }
 
 namespace {
-int g_tile_pixels = 0;  // 0 = heuristic; set through MVSDET_SWEEP_TILE for tuning runs
-
-template <int TP, bool NT>
+template <int TW, bool NT>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var, int N,
                  int K, int C, int D, int H, int W, hipStream_t stream) {
-    const int G = (C + 3) / 4;
-    const int HW = H * W;
-    const int tiles = (HW + TP - 1) / TP;
-    int lp_log2 = pow2ceil_log2(G < 64 ? G : 64);
-    // a wave must own at least one whole pixel step: PPI = 64/LP <= TP/4
-    while ((64 >> lp_log2) > TP / 4) ++lp_log2;
-    const long long nblocks = (long long)N * tiles;
+    constexpr int TH = kTilePix / TW;
+    const int S = num_slabs(C);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y;
+    const long long nblocks = (long long)N * tiles * S;
     if (nblocks > INT32_MAX) {
         set_error("plane_sweep_variance: grid too large");
         return MVSDET_ERR_INVALID_ARG;
     }
-    // every block sweeps all its planes (taps of neighbouring planes overlap -> L1/L2 reuse) unless the
-    // grid would be too small to fill 256 CUs
+    // every block sweeps all its planes (reference features stay in registers, neighbouring planes reuse
+    // source rows) unless the grid would be too small to fill 256 CUs
     int dsplit = 1;
     while (nblocks * dsplit < 2048 && dsplit < D) dsplit *= 2;
     const int d_per_block = (D + dsplit - 1) / dsplit;
     dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
 #define MVS_SWEEP_CASE(KV)                                                                                           \
     case KV:                                                                                                         \
-        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TP, NT>), grid, dim3(kThreads), 0, stream, packed, nbr, proj, \
-                           depth, var, N, C, G, D, H, W, tiles, d_per_block, lp_log2);                                \
+        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT>), grid, dim3(kThreads), 0, stream, packed, nbr,   \
+                           proj, depth, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block);                          \
         break;
     switch (K) {
         MVS_SWEEP_CASE(0)
@@ -266,19 +138,18 @@ extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const
                 C, D, H, W);
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "plane_sweep_variance: K=%d outside [0,%d]", K, MVSDET_MAX_NEIGHBORS);
     MVS_REQUIRE(D <= 65535, "plane_sweep_variance: D > 65535");
-    MVS_REQUIRE((size_t)H * W * 4 * ((C + 3) / 4) < (size_t)INT32_MAX, "plane_sweep_variance: one view exceeds 2^31 elements");
-    {  // tuning knobs, read per call so A/B runs can flip them inside one process
-        const char* e = getenv("MVSDET_SWEEP_TILE");
-        g_tile_pixels = e ? atoi(e) : -1;
-    }
-    const int tp = (g_tile_pixels == 32 || g_tile_pixels == 64) ? g_tile_pixels : 32;
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "plane_sweep_variance: one slab image exceeds 2^31 elements");
+    // tuning knobs, read per call so A/B runs can flip them inside one process
+    const char* e = getenv("MVSDET_SWEEP_TW");
+    int tw = e ? atoi(e) : 0;
+    if (tw != 16 && tw != 32) tw = (W % 32 == 0 || W % 16 != 0) ? 32 : 16;
     const char* ent = getenv("MVSDET_SWEEP_NT");
     const bool nt = ent ? atoi(ent) != 0 : true;
     hipStream_t st = (hipStream_t)stream;
-    if (tp == 32) return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
-                            : launch_sweep<32, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
-    return nt ? launch_sweep<64, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
-              : launch_sweep<64, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
+    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
+                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
+    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
+              : launch_sweep<32, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,

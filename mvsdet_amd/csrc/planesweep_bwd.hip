@@ -33,8 +33,9 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_bwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int LP = 1 << lp_log2, PPI = 64 >> lp_log2;
     const int gl = lane & (LP - 1), ps = lane >> lp_log2;
-    const int G4 = 4 * G;
-    const size_t view_stride = (size_t)HW * G4;
+    // packed layout (pack.h): [view][slab][pixel][32]; channel group gg = 8*slab + g, G = 8*S groups
+    const size_t slab_stride = (size_t)HW * kSlab;
+    const size_t view_stride = slab_stride * (size_t)(G / 8);
     const float* ref_base = packed + (size_t)n * view_stride;
     size_t nb_view[KK];
 #pragma unroll
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_bwd_kernel(
     for (int ci = 0; ci < chunks; ++ci) {
         const int rg = min(64, G - ci * 64);
         const bool gvalid = gl < rg;
-        const int g = ci * 64 + (gvalid ? gl : 0);
+        const int gq_ = ci * 64 + (gvalid ? gl : 0);
+        const size_t goff = (size_t)(gq_ >> 3) * slab_stride + 4 * (gq_ & 7);  // slab image + lane slot
         for (int d = 0; d < D; ++d) {
             // tap table + gradient tile [channel row][pixel]
             if (K > 0) {
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_bwd_kernel(
                     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (pix < HW) {
                         const int y = pix / W, x = pix - y * W;
-                        compute_taps(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W, G4, o, w);
+                        compute_taps(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W, kSlab, o, w);
                     }
                     s_off[j][p] = o;
                     s_w[j][p] = w;
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_bwd_kernel(
                 const bool pvalid = pix0 + pp < HW;
                 for (int rr = wave * RPI + rsub; rr < rows; rr += 4 * RPI) {
                     const int i = rr / rg, gg = rr - i * rg;
-                    const int c = i * G + ci * 64 + gg;
+                    const int gq = ci * 64 + gg;
+                    const int c = (gq >> 3) * kSlab + 8 * i + (gq & 7);
                     float v = 0.0f;
                     if (c < C && pvalid) v = gvar[(((size_t)n * C + c) * D + d) * HW + pix0 + pp];
                     s_tile[rr * (TP + 1) + pp] = v;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_bwd_kernel(
                 const int p = wave * PW + s * PPI + ps;
                 const bool live = gvalid && (pix0 + p < HW);
                 const int pix = min(pix0 + p, HW - 1);
-                const float4 f = *reinterpret_cast<const float4*>(ref_base + (size_t)pix * G4 + 4 * g);
+                const float4 f = *reinterpret_cast<const float4*>(ref_base + (size_t)pix * kSlab + goff);
                 const float* t = s_tile + gl * (TP + 1) + p;
                 float go[4] = {0.f, 0.f, 0.f, 0.f};
                 if (gvalid) {
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_bwd_kernel(
                 for (int j = 0; j < K; ++j) {
                     const int4 o = s_off[j][p];
                     const float4 w = s_w[j][p];
-                    const float* b = packed + nb_view[j] + 4 * g;
+                    const float* b = packed + nb_view[j] + goff;
                     const float4 t0 = *reinterpret_cast<const float4*>(b + o.x);
                     const float4 t1 = *reinterpret_cast<const float4*>(b + o.y);
                     const float4 t2 = *reinterpret_cast<const float4*>(b + o.z);
@@ -120,14 +123,14 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_variance_bwd_kernel(
                     }
                 }
                 if (live) {
-                    float* gref = gpacked + (size_t)n * view_stride + (size_t)pix * G4 + 4 * g;
+                    float* gref = gpacked + (size_t)n * view_stride + (size_t)pix * kSlab + goff;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) atomicAdd(gref + i, go[i] * (two_r * fv[i] - two_r2 * S[i]));
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
                         const int4 o = s_off[j][p];
                         const float4 w = s_w[j][p];
-                        float* gb = gpacked + nb_view[j] + 4 * g;
+                        float* gb = gpacked + nb_view[j] + goff;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float gw = go[i] * (two_r * wv[j][i] - two_r2 * S[i]);
@@ -158,7 +161,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     MVS_REQUIRE(K == 0 || (nbr && proj), "plane_sweep_variance_bwd: NULL neighbour arrays with K=%d", K);
     MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "plane_sweep_variance_bwd: bad shape");
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "plane_sweep_variance_bwd: K=%d outside [0,%d]", K, MVSDET_MAX_NEIGHBORS);
-    MVS_REQUIRE((size_t)H * W * 4 * ((C + 3) / 4) < (size_t)INT32_MAX, "plane_sweep_variance_bwd: one view exceeds 2^31 elements");
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "plane_sweep_variance_bwd: one slab image exceeds 2^31 elements");
     const size_t pb = mvsdet_packed_bytes(N, C, H, W);
     if (workspace_bytes < 2 * pb) {
         set_error("plane_sweep_variance_bwd: workspace %zu B < %zu B", workspace_bytes, 2 * pb);
@@ -173,7 +176,8 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
         return MVSDET_ERR_HIP;
     }
     constexpr int TP = 32;
-    const int G = (C + 3) / 4;
+    const int S = num_slabs(C);
+    const int G = 8 * S;  // channel groups of 4, slab padding included
     const int HW = H * W;
     const int tiles = (HW + TP - 1) / TP;
     int lp_log2 = 0;
@@ -196,8 +200,8 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     }
 #undef MVS_BWD_CASE
     MVS_LAUNCH_CHECK("plane_sweep_variance_bwd");
-    dim3 ugrid((HW + 63) / 64, (G + 15) / 16, N);
-    hipLaunchKernelGGL(unpack_features_kernel, ugrid, dim3(kThreads), 0, stream, gpacked, gfeat, C, G, H, W);
+    dim3 ugrid((HW + 63) / 64, S, N);
+    hipLaunchKernelGGL(unpack_features_kernel, ugrid, dim3(kThreads), 0, stream, gpacked, gfeat, C, S, H, W);
     MVS_LAUNCH_CHECK("unpack_features");
     return MVSDET_OK;
 }

@@ -47,7 +47,7 @@ def pack_features(feat: Tensor) -> Tensor:
 @pack_features.register_fake
 def _(feat):
     N, C, H, W = feat.shape
-    return feat.new_empty(N * H * W * 4 * ((C + 3) // 4))
+    return feat.new_empty(N * H * W * 32 * ((C + 31) // 32))
 
 
 # ------------------------------------------------------------------------------------------- a3

@@ -15,8 +15,8 @@ from mvsdet_amd.hotpath import MVSDetHotPath  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "scannet_40v_64d_120x160"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 VARIANTS = [dict(x.split("=") for x in v.split(",")) for v in os.environ.get(
-    "AB_VARIANTS", "MVSDET_SWEEP_TILE=32,MVSDET_SWEEP_NT=1;MVSDET_SWEEP_TILE=32,MVSDET_SWEEP_NT=0;"
-                   "MVSDET_SWEEP_TILE=64,MVSDET_SWEEP_NT=1;MVSDET_SWEEP_TILE=64,MVSDET_SWEEP_NT=0").split(";")]
+    "AB_VARIANTS", "MVSDET_SWEEP_TW=32,MVSDET_SWEEP_NT=1;MVSDET_SWEEP_TW=32,MVSDET_SWEEP_NT=0;"
+                   "MVSDET_SWEEP_TW=16,MVSDET_SWEEP_NT=1;MVSDET_SWEEP_TW=16,MVSDET_SWEEP_NT=0").split(";")]
 w = bench.WORKLOADS[name]
 dev = torch.device("cuda:0")
 hp = MVSDetHotPath(bench.N_VOXELS, bench.VOXEL_SIZE, list(w["near_far"]), w["D"])
