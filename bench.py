@@ -58,8 +58,7 @@ class SceneInputs:
 
 
 def run_gpu(args, w, rank, world, device):
-    import torch.distributed as dist
-    from mvsdet_amd import ops
+    from mvsdet_amd import ops, parallel
     from mvsdet_amd.hotpath import MVSDetHotPath
 
     hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3)
@@ -83,9 +82,7 @@ def run_gpu(args, w, rank, world, device):
         vol, valid = hp.lift(feat, packed, geo, est_depth, est_dens)
         return var, vol, valid
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = parallel.barrier if world > 1 else (lambda: None)
 
     for i in range(args.warmup):
         out = step(i, False)
@@ -102,9 +99,7 @@ def run_gpu(args, w, rank, world, device):
     del out
     sweep_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = parallel.max_over_ranks(elapsed, device)
     return elapsed, sweep_ms, checksum, hp, scenes
 
 
@@ -218,9 +213,8 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from mvsdet_amd import parallel
+        parallel.init_distributed("nccl", device)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -246,7 +240,7 @@ def main():
         "scenes_per_sec": round(args.steps * world / elapsed, 4),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "plane_sweep_variance_kernel<2,TP>", "kernel_ms": round(sweep_ms, 4),
+                     "kernel": "plane_sweep_variance_kernel<2,TW,NT>", "kernel_ms": round(sweep_ms, 4),
                      "algorithmic_bytes_per_launch": bytes_launch},
         "checksum": checksum,
     }
