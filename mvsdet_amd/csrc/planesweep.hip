@@ -93,7 +93,7 @@ extern "C" int mvsdet_homo_warp_f32(const float* src, const float* proj, const f
 }
 
 namespace {
-template <int TW, bool NT>
+template <int TW, bool NT, bool DMA>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var, int N,
                  int K, int C, int D, int H, int W, hipStream_t stream) {
     constexpr int TH = kTilePix / TW;
@@ -113,7 +113,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
 #define MVS_SWEEP_CASE(KV)                                                                                           \
     case KV:                                                                                                         \
-        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT>), grid, dim3(kThreads), 0, stream, packed, nbr,   \
+        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, DMA>), grid, dim3(kThreads), 0, stream, packed, nbr,   \
                            proj, depth, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block);                          \
         break;
     switch (K) {
@@ -145,11 +145,18 @@ extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const
     if (tw != 16 && tw != 32) tw = (W % 32 == 0 || W % 16 != 0) ? 32 : 16;
     const char* ent = getenv("MVSDET_SWEEP_NT");
     const bool nt = ent ? atoi(ent) != 0 : true;
+    const char* edma = getenv("MVSDET_SWEEP_DMA");
+    const bool dma = edma ? atoi(edma) != 0 : true;
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
-                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
-    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
-              : launch_sweep<32, false>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st);
+#define MVS_GO(TWV, NTV, DMAV) return launch_sweep<TWV, NTV, DMAV>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
+    if (tw == 16) {
+        if (nt) { if (dma) MVS_GO(16, true, true); else MVS_GO(16, true, false); }
+        else    { if (dma) MVS_GO(16, false, true); else MVS_GO(16, false, false); }
+    }
+    if (nt) { if (dma) MVS_GO(32, true, true); else MVS_GO(32, true, false); }
+    if (dma) MVS_GO(32, false, true);
+    MVS_GO(32, false, false);
+#undef MVS_GO
 }
 
 extern "C" int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,

@@ -53,7 +53,7 @@ __device__ __forceinline__ int wave_reduce(int v) {
     return kMin ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d));
 }
 
-template <int K, int TW, bool NT>
+template <int K, int TW, bool NT, bool DMA>
 __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
     const float* __restrict__ depth, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
@@ -201,7 +201,18 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
                 for (int row = wave; row < nr[j]; row += 4) {
                     const float4* src = nb_img[j] + ((size_t)(by0[j] + row) * W + bx0[j]) * 8;  // wave-uniform
                     float4* dst = s_box + row * row_f4;
-                    for (int q = lane; q < row_f4; q += 64) dst[q] = src[q];
+                    if (DMA) {
+                        // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs; the LDS
+                        // address is the wave-uniform base + 16*lane, the global address is per lane.  The DMA counts
+                        // on vmcnt, which the __syncthreads() below drains.
+                        for (int q0 = 0; q0 < row_f4; q0 += 64)
+                            if (q0 + lane < row_f4)
+                                __builtin_amdgcn_global_load_lds(
+                                    (const __attribute__((address_space(1))) void*)(src + q0 + lane),
+                                    (__attribute__((address_space(3))) void*)(dst + q0), 16, 0, 0);
+                    } else {
+                        for (int q = lane; q < row_f4; q += 64) dst[q] = src[q];
+                    }
                 }
             }
             __syncthreads();  // box (and, for the first neighbour, the tap offsets) visible
