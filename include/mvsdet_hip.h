@@ -75,12 +75,18 @@ int mvsdet_homo_warp_f32(const float* src, const float* proj, const float* depth
  *   packed (see above) features of all N views; nbr (N,K) int64 neighbour view ids (mvsdet.py:434);
  *   proj (N,K,4,4) = nei_proj[n][j] @ inverse(ref_proj[n]);  depth (N,D);
  *   var (N,C,D,H,W) = sum_sq/(K+1) - (sum/(K+1))^2 over {ref, warped_1..K}  (mvsdet.py:467).
+ * `scratch` (16-byte aligned, >= mvsdet_plane_sweep_scratch_bytes(N,K,D,H,W)) receives the
+ * channel-independent sampling table the sweep builds first: 16 B per (view, neighbour, plane,
+ * pixel), about 3 % of the cost volume.
  * The _f32 form packs `feat` (N,C,H,W dense) into `workspace` first
- * (workspace_bytes >= mvsdet_packed_bytes(N,C,H,W)).
+ * (workspace_bytes >= mvsdet_plane_sweep_workspace_bytes(N,K,C,D,H,W) = packed + scratch).
  * ------------------------------------------------------------------------------------------- */
+size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W);
+size_t mvsdet_plane_sweep_workspace_bytes(int N, int K, int C, int D, int H, int W);
 int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
-                                           const float* depth, float* var, int N, int K, int C, int D,
-                                           int H, int W, mvsdet_stream_t stream);
+                                           const float* depth, float* var, void* scratch,
+                                           size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
+                                           mvsdet_stream_t stream);
 int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,
                                     const float* depth, float* var, void* workspace, size_t workspace_bytes,
                                     int N, int K, int C, int D, int H, int W, mvsdet_stream_t stream);

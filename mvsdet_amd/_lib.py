@@ -26,7 +26,9 @@ SIGNATURES = {
     "mvsdet_packed_bytes": [_i, _i, _i, _i],
     "mvsdet_pack_features_f32": [_vp, _i64p, _vp, _i, _i, _i, _i, _vp],
     "mvsdet_homo_warp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "mvsdet_plane_sweep_variance_packed_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_scratch_bytes": [_i, _i, _i, _i, _i],
+    "mvsdet_plane_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],
+    "mvsdet_plane_sweep_variance_packed_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_depth_prob_topk_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
@@ -42,7 +44,8 @@ SIGNATURES = {
                                               _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_copy_f32": [_vp, _vp, _sz, _vp],
 }
-_RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_packed_bytes": ctypes.c_size_t}
+_RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_packed_bytes": ctypes.c_size_t,
+            "mvsdet_plane_sweep_scratch_bytes": ctypes.c_size_t, "mvsdet_plane_sweep_workspace_bytes": ctypes.c_size_t}
 
 
 def build(verbose: bool = False) -> str:

@@ -22,6 +22,8 @@
 // A footprint that does not fit the LDS box (extreme roll / scale, or planes behind the camera) falls back
 // to direct global gathers for that (tile, plane, neighbour) -- same arithmetic, same result.
 #include "common.h"
+
+#include <algorithm>
 #include "pack.h"
 #include "sweep_kernel.h"
 
@@ -93,9 +95,22 @@ extern "C" int mvsdet_homo_warp_f32(const float* src, const float* proj, const f
 }
 
 namespace {
-template <int TW, bool NT, bool DMA>
-int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var, int N,
-                 int K, int C, int D, int H, int W, hipStream_t stream) {
+int pick_tile_width(int W) {
+    // tuning knob, read per call so A/B runs can flip it inside one process
+    const char* e = getenv("MVSDET_SWEEP_TW");
+    const int tw = e ? atoi(e) : 0;
+    if (tw == 16 || tw == 32) return tw;
+    return (W % 32 == 0 || W % 16 != 0) ? 32 : 16;
+}
+
+int num_tiles(int H, int W, int tw) {
+    const int th = kTilePix / tw;
+    return ((W + tw - 1) / tw) * ((H + th - 1) / th);
+}
+
+template <int TW, bool NT>
+int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var,
+                 void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream) {
     constexpr int TH = kTilePix / TW;
     const int S = num_slabs(C);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -110,14 +125,25 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     int dsplit = 1;
     while (nblocks * dsplit < 2048 && dsplit < D) dsplit *= 2;
     const int d_per_block = (D + dsplit - 1) / dsplit;
+    const char* ecap = getenv("MVSDET_SWEEP_BOXCAP");  // tuning knob: 0 forces the global-gather path
+    int box_cap = ecap ? atoi(ecap) : kBoxCap;
+    box_cap = box_cap < 0 ? 0 : (box_cap > kBoxCap ? kBoxCap : box_cap);
+    uint4* table = reinterpret_cast<uint4*>(scratch);
+    int4* boxes = reinterpret_cast<int4*>(table + (size_t)N * tiles * D * K * kTilePix);
+    dim3 cgrid((unsigned)(N * tiles), (D + d_per_block - 1) / d_per_block);
     dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
-#define MVS_SWEEP_CASE(KV)                                                                                           \
-    case KV:                                                                                                         \
-        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, DMA>), grid, dim3(kThreads), 0, stream, packed, nbr,   \
-                           proj, depth, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block);                          \
+#define MVS_SWEEP_CASE(KV)                                                                                            \
+    case KV:                                                                                                          \
+        hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads), 0, stream, proj, depth, table,  \
+                           boxes, D, H, W, tiles_x, tiles, d_per_block);                                               \
+        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT>), grid, dim3(kThreads), 0, stream, packed, nbr,    \
+                           table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap);                 \
         break;
     switch (K) {
-        MVS_SWEEP_CASE(0)
+        case 0:
+            hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT>), grid, dim3(kThreads), 0, stream, packed, nbr,
+                               table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap);
+            break;
         MVS_SWEEP_CASE(1)
         MVS_SWEEP_CASE(2)
         MVS_SWEEP_CASE(3)
@@ -129,47 +155,58 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
 }
 }  // namespace
 
+extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W) {
+    if (N <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    // sampling table (16 B per view, neighbour, plane, tile pixel) + footprint boxes (16 B per view, neighbour,
+    // plane, tile); sized for the larger of the two tile shapes so the knob cannot outgrow it
+    const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
+    return (size_t)N * tiles * D * K * (kTilePix + 1) * 16;
+}
+
 extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
-                                                      const float* depth, float* var, int N, int K, int C, int D, int H,
-                                                      int W, mvsdet_stream_t stream) {
-    MVS_REQUIRE(packed && depth && var, "plane_sweep_variance: NULL pointer");
-    MVS_REQUIRE(K == 0 || (nbr && proj), "plane_sweep_variance: NULL neighbour arrays with K=%d", K);
+                                                      const float* depth, float* var, void* scratch,
+                                                      size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
+                                                      mvsdet_stream_t stream) {
+    MVS_REQUIRE(packed && var, "plane_sweep_variance: NULL pointer");
+    MVS_REQUIRE(K == 0 || (nbr && proj && depth && scratch), "plane_sweep_variance: NULL neighbour arrays / scratch with K=%d", K);
     MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "plane_sweep_variance: bad shape N=%d C=%d D=%d H=%d W=%d", N,
                 C, D, H, W);
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "plane_sweep_variance: K=%d outside [0,%d]", K, MVSDET_MAX_NEIGHBORS);
-    MVS_REQUIRE(D <= 65535, "plane_sweep_variance: D > 65535");
+    MVS_REQUIRE(D <= 65535 && H < 65535 && W < 65535, "plane_sweep_variance: D, H or W > 65534");
     MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "plane_sweep_variance: one slab image exceeds 2^31 elements");
-    // tuning knobs, read per call so A/B runs can flip them inside one process
-    const char* e = getenv("MVSDET_SWEEP_TW");
-    int tw = e ? atoi(e) : 0;
-    if (tw != 16 && tw != 32) tw = (W % 32 == 0 || W % 16 != 0) ? 32 : 16;
+    if (scratch_bytes < mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)) {
+        set_error("plane_sweep_variance: scratch %zu B < %zu B", scratch_bytes, mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W));
+        return MVSDET_ERR_WORKSPACE;
+    }
+    MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "plane_sweep_variance: scratch must be 16-byte aligned");
+    const int tw = pick_tile_width(W);
     const char* ent = getenv("MVSDET_SWEEP_NT");
     const bool nt = ent ? atoi(ent) != 0 : true;
-    const char* edma = getenv("MVSDET_SWEEP_DMA");
-    const bool dma = edma ? atoi(edma) != 0 : true;
     hipStream_t st = (hipStream_t)stream;
-#define MVS_GO(TWV, NTV, DMAV) return launch_sweep<TWV, NTV, DMAV>(packed, nbr, proj, depth, var, N, K, C, D, H, W, st)
-    if (tw == 16) {
-        if (nt) { if (dma) MVS_GO(16, true, true); else MVS_GO(16, true, false); }
-        else    { if (dma) MVS_GO(16, false, true); else MVS_GO(16, false, false); }
-    }
-    if (nt) { if (dma) MVS_GO(32, true, true); else MVS_GO(32, true, false); }
-    if (dma) MVS_GO(32, false, true);
-    MVS_GO(32, false, false);
-#undef MVS_GO
+    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st)
+                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st);
+    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st)
+              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,
                                                const float* depth, float* var, void* workspace, size_t workspace_bytes,
                                                int N, int K, int C, int D, int H, int W, mvsdet_stream_t stream) {
     MVS_REQUIRE(feat && workspace, "plane_sweep_variance: NULL pointer");
-    MVS_REQUIRE(N > 0 && C > 0 && H > 1 && W > 1, "plane_sweep_variance: bad shape");
-    if (workspace_bytes < mvsdet_packed_bytes(N, C, H, W)) {
-        set_error("plane_sweep_variance: workspace %zu B < %zu B", workspace_bytes, mvsdet_packed_bytes(N, C, H, W));
+    MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "plane_sweep_variance: bad shape");
+    const size_t pb = (mvsdet_packed_bytes(N, C, H, W) + 255) / 256 * 256;
+    const size_t sb = mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W);
+    if (workspace_bytes < pb + sb) {
+        set_error("plane_sweep_variance: workspace %zu B < %zu B", workspace_bytes, pb + sb);
         return MVSDET_ERR_WORKSPACE;
     }
     const int64_t fs[4] = {(int64_t)C * H * W, (int64_t)H * W, W, 1};
     int rc = mvsdet_pack_features_f32(feat, fs, (float*)workspace, N, C, H, W, stream);
     if (rc) return rc;
-    return mvsdet_plane_sweep_variance_packed_f32((const float*)workspace, nbr, proj, depth, var, N, K, C, D, H, W, stream);
+    return mvsdet_plane_sweep_variance_packed_f32((const float*)workspace, nbr, proj, depth, var, (char*)workspace + pb, sb,
+                                                  N, K, C, D, H, W, stream);
+}
+
+extern "C" size_t mvsdet_plane_sweep_workspace_bytes(int N, int K, int C, int D, int H, int W) {
+    return (mvsdet_packed_bytes(N, C, H, W) + 255) / 256 * 256 + mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W);
 }

@@ -1,26 +1,34 @@
-// a3+a4 fused: plane-sweep variance, slab kernel (included by planesweep.hip).
+// a3+a4 fused: plane-sweep variance (included by planesweep.hip).  Two kernels:
 //
-//   block   = (reference view n, TWxTH pixel tile (128 pixels), 32-channel slab s, depth chunk)
-//             logical id = (n*tiles + tile)*S + s, so consecutive blocks are the S slabs of one tile and the
-//             round-robin block->XCD dispatch sends slab s of every tile to the same XCD when S == 8.
-//   lanes   = (pixel slot ps = lane>>3, channel group g = lane&7); a wave-instruction covers 8 pixels x
-//             128 B; each wave owns 32 pixels = 4 steps; the reference features of those pixels stay in
-//             registers across the depth loop.
-//   per depth plane
-//     P1   one thread per (pixel, neighbour): sampling position -> {x0,y0}, weights in LDS; the valid tap
-//          ranges are min/max-reduced with DPP + readlane into the footprint box of each neighbour
-//     P1b  the same thread turns {x0,y0} into the four tap offsets inside the box (or inside the slab image
-//          when the footprint does not fit and the neighbour falls back to global gathers)
-//     per neighbour j
-//       P2  every wave copies whole box rows (contiguous nc*128 B runs of the slab image) into LDS
-//       P3  taps = 4 x ds_read_b128 per step; fma chain -> S, Q
-//     P4   variance -> LDS tile [32 channels][128 pixels] (aliases the box storage)
-//     P5   tile rows -> global, TW*4-byte contiguous runs, non-temporal, scalar row base + per-lane offset
+// (1) plane_sweep_coords_kernel -- everything that depends on (view, neighbour, plane, pixel) but NOT on the
+//     channel: the sampling position of mvs_models/module.py:116-143, reduced to a 16-byte table entry
+//     {tap origin x0,y0; fractional weights wx,wy; validity bits} plus, per (tile, neighbour, plane), the
+//     bounding box of the valid taps.  The reference builds its sampling grid once per plane too.
+//     Cost: N*K*D*H*W entries (1.6 GB at the 64-plane shape, 3 % of the cost volume), written once.
 //
-// The kernel is VALU-issue bound, not bandwidth bound (profiles/r01_v2_*: 82 % VALU busy at 2*FETCH+WRITE =
-// algorithmic bytes), so the code below is arranged to keep address arithmetic out of the inner loops:
-// per-thread offsets are loop invariants, row bases are wave-uniform scalars, LDS addresses are one VGPR
-// plus immediates.
+// (2) plane_sweep_variance_kernel -- the channel work, one 32-channel slab per block:
+//       block   = (reference view n, TWxTH pixel tile (128 pixels), slab s, depth chunk)
+//                 logical id = (n*tiles + tile)*S + s: consecutive blocks are the S slabs of one tile and the
+//                 round-robin block->XCD dispatch sends slab s of every tile to the same XCD when S == 8, so
+//                 an XCD only ever touches ONE 128-byte slab of each source texel and its live working set
+//                 fits its 4 MiB L2 (rocprofv3: 2*FETCH_SIZE + WRITE_SIZE == algorithmic bytes).
+//       lanes   = (pixel slot ps = lane>>3, channel group g = lane&7); a wave-instruction covers 8 pixels x
+//                 128 B; each wave owns 32 pixels = 4 steps; the reference features of those pixels stay in
+//                 registers across the depth loop.
+//       per depth plane
+//         P1  scalar-load the footprint boxes; start the LDS-DMA of neighbour 0's box; one thread per (pixel,
+//             neighbour) decodes its table entry into 4 weights + 4 tap offsets inside the box (or inside the
+//             slab image when the footprint does not fit in LDS and that neighbour gathers from global memory)
+//         per neighbour j
+//           P2  LDS-DMA of the box rows (contiguous nc*128-byte runs of the slab image), 1 KiB per wave-instruction
+//           P3  taps = 4 x ds_read_b128 per step; fma chain -> S, Q
+//         P4  variance -> LDS tile [32 channels][128 pixels] (aliases the box storage)
+//         P5  tile rows -> global as 16-byte non-temporal stores, 128 B contiguous per (channel, tile row)
+//
+// Why this shape: v1 (all channels per block, taps gathered from global memory) saturated the fabric at a 43 %
+// L2 hit rate (profiles/r01_v1_*); with slabs the kernel became VALU-issue bound (82 % busy), so everything
+// that is not per-channel arithmetic was moved out of the per-slab loop (the table), made scalar (row bases,
+// boxes) or turned into immediates (LDS addresses).
 //
 // Arithmetic (device rounding, oracle mode 1): warped = fma chain over the 4 taps; S = f + w1 + ..;
 // Q = fma(w,w,Q); var = fma(-m, m, Q*r) with m = S*r, r = 1/(K+1).
@@ -53,25 +61,117 @@ __device__ __forceinline__ int wave_reduce(int v) {
     return kMin ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d));
 }
 
-template <int K, int TW, bool NT, bool DMA>
+// Table entry: x = (x0+1) | (y0+1) << 16 with the clamped tap origin of compute_taps_xy(); y, z = bit patterns
+// of wx, wy; w = validity bits (1: column x0 inside, 2: column x0+1 inside, 4: row y0 inside, 8: row y0+1 inside).
+__device__ __forceinline__ uint4 encode_taps(const float* __restrict__ P, float x, float y, float d, int H, int W,
+                                             int& xlo, int& xhi, int& ylo, int& yhi) {
+    const float rx = fmaf(P[1], y, P[0] * x) + P[2];
+    const float ry = fmaf(P[5], y, P[4] * x) + P[6];
+    const float rz = fmaf(P[9], y, P[8] * x) + P[10];
+    const float X = rx * d + P[3];
+    const float Y = ry * d + P[7];
+    const float Z = rz * d + P[11];
+    const float px = X / Z;
+    const float py = Y / Z;
+    const float gx = px / ((float)(W - 1) * 0.5f) - 1.0f;
+    const float gy = py / ((float)(H - 1) * 0.5f) - 1.0f;
+    const float ix = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);
+    const float iy = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    const float wx = ix - x0, wy = iy - y0;
+    const bool x0in = (x0 >= 0.0f) && (x0 <= (float)(W - 1));
+    const bool x1in = (x0 >= -1.0f) && (x0 <= (float)(W - 2));
+    const bool y0in = (y0 >= 0.0f) && (y0 <= (float)(H - 1));
+    const bool y1in = (y0 >= -1.0f) && (y0 <= (float)(H - 2));
+    const int xi = (int)fminf(fmaxf(x0, -1.0f), (float)(W - 1));  // NaN / Inf positions become finite indices
+    const int yi = (int)fminf(fmaxf(y0, -1.0f), (float)(H - 1));
+    const bool any = (x0in || x1in) && (y0in || y1in);
+    xlo = any ? (x0in ? xi : xi + 1) : INT32_MAX;
+    xhi = any ? (x1in ? xi + 1 : xi) : INT32_MIN;
+    ylo = any ? (y0in ? yi : yi + 1) : INT32_MAX;
+    yhi = any ? (y1in ? yi + 1 : yi) : INT32_MIN;
+    uint4 e;
+    e.x = (unsigned)(xi + 1) | ((unsigned)(yi + 1) << 16);
+    e.y = __float_as_uint(wx);
+    e.z = __float_as_uint(wy);
+    e.w = (x0in ? 1u : 0u) | (x1in ? 2u : 0u) | (y0in ? 4u : 0u) | (y1in ? 8u : 0u);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (1) sampling table: block = (view, tile); thread = (neighbour, pixel); loops over the planes of its chunk.
+//     table [((n*tiles + tile)*D + d)*K + j][128] uint4;  boxes [((n*tiles + tile)*D + d)*K + j] int4.
+// ---------------------------------------------------------------------------------------------
+template <int K, int TW>
+__global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const float* __restrict__ proj,
+                                                                       const float* __restrict__ depth,
+                                                                       uint4* __restrict__ table, int4* __restrict__ boxes,
+                                                                       int D, int H, int W, int tiles_x, int tiles,
+                                                                       int d_per_block) {
+    constexpr int TH = kTilePix / TW;
+    constexpr int ITER = (K * kTilePix + kThreads - 1) / kThreads;
+    __shared__ int s_red[2][K][2][4];  // [plane parity][neighbour][wave of the neighbour][xlo,xhi,ylo,yhi]
+    const int bt = blockIdx.x;  // n*tiles + tile
+    const int tile = bt % tiles, n = bt / tiles;
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = tid % kTilePix;
+    const int x = tx0 + (p % TW), y = ty0 + (p / TW);
+    const bool inside = (x < W) && (y < H);
+    const int d_begin = blockIdx.y * d_per_block, d_end = min(D, d_begin + d_per_block);
+    for (int d = d_begin; d < d_end; ++d) {
+        const int par = (d - d_begin) & 1;
+        const float dval = depth[(size_t)n * D + d];
+        const size_t base = ((size_t)bt * D + d) * K;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            // 128 pixels = 2 whole waves per neighbour: j is wave-uniform
+            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
+            if (j < K) {
+                int xlo = INT32_MAX, xhi = INT32_MIN, ylo = INT32_MAX, yhi = INT32_MIN;
+                uint4 e = make_uint4(0x00010001u, 0u, 0u, 0u);  // pixel outside the image: no taps, no footprint
+                if (inside) e = encode_taps(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W, xlo, xhi, ylo, yhi);
+                table[(base + j) * kTilePix + p] = e;
+                xlo = wave_reduce<true>(xlo);
+                xhi = wave_reduce<false>(xhi);
+                ylo = wave_reduce<true>(ylo);
+                yhi = wave_reduce<false>(yhi);
+                if (lane == 0) {
+                    int* r = s_red[par][j][(tid >> 6) & 1];
+                    r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi;
+                }
+            }
+        }
+        __syncthreads();  // one barrier per plane: s_red is double-buffered by plane parity
+        if (tid < K) {
+            const int* a = s_red[par][tid][0];
+            const int* b = s_red[par][tid][1];
+            boxes[base + tid] = make_int4(min(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), max(a[3], b[3]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (2) the slab kernel
+// ---------------------------------------------------------------------------------------------
+template <int K, int TW, bool NT>
 __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
-    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
-    const float* __restrict__ depth, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int d_per_block) {
+    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const uint4* __restrict__ table,
+    const int4* __restrict__ boxes, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
+    int tiles, int d_per_block, int box_cap) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
+    constexpr int ITER = (K * kTilePix + kThreads - 1) / kThreads;
     static_assert(kBoxCap * 8 >= 32 * kTileStride / 4, "output tile must fit in the box storage");
     __shared__ float4 s_box[kBoxCap * 8];       // footprint box of one neighbour; later the output tile
-    __shared__ int2 s_xy[KK][kTilePix];         // tap origin per (neighbour, pixel)
     __shared__ int4 s_off[KK][kTilePix];        // float4 index of the 4 taps (inside s_box or the slab image)
     __shared__ float4 s_w[KK][kTilePix];        // tap weights
-    __shared__ int s_bounds[2][KK][4];          // xlo, xhi, ylo, yhi of the valid taps; double-buffered by plane
 
     const int HW = H * W;
     const int id = blockIdx.x;
     const int slab = id % S;
-    const int t_ = id / S;
-    const int tile = t_ % tiles, n = t_ / tiles;
+    const int bt = id / S;  // n*tiles + tile
+    const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int d_begin = blockIdx.y * d_per_block;
     const int d_end = min(D, d_begin + d_per_block);
@@ -99,91 +199,72 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         const int pix = min(y, H - 1) * W + min(x, W - 1);
         f[s] = *reinterpret_cast<const float4*>(ref_img + (size_t)pix * kSlab + 4 * g);
     }
-    // ... and the two output pixels it stores in P5 (tile pixel index lane and lane + 64)
-    int st_off[2];
-    bool st_ok[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int pp = lane + 64 * h;
-        const int x = tx0 + (pp % TW), y = ty0 + (pp / TW);
-        st_ok[h] = (x < W) && (y < H);
-        st_off[h] = y * W + x;
-    }
-    if (tid < 2 * KK * 4) {  // both bounds buffers start empty
-        const int e = tid & 3;
-        (&s_bounds[0][0][0])[tid] = (e == 0 || e == 2) ? INT32_MAX : INT32_MIN;
-    }
-    __syncthreads();
+    // ... and the 4 consecutive output pixels it stores in P5: float4 slot q = lane & 31 of the 128-pixel tile
+    // (TW/4 slots per tile row), for the two channel rows 2*k + (lane >> 5)
+    const int sq = lane & 31, sh = lane >> 5;
+    const int st_x = tx0 + (sq % (TW / 4)) * 4, st_y = ty0 + sq / (TW / 4);
+    const int st_off = st_y * W + st_x;
+    const int st_n = (st_y < H) ? max(0, min(4, W - st_x)) : 0;        // how many of the 4 pixels are inside the image
+    const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);  // 16-byte aligned in every channel row
+
+    auto load_box = [&](int j, int bx0, int by0, int nc, int nr) {
+        // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs; the LDS address is the
+        // wave-uniform base + 16*lane, the global address is per lane.  The DMA counts on vmcnt, which the next
+        // __syncthreads() drains.  Every wave copies whole rows: one contiguous nc*128-byte run each.
+        const int row_f4 = nc * 8;
+        for (int row = wave; row < nr; row += 4) {
+            const float4* src = nb_img[j] + ((size_t)(by0 + row) * W + bx0) * 8;  // wave-uniform
+            float4* dst = s_box + row * row_f4;
+            for (int q0 = 0; q0 < row_f4; q0 += 64)
+                if (q0 + lane < row_f4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q0 + lane),
+                                                     (__attribute__((address_space(3))) void*)(dst + q0), 16, 0, 0);
+        }
+    };
 
     for (int d = d_begin; d < d_end; ++d) {
-        const int cur = (d - d_begin) & 1;
-        // ---- P1: sampling positions + footprint box
-        if (K > 0) {
-            const float dval = depth[(size_t)n * D + d];
-#pragma unroll
-            for (int it = 0; it < (K * kTilePix + kThreads - 1) / kThreads; ++it) {
-                // 128 pixels = 2 whole waves per neighbour: j is wave-uniform
-                const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
-                if (j < K) {
-                    const int p = tid % kTilePix;
-                    const int x = tx0 + (p % TW), y = ty0 + (p / TW);
-                    TapXY t;
-                    if (x < W && y < H) {
-                        t = compute_taps_xy(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W);
-                    } else {  // pixel outside the image: no taps, no footprint
-                        t.x0 = t.y0 = 0;
-                        t.w = make_float4(0.f, 0.f, 0.f, 0.f);
-                        t.xlo = t.ylo = INT32_MAX;
-                        t.xhi = t.yhi = INT32_MIN;
-                    }
-                    s_xy[j][p] = make_int2(t.x0, t.y0);
-                    s_w[j][p] = t.w;
-                    const int xlo = wave_reduce<true>(t.xlo), xhi = wave_reduce<false>(t.xhi);
-                    const int ylo = wave_reduce<true>(t.ylo), yhi = wave_reduce<false>(t.yhi);
-                    if (lane == 0) {
-                        atomicMin(&s_bounds[cur][j][0], xlo);
-                        atomicMax(&s_bounds[cur][j][1], xhi);
-                        atomicMin(&s_bounds[cur][j][2], ylo);
-                        atomicMax(&s_bounds[cur][j][3], yhi);
-                    }
-                }
-            }
-            if (tid < KK * 4) {  // reset the other buffer for the next plane (its readers are behind a barrier)
-                const int e = tid & 3;
-                (&s_bounds[cur ^ 1][0][0])[tid] = (e == 0 || e == 2) ? INT32_MAX : INT32_MIN;
-            }
-        }
-        __syncthreads();
-
-        // footprint boxes (block-uniform scalars)
+        // ---- P1: footprint boxes (block-uniform scalars, computed once per tile by the coords kernel)
         int bx0[KK], bx1[KK], by0[KK], by1[KK], nc[KK], nr[KK];
         bool staged[KK];
+        const size_t tbase = ((size_t)bt * D + d) * K;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            bx0[j] = __builtin_amdgcn_readfirstlane(s_bounds[cur][j][0]);
-            bx1[j] = __builtin_amdgcn_readfirstlane(s_bounds[cur][j][1]);
-            by0[j] = __builtin_amdgcn_readfirstlane(s_bounds[cur][j][2]);
-            by1[j] = __builtin_amdgcn_readfirstlane(s_bounds[cur][j][3]);
+            const int4 b = boxes[tbase + j];
+            bx0[j] = __builtin_amdgcn_readfirstlane(b.x);
+            bx1[j] = __builtin_amdgcn_readfirstlane(b.y);
+            by0[j] = __builtin_amdgcn_readfirstlane(b.z);
+            by1[j] = __builtin_amdgcn_readfirstlane(b.w);
             nc[j] = bx1[j] - bx0[j] + 1;
             nr[j] = by1[j] - by0[j] + 1;
-            staged[j] = (bx1[j] >= bx0[j]) && (by1[j] >= by0[j]) && (nc[j] * nr[j] <= kBoxCap);
+            staged[j] = (bx1[j] >= bx0[j]) && (by1[j] >= by0[j]) && (nc[j] * nr[j] <= box_cap);
         }
-        // ---- P1b: tap offsets (float4 units, lane slot g not yet added) inside the box / the slab image
-        if (K > 0) {
+        // the previous plane's tile reads (P5) must be over before the box storage is refilled
+        if (d != d_begin) __syncthreads();
+        if (K > 0 && staged[0]) load_box(0, bx0[0], by0[0], nc[0], nr[0]);  // in flight while the table is decoded
+        // ---- table entry -> weights + tap offsets (float4 units, lane slot g not yet added)
 #pragma unroll
-            for (int it = 0; it < (K * kTilePix + kThreads - 1) / kThreads; ++it) {
-                const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
-                if (j < K) {
-                    const int p = tid % kTilePix;
-                    const int2 xy = s_xy[j][p];
-                    int lox = 0, hix = W - 1, loy = 0, hiy = H - 1, pitch = W;
+        for (int it = 0; it < ITER; ++it) {
+            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
+            if (j < K) {
+                const int p = tid % kTilePix;
+                const uint4 e = table[(tbase + j) * kTilePix + p];
+                const int x0 = (int)(e.x & 0xffffu) - 1, y0 = (int)(e.x >> 16) - 1;
+                const float wx = __uint_as_float(e.y), wy = __uint_as_float(e.z);
+                const float ex = 1.0f - wx, sy = 1.0f - wy;
+                const float wnw = sy * ex, wne = sy * wx, wsw = wy * ex, wse = wy * wx;
+                float4 w;  // an outside tap carries weight*0, so Inf/NaN positions give NaN as ATen-CPU does
+                w.x = ((e.w & 5u) == 5u) ? wnw : wnw * 0.0f;
+                w.y = ((e.w & 6u) == 6u) ? wne : wne * 0.0f;
+                w.z = ((e.w & 9u) == 9u) ? wsw : wsw * 0.0f;
+                w.w = ((e.w & 10u) == 10u) ? wse : wse * 0.0f;
+                s_w[j][p] = w;
+                int lox = 0, hix = W - 1, loy = 0, hiy = H - 1, pitch = W;
 #pragma unroll
-                    for (int jj = 0; jj < K; ++jj)
-                        if (jj == j && staged[jj]) { lox = bx0[jj]; hix = bx1[jj]; loy = by0[jj]; hiy = by1[jj]; pitch = nc[jj]; }
-                    const int xa = clampi(xy.x, lox, hix) - lox, xb = clampi(xy.x + 1, lox, hix) - lox;
-                    const int ya = (clampi(xy.y, loy, hiy) - loy) * pitch, yb = (clampi(xy.y + 1, loy, hiy) - loy) * pitch;
-                    s_off[j][p] = make_int4((ya + xa) * 8, (ya + xb) * 8, (yb + xa) * 8, (yb + xb) * 8);
-                }
+                for (int jj = 0; jj < K; ++jj)
+                    if (jj == j && staged[jj]) { lox = bx0[jj]; hix = bx1[jj]; loy = by0[jj]; hiy = by1[jj]; pitch = nc[jj]; }
+                const int xa = clampi(x0, lox, hix) - lox, xb = clampi(x0 + 1, lox, hix) - lox;
+                const int ya = (clampi(y0, loy, hiy) - loy) * pitch, yb = (clampi(y0 + 1, loy, hiy) - loy) * pitch;
+                s_off[j][p] = make_int4((ya + xa) * 8, (ya + xb) * 8, (yb + xa) * 8, (yb + xb) * 8);
             }
         }
 
@@ -195,27 +276,8 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if (staged[j]) {
-                // ---- P2: every wave copies whole rows of the box: one contiguous nc*128-byte run each
-                const int row_f4 = nc[j] * 8;
-                for (int row = wave; row < nr[j]; row += 4) {
-                    const float4* src = nb_img[j] + ((size_t)(by0[j] + row) * W + bx0[j]) * 8;  // wave-uniform
-                    float4* dst = s_box + row * row_f4;
-                    if (DMA) {
-                        // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs; the LDS
-                        // address is the wave-uniform base + 16*lane, the global address is per lane.  The DMA counts
-                        // on vmcnt, which the __syncthreads() below drains.
-                        for (int q0 = 0; q0 < row_f4; q0 += 64)
-                            if (q0 + lane < row_f4)
-                                __builtin_amdgcn_global_load_lds(
-                                    (const __attribute__((address_space(1))) void*)(src + q0 + lane),
-                                    (__attribute__((address_space(3))) void*)(dst + q0), 16, 0, 0);
-                    } else {
-                        for (int q = lane; q < row_f4; q += 64) dst[q] = src[q];
-                    }
-                }
-            }
-            __syncthreads();  // box (and, for the first neighbour, the tap offsets) visible
+            if (j > 0 && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
+            if (staged[j] || j == 0) __syncthreads();  // box (and, for the first neighbour, the tables) visible
             // ---- P3: taps -> warped value -> running sums
             if (staged[j]) {
 #pragma unroll
@@ -257,7 +319,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
                     }
                 }
             }
-            __syncthreads();  // box fully read before it is overwritten (next neighbour / output tile)
+            if (staged[j]) __syncthreads();  // box fully read before it is overwritten (next neighbour / output tile)
         }
         // ---- P4: variance -> output tile [channel row 8*i+g][pixel]
         float* s_tile = reinterpret_cast<float*>(s_box);
@@ -273,29 +335,30 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
             }
         }
         __syncthreads();
-        // ---- P5: wave w stores channel rows w, w+4, ..: scalar row base, per-lane pixel offset
+        // ---- P5: wave w stores channel rows 8*w .. 8*w+7, two rows per instruction, 16 bytes per lane
         {
-            const float* t = s_tile + wave * kTileStride + lane;
+            const float* t = s_tile + (wave * 8 + sh) * kTileStride + 4 * sq;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int c = slab * kSlab + wave + 4 * k;  // wave-uniform
+            for (int k = 0; k < 4; ++k) {
+                const int c = slab * kSlab + wave * 8 + 2 * k + sh;
+                const float4 v = *reinterpret_cast<const float4*>(t + 2 * k * kTileStride);
                 if (c < C) {
-                    float* row = var + (((size_t)n * C + c) * D + d) * HW;
+                    float* dst = var + (((size_t)n * C + c) * D + d) * HW + st_off;
+                    // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs
+                    if (st_vec) {
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        const v4f vv = {v.x, v.y, v.z, v.w};
+                        if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
+                        else *reinterpret_cast<v4f*>(dst) = vv;
+                    } else {
+                        const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float v = t[4 * k * kTileStride + 64 * h];
-                        if (st_ok[h]) {
-                            // written once, never re-read here: keep the stream from evicting the source slabs
-                            if (NT) __builtin_nontemporal_store(v, row + st_off[h]);
-                            else row[st_off[h]] = v;
-                        }
+                        for (int i = 0; i < 4; ++i)
+                            if (i < st_n) dst[i] = a[i];
                     }
                 }
             }
         }
-        // The next plane writes s_box again only after the barriers that follow its P1, which every thread
-        // reaches after its tile reads above -- unless K == 0, where P4 follows directly.
-        if (K == 0) __syncthreads();
     }
 }
 

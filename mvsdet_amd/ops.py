@@ -106,10 +106,14 @@ def plane_sweep_variance_packed(packed: Tensor, nbr: Tensor, proj: Tensor, depth
         raise ValueError("plane_sweep_variance_packed: proj/depth shape mismatch")
     nbr, proj, depth = nbr.contiguous(), proj.contiguous(), depth.contiguous()
     out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=packed.device)
+    # channel-independent sampling table (16 B per view, neighbour, plane, pixel), built by the op's first kernel
+    sbytes = lib.mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)
+    scratch = torch.empty(max(sbytes // 4, 4), dtype=torch.float32, device=packed.device)
     with torch.cuda.device(packed.device):
         _lib.check(lib.mvsdet_plane_sweep_variance_packed_f32(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(proj),
-                                                              _lib.ptr(depth), _lib.ptr(out), N, K, C, D, H, W,
-                                                              _stream(packed)), "plane_sweep_variance_packed")
+                                                              _lib.ptr(depth), _lib.ptr(out), _lib.ptr(scratch), sbytes,
+                                                              N, K, C, D, H, W, _stream(packed)),
+                   "plane_sweep_variance_packed")
     return out
 
 

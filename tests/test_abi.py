@@ -64,12 +64,20 @@ def test_argument_checks_do_not_launch(lib):
     one = ctypes.c_void_p(16)
     assert lib.mvsdet_homo_warp_f32(one, one, one, one, 1, 1, 1, 1, 1, None) == 1  # H, W must be > 1
     assert b"bad shape" in lib.mvsdet_last_error()
-    assert lib.mvsdet_plane_sweep_variance_packed_f32(one, one, one, one, one, 2, 9, 4, 3, 8, 8, None) == 1
+    assert lib.mvsdet_plane_sweep_variance_packed_f32(one, one, one, one, one, one, 1 << 30, 2, 9, 4, 3, 8, 8, None) == 1
     assert b"K=9" in lib.mvsdet_last_error()
     assert lib.mvsdet_depth_prob_topk_f32(one, one, one, one, one, one, None, one, 1, 4, 2, 2, 5, 0.2, 0.4, None) == 1
     assert b"topk" in lib.mvsdet_last_error()
     assert lib.mvsdet_plane_sweep_variance_f32(one, one, one, one, one, one, 8, 2, 2, 4, 3, 8, 8, None) == 2
     assert b"workspace" in lib.mvsdet_last_error()
+    sixteen = ctypes.c_void_p(4096)
+    assert lib.mvsdet_plane_sweep_variance_packed_f32(one, one, one, one, one, sixteen, 64, 2, 2, 4, 3, 8, 8, None) == 2
+    assert b"scratch" in lib.mvsdet_last_error()
+    # scratch: 16 B per (view, neighbour, plane, tile pixel) + one box per tile
+    assert lib.mvsdet_plane_sweep_scratch_bytes(40, 2, 64, 120, 160) == 40 * 150 * 64 * 2 * 129 * 16
+    assert lib.mvsdet_plane_sweep_scratch_bytes(40, 0, 64, 120, 160) == 0
+    assert lib.mvsdet_plane_sweep_workspace_bytes(40, 2, 256, 64, 120, 160) == \
+        lib.mvsdet_packed_bytes(40, 256, 120, 160) + lib.mvsdet_plane_sweep_scratch_bytes(40, 2, 64, 120, 160)
 
 
 def test_ops_have_no_cpu_path():
