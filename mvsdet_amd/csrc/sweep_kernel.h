@@ -39,7 +39,8 @@
 namespace mvsdet {
 
 constexpr int kTilePix = 128;       // pixels per tile
-constexpr int kBoxPool = 352;       // texels (128 B each) of the LDS pool that holds the footprint boxes of one plane: 44 KiB
+constexpr int kBoxCap = 224;        // texels (128 B each) of the LDS footprint box: 28 KiB
+constexpr int kTileStride = 132;    // floats per channel row of the output tile (132 % 32 == 4: conflict-free writes)
 
 // Wave-wide integer min / max: butterfly inside each row of 16 lanes with DPP (4 VALU), then the four row
 // results are combined on the scalar unit.  The result is wave-uniform (an SGPR).
@@ -153,15 +154,16 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
 // ---------------------------------------------------------------------------------------------
 // (2) the slab kernel
 // ---------------------------------------------------------------------------------------------
-template <int K, int TW, bool NT, bool STAMP>
-__global__ __launch_bounds__(kThreads, 3) void plane_sweep_variance_kernel(
+template <int K, int TW, bool NT>
+__global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const uint4* __restrict__ table,
     const int4* __restrict__ boxes, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps) {
+    int tiles, int d_per_block, int box_cap) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
     constexpr int ITER = (KK * kTilePix + kThreads - 1) / kThreads;
-    __shared__ float4 s_box[kBoxPool * 8];      // footprint boxes of all neighbours of the current plane, back to back
+    static_assert(kBoxCap * 8 >= 32 * kTileStride / 4, "output tile must fit in the box storage");
+    __shared__ float4 s_box[kBoxCap * 8];       // footprint box of one neighbour; later the output tile
     __shared__ int4 s_off[KK][kTilePix];        // float4 index of the 4 taps (inside s_box or the slab image)
     __shared__ float4 s_w[KK][kTilePix];        // tap weights
 
@@ -188,295 +190,203 @@ __global__ __launch_bounds__(kThreads, 3) void plane_sweep_variance_kernel(
     }
     const float rcp = 1.0f / (float)(K + 1);
 
-    // This lane owns 4 CONSECUTIVE pixels of one tile row (float4 slot q of the 128-pixel tile, TW/4 slots per
-    // row) for the 4 channels 8*i + g of the slab: its results go to global memory straight from registers as
-    // 16-byte stores, and a wave-instruction writes 8 channel rows x 128 contiguous bytes.
-    const int q = wave * 8 + ps;
-    const int st_x = tx0 + (q % (TW / 4)) * 4, st_y = ty0 + q / (TW / 4);
-    const int st_off = st_y * W + st_x;
-    const int st_n = (st_y < H) ? max(0, min(4, W - st_x)) : 0;            // how many of the 4 pixels are inside the image
-    const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);  // 16-byte aligned in every channel row
-    // Number of vector-store instructions this wave issues per plane (wave-uniform), or -1 when some lane takes the
-    // scalar edge path: lets the loop wait for the LDS-DMA with a COUNTED vmcnt that leaves the stores in flight.
-    int nst = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) nst += (slab * kSlab + 8 * i < C) ? 1 : 0;
-    if (!__all(st_vec)) nst = -1;
-    nst = __builtin_amdgcn_readfirstlane(nst);
-    // element offset of this lane's 4 pixels in channel row 8*i + g at plane d_begin; advanced by HW per plane
-    size_t st_idx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        st_idx[i] = (((size_t)n * C + min(slab * kSlab + 8 * i + g, C - 1)) * D + d_begin) * HW + st_off;
-    float4 f[4];  // reference features of the 4 pixels, kept across the depth loop
+    // loop invariants of this lane: reference features of its 4 pixels (one per step) ...
+    float4 f[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int pix = min(st_y, H - 1) * W + min(st_x + s, W - 1);
+        const int p = (wave * 4 + s) * 8 + ps;
+        const int x = tx0 + (p % TW), y = ty0 + (p / TW);
+        const int pix = min(y, H - 1) * W + min(x, W - 1);
         f[s] = *reinterpret_cast<const float4*>(ref_img + (size_t)pix * kSlab + 4 * g);
     }
+    // ... and the 4 consecutive output pixels it stores in P5: float4 slot q = lane & 31 of the 128-pixel tile
+    // (TW/4 slots per tile row), for the two channel rows 2*k + (lane >> 5)
+    const int sq = lane & 31, sh = lane >> 5;
+    const int st_x = tx0 + (sq % (TW / 4)) * 4, st_y = ty0 + sq / (TW / 4);
+    const int st_off = st_y * W + st_x;
+    const int st_n = (st_y < H) ? max(0, min(4, W - st_x)) : 0;        // how many of the 4 pixels are inside the image
+    const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);  // 16-byte aligned in every channel row
 
-    // Footprint boxes of one plane: block-uniform scalars, computed once per tile by the coords kernel.  Plain
-    // arrays + macros (no structs / lambdas): everything below must stay in SGPRs / VGPRs after unrolling.
-#define MVS_LOAD_BOXES(DD, BV)                                                                                  \
-    _Pragma("unroll") for (int j = 0; j < K; ++j) BV[j] = boxes[((size_t)bt * D + (DD)) * K + j];
-#define MVS_UNPACK_BOXES(BV, BX0, BY0, BX1, BY1, NC, NR, BASE, STG)                                            \
-    {                                                                                                          \
-        int used_ = 0;                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < K; ++j) {                                                        \
-            BX0[j] = __builtin_amdgcn_readfirstlane(BV[j].x);                                                  \
-            BX1[j] = __builtin_amdgcn_readfirstlane(BV[j].y);                                                  \
-            BY0[j] = __builtin_amdgcn_readfirstlane(BV[j].z);                                                  \
-            BY1[j] = __builtin_amdgcn_readfirstlane(BV[j].w);                                                  \
-            NC[j] = BX1[j] - BX0[j] + 1;                                                                       \
-            NR[j] = BY1[j] - BY0[j] + 1;                                                                       \
-            const int need_ = NC[j] * NR[j];                                                                   \
-            STG[j] = (BX1[j] >= BX0[j]) && (BY1[j] >= BY0[j]) && (used_ + need_ <= box_cap);                   \
-            BASE[j] = used_ * 8; /* float4 index of this neighbour's box inside the pool */                    \
-            if (STG[j]) used_ += need_;                                                                        \
-        }                                                                                                      \
-    }
-#define MVS_READ_BOXES(DD, BX0, BY0, BX1, BY1, NC, NR, BASE, STG)                                              \
-    {                                                                                                          \
-        int4 bv_[KK];                                                                                          \
-        MVS_LOAD_BOXES(DD, bv_)                                                                                \
-        MVS_UNPACK_BOXES(bv_, BX0, BY0, BX1, BY1, NC, NR, BASE, STG)                                           \
-    }
-    // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs; the LDS address is the
-    // wave-uniform base + 16*lane, the global address is per lane.  The DMA counts on vmcnt, which the next
-    // __syncthreads() drains.  Every wave copies whole rows: one contiguous nc*128-byte run each.
-#define MVS_ISSUE_DMA(BX0, BY0, NC, NR, BASE, STG)                                                             \
-    _Pragma("unroll") for (int j = 0; j < K; ++j) {                                                            \
-        if (STG[j]) {                                                                                          \
-            const int row_f4_ = NC[j] * 8;                                                                     \
-            for (int row = wave; row < NR[j]; row += 4) {                                                      \
-                const float4* src_ = nb_img[j] + ((size_t)(BY0[j] + row) * W + BX0[j]) * 8; /* wave-uniform */ \
-                float4* dst_ = s_box + BASE[j] + row * row_f4_;                                                \
-                for (int q0 = 0; q0 < row_f4_; q0 += 64)                                                       \
-                    if (q0 + lane < row_f4_)                                                                   \
-                        __builtin_amdgcn_global_load_lds(                                                      \
-                            (const __attribute__((address_space(1))) void*)(src_ + q0 + lane),                 \
-                            (__attribute__((address_space(3))) void*)(dst_ + q0), 16, 0, 0);                   \
-            }                                                                                                  \
-        }                                                                                                      \
-    }
-    // table entry of (neighbour, pixel) = thread -> registers
-#define MVS_LOAD_ENTRIES(DD, E)                                                                                \
-    _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                                      \
-        const int j_ = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);                       \
-        E[it] = make_uint4(0x00010001u, 0u, 0u, 0u);                                                           \
-        if (j_ < K) E[it] = table[(((size_t)bt * D + (DD)) * K + j_) * kTilePix + (tid % kTilePix)];           \
-    }
-    // entry -> weights + tap offsets (float4 units, lane slot g not yet added) in LDS
-#define MVS_DECODE(E, BX0, BY0, BX1, BY1, NC, BASE, STG)                                                       \
-    _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                                      \
-        const int j_ = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);                       \
-        if (j_ < K) {                                                                                          \
-            const int p_ = tid % kTilePix;                                                                     \
-            const uint4 e_ = E[it];                                                                            \
-            const int x0_ = (int)(e_.x & 0xffffu) - 1, y0_ = (int)(e_.x >> 16) - 1;                            \
-            const float wx_ = __uint_as_float(e_.y), wy_ = __uint_as_float(e_.z);                             \
-            const float ex_ = 1.0f - wx_, sy_ = 1.0f - wy_;                                                    \
-            const float wnw_ = sy_ * ex_, wne_ = sy_ * wx_, wsw_ = wy_ * ex_, wse_ = wy_ * wx_;                \
-            float4 w_; /* an outside tap carries weight*0, so Inf/NaN positions give NaN as ATen-CPU does */   \
-            w_.x = ((e_.w & 5u) == 5u) ? wnw_ : wnw_ * 0.0f;                                                   \
-            w_.y = ((e_.w & 6u) == 6u) ? wne_ : wne_ * 0.0f;                                                   \
-            w_.z = ((e_.w & 9u) == 9u) ? wsw_ : wsw_ * 0.0f;                                                   \
-            w_.w = ((e_.w & 10u) == 10u) ? wse_ : wse_ * 0.0f;                                                 \
-            s_w[j_][p_] = w_;                                                                                  \
-            int lox_ = 0, hix_ = W - 1, loy_ = 0, hiy_ = H - 1, pitch_ = W, base_ = 0;                         \
-            _Pragma("unroll") for (int jj = 0; jj < K; ++jj) if (jj == j_ && STG[jj]) {                        \
-                lox_ = BX0[jj]; hix_ = BX1[jj]; loy_ = BY0[jj]; hiy_ = BY1[jj]; pitch_ = NC[jj]; base_ = BASE[jj]; \
-            }                                                                                                  \
-            const int xa_ = clampi(x0_, lox_, hix_) - lox_, xb_ = clampi(x0_ + 1, lox_, hix_) - lox_;          \
-            const int ya_ = (clampi(y0_, loy_, hiy_) - loy_) * pitch_;                                         \
-            const int yb_ = (clampi(y0_ + 1, loy_, hiy_) - loy_) * pitch_;                                     \
-            s_off[j_][p_] = make_int4(base_ + (ya_ + xa_) * 8, base_ + (ya_ + xb_) * 8, base_ + (yb_ + xa_) * 8, \
-                                      base_ + (yb_ + xb_) * 8);                                                \
-        }                                                                                                      \
-    }
+    auto load_box = [&](int j, int bx0, int by0, int nc, int nr) {
+        // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs; the LDS address is the
+        // wave-uniform base + 16*lane, the global address is per lane.  The DMA counts on vmcnt, which the next
+        // __syncthreads() drains.  Every wave copies whole rows: one contiguous nc*128-byte run each.
+        const int row_f4 = nc * 8;
+        const int cpr = (row_f4 + 63) >> 6;  // 1-KiB chunks per row; units (row, chunk) are dealt round-robin to the waves
+        int row = 0, chunk = wave;
+        while (chunk >= cpr) { chunk -= cpr; ++row; }
+        while (row < nr) {
+            const float4* src = nb_img[j] + ((size_t)(by0 + row) * W + bx0) * 8 + chunk * 64;  // wave-uniform
+            float4* dst = s_box + row * row_f4 + chunk * 64;
+            if (chunk * 64 + lane < row_f4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            chunk += 4;
+            while (chunk >= cpr) { chunk -= cpr; ++row; }
+        }
+    };
 
-    // c_*: boxes of the plane being computed; n_*: boxes of the next plane (its DMA is issued one plane ahead);
-    // en: table entries of the next plane, loaded two vm-operations ahead of the result stores so that no wait
-    // for them ever has to wait for a store acknowledgement (vmcnt retires in order).
-    int c_bx0[KK], c_by0[KK], c_bx1[KK], c_by1[KK], c_nc[KK], c_nr[KK], c_base[KK];
-    bool c_stg[KK];
-    int n_bx0[KK], n_by0[KK], n_bx1[KK], n_by1[KK], n_nc[KK], n_nr[KK], n_base[KK];
-    bool n_stg[KK];
+    // Boxes and table entries are requested one plane ahead (during the taps of the previous plane), so the loop
+    // never stalls on them; they are issued BEFORE that plane's result stores, so waiting for them does not wait
+    // for store acknowledgements either (vmcnt retires in order).
+    int4 bn[KK];
     uint4 en[ITER];
 #pragma unroll
-    for (int j = 0; j < KK; ++j) {
-        c_bx0[j] = c_by0[j] = n_bx0[j] = n_by0[j] = 0;
-        c_bx1[j] = c_by1[j] = n_bx1[j] = n_by1[j] = -1;
-        c_nc[j] = c_nr[j] = c_base[j] = n_nc[j] = n_nr[j] = n_base[j] = 0;
-        c_stg[j] = n_stg[j] = false;
-    }
+    for (int j = 0; j < KK; ++j) bn[j] = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) en[it] = make_uint4(0x00010001u, 0u, 0u, 0u);
-    // ---- prologue: boxes, DMA and tables of the first plane; boxes and entries of the second
-    if (K > 0 && d_begin < d_end) {
-        uint4 e0[ITER];
-        MVS_READ_BOXES(d_begin, c_bx0, c_by0, c_bx1, c_by1, c_nc, c_nr, c_base, c_stg)
-        MVS_LOAD_ENTRIES(d_begin, e0)
-        MVS_ISSUE_DMA(c_bx0, c_by0, c_nc, c_nr, c_base, c_stg)
-        MVS_DECODE(e0, c_bx0, c_by0, c_bx1, c_by1, c_nc, c_base, c_stg)
-        if (d_begin + 1 < d_end) {
-            MVS_READ_BOXES(d_begin + 1, n_bx0, n_by0, n_bx1, n_by1, n_nc, n_nr, n_base, n_stg)
-            MVS_LOAD_ENTRIES(d_begin + 1, en)
+    auto prefetch = [&](int d) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) bn[j] = boxes[((size_t)bt * D + d) * K + j];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
+            if (j < K) en[it] = table[(((size_t)bt * D + d) * K + j) * kTilePix + (tid % kTilePix)];
         }
-    }
-    // diagnostic build only (STAMP): cycles spent per loop segment, summed per wave
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define MVS_STAMP(IDX)                                                           \
-    if (STAMP) {                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();             \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-        if ((IDX) >= 0) tacc[(IDX) < 0 ? 0 : (IDX)] += tn_ - tprev;              \
-        tprev = tn_;                                                             \
-    }
+    };
+    if (K > 0 && d_begin < d_end) prefetch(d_begin);
+
     for (int d = d_begin; d < d_end; ++d) {
-        MVS_STAMP(-1)
-        // ---- barrier 1 of 2: the boxes (DMA drained) and the tables of plane d are visible.
-        // Memory operations of this wave still in flight here, oldest first: the DMA of plane d, then the nst
-        // result stores of plane d-1.  vmcnt(nst) retires the DMA and leaves the
-        // stores alone (waiting for their acknowledgements every plane was the longest stall of the loop).  hipcc
-        // does not carry a pending LDS-DMA across the loop back-edge, and with an inline wait in front of the
-        // barrier it also left out the lgkmcnt(0) for the table writes (rare stale reads): both are written out.
-        if (d == d_begin || nst < 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (nst == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if (nst == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else if (nst == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if (nst == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        MVS_STAMP(0)
-        const bool more = (d + 1 < d_end);
-        // boxes / table entries of plane d+2: requested here, so their latency hides behind the taps of plane d and
-        // the only older memory operations they can be queued behind are the (long finished) stores of plane d-1
-        int4 bm[KK];
-        uint4 em[ITER];
-        const bool more2 = (K > 0) && (d + 2 < d_end);
-        if (more2) {
-            MVS_LOAD_BOXES(d + 2, bm)
-            MVS_LOAD_ENTRIES(d + 2, em)
+        // ---- P1: footprint boxes (block-uniform scalars, computed once per tile by the coords kernel)
+        int bx0[KK], bx1[KK], by0[KK], by1[KK], nc[KK], nr[KK];
+        bool staged[KK];
+        // make sure the prefetched values have landed before the DMA below is queued behind them
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) asm volatile("" ::"v"(en[it].x), "v"(en[it].y), "v"(en[it].z), "v"(en[it].w));
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int4 b = bn[j];
+            bx0[j] = __builtin_amdgcn_readfirstlane(b.x);
+            bx1[j] = __builtin_amdgcn_readfirstlane(b.y);
+            by0[j] = __builtin_amdgcn_readfirstlane(b.z);
+            by1[j] = __builtin_amdgcn_readfirstlane(b.w);
+            nc[j] = bx1[j] - bx0[j] + 1;
+            nr[j] = by1[j] - by0[j] + 1;
+            staged[j] = (bx1[j] >= bx0[j]) && (by1[j] >= by0[j]) && (nc[j] * nr[j] <= box_cap);
         }
+        // the previous plane's tile reads (P5) must be over before the box storage is refilled
+        if (d != d_begin) __syncthreads();
+        if (K > 0 && staged[0]) load_box(0, bx0[0], by0[0], nc[0], nr[0]);  // in flight while the table is decoded
+        // ---- table entry -> weights + tap offsets (float4 units, lane slot g not yet added)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
+            if (j < K) {
+                const int p = tid % kTilePix;
+                const uint4 e = en[it];
+                const int x0 = (int)(e.x & 0xffffu) - 1, y0 = (int)(e.x >> 16) - 1;
+                const float wx = __uint_as_float(e.y), wy = __uint_as_float(e.z);
+                const float ex = 1.0f - wx, sy = 1.0f - wy;
+                const float wnw = sy * ex, wne = sy * wx, wsw = wy * ex, wse = wy * wx;
+                float4 w;  // an outside tap carries weight*0, so Inf/NaN positions give NaN as ATen-CPU does
+                w.x = ((e.w & 5u) == 5u) ? wnw : wnw * 0.0f;
+                w.y = ((e.w & 6u) == 6u) ? wne : wne * 0.0f;
+                w.z = ((e.w & 9u) == 9u) ? wsw : wsw * 0.0f;
+                w.w = ((e.w & 10u) == 10u) ? wse : wse * 0.0f;
+                s_w[j][p] = w;
+                int lox = 0, hix = W - 1, loy = 0, hiy = H - 1, pitch = W;
+#pragma unroll
+                for (int jj = 0; jj < K; ++jj)
+                    if (jj == j && staged[jj]) { lox = bx0[jj]; hix = bx1[jj]; loy = by0[jj]; hiy = by1[jj]; pitch = nc[jj]; }
+                const int xa = clampi(x0, lox, hix) - lox, xb = clampi(x0 + 1, lox, hix) - lox;
+                const int ya = (clampi(y0, loy, hiy) - loy) * pitch, yb = (clampi(y0 + 1, loy, hiy) - loy) * pitch;
+                s_off[j][p] = make_int4((ya + xa) * 8, (ya + xb) * 8, (yb + xa) * 8, (yb + xb) * 8);
+            }
+        }
+
         float S_[4][4], Q_[4][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             S_[s][0] = f[s].x; S_[s][1] = f[s].y; S_[s][2] = f[s].z; S_[s][3] = f[s].w;
             Q_[s][0] = f[s].x * f[s].x; Q_[s][1] = f[s].y * f[s].y; Q_[s][2] = f[s].z * f[s].z; Q_[s][3] = f[s].w * f[s].w;
         }
-        // ---- taps -> warped value -> running sums, all neighbours back to back.  The LDS and the global variant
-        // are separate loops on purpose: a per-tap select between them makes the compiler emit FLAT loads.
-#define MVS_ACCUMULATE(T0, T1, T2, T3)                                                                  \
-    {                                                                                                   \
-        const float a0[4] = {T0.x, T0.y, T0.z, T0.w}, a1[4] = {T1.x, T1.y, T1.z, T1.w};                 \
-        const float a2[4] = {T2.x, T2.y, T2.z, T2.w}, a3[4] = {T3.x, T3.y, T3.z, T3.w};                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
-            float v = a0[i] * w.x;                                                                      \
-            v = fmaf(a1[i], w.y, v);                                                                    \
-            v = fmaf(a2[i], w.z, v);                                                                    \
-            v = fmaf(a3[i], w.w, v);                                                                    \
-            S_[s][i] = S_[s][i] + v;                                                                    \
-            Q_[s][i] = fmaf(v, v, Q_[s][i]);                                                            \
-        }                                                                                               \
-    }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if (c_stg[j]) {  // block-uniform
+            if (j > 0 && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
+            if (staged[j] || j == 0) __syncthreads();  // box (and, for the first neighbour, the tables) visible
+            if (j == 0 && d + 1 < d_end) prefetch(d + 1);     // lands while the taps below are computed
+            // ---- P3: taps -> warped value -> running sums
+            if (staged[j]) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const int p = 4 * q + s;
+                    const int p = (wave * 4 + s) * 8 + ps;
                     const int4 o = s_off[j][p];
                     const float4 w = s_w[j][p];
                     const float4 t0 = s_box[o.x + g], t1 = s_box[o.y + g], t2 = s_box[o.z + g], t3 = s_box[o.w + g];
-                    MVS_ACCUMULATE(t0, t1, t2, t3)
+                    const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};
+                    const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = a0[i] * w.x;
+                        v = fmaf(a1[i], w.y, v);
+                        v = fmaf(a2[i], w.z, v);
+                        v = fmaf(a3[i], w.w, v);
+                        S_[s][i] = S_[s][i] + v;
+                        Q_[s][i] = fmaf(v, v, Q_[s][i]);
+                    }
                 }
-            } else {  // footprint too large for the pool (or empty): taps straight from the slab image (L2)
+            } else {  // fallback: footprint too large (or empty): taps straight from the slab image
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const int p = 4 * q + s;
+                    const int p = (wave * 4 + s) * 8 + ps;
                     const int4 o = s_off[j][p];
                     const float4 w = s_w[j][p];
                     const float4* b = nb_img[j] + g;
                     const float4 t0 = b[o.x], t1 = b[o.y], t2 = b[o.z], t3 = b[o.w];
-                    MVS_ACCUMULATE(t0, t1, t2, t3)
+                    const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};
+                    const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = a0[i] * w.x;
+                        v = fmaf(a1[i], w.y, v);
+                        v = fmaf(a2[i], w.z, v);
+                        v = fmaf(a3[i], w.w, v);
+                        S_[s][i] = S_[s][i] + v;
+                        Q_[s][i] = fmaf(v, v, Q_[s][i]);
+                    }
                 }
             }
+            if (staged[j]) __syncthreads();  // box fully read before it is overwritten (next neighbour / output tile)
         }
-#undef MVS_ACCUMULATE
-        MVS_STAMP(1)
-        // ---- barrier 2 of 2: every wave is done with the boxes and tables of plane d
-        int m_bx0[KK], m_by0[KK], m_bx1[KK], m_by1[KK], m_nc[KK], m_nr[KK], m_base[KK];
-        bool m_stg[KK];
-        if (more2) MVS_UNPACK_BOXES(bm, m_bx0, m_by0, m_bx1, m_by1, m_nc, m_nr, m_base, m_stg)
-        if (K > 0 && more) {
-            __syncthreads();
-            MVS_STAMP(2)
-            // next plane's boxes fly while this plane's results are stored and its tables decoded; nothing else is
-            // requested from memory between here and the loop top (the counted vmcnt there relies on it)
-            MVS_ISSUE_DMA(n_bx0, n_by0, n_nc, n_nr, n_base, n_stg)
-        }
-        MVS_STAMP(3)
-        // ---- variance, stored straight from registers: channel 8*i + g, 4 consecutive pixels
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = slab * kSlab + 8 * i + g;
-            float r_[4];
+        // ---- P4: variance -> output tile [channel row 8*i+g][pixel]
+        float* s_tile = reinterpret_cast<float*>(s_box);
+        {
+            float* t = s_tile + g * kTileStride + wave * 32 + ps;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float m = S_[s][i] * rcp;
-                r_[s] = fmaf(-m, m, Q_[s][i] * rcp);
-            }
-            if (c < C) {
-                float* dst = var + st_idx[i];
-                // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs
-                if (st_vec) {
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    const v4f vv = {r_[0], r_[1], r_[2], r_[3]};
-                    if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
-                    else *reinterpret_cast<v4f*>(dst) = vv;
-                } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        if (s < st_n) dst[s] = r_[s];
+                for (int i = 0; i < 4; ++i) {
+                    const float m = S_[s][i] * rcp;
+                    t[8 * i * kTileStride + s * 8] = fmaf(-m, m, Q_[s][i] * rcp);
                 }
             }
         }
+        __syncthreads();
+        // ---- P5: wave w stores channel rows 8*w .. 8*w+7, two rows per instruction, 16 bytes per lane
+        {
+            const float* t = s_tile + (wave * 8 + sh) * kTileStride + 4 * sq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st_idx[i] += HW;
-        MVS_STAMP(4)
-        if (K > 0 && more) {
-            MVS_DECODE(en, n_bx0, n_by0, n_bx1, n_by1, n_nc, n_base, n_stg)
+            for (int k = 0; k < 4; ++k) {
+                const int c = slab * kSlab + wave * 8 + 2 * k + sh;
+                const float4 v = *reinterpret_cast<const float4*>(t + 2 * k * kTileStride);
+                if (c < C) {
+                    float* dst = var + (((size_t)n * C + c) * D + d) * HW + st_off;
+                    // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs
+                    if (st_vec) {
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        const v4f vv = {v.x, v.y, v.z, v.w};
+                        if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
+                        else *reinterpret_cast<v4f*>(dst) = vv;
+                    } else {
+                        const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                c_bx0[j] = n_bx0[j]; c_by0[j] = n_by0[j]; c_bx1[j] = n_bx1[j]; c_by1[j] = n_by1[j];
-                c_nc[j] = n_nc[j]; c_nr[j] = n_nr[j]; c_base[j] = n_base[j]; c_stg[j] = n_stg[j];
-            }
-            if (more2) {
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    n_bx0[j] = m_bx0[j]; n_by0[j] = m_by0[j]; n_bx1[j] = m_bx1[j]; n_by1[j] = m_by1[j];
-                    n_nc[j] = m_nc[j]; n_nr[j] = m_nr[j]; n_base[j] = m_base[j]; n_stg[j] = m_stg[j];
+                        for (int i = 0; i < 4; ++i)
+                            if (i < st_n) dst[i] = a[i];
+                    }
                 }
-#pragma unroll
-                for (int it = 0; it < ITER; ++it) en[it] = em[it];
             }
         }
-        MVS_STAMP(5)
     }
-    if (STAMP && stamps && lane == 0 && blockIdx.x < 65536) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) stamps[((size_t)blockIdx.x * 4 + wave) * 8 + k] = tacc[k];
-    }
-#undef MVS_STAMP
-#undef MVS_READ_BOXES
-#undef MVS_LOAD_BOXES
-#undef MVS_UNPACK_BOXES
-#undef MVS_ISSUE_DMA
-#undef MVS_LOAD_ENTRIES
-#undef MVS_DECODE
 }
 
 }  // namespace mvsdet
