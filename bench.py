@@ -229,6 +229,14 @@ def main():
     value = n_cv / elapsed
     bytes_launch = sweep_bytes_per_cv(w) * w["N"]
     achieved = bytes_launch / (sweep_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes of the same kernel and workload
+    # (profiles/r01_final_sweep_pmc.txt; bench.py cannot collect counters itself)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")) as fh:
+            traffic = json.load(fh).get(name, {}).get("traffic_bytes")
+    except OSError:
+        pass
     line = {
         "metric": "cost volumes/sec (plane-sweep variance, one per reference view) through the full hot path",
         "value": round(value, 3), "unit": "cost volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,8 +247,9 @@ def main():
                    "parallelism": f"scene-sharded x{world}, no data-path collective"},
         "scenes_per_sec": round(args.steps * world / elapsed, 4),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "plane_sweep_variance_kernel<2,TW,NT>", "kernel_ms": round(sweep_ms, 4),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "kernel": "plane_sweep_variance_kernel<2,TW,NT> (+ its plane_sweep_coords_kernel, ~2.5 % of the time)",
+                     "kernel_ms": round(sweep_ms, 4),
                      "algorithmic_bytes_per_launch": bytes_launch},
         "checksum": checksum,
     }

@@ -16,8 +16,17 @@ void set_error(const char* fmt, ...) {
 
 // float4 grid-stride copy: the achievable-HBM yardstick of bench.py (MI355X_MICROARCH: 6.29 TB/s measured).
 __global__ __launch_bounds__(kThreads) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    // 4 independent 16-byte loads in flight per lane before the first store
     const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 __global__ void copy_tail_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t begin, size_t n) {
@@ -39,7 +48,7 @@ extern "C" int mvsdet_copy_f32(const float* src, float* dst, size_t n, mvsdet_st
     const size_t n4 = n / 4;
     if (n4) {
         const size_t want = (n4 + kThreads - 1) / kThreads;
-        const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+        const unsigned grid = (unsigned)(want < 2048 ? want : 2048);  // 256 CUs x 8 blocks, grid-stride the rest
         hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n4);
     }
     if (n % 4) hipLaunchKernelGGL(copy_tail_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, src, dst, n4 * 4, n);

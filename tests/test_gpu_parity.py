@@ -385,3 +385,20 @@ def test_error_behaviour(gpu):
     assert torch.isfinite(out).all()
     rc = _lib.load().mvsdet_homo_warp_f32(None, None, None, None, 1, 1, 1, 2, 2, None)
     assert rc == 1 and b"NULL" in _lib.load().mvsdet_last_error()
+
+
+def test_plane_sweep_is_deterministic(gpu):
+    """The sweep synchronises LDS-DMA, LDS tables and barriers by hand: repeated launches on the reference-true
+    shape must be bit-identical (a missing wait shows up as rare stale reads in a few pixels of one block)."""
+    from mvsdet_amd import ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw = 40, 256, 12, (60, 80)
+    hp = MVSDetHotPath([40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], D)
+    feat = synthetic.make_features(N, C, hw, seed=3, device=gpu)
+    geo = hp.prepare_scene(synthetic.make_img_meta(N, hw, seed=3), gpu)
+    packed = ops.pack_features(feat)
+    ref = ops.plane_sweep_variance_packed(packed, geo.neighbor_ids, geo.proj_rel, geo.depth_values, C, *hw)
+    for _ in range(25):
+        again = ops.plane_sweep_variance_packed(packed, geo.neighbor_ids, geo.proj_rel, geo.depth_values, C, *hw)
+        assert torch.equal(again, ref)
+        del again
