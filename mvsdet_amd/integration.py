@@ -1,0 +1,95 @@
+"""Drop-in wiring for the reference code base (Pixie8888/MVSDet, projects/NeRF-Det/nerfdet/mvsdet.py).
+
+`patch_reference(mvsdet_module)` rebinds, inside the reference's own module, the functions of the hot path to the
+HIP-backed mirrors of this package -- same names, same signatures, same return arity -- so that
+`MVSDet.extract_feat` (mvsdet.py:336-698) runs them without any change to the reference source or to
+projects/NeRF-Det/configs/mvsdet_res50_2x_low_res.py:
+
+    homo_warping           (imported at mvsdet.py:31 from mvs_models/module.py:105)
+    backproject_Weigh      (mvsdet.py:1372)
+    get_nearest_pose_ids   (mvsdet.py:67)      -- same ATen ops, kept for completeness
+    get_points             (mvsdet.py:1316)
+    MVSDet.sample_depth_prob / MVSDet.compute_avg_depth / MVSDet.collect_proj  (mvsdet.py:266, 298, 249)
+
+With mmengine the patch is applied by adding this module to the config's `custom_imports` AFTER the reference
+module; `apply_on_import()` then finds the already imported reference module in sys.modules.
+
+Function-level patching keeps the reference's Python loop structure (k calls of homo_warping, separate softmax,
+per-view volume followed by a sum over views).  The fused path -- one plane-sweep launch for all neighbours, fused
+soft-max/top-k, fused per-voxel mean -- is `mvsdet_amd.hotpath.MVSDetHotPath.forward_scene`, which replaces
+mvsdet.py:404-515 as a block (INTEGRATION.md shows the 12-line edit).
+"""
+from __future__ import annotations
+
+import sys
+
+from . import functional as F_
+
+
+def _sample_depth_prob(self, prob_volume, off_pred, topk=3):
+    from . import ops
+    est_depth, est_dens, _, _ = ops.sample_depth_prob(prob_volume, off_pred, float(self.near_far_range[0]),
+                                                      float(self.depth_interval), int(topk))
+    return est_depth, est_dens
+
+
+def _compute_avg_depth(self, prob_volume, off_pred):
+    from . import ops
+    k = min(3, prob_volume.shape[1])
+    return ops.sample_depth_prob(prob_volume, off_pred, float(self.near_far_range[0]), float(self.depth_interval), k)[3]
+
+
+def _collect_proj(self, w2c, intr, neighbor_ids):
+    return F_.collect_proj(w2c, intr, neighbor_ids)
+
+
+PATCHED_FUNCTIONS = {
+    "homo_warping": F_.homo_warping,
+    "backproject_Weigh": F_.backproject_Weigh,
+    "get_nearest_pose_ids": F_.get_nearest_pose_ids,
+    "knn": F_.knn,
+    "get_points": F_.get_points,
+}
+PATCHED_METHODS = {
+    "sample_depth_prob": _sample_depth_prob,
+    "compute_avg_depth": _compute_avg_depth,
+    "collect_proj": _collect_proj,
+}
+
+
+def patch_reference(mvsdet_module) -> dict:
+    """Rebind the hot-path functions of an imported reference `mvsdet` module; returns {name: original}."""
+    originals = {}
+    for name, fn in PATCHED_FUNCTIONS.items():
+        if hasattr(mvsdet_module, name):
+            originals[name] = getattr(mvsdet_module, name)
+            setattr(mvsdet_module, name, fn)
+    cls = getattr(mvsdet_module, "MVSDet", None)
+    if cls is not None:
+        for name, fn in PATCHED_METHODS.items():
+            if hasattr(cls, name):
+                originals["MVSDet." + name] = getattr(cls, name)
+                setattr(cls, name, fn)
+    return originals
+
+
+def unpatch_reference(mvsdet_module, originals: dict) -> None:
+    for name, fn in originals.items():
+        if name.startswith("MVSDet."):
+            setattr(mvsdet_module.MVSDet, name.split(".", 1)[1], fn)
+        else:
+            setattr(mvsdet_module, name, fn)
+
+
+def apply_on_import() -> bool:
+    """Patch every already-imported module that looks like the reference's mvsdet.py (defines MVSDet,
+    homo_warping and backproject_Weigh).  Returns True if something was patched."""
+    done = False
+    for mod in list(sys.modules.values()):
+        if mod is None or not hasattr(mod, "__dict__"):
+            continue
+        d = mod.__dict__
+        if "MVSDet" in d and "backproject_Weigh" in d and "homo_warping" in d and d["backproject_Weigh"] is not F_.backproject_Weigh:
+            patch_reference(mod)
+            done = True
+    return done
