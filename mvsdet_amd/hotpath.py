@@ -69,7 +69,19 @@ class MVSDetHotPath:
 
     # ---- host-side camera algebra -----------------------------------------------------------------------
     def prepare_scene(self, img_meta: dict, device) -> SceneGeometry:
-        """mvsdet.py:407-450 for one scene, evaluated with ATen-CPU exactly as the reference does, then uploaded."""
+        """mvsdet.py:407-450 for one scene, evaluated with ATen-CPU exactly as the reference does, then uploaded.
+        The tensors are tiny (N 4x4 matrices): run the ATen calls single-threaded -- on a 256-core host the OpenMP
+        fork/join of the default thread pool costs ~10 ms per scene, 10x the GPU time of the reference-true shape."""
+        nthreads = torch.get_num_threads()
+        if nthreads > 1:
+            torch.set_num_threads(1)
+        try:
+            return self._prepare_scene(img_meta, device)
+        finally:
+            if nthreads > 1:
+                torch.set_num_threads(nthreads)
+
+    def _prepare_scene(self, img_meta: dict, device) -> SceneGeometry:
         stride = self.stride
         projection = F_.compute_projection(img_meta, stride)
         points = F_.get_points(n_voxels=torch.tensor(self.n_voxels), voxel_size=torch.tensor(self.voxel_size),
