@@ -108,6 +108,8 @@ int num_tiles(int H, int W, int tw) {
     return ((W + tw - 1) / tw) * ((H + th - 1) / th);
 }
 
+unsigned long long* g_stamps = nullptr;  // diagnostic runs only (mvsdet_debug_set_stamp_buffer)
+
 template <int TW, bool NT>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var,
                  void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream) {
@@ -136,13 +138,17 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     case KV:                                                                                                          \
         hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads), 0, stream, proj, depth, table,  \
                            boxes, D, H, W, tiles_x, tiles, d_per_block);                                               \
-        hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT>), grid, dim3(kThreads), 0, stream, packed, nbr,    \
-                           table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap);                 \
+        if (g_stamps)                                                                                                 \
+            hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, true>), grid, dim3(kThreads), 0, stream, packed, \
+                               nbr, table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, \
+                               nbr, table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
         break;
     switch (K) {
         case 0:
-            hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT>), grid, dim3(kThreads), 0, stream, packed, nbr,
-                               table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap);
+            hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, nbr,
+                               table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
             break;
         MVS_SWEEP_CASE(1)
         MVS_SWEEP_CASE(2)
@@ -154,6 +160,10 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     return MVSDET_OK;
 }
 }  // namespace
+
+// Diagnostic hook (not part of include/mvsdet_hip.h): a device buffer of 65536*4*8 u64 makes the next sweeps run the
+// instrumented instantiation, which adds up the cycles each wave spends per loop segment.  NULL switches it off.
+extern "C" void mvsdet_debug_set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W) {
     if (N <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;

@@ -154,11 +154,11 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
 // ---------------------------------------------------------------------------------------------
 // (2) the slab kernel
 // ---------------------------------------------------------------------------------------------
-template <int K, int TW, bool NT>
+template <int K, int TW, bool NT, bool STAMP>
 __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const uint4* __restrict__ table,
     const int4* __restrict__ boxes, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int d_per_block, int box_cap) {
+    int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
     constexpr int ITER = (KK * kTilePix + kThreads - 1) / kThreads;
@@ -246,7 +246,18 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     };
     if (K > 0 && d_begin < d_end) prefetch(d_begin);
 
+    // diagnostic instantiation only (STAMP, tools/stamp_sweep.py): cycles per loop segment, summed per wave
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define MVS_STAMP(IDX)                                                           \
+    if (STAMP) {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();             \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        if ((IDX) >= 0) tacc[(IDX) < 0 ? 0 : (IDX)] += tn_ - tprev;              \
+        tprev = tn_;                                                             \
+    }
     for (int d = d_begin; d < d_end; ++d) {
+        MVS_STAMP(-1)
         // ---- P1: footprint boxes (block-uniform scalars, computed once per tile by the coords kernel)
         int bx0[KK], bx1[KK], by0[KK], by1[KK], nc[KK], nr[KK];
         bool staged[KK];
@@ -266,6 +277,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         }
         // the previous plane's tile reads (P5) must be over before the box storage is refilled
         if (d != d_begin) __syncthreads();
+        MVS_STAMP(0)  // unpack boxes + wait for the prefetch + barrier (previous tile reads)
         if (K > 0 && staged[0]) load_box(0, bx0[0], by0[0], nc[0], nr[0]);  // in flight while the table is decoded
         // ---- table entry -> weights + tap offsets (float4 units, lane slot g not yet added)
 #pragma unroll
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
             }
         }
 
+        MVS_STAMP(1)  // DMA issue of neighbour 0 + decode
         float S_[4][4], Q_[4][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -304,6 +317,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         for (int j = 0; j < K; ++j) {
             if (j > 0 && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
             if (staged[j] || j == 0) __syncthreads();  // box (and, for the first neighbour, the tables) visible
+            MVS_STAMP(2 + 2 * (j > 0 ? 1 : 0))  // (DMA issue of neighbour j>0) + wait for the box + barrier
             if (j == 0 && d + 1 < d_end) prefetch(d + 1);     // lands while the taps below are computed
             // ---- P3: taps -> warped value -> running sums
             if (staged[j]) {
@@ -347,6 +361,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
                 }
             }
             if (staged[j]) __syncthreads();  // box fully read before it is overwritten (next neighbour / output tile)
+            MVS_STAMP(3 + 2 * (j > 0 ? 1 : 0))  // taps + barrier
         }
         // ---- P4: variance -> output tile [channel row 8*i+g][pixel]
         float* s_tile = reinterpret_cast<float*>(s_box);
@@ -362,6 +377,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
             }
         }
         __syncthreads();
+        MVS_STAMP(6)  // variance -> LDS tile + barrier
         // ---- P5: wave w stores channel rows 8*w .. 8*w+7, two rows per instruction, 16 bytes per lane
         {
             const float* t = s_tile + (wave * 8 + sh) * kTileStride + 4 * sq;
@@ -386,7 +402,13 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
                 }
             }
         }
+        MVS_STAMP(7)  // tile -> global stores
     }
+    if (STAMP && stamps && lane == 0 && blockIdx.x < 65536) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) stamps[((size_t)blockIdx.x * 4 + wave) * 8 + kk] = tacc[kk];
+    }
+#undef MVS_STAMP
 }
 
 }  // namespace mvsdet

@@ -24,11 +24,11 @@ for stamped in (False, True, True):
     print("stamped" if stamped else "plain", e0.elapsed_time(e1), "ms")
     del var
 lib.mvsdet_debug_set_stamp_buffer(None)
-t = buf.view(65536, 4, 8)[:, :, :6].double()
+t = buf.view(65536, 4, 8).double()
 t = t[t.sum(dim=(1, 2)) > 0]
 per = t.mean(dim=(0, 1)) / w["D"]
-names = ["wait+barrier1", "taps(P3)", "barrier2", "dma issue+prefetch", "variance+stores", "decode"]
+names = ["boxes+prefetch wait+barrier", "dma0 issue+decode", "box0 wait+barrier", "taps0+barrier", "dma1 issue+wait+barrier", "taps1+barrier", "variance->tile+barrier", "tile->global stores"]
 tot = per.sum().item()
 for n_, v in zip(names, per.tolist()):
-    print(f"{n_:22s} {v:9.0f} cycles/plane  {100 * v / tot:5.1f} %")
+    print(f"{n_:30s} {v:9.0f} cycles/plane  {100 * v / tot:5.1f} %")
 print("total", tot, "cycles per plane per wave; blocks sampled", t.shape[0])
