@@ -58,7 +58,10 @@ def test_plane_sweep_variance_golden(gpu, oracle, tag):
     (3, 1, 7, 2, 6, 5),       # C < 8, k = 1
     (2, 0, 12, 3, 8, 8),      # no neighbour: variance of a single view is 0
     (6, 4, 64, 2, 12, 16),    # k = 4
-    (2, 2, 300, 2, 10, 12),   # C > 256: two channel chunks
+    (2, 2, 300, 2, 10, 12),   # C > 256: more than 8 slabs
+    (50, 2, 32, 96, 12, 16),  # BASELINE config 4 plane / view counts (ARKit-like: 50 views, 96 planes)
+    (4, 2, 64, 128, 10, 12),  # BASELINE config 5 plane count
+    (3, 2, 32, 5, 33, 47),    # odd map: ragged tiles in x and y, unaligned rows (scalar store path)
 ])
 def test_plane_sweep_variance_shapes(gpu, oracle, N, K, C, D, H, W):
     from mvsdet_amd import functional as F_, ops, synthetic
