@@ -87,6 +87,15 @@ int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* n
                                            const float* depth, float* var, void* scratch,
                                            size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
                                            mvsdet_stream_t stream);
+/* The two halves of the call above, for callers that want to time / overlap / reuse them:
+ *   mvsdet_plane_sweep_table_f32           builds the sampling table of a scene's geometry into `scratch`;
+ *   mvsdet_plane_sweep_variance_tabled_f32 runs the per-channel sweep on a table built by it for the SAME
+ *                                          (N,K,D,H,W) (table_bytes = the scratch size passed there). */
+int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,
+                                 int N, int K, int D, int H, int W, mvsdet_stream_t stream);
+int mvsdet_plane_sweep_variance_tabled_f32(const float* packed, const int64_t* nbr, const void* table,
+                                           size_t table_bytes, float* var, int N, int K, int C, int D, int H,
+                                           int W, mvsdet_stream_t stream);
 int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,
                                     const float* depth, float* var, void* workspace, size_t workspace_bytes,
                                     int N, int K, int C, int D, int H, int W, mvsdet_stream_t stream);

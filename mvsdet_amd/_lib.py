@@ -29,6 +29,8 @@ SIGNATURES = {
     "mvsdet_plane_sweep_scratch_bytes": [_i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_variance_packed_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_table_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_variance_tabled_f32": [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_depth_prob_topk_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],

@@ -112,7 +112,8 @@ unsigned long long* g_stamps = nullptr;  // diagnostic runs only (mvsdet_debug_s
 
 template <int TW, bool NT>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var,
-                 void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream) {
+                 void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases = 3) {
+    // phases: bit 0 = build the sampling table (coords kernel), bit 1 = run the slab kernel
     constexpr int TH = kTilePix / TW;
     const int S = num_slabs(C);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -136,8 +137,10 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
 #define MVS_SWEEP_CASE(KV)                                                                                            \
     case KV:                                                                                                          \
-        hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads), 0, stream, proj, depth, table,  \
-                           boxes, D, H, W, tiles_x, tiles, d_per_block);                                               \
+        if (phases & 1)                                                                                               \
+            hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads), 0, stream, proj, depth,    \
+                               table, boxes, D, H, W, tiles_x, tiles, d_per_block);                                   \
+        if (!(phases & 2)) break;                                                                                     \
         if (g_stamps)                                                                                                 \
             hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, true>), grid, dim3(kThreads), 0, stream, packed, \
                                nbr, table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
@@ -147,7 +150,8 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         break;
     switch (K) {
         case 0:
-            hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, nbr,
+            if (phases & 2)
+                hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, nbr,
                                table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
             break;
         MVS_SWEEP_CASE(1)
@@ -173,30 +177,51 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
     return (size_t)N * tiles * D * K * (kTilePix + 1) * 16;
 }
 
-extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
-                                                      const float* depth, float* var, void* scratch,
-                                                      size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
-                                                      mvsdet_stream_t stream) {
-    MVS_REQUIRE(packed && var, "plane_sweep_variance: NULL pointer");
-    MVS_REQUIRE(K == 0 || (nbr && proj && depth && scratch), "plane_sweep_variance: NULL neighbour arrays / scratch with K=%d", K);
-    MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "plane_sweep_variance: bad shape N=%d C=%d D=%d H=%d W=%d", N,
-                C, D, H, W);
-    MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "plane_sweep_variance: K=%d outside [0,%d]", K, MVSDET_MAX_NEIGHBORS);
-    MVS_REQUIRE(D <= 65535 && H < 65535 && W < 65535, "plane_sweep_variance: D, H or W > 65534");
-    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "plane_sweep_variance: one slab image exceeds 2^31 elements");
+static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,
+                       float* var, void* scratch, size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
+                       mvsdet_stream_t stream, int phases) {
+    MVS_REQUIRE(!(phases & 2) || (packed && var), "%s: NULL pointer", name);
+    MVS_REQUIRE(K == 0 || scratch, "%s: NULL scratch with K=%d", name, K);
+    MVS_REQUIRE(K == 0 || !(phases & 1) || (proj && depth), "%s: NULL proj / depth", name);
+    MVS_REQUIRE(K == 0 || !(phases & 2) || nbr, "%s: NULL neighbour ids", name);
+    MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "%s: bad shape N=%d C=%d D=%d H=%d W=%d", name, N, C, D, H, W);
+    MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "%s: K=%d outside [0,%d]", name, K, MVSDET_MAX_NEIGHBORS);
+    MVS_REQUIRE(D <= 65535 && H < 65535 && W < 65535, "%s: D, H or W > 65534", name);
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "%s: one slab image exceeds 2^31 elements", name);
     if (scratch_bytes < mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)) {
-        set_error("plane_sweep_variance: scratch %zu B < %zu B", scratch_bytes, mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W));
+        set_error("%s: scratch %zu B < %zu B", name, scratch_bytes, mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W));
         return MVSDET_ERR_WORKSPACE;
     }
-    MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "plane_sweep_variance: scratch must be 16-byte aligned");
+    MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "%s: scratch must be 16-byte aligned", name);
     const int tw = pick_tile_width(W);
     const char* ent = getenv("MVSDET_SWEEP_NT");
     const bool nt = ent ? atoi(ent) != 0 : true;
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st)
-                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st);
-    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st)
-              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st);
+    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases)
+                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases);
+    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases)
+              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases);
+}
+
+extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
+                                                      const float* depth, float* var, void* scratch,
+                                                      size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
+                                                      mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_variance", packed, nbr, proj, depth, var, scratch, scratch_bytes, N, K, C, D, H, W,
+                       stream, 3);
+}
+
+extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,
+                                            int N, int K, int D, int H, int W, mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_table", nullptr, nullptr, proj, depth, nullptr, scratch, scratch_bytes, N, K, 1, D, H, W,
+                       stream, 1);
+}
+
+extern "C" int mvsdet_plane_sweep_variance_tabled_f32(const float* packed, const int64_t* nbr, const void* table,
+                                                      size_t table_bytes, float* var, int N, int K, int C, int D, int H,
+                                                      int W, mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_variance_tabled", packed, nbr, nullptr, nullptr, var, const_cast<void*>(table),
+                       table_bytes, N, K, C, D, H, W, stream, 2);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,

@@ -122,6 +122,50 @@ def _(packed, nbr, proj, depth, C, H, W):
     return packed.new_empty((nbr.shape[0], C, depth.shape[1], H, W))
 
 
+@torch.library.custom_op(f"{_NS}::plane_sweep_table", mutates_args=(), device_types="cuda")
+def plane_sweep_table(proj: Tensor, depth: Tensor, H: int, W: int) -> Tensor:
+    """Channel-independent sampling table of a scene (16 B per view, neighbour, plane, pixel): proj (N,K,4,4),
+    depth (N,D) -> opaque flat buffer for plane_sweep_variance_tabled."""
+    _req(proj, "proj", dim=4)
+    _req(depth, "depth", dim=2)
+    N, K = proj.shape[:2]
+    D = depth.shape[1]
+    lib = _lib.load()
+    sbytes = lib.mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)
+    table = torch.empty(max(sbytes // 4, 4), dtype=torch.float32, device=proj.device)
+    proj, depth = proj.contiguous(), depth.contiguous()
+    with torch.cuda.device(proj.device):
+        _lib.check(lib.mvsdet_plane_sweep_table_f32(_lib.ptr(proj), _lib.ptr(depth), _lib.ptr(table), sbytes, N, K, D, H, W,
+                                                    _stream(proj)), "plane_sweep_table")
+    return table
+
+
+@plane_sweep_table.register_fake
+def _(proj, depth, H, W):
+    return proj.new_empty(4)
+
+
+@torch.library.custom_op(f"{_NS}::plane_sweep_variance_tabled", mutates_args=(), device_types="cuda")
+def plane_sweep_variance_tabled(packed: Tensor, nbr: Tensor, table: Tensor, C: int, D: int, H: int, W: int) -> Tensor:
+    """The per-channel half of the sweep on a table from plane_sweep_table -> (N,C,D,H,W)."""
+    _req(packed, "packed", dim=1)
+    _req(nbr, "nbr", dtype=torch.int64, dim=2)
+    _req(table, "table", dim=1)
+    N, K = nbr.shape
+    nbr = nbr.contiguous()
+    out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=packed.device)
+    with torch.cuda.device(packed.device):
+        _lib.check(_lib.load().mvsdet_plane_sweep_variance_tabled_f32(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(table),
+                                                                      table.numel() * 4, _lib.ptr(out), N, K, C, D, H, W,
+                                                                      _stream(packed)), "plane_sweep_variance_tabled")
+    return out
+
+
+@plane_sweep_variance_tabled.register_fake
+def _(packed, nbr, table, C, D, H, W):
+    return packed.new_empty((nbr.shape[0], C, D, H, W))
+
+
 @torch.library.custom_op(f"{_NS}::plane_sweep_variance", mutates_args=(), device_types="cuda")
 def plane_sweep_variance(feat: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor) -> Tensor:
     """a3+a4 (mvsdet.py:439-467): feat (N,C,H,W), nbr (N,K) int64, proj (N,K,4,4), depth (N,D) -> (N,C,D,H,W)."""

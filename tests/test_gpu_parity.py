@@ -405,3 +405,19 @@ def test_plane_sweep_is_deterministic(gpu):
         again = ops.plane_sweep_variance_packed(packed, geo.neighbor_ids, geo.proj_rel, geo.depth_values, C, *hw)
         assert torch.equal(again, ref)
         del again
+
+
+def test_sweep_split_entry_points(gpu, oracle):
+    """table + tabled sweep (the two halves of the packed entry point) == the one-call form."""
+    from mvsdet_amd import ops
+    g = load_golden("g2_variance_n3_d8")
+    feat = dev(g["feature"], gpu)
+    N, C, H, W = feat.shape
+    nbr, proj, depth = dev(g["neighbor_ids"], gpu), dev(g["proj_rel"], gpu), dev(g["depth_values"], gpu)
+    packed = ops.pack_features(feat)
+    table = ops.plane_sweep_table(proj, depth, H, W)
+    a = ops.plane_sweep_variance_tabled(packed, nbr, table, C, depth.shape[1], H, W)
+    b = ops.plane_sweep_variance_packed(packed, nbr, proj, depth, C, H, W)
+    assert torch.equal(a, b)
+    ref = oracle.plane_sweep_variance(g["feature"], g["neighbor_ids"], g["proj_rel"], g["depth_values"], mode=1)
+    np.testing.assert_array_equal(a.cpu().numpy(), ref)
