@@ -36,6 +36,8 @@ WORKLOADS = {
     "scannet_ref_40v_12d_60x80": dict(N=40, C=256, D=12, H=60, W=80, near_far=(0.2, 5.0), per_view_K=False),
     # BASELINE.json configs[3]
     "arkit_50v_96d_60x80": dict(N=50, C=256, D=96, H=60, W=80, near_far=(0.5, 5.5), per_view_K=True),
+    # BASELINE.json configs[4] at C=32 (fp32, unchunked: 126 GB cost volume; the C=256 fp16 form needs view chunks)
+    "stress_100v_128d_240x320_c32": dict(N=100, C=32, D=128, H=240, W=320, near_far=(0.2, 5.0), per_view_K=False),
     # BASELINE.json configs[0] (plumbing)
     "tiny_3v_8d_48x64": dict(N=3, C=32, D=8, H=48, W=64, near_far=(0.2, 5.0), per_view_K=False),
 }
@@ -85,13 +87,17 @@ def run_gpu(args, w, rank, world, device):
 
     barrier = parallel.barrier if world > 1 else (lambda: None)
 
+    out = None
     for i in range(args.warmup):
+        out = None
         out = step(i, False)
     del out
     barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
+    out = None
     for i in range(args.steps):
+        out = None  # release the previous cost volume before the next one is allocated (126 GB at the stress shape)
         out = step(i, True)
     torch.cuda.synchronize(device)
     barrier()
