@@ -101,7 +101,9 @@ int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const
                                     int N, int K, int C, int D, int H, int W, mvsdet_stream_t stream);
 /* backward of the above w.r.t. feat (the sampling grid carries no gradient, module.py:115).
  *   g (N,C,D,H,W) = dL/dvar;  gfeat (N,C,H,W) is OVERWRITTEN with dL/dfeat.
- *   workspace_bytes >= 2*mvsdet_packed_bytes(N,C,H,W)  (packed features + packed gradient). */
+ *   workspace_bytes >= mvsdet_plane_sweep_bwd_workspace_bytes(N,K,C,D,H,W)
+ *   (packed features + packed gradient + sampling table). */
+size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, int D, int H, int W);
 int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, const float* proj,
                                         const float* depth, const float* g, float* gfeat, void* workspace,
                                         size_t workspace_bytes, int N, int K, int C, int D, int H, int W,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mvsdet_plane_sweep_table_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_tabled_f32": [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_bwd_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_variance_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_depth_prob_topk_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "mvsdet_sample_depth_prob_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
@@ -47,7 +48,8 @@ SIGNATURES = {
     "mvsdet_copy_f32": [_vp, _vp, _sz, _vp],
 }
 _RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_packed_bytes": ctypes.c_size_t,
-            "mvsdet_plane_sweep_scratch_bytes": ctypes.c_size_t, "mvsdet_plane_sweep_workspace_bytes": ctypes.c_size_t}
+            "mvsdet_plane_sweep_scratch_bytes": ctypes.c_size_t, "mvsdet_plane_sweep_workspace_bytes": ctypes.c_size_t,
+            "mvsdet_plane_sweep_bwd_workspace_bytes": ctypes.c_size_t}
 
 
 def build(verbose: bool = False) -> str:

@@ -169,6 +169,10 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
 // instrumented instantiation, which adds up the cycles each wave spends per loop segment.  NULL switches it off.
 extern "C" void mvsdet_debug_set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
 
+namespace mvsdet {
+int sweep_tile_width(int W) { return pick_tile_width(W); }  // shared with planesweep_bwd.hip
+}
+
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W) {
     if (N <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     // sampling table (16 B per view, neighbour, plane, tile pixel) + footprint boxes (16 B per view, neighbour,

@@ -188,7 +188,7 @@ def plane_sweep_variance_backward(feat: Tensor, nbr: Tensor, proj: Tensor, depth
         raise ValueError("plane_sweep_variance_backward: grad shape mismatch")
     feat, nbr, proj, depth, grad = feat.contiguous(), nbr.contiguous(), proj.contiguous(), depth.contiguous(), grad.contiguous()
     lib = _lib.load()
-    wbytes = 2 * lib.mvsdet_packed_bytes(N, C, H, W)
+    wbytes = lib.mvsdet_plane_sweep_bwd_workspace_bytes(N, K, C, D, H, W)
     ws = torch.empty(wbytes // 4, dtype=torch.float32, device=feat.device)
     gfeat = torch.empty_like(feat)
     with torch.cuda.device(feat.device):
