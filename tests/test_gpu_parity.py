@@ -421,3 +421,41 @@ def test_sweep_split_entry_points(gpu, oracle):
     assert torch.equal(a, b)
     ref = oracle.plane_sweep_variance(g["feature"], g["neighbor_ids"], g["proj_rel"], g["depth_values"], mode=1)
     np.testing.assert_array_equal(a.cpu().numpy(), ref)
+
+
+def test_training_step_through_forward_scene(gpu):
+    """Training configuration in miniature: a trainable stand-in for CostRegNet_3DGS between the stages; one
+    optimiser step through a1..a10 (what DDP wraps on 8 GPUs).  Gradients reach the 2-D features and the module."""
+    from mvsdet_amd import synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    torch.manual_seed(0)
+    N, C, D, hw = 4, 32, 12, (60, 80)
+    net = torch.nn.Conv3d(C, 2, 3, padding=1).to(gpu)
+    hp = MVSDetHotPath([40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], D, topk=3, cost_regularization=net)
+    meta = synthetic.make_img_meta(N, hw, seed=11)
+    feat = synthetic.make_features(N, C, hw, seed=11).to(gpu).requires_grad_(True)
+    opt = torch.optim.SGD(list(net.parameters()), lr=1e-3)
+    out = hp.forward_scene(feat, meta)
+    loss = out["volume"].pow(2).mean() + out["depth_coding"].mean() + 0.1 * out["prob_volume"].max(dim=1)[0].mean()
+    loss.backward()
+    assert torch.isfinite(feat.grad).all() and feat.grad.abs().sum().item() > 0
+    for p in net.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum().item() > 0
+    before = [p.detach().clone() for p in net.parameters()]
+    opt.step()
+    assert any(not torch.equal(a, b) for a, b in zip(before, net.parameters()))
+    # the op-level gradient agrees with a central finite difference of the loss in a random feature direction
+    with torch.no_grad():
+        v = torch.randn_like(feat)
+        v /= v.norm()
+    def L(f_):
+        with torch.no_grad():
+            o = hp.forward_scene(f_, meta)
+            return (o["variance"].double() ** 2).mean()
+    feat.grad = None
+    o = hp.forward_scene(feat, meta)
+    (o["variance"].double() ** 2).mean().backward()
+    eps = 1e-2
+    fd = (L(feat.detach() + eps * v) - L(feat.detach() - eps * v)) / (2 * eps)
+    an = (feat.grad.double() * v.double()).sum()
+    assert abs(fd.item() - an.item()) <= 2e-2 * max(abs(an.item()), 1e-6) + 1e-7, (fd.item(), an.item())
