@@ -459,3 +459,74 @@ def test_training_step_through_forward_scene(gpu):
     fd = (L(feat.detach() + eps * v) - L(feat.detach() - eps * v)) / (2 * eps)
     an = (feat.grad.double() * v.double()).sum()
     assert abs(fd.item() - an.item()) <= 2e-2 * max(abs(an.item()), 1e-6) + 1e-7, (fd.item(), an.item())
+
+
+def test_sweep_variants_are_bit_identical(gpu, monkeypatch):
+    """The tuning knobs only change the schedule: tile shape 16x8 vs 32x4, LDS-staged boxes vs the global-gather
+    fallback (what a footprint larger than the LDS box takes) and plain vs non-temporal stores give the same bits."""
+    from mvsdet_amd import ops
+    g = load_golden("g2_variance_n3_d8")
+    feat = dev(g["feature"], gpu)
+    N, C, H, W = feat.shape
+    args = (ops.pack_features(feat), dev(g["neighbor_ids"], gpu), dev(g["proj_rel"], gpu), dev(g["depth_values"], gpu), C, H, W)
+    ref = ops.plane_sweep_variance_packed(*args)
+    for env in ({"MVSDET_SWEEP_TW": "16"}, {"MVSDET_SWEEP_TW": "32"}, {"MVSDET_SWEEP_BOXCAP": "0"},
+                {"MVSDET_SWEEP_BOXCAP": "40"}, {"MVSDET_SWEEP_NT": "0"}, {"MVSDET_SWEEP_TW": "16", "MVSDET_SWEEP_BOXCAP": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = ops.plane_sweep_variance_packed(*args)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert torch.equal(out, ref), env
+
+
+def test_sweep_degenerate_geometry(gpu, oracle):
+    """Planes through the source camera centre (z == 0 -> Inf/NaN sample positions), views entirely behind the
+    source camera and wildly out-of-image footprints: no fault, and the same values as the oracle (NaN where the
+    reference's ATen-CPU path produces NaN)."""
+    from mvsdet_amd import ops
+    N, K, C, D, H, W = 3, 2, 8, 4, 12, 16
+    gen = torch.Generator().manual_seed(5)
+    feat = torch.randn(N, C, H, W, generator=gen)
+    nbr = torch.tensor([[1, 2], [2, 0], [0, 1]])
+    proj = torch.eye(4).repeat(N, K, 1, 1)
+    proj[0, 0, 2, :] = torch.tensor([0.0, 0.0, 0.0, 0.0])        # z = 0 for every pixel and plane -> NaN / Inf
+    proj[0, 1, 2, :] = torch.tensor([0.0, 0.0, -1.0, -0.5])      # z < 0: mirrored positions, finite
+    proj[1, 0, 0, 3] = 1e6                                        # far outside the image: all taps invalid
+    proj[1, 1, :3, :3] *= 40.0                                    # 40x scale: footprint larger than any LDS box
+    proj[2, 0, 0, 3], proj[2, 0, 1, 3] = 3.3, -2.1                # ordinary shift
+    depth = torch.tensor([0.5, 1.0, 2.0, 4.0]).repeat(N, 1)
+    out = ops.plane_sweep_variance(feat.to(gpu), nbr.to(gpu), proj.to(gpu), depth.to(gpu)).cpu().numpy()
+    ref = oracle.plane_sweep_variance(feat, nbr, proj, depth, mode=1)
+    assert np.isnan(ref[0]).any() and np.isfinite(ref[1:]).all()
+    np.testing.assert_array_equal(np.isnan(out), np.isnan(ref))
+    np.testing.assert_array_equal(out[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+def test_full_size_64_plane_shape(gpu, oracle):
+    """BASELINE configs[1] at full size (40 views, 64 planes, 120x160, C=256: a 50 GB cost volume): exact x4
+    scaling, finiteness, and a slice (one reference view, 8 channels) recomputed by the oracle on the 3-view
+    sub-scene {view, neighbour 0, neighbour 1}."""
+    free = torch.cuda.mem_get_info(gpu)[0]
+    if free < 130 * (1 << 30):
+        pytest.skip("needs ~110 GB of free HBM")
+    from mvsdet_amd import ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw = 40, 256, 64, (120, 160)
+    hp = MVSDetHotPath([40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], D)
+    feat = synthetic.make_features(N, C, hw, seed=1, device=gpu)
+    geo = hp.prepare_scene(synthetic.make_img_meta(N, hw, seed=1), gpu)
+    var = ops.plane_sweep_variance(feat, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+    assert var.shape == (N, C, D, 120, 160)
+    n0, ch = 17, [0, 31, 32, 100, 129, 200, 254, 255]
+    nb = geo.neighbor_ids[n0].tolist()
+    sub_feat = feat[[n0] + nb][:, ch].cpu()
+    sub = oracle.plane_sweep_variance(sub_feat, np.array([[1, 2], [0, 2], [0, 1]]), np.stack(
+        [geo.proj_rel[n0].cpu().numpy()] * 3), geo.depth_values[:3].cpu(), mode=1)
+    np.testing.assert_array_equal(var[n0, ch].cpu().numpy(), sub[0])
+    mn = float(var.min())
+    assert mn > -1e-4 and bool(torch.isfinite(var[::7, ::31]).all())
+    var2 = ops.plane_sweep_variance(feat * 2.0, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+    step = 5  # compare in slabs to keep temporaries small
+    for i in range(0, N, step):
+        assert torch.equal(var2[i:i + step], var[i:i + step] * 4.0)
