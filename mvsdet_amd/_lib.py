@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvsdet_hip.so")
+# MVSDET_HIP_LIB: load another build of the same C ABI (kernel A/B runs); the default is the in-tree library
+LIB_PATH = os.environ.get("MVSDET_HIP_LIB") or os.path.join(_HERE, "libmvsdet_hip.so")
 _lib = None
 
 _vp = ctypes.c_void_p
