@@ -87,6 +87,14 @@ int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* n
                                            const float* depth, float* var, void* scratch,
                                            size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
                                            mvsdet_stream_t stream);
+/* View shard of the same sweep (intra-scene split): the M reference views ref_first .. ref_first+M-1
+ * of a scene whose N_src views are ALL in `packed` (neighbours are arbitrary views).  nbr (M,K) holds GLOBAL view
+ * ids; nbr, proj (M,K,4,4), depth (M,D), var (M,C,D,H,W) and scratch (sized for M views) are indexed by the local
+ * view.  Row m of the result is bit-identical to row ref_first+m of the unsharded call. */
+int mvsdet_plane_sweep_variance_shard_f32(const float* packed, const int64_t* nbr, const float* proj,
+                                          const float* depth, float* var, void* scratch, size_t scratch_bytes,
+                                          int N_src, int ref_first, int M, int K, int C, int D, int H, int W,
+                                          mvsdet_stream_t stream);
 /* The two halves of the call above, for callers that want to time / overlap / reuse them:
  *   mvsdet_plane_sweep_table_f32           builds the sampling table of a scene's geometry into `scratch`;
  *   mvsdet_plane_sweep_variance_tabled_f32 runs the per-channel sweep on a table built by it for the SAME
@@ -157,6 +165,14 @@ int mvsdet_backproject_weigh_mean_packed_f32(const float* packed, const float* p
                                              const int64_t* dd_strides /*HOST[4]*/, float* mean, int32_t* count,
                                              int N, int C, int H, int W, int h, int w, int V, int J, float vz,
                                              mvsdet_stream_t stream);
+/* Same kernel without the division: sum (C,V) = sum_i volume_i over the N views handed in, count (V).  A rank that
+ * owns a contiguous shard of the views passes packed / projection / depth / dens offset to its first view; the
+ * ranks' sums and counts are then all-reduced and divided once (mvsdet_amd/parallel.py). */
+int mvsdet_backproject_weigh_sum_packed_f32(const float* packed, const float* points, const float* projection,
+                                            const float* depth, const float* dens,
+                                            const int64_t* dd_strides /*HOST[4]*/, float* sum, int32_t* count,
+                                            int N, int C, int H, int W, int h, int w, int V, int J, float vz,
+                                            mvsdet_stream_t stream);
 /* backward of a9 w.r.t. features and dens (depth carries no gradient).
  *   g (N,C,V); gfeat (N,C,h,w) dense and gdens (N,J,h,w) dense are OVERWRITTEN. */
 int mvsdet_backproject_weigh_bwd_f32(const float* feat, const int64_t* feat_strides /*HOST[4]*/, const float* points,

@@ -30,6 +30,7 @@ SIGNATURES = {
     "mvsdet_plane_sweep_scratch_bytes": [_i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_variance_packed_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_variance_shard_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_table_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_tabled_f32": [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
@@ -42,6 +43,8 @@ SIGNATURES = {
                                      _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_backproject_weigh_mean_packed_f32": [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp,
                                                  _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "mvsdet_backproject_weigh_sum_packed_f32": [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp,
+                                                _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_backproject_weigh_bwd_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp,
                                          _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_backproject_weigh_mean_bwd_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp,

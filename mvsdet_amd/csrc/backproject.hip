@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void backproject_mean_kernel(
     const float* __restrict__ packed, const float* __restrict__ points, const float* __restrict__ projection,
     const float* __restrict__ depth, const float* __restrict__ dens, int64_t ds0, int64_t ds1, int64_t ds2, int64_t ds3,
     float* __restrict__ mean, int32_t* __restrict__ count, int N, int C, int G, int H, int W, int h, int w, int V, int J,
-    float vz, int lp_log2) {
+    float vz, int lp_log2, int normalize) {
     constexpr int PW = TP / 4;
     constexpr int MAXSTEPS = PW;  // PPI >= 1
     __shared__ float s_tile[256 * (TP + 1)];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void backproject_mean_kernel(
                 if (gvalid) {
                     float* t = s_tile + gl * (TP + 1) + p;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) t[i * rg * (TP + 1)] = cnt[s] > 0 ? acc[s][i] / den : 0.0f;
+                    for (int i = 0; i < 4; ++i) t[i * rg * (TP + 1)] = !normalize ? acc[s][i] : (cnt[s] > 0 ? acc[s][i] / den : 0.0f);
                 }
                 if (ci == 0 && gl == 0 && v0 + p < V) count[v0 + p] = cnt[s];
             }
@@ -253,14 +253,14 @@ extern "C" int mvsdet_backproject_weigh_f32(const float* feat, const int64_t* fs
     return MVSDET_OK;
 }
 
-extern "C" int mvsdet_backproject_weigh_mean_packed_f32(const float* packed, const float* points, const float* projection,
-                                                        const float* depth, const float* dens, const int64_t* ds,
-                                                        float* mean, int32_t* count, int N, int C, int H, int W, int h,
-                                                        int w, int V, int J, float vz, mvsdet_stream_t stream) {
-    MVS_REQUIRE(packed && points && projection && depth && dens && ds && mean && count, "backproject_weigh_mean: NULL pointer");
-    if (int rc = check_stage3("backproject_weigh_mean", N, C, h, w, V, J)) return rc;
-    MVS_REQUIRE(h <= H && w <= W, "backproject_weigh_mean: crop %dx%d exceeds map %dx%d", h, w, H, W);
-    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "backproject_weigh_mean: one slab image exceeds 2^31 elements");
+static int launch_stage3_fused(const char* name, const float* packed, const float* points, const float* projection,
+                               const float* depth, const float* dens, const int64_t* ds, float* out, int32_t* count, int N,
+                               int C, int H, int W, int h, int w, int V, int J, float vz, mvsdet_stream_t stream,
+                               int normalize) {
+    MVS_REQUIRE(packed && points && projection && depth && dens && ds && out && count, "%s: NULL pointer", name);
+    if (int rc = check_stage3(name, N, C, h, w, V, J)) return rc;
+    MVS_REQUIRE(h <= H && w <= W, "%s: crop %dx%d exceeds map %dx%d", name, h, w, H, W);
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "%s: one slab image exceeds 2^31 elements", name);
     constexpr int TP = 32;
     const int G = 8 * num_slabs(C);  // channel groups of 4, slab padding included
     int lp_log2 = 0;
@@ -268,10 +268,26 @@ extern "C" int mvsdet_backproject_weigh_mean_packed_f32(const float* packed, con
     while ((64 >> lp_log2) > TP / 4) ++lp_log2;
     dim3 grid((V + TP - 1) / TP);
     hipLaunchKernelGGL((backproject_mean_kernel<TP>), grid, dim3(kThreads), 0, (hipStream_t)stream, packed, points,
-                       projection, depth, dens, ds[0], ds[1], ds[2], ds[3], mean, count, N, C, G, H, W, h, w, V, J, vz,
-                       lp_log2);
-    MVS_LAUNCH_CHECK("backproject_weigh_mean");
+                       projection, depth, dens, ds[0], ds[1], ds[2], ds[3], out, count, N, C, G, H, W, h, w, V, J, vz,
+                       lp_log2, normalize);
+    MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
+}
+
+extern "C" int mvsdet_backproject_weigh_mean_packed_f32(const float* packed, const float* points, const float* projection,
+                                                        const float* depth, const float* dens, const int64_t* ds,
+                                                        float* mean, int32_t* count, int N, int C, int H, int W, int h,
+                                                        int w, int V, int J, float vz, mvsdet_stream_t stream) {
+    return launch_stage3_fused("backproject_weigh_mean", packed, points, projection, depth, dens, ds, mean, count, N, C, H,
+                               W, h, w, V, J, vz, stream, 1);
+}
+
+extern "C" int mvsdet_backproject_weigh_sum_packed_f32(const float* packed, const float* points, const float* projection,
+                                                       const float* depth, const float* dens, const int64_t* ds,
+                                                       float* sum, int32_t* count, int N, int C, int H, int W, int h,
+                                                       int w, int V, int J, float vz, mvsdet_stream_t stream) {
+    return launch_stage3_fused("backproject_weigh_sum", packed, points, projection, depth, dens, ds, sum, count, N, C, H,
+                               W, h, w, V, J, vz, stream, 0);
 }
 
 static int launch_stage3_bwd(const char* name, const float* feat, const int64_t* fs, const float* points,

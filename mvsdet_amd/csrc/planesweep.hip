@@ -112,8 +112,11 @@ unsigned long long* g_stamps = nullptr;  // diagnostic runs only (mvsdet_debug_s
 
 template <int TW, bool NT>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var,
-                 void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases = 3) {
+                 void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
+                 int ref_first) {
     // phases: bit 0 = build the sampling table (coords kernel), bit 1 = run the slab kernel
+    // N reference views starting at view ref_first of the n_src packed source views (a view shard; N == n_src
+    // and ref_first == 0 for a whole scene); nbr / proj / depth / var / scratch are indexed by the LOCAL view
     constexpr int TH = kTilePix / TW;
     const int S = num_slabs(C);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -135,6 +138,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     int4* boxes = reinterpret_cast<int4*>(table + (size_t)N * tiles * D * K * kTilePix);
     dim3 cgrid((unsigned)(N * tiles), (D + d_per_block - 1) / d_per_block);
     dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
+    const float* ref_packed = packed ? packed + (size_t)ref_first * S * H * W * kSlab : nullptr;
 #define MVS_SWEEP_CASE(KV)                                                                                            \
     case KV:                                                                                                          \
         if (phases & 1)                                                                                               \
@@ -143,16 +147,16 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         if (!(phases & 2)) break;                                                                                     \
         if (g_stamps)                                                                                                 \
             hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, true>), grid, dim3(kThreads), 0, stream, packed, \
-                               nbr, table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
+                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
         else                                                                                                          \
             hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, \
-                               nbr, table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
+                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
         break;
     switch (K) {
         case 0:
             if (phases & 2)
-                hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, nbr,
-                               table, boxes, var, N, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
+                hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, ref_packed, nbr,
+                               table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
             break;
         MVS_SWEEP_CASE(1)
         MVS_SWEEP_CASE(2)
@@ -183,7 +187,10 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
 
 static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,
                        float* var, void* scratch, size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
-                       mvsdet_stream_t stream, int phases) {
+                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0) {
+    if (n_src < 0) n_src = N;
+    MVS_REQUIRE(ref_first >= 0 && N <= n_src && ref_first <= n_src - N,
+                "%s: reference views [%d, %d) outside the %d packed views", name, ref_first, ref_first + N, n_src);
     MVS_REQUIRE(!(phases & 2) || (packed && var), "%s: NULL pointer", name);
     MVS_REQUIRE(K == 0 || scratch, "%s: NULL scratch with K=%d", name, K);
     MVS_REQUIRE(K == 0 || !(phases & 1) || (proj && depth), "%s: NULL proj / depth", name);
@@ -201,10 +208,10 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     const char* ent = getenv("MVSDET_SWEEP_NT");
     const bool nt = ent ? atoi(ent) != 0 : true;
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases)
-                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases);
-    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases)
-              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases);
+    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first)
+                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first);
+    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first)
+              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
@@ -213,6 +220,14 @@ extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const
                                                       mvsdet_stream_t stream) {
     return sweep_entry("plane_sweep_variance", packed, nbr, proj, depth, var, scratch, scratch_bytes, N, K, C, D, H, W,
                        stream, 3);
+}
+
+extern "C" int mvsdet_plane_sweep_variance_shard_f32(const float* packed, const int64_t* nbr, const float* proj,
+                                                     const float* depth, float* var, void* scratch,
+                                                     size_t scratch_bytes, int N_src, int ref_first, int M, int K, int C,
+                                                     int D, int H, int W, mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_variance_shard", packed, nbr, proj, depth, var, scratch, scratch_bytes, M, K, C, D, H,
+                       W, stream, 3, N_src, ref_first);
 }
 
 extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,

@@ -156,8 +156,8 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
 // ---------------------------------------------------------------------------------------------
 template <int K, int TW, bool NT, bool STAMP>
 __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
-    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const uint4* __restrict__ table,
-    const int4* __restrict__ boxes, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
+    const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
+    const uint4* __restrict__ table, const int4* __restrict__ boxes, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
     int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it scalar
     const int g = lane & 7, ps = lane >> 3;
     const size_t slab_stride = (size_t)HW * kSlab;       // floats per (view, slab) image
-    const float* ref_img = packed + ((size_t)n * S + slab) * slab_stride;
+    // ref_packed = packed + first reference view of this launch (a view shard); N bounds the NEIGHBOUR ids
+    const float* ref_img = ref_packed + ((size_t)n * S + slab) * slab_stride;
     const float4* nb_img[KK];
 #pragma unroll
     for (int j = 0; j < K; ++j) {

@@ -122,6 +122,42 @@ def _(packed, nbr, proj, depth, C, H, W):
     return packed.new_empty((nbr.shape[0], C, depth.shape[1], H, W))
 
 
+@torch.library.custom_op(f"{_NS}::plane_sweep_variance_shard", mutates_args=(), device_types="cuda")
+def plane_sweep_variance_shard(packed: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor, n_src: int, ref_first: int,
+                               C: int, H: int, W: int) -> Tensor:
+    """a3+a4 for the reference views ref_first .. ref_first+M-1 of a scene whose n_src views are all in `packed`
+    (intra-scene view sharding).  nbr (M,K) holds global view ids -> (M,C,D,H,W), bit-identical to the
+    same rows of plane_sweep_variance_packed.  Forward only."""
+    _req(packed, "packed", dim=1)
+    _req(nbr, "nbr", dtype=torch.int64, dim=2)
+    _req(proj, "proj", dim=4)
+    _req(depth, "depth", dim=2)
+    M, K = nbr.shape
+    D = depth.shape[1]
+    lib = _lib.load()
+    if packed.numel() * 4 != lib.mvsdet_packed_bytes(n_src, C, H, W):
+        raise ValueError("plane_sweep_variance_shard: packed buffer does not match (n_src,C,H,W)")
+    if proj.shape != (M, K, 4, 4) or depth.shape[0] != M:
+        raise ValueError("plane_sweep_variance_shard: proj/depth shape mismatch")
+    if M < 1 or ref_first < 0 or ref_first + M > n_src:
+        raise ValueError(f"plane_sweep_variance_shard: views [{ref_first},{ref_first + M}) outside the {n_src} packed views")
+    nbr, proj, depth = nbr.contiguous(), proj.contiguous(), depth.contiguous()
+    out = torch.empty((M, C, D, H, W), dtype=torch.float32, device=packed.device)
+    sbytes = lib.mvsdet_plane_sweep_scratch_bytes(M, K, D, H, W)
+    scratch = torch.empty(max(sbytes // 4, 4), dtype=torch.float32, device=packed.device)
+    with torch.cuda.device(packed.device):
+        _lib.check(lib.mvsdet_plane_sweep_variance_shard_f32(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(proj),
+                                                             _lib.ptr(depth), _lib.ptr(out), _lib.ptr(scratch), sbytes,
+                                                             n_src, ref_first, M, K, C, D, H, W, _stream(packed)),
+                   "plane_sweep_variance_shard")
+    return out
+
+
+@plane_sweep_variance_shard.register_fake
+def _(packed, nbr, proj, depth, n_src, ref_first, C, H, W):
+    return packed.new_empty((nbr.shape[0], C, depth.shape[1], H, W))
+
+
 @torch.library.custom_op(f"{_NS}::plane_sweep_table", mutates_args=(), device_types="cuda")
 def plane_sweep_table(proj: Tensor, depth: Tensor, H: int, W: int) -> Tensor:
     """Channel-independent sampling table of a scene (16 B per view, neighbour, plane, pixel): proj (N,K,4,4),
@@ -468,6 +504,47 @@ def _(features, packed, points, projection, est_depth, est_dens, H, W, vz):
     C = features.shape[1]
     V = points.numel() // 3
     return features.new_empty((C, V)), features.new_empty((V,), dtype=torch.int32)
+
+
+@torch.library.custom_op(f"{_NS}::backproject_weigh_sum_shard", mutates_args=(), device_types="cuda")
+def backproject_weigh_sum_shard(packed: Tensor, points: Tensor, projection: Tensor, est_depth: Tensor, est_dens: Tensor,
+                                n_src: int, ref_first: int, C: int, H: int, W: int, vz: float) -> Tuple[Tensor, Tensor]:
+    """a9 summed over the M views ref_first .. ref_first+M-1 only, NOT divided (the a10 division happens after the
+    ranks' sums and counts are all-reduced).  projection (M,3,4), est_depth / est_dens (M,J,h,w) are the shard's;
+    `packed` holds all n_src views.  -> sum (C,V) fp32, count (V) int32.  Forward only."""
+    _req(packed, "packed", dim=1)
+    _req(points, "points")
+    _req(projection, "projection", dim=3)
+    _req(est_depth, "est_depth", dim=4)
+    _req(est_dens, "est_dens", dim=4)
+    M, J, h, w = est_depth.shape
+    V = points.numel() // 3
+    lib = _lib.load()
+    if packed.numel() * 4 != lib.mvsdet_packed_bytes(n_src, C, H, W):
+        raise ValueError("backproject_weigh_sum_shard: packed buffer does not match (n_src,C,H,W)")
+    if points.shape[0] != 3 or projection.shape != (M, 3, 4) or est_dens.shape != est_depth.shape:
+        raise ValueError("backproject_weigh_sum_shard: points / projection / est_dens shape mismatch")
+    if M < 1 or ref_first < 0 or ref_first + M > n_src:
+        raise ValueError(f"backproject_weigh_sum_shard: views [{ref_first},{ref_first + M}) outside the {n_src} packed views")
+    if est_depth.stride() != est_dens.stride():
+        est_depth, est_dens = est_depth.contiguous(), est_dens.contiguous()
+    points, projection = points.contiguous(), projection.contiguous()
+    dev = packed.device
+    total = torch.empty((C, V), dtype=torch.float32, device=dev)
+    count = torch.empty((V,), dtype=torch.int32, device=dev)
+    view_floats = lib.mvsdet_packed_bytes(1, C, H, W) // 4
+    with torch.cuda.device(dev):
+        _lib.check(lib.mvsdet_backproject_weigh_sum_packed_f32(
+            _lib.ptr(packed[view_floats * ref_first:]), _lib.ptr(points), _lib.ptr(projection), _lib.ptr(est_depth),
+            _lib.ptr(est_dens), _lib.strides4(est_depth), _lib.ptr(total), _lib.ptr(count), M, C, H, W, h, w, V, J, vz,
+            _stream(packed)), "backproject_weigh_sum_shard")
+    return total, count
+
+
+@backproject_weigh_sum_shard.register_fake
+def _(packed, points, projection, est_depth, est_dens, n_src, ref_first, C, H, W, vz):
+    V = points.numel() // 3
+    return packed.new_empty((C, V)), packed.new_empty((V,), dtype=torch.int32)
 
 
 @torch.library.custom_op(f"{_NS}::backproject_weigh_mean_backward", mutates_args=(), device_types="cuda")

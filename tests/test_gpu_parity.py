@@ -530,3 +530,55 @@ def test_full_size_64_plane_shape(gpu, oracle):
     step = 5  # compare in slabs to keep temporaries small
     for i in range(0, N, step):
         assert torch.equal(var2[i:i + step], var[i:i + step] * 4.0)
+
+
+# --------------------------------------------------------------------------------------------- view shards (8e)
+def test_view_shards_reassemble_the_scene(gpu, oracle):
+    """Intra-scene split: the per-shard sweep rows are bit-identical to the unsharded rows, the shards' stage-3
+    sums and counts add up to the fused mean, and parallel.forward_scene_view_sharded (one rank) agrees with
+    MVSDetHotPath.forward_scene."""
+    from mvsdet_amd import ops, parallel, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw = 7, 40, 12, (24, 32)
+    hp = MVSDetHotPath([16, 16, 8], [.4, .4, .4], [0.2, 5.0], D)
+    meta = synthetic.make_img_meta(N, hw, seed=4)
+    feat = synthetic.make_features(N, C, hw, seed=4).to(gpu)
+    logits = synthetic.make_cost_logits(N, D, hw, seed=4, sharp=2.0).to(gpu)
+    full = hp.forward_scene(feat, meta, cost_logits=logits)
+    geo = full["geometry"]
+    packed = ops.pack_features(feat)
+    stages = parallel.HipStages(hp)
+    total = torch.zeros((C, 16 * 16 * 8), device=gpu)
+    count = torch.zeros((16 * 16 * 8,), dtype=torch.int32, device=gpu)
+    for world in (2, 3):
+        total.zero_(); count.zero_()
+        for rank in range(world):
+            first, m = parallel.view_shard(N, rank, world)
+            var = stages.cost_volume_shard(packed, geo, first, m, N, C, *hw)
+            assert torch.equal(var, full["variance"][first:first + m])
+            prob, off, ed, en, _, avg = stages.depth_distribution(logits[first:first + m])
+            assert torch.equal(ed[:, :, :geo.height, :geo.width], full["est_depth"][first:first + m])
+            s, c = stages.lift_sum_shard(packed, geo, ed, en, first, m, N, C, *hw)
+            total += s
+            count += c
+        assert torch.equal(count.view_as(full["valid"][0]).long(), full["valid"][0])
+        mean = torch.where(count > 0, total / (count + 1e-8), torch.zeros((), device=gpu)).view_as(full["volume"])
+        np.testing.assert_allclose(mean.cpu().numpy(), full["volume"].cpu().numpy(), rtol=0, atol=2e-6)
+    # the un-normalised sum of ALL views against the oracle's per-view volumes
+    h, w = geo.height, geo.width
+    o = oracle.backproject_weigh(feat.cpu().numpy()[:, :, :h, :w], geo.points.reshape(3, -1).cpu().numpy(),
+                                 geo.projection.cpu().numpy(), full["est_depth"].cpu().numpy(),
+                                 full["est_densities"].cpu().numpy(), hp.voxel_size[-1])
+    prob, off, ed, en, _, avg = stages.depth_distribution(logits)
+    s, c = stages.lift_sum_shard(packed, geo, ed, en, 0, N, N, C, *hw)
+    np.testing.assert_array_equal(c.cpu().numpy(), o["valid"].sum(0))
+    acc = np.zeros_like(o["volume"][0])
+    for i in range(N):                       # ascending view order, the kernel's order
+        acc = acc + o["volume"][i]
+    np.testing.assert_array_equal(s.cpu().numpy(), acc)
+    one = parallel.forward_scene_view_sharded(hp, feat, meta, cost_logits=logits)
+    assert one["view_range"] == (0, N) and torch.equal(one["valid"], full["valid"])
+    assert torch.equal(one["variance"], full["variance"]) and torch.equal(one["depth_coding"], full["depth_coding"])
+    np.testing.assert_allclose(one["volume"].cpu().numpy(), full["volume"].cpu().numpy(), rtol=0, atol=2e-6)
+    with pytest.raises(ValueError):
+        ops.plane_sweep_variance_shard(packed, geo.neighbor_ids[:3], geo.proj_rel[:3], geo.depth_values[:3], N, 5, C, *hw)
