@@ -38,6 +38,10 @@ WORKLOADS = {
     "arkit_50v_96d_60x80": dict(N=50, C=256, D=96, H=60, W=80, near_far=(0.5, 5.5), per_view_K=True),
     # BASELINE.json configs[4] at C=32 (fp32, unchunked: 126 GB cost volume; the C=256 fp16 form needs view chunks)
     "stress_100v_128d_240x320_c32": dict(N=100, C=32, D=128, H=240, W=320, near_far=(0.2, 5.0), per_view_K=False),
+    # BASELINE.json configs[4] as worded: C=256, fp16 features and fp16 cost volume (503 GB) produced in chunks of
+    # 10 reference views (50 GB each, consumed and released before the next chunk)
+    "stress_100v_128d_240x320_c256_f16": dict(N=100, C=256, D=128, H=240, W=320, near_far=(0.2, 5.0), per_view_K=False,
+                                              half=True, chunk=10),
     # BASELINE.json configs[0] (plumbing)
     "tiny_3v_8d_48x64": dict(N=3, C=32, D=8, H=48, W=64, near_far=(0.2, 5.0), per_view_K=False),
 }
@@ -46,8 +50,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 
 
 def sweep_bytes_per_cv(w, K=2):
-    """(K+1)*C*H*W*4 read + C*D*H*W*4 written per cost volume."""
-    return (K + 1) * w["C"] * w["H"] * w["W"] * 4 + w["C"] * w["D"] * w["H"] * w["W"] * 4
+    """(K+1)*C*H*W*b read + C*D*H*W*b written per cost volume (b = 4 fp32, 2 fp16)."""
+    b = 2 if w.get("half") else 4
+    return (K + 1) * w["C"] * w["H"] * w["W"] * b + w["C"] * w["D"] * w["H"] * w["W"] * b
 
 
 class SceneInputs:
@@ -56,6 +61,8 @@ class SceneInputs:
         hw = (w["H"], w["W"])
         self.meta = synthetic.make_img_meta(w["N"], hw, seed=seed, per_view_intrinsics=w["per_view_K"])
         self.features = synthetic.make_features(w["N"], w["C"], hw, seed=seed, device=device)
+        if w.get("half"):
+            self.features = self.features.half()
         self.cost_logits = synthetic.make_cost_logits(w["N"], w["D"], hw, seed=seed, device=device)
 
 
@@ -68,7 +75,23 @@ def run_gpu(args, w, rank, world, device):
     torch.cuda.synchronize(device)
     ev = []
 
+    def step_chunked(i, timed):
+        """Cost volume produced in chunks of reference views (fp16 storage); every launch is one chunk."""
+        s = scenes[i % len(scenes)]
+        geo = hp.prepare_scene(s.meta, device)
+        packed = ops.pack_features(s.features)
+        keep = None
+        for first, var in hp.cost_volume_chunks(packed, geo, w["C"], w["H"], w["W"], w["chunk"], half_out=w.get("half", False),
+                                                events=ev if timed else None):
+            keep = var[0, 0, 0].float().abs().sum().reshape(1, 1, 1)  # the consumer stand-in touches the chunk, then drops it
+            del var
+        prob, off, est_depth, est_dens, est_idx, avg = hp.depth_distribution(s.cost_logits)
+        vol, valid = hp.lift_packed(packed, geo, est_depth, est_dens, w["C"], w["H"], w["W"])
+        return keep, vol, valid
+
     def step(i, timed):
+        if w.get("chunk"):
+            return step_chunked(i, timed)
         s = scenes[i % len(scenes)]
         feat = s.features
         geo = hp.prepare_scene(s.meta, device)
@@ -241,7 +264,9 @@ def main():
     elapsed, sweep_ms, checksum, hp, scenes = run_gpu(args, w, rank, world, device)
     n_cv = w["N"] * args.steps * world
     value = n_cv / elapsed
-    bytes_launch = sweep_bytes_per_cv(w) * w["N"]
+    # one launch = the reference views of one scene, or of one view chunk for the chunked workload (there the
+    # events bracket the table kernel too: the shard entry point enqueues both)
+    bytes_launch = sweep_bytes_per_cv(w) * (w.get("chunk") or w["N"])
     achieved = bytes_launch / (sweep_ms * 1e-3) / 1e9
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes of the same kernel and workload
     # (profiles/r01_final_sweep_pmc.txt; bench.py cannot collect counters itself)
@@ -255,7 +280,7 @@ def main():
         "metric": "cost volumes/sec (plane-sweep variance, one per reference view) through the full hot path",
         "value": round(value, 3), "unit": "cost volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (f16 storage)" if w.get("half") else "f32", "data": "synthetic",
         "config": {"workload": name, "views": w["N"], "neighbors": 2, "channels": w["C"], "depth_planes": w["D"],
                    "feat_hw": [w["H"], w["W"]], "voxels": N_VOXELS, "scenes_per_step_per_gpu": 1,
                    "parallelism": f"scene-sharded x{world}, no data-path collective"},
@@ -267,7 +292,9 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_launch},
         "checksum": checksum,
     }
-    if rank == 0 and world == 1 and not args.no_extras:
+    if w.get("chunk"):
+        line["config"]["views_per_launch"] = w["chunk"]
+    if rank == 0 and world == 1 and not args.no_extras and not w.get("chunk"):
         line["stage_ms"] = stage_breakdown(w, hp, scenes[0], device)
         del scenes
         torch.cuda.empty_cache()
@@ -285,7 +312,7 @@ def main():
                                             "sweep_GBps": round(br / (sm * 1e-3) / 1e9, 1),
                                             "stage_ms": stage_breakdown(wr, hp_r, sc_r[0], device)}
             del sc_r
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and not w.get("half"):
         line["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
     if rank == 0:

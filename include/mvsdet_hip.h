@@ -56,6 +56,10 @@ const char* mvsdet_last_error(void);
 size_t mvsdet_packed_bytes(int N, int C, int H, int W);
 int mvsdet_pack_features_f32(const float* feat, const int64_t* feat_strides /*HOST[4]*/, float* packed,
                              int N, int C, int H, int W, mvsdet_stream_t stream);
+/* Same for IEEE binary16 feature maps (BASELINE configs[4], `--amp` style fp16 features): element strides of the
+ * half tensor; the packed maps are fp32 (conversion is exact), so every consumer below is unchanged. */
+int mvsdet_pack_features_f16(const void* feat_f16, const int64_t* feat_strides /*HOST[4]*/, float* packed,
+                             int N, int C, int H, int W, mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a3  homo_warping -- mvs_models/module.py:105-146.
@@ -93,6 +97,13 @@ int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* n
  * view.  Row m of the result is bit-identical to row ref_first+m of the unsharded call. */
 int mvsdet_plane_sweep_variance_shard_f32(const float* packed, const int64_t* nbr, const float* proj,
                                           const float* depth, float* var, void* scratch, size_t scratch_bytes,
+                                          int N_src, int ref_first, int M, int K, int C, int D, int H, int W,
+                                          mvsdet_stream_t stream);
+/* fp16 storage of the cost volume: identical fp32 arithmetic, var_f16 (M,C,D,H,W) IEEE binary16 = the fp32 result
+ * rounded to nearest-even at the store (values above 65504 become +inf).  Halves the write stream, which is 96 % of
+ * the sweep's bytes; with view shards it is how the 100-view / 128-plane / 240x320 configuration fits in HBM. */
+int mvsdet_plane_sweep_variance_shard_f16(const float* packed, const int64_t* nbr, const float* proj,
+                                          const float* depth, void* var_f16, void* scratch, size_t scratch_bytes,
                                           int N_src, int ref_first, int M, int K, int C, int D, int H, int W,
                                           mvsdet_stream_t stream);
 /* The two halves of the call above, for callers that want to time / overlap / reuse them:

@@ -26,11 +26,13 @@ SIGNATURES = {
     "mvsdet_last_error": [],
     "mvsdet_packed_bytes": [_i, _i, _i, _i],
     "mvsdet_pack_features_f32": [_vp, _i64p, _vp, _i, _i, _i, _i, _vp],
+    "mvsdet_pack_features_f16": [_vp, _i64p, _vp, _i, _i, _i, _i, _vp],
     "mvsdet_homo_warp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_scratch_bytes": [_i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_variance_packed_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_shard_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_variance_shard_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_table_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_tabled_f32": [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],

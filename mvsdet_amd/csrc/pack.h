@@ -11,6 +11,7 @@
 //
 // Kernels are static: each translation unit that launches them carries its own copy (no -fgpu-rdc).
 #pragma once
+#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace mvsdet {
@@ -19,9 +20,14 @@ constexpr int kSlab = 32;  // channels per slab
 
 __host__ __device__ __forceinline__ int num_slabs(int C) { return (C + kSlab - 1) / kSlab; }
 
+__device__ __forceinline__ float load_as_float(const float* p) { return *p; }
+__device__ __forceinline__ float load_as_float(const __half* p) { return __half2float(*p); }  // exact
+
 // One block = 64 pixels x one slab.  Reads are coalesced along W (256 B per channel row), writes are
-// 128-byte texels, 8 KiB contiguous per block.
-static __global__ __launch_bounds__(kThreads) void pack_features_kernel(const float* __restrict__ feat, int64_t s0,
+// 128-byte texels, 8 KiB contiguous per block.  InT = float, or __half for fp16 feature maps (the packed
+// maps stay fp32: they are 4 % of the sweep's traffic and the arithmetic is fp32 either way).
+template <typename InT>
+static __global__ __launch_bounds__(kThreads) void pack_features_kernel(const InT* __restrict__ feat, int64_t s0,
                                                                          int64_t s1, int64_t s2, int64_t s3,
                                                                          float* __restrict__ packed, int C, int S,
                                                                          int H, int W) {
@@ -32,11 +38,11 @@ static __global__ __launch_bounds__(kThreads) void pack_features_kernel(const fl
     {
         const int pix = pix0 + lane;
         const int y = pix / W, x = pix - y * W;
-        const float* src = feat + (int64_t)n * s0 + (int64_t)y * s2 + (int64_t)x * s3;
+        const InT* src = feat + (int64_t)n * s0 + (int64_t)y * s2 + (int64_t)x * s3;
         for (int r = wave; r < kSlab; r += 4) {
             const int c = s * kSlab + r;
             float v = 0.0f;
-            if (pix < HW && c < C) v = src[(int64_t)c * s1];
+            if (pix < HW && c < C) v = load_as_float(src + (int64_t)c * s1);
             tile[r][lane] = v;
         }
     }

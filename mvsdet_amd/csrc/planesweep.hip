@@ -68,18 +68,29 @@ extern "C" size_t mvsdet_packed_bytes(int N, int C, int H, int W) {
     return (size_t)N * num_slabs(C) * H * W * kSlab * sizeof(float);
 }
 
-extern "C" int mvsdet_pack_features_f32(const float* feat, const int64_t* fs, float* packed, int N, int C, int H, int W,
-                                        mvsdet_stream_t stream) {
-    MVS_REQUIRE(feat && fs && packed, "pack_features: NULL pointer");
-    MVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "pack_features: bad shape N=%d C=%d H=%d W=%d", N, C, H, W);
-    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "pack_features: one slab image exceeds 2^31 elements");
-    MVS_REQUIRE(N <= 65535 && num_slabs(C) <= 65535, "pack_features: N or C too large");
+template <typename InT>
+static int pack_entry(const char* name, const InT* feat, const int64_t* fs, float* packed, int N, int C, int H, int W,
+                      mvsdet_stream_t stream) {
+    MVS_REQUIRE(feat && fs && packed, "%s: NULL pointer", name);
+    MVS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "%s: bad shape N=%d C=%d H=%d W=%d", name, N, C, H, W);
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "%s: one slab image exceeds 2^31 elements", name);
+    MVS_REQUIRE(N <= 65535 && num_slabs(C) <= 65535, "%s: N or C too large", name);
     const int S = num_slabs(C);
     dim3 grid((H * W + 63) / 64, S, N);
-    hipLaunchKernelGGL(pack_features_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, feat, fs[0], fs[1], fs[2],
+    hipLaunchKernelGGL(pack_features_kernel<InT>, grid, dim3(kThreads), 0, (hipStream_t)stream, feat, fs[0], fs[1], fs[2],
                        fs[3], packed, C, S, H, W);
-    MVS_LAUNCH_CHECK("pack_features");
+    MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
+}
+
+extern "C" int mvsdet_pack_features_f32(const float* feat, const int64_t* fs, float* packed, int N, int C, int H, int W,
+                                        mvsdet_stream_t stream) {
+    return pack_entry<float>("pack_features", feat, fs, packed, N, C, H, W, stream);
+}
+
+extern "C" int mvsdet_pack_features_f16(const void* feat_f16, const int64_t* fs, float* packed, int N, int C, int H, int W,
+                                        mvsdet_stream_t stream) {
+    return pack_entry<__half>("pack_features_f16", static_cast<const __half*>(feat_f16), fs, packed, N, C, H, W, stream);
 }
 
 extern "C" int mvsdet_homo_warp_f32(const float* src, const float* proj, const float* depth, float* out, int B, int C,
@@ -111,9 +122,11 @@ int num_tiles(int H, int W, int tw) {
 unsigned long long* g_stamps = nullptr;  // diagnostic runs only (mvsdet_debug_set_stamp_buffer)
 
 template <int TW, bool NT>
-int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, float* var,
+int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, void* var_any,
                  void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
-                 int ref_first) {
+                 int ref_first, bool half_out) {
+    float* var = static_cast<float*>(var_any);
+    __half* var16 = static_cast<__half*>(var_any);  // half_out: same kernel, variance rounded to fp16 at the store
     // phases: bit 0 = build the sampling table (coords kernel), bit 1 = run the slab kernel
     // N reference views starting at view ref_first of the n_src packed source views (a view shard; N == n_src
     // and ref_first == 0 for a whole scene); nbr / proj / depth / var / scratch are indexed by the LOCAL view
@@ -145,7 +158,10 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
             hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads), 0, stream, proj, depth,    \
                                table, boxes, D, H, W, tiles_x, tiles, d_per_block);                                   \
         if (!(phases & 2)) break;                                                                                     \
-        if (g_stamps)                                                                                                 \
+        if (half_out)                                                                                                 \
+            hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, true, false, __half>), grid, dim3(kThreads), 0, stream, packed, \
+                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
+        else if (g_stamps)                                                                                                 \
             hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, true>), grid, dim3(kThreads), 0, stream, packed, \
                                ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
         else                                                                                                          \
@@ -154,7 +170,10 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         break;
     switch (K) {
         case 0:
-            if (phases & 2)
+            if ((phases & 2) && half_out)
+                hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, true, false, __half>), grid, dim3(kThreads), 0, stream, packed,
+                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
+            else if (phases & 2)
                 hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, ref_packed, nbr,
                                table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
             break;
@@ -186,8 +205,8 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
 }
 
 static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,
-                       float* var, void* scratch, size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
-                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0) {
+                       void* var, void* scratch, size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
+                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0, bool half_out = false) {
     if (n_src < 0) n_src = N;
     MVS_REQUIRE(ref_first >= 0 && N <= n_src && ref_first <= n_src - N,
                 "%s: reference views [%d, %d) outside the %d packed views", name, ref_first, ref_first + N, n_src);
@@ -208,10 +227,10 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     const char* ent = getenv("MVSDET_SWEEP_NT");
     const bool nt = ent ? atoi(ent) != 0 : true;
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first)
-                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first);
-    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first)
-              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first);
+    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out)
+                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out)
+              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
@@ -228,6 +247,14 @@ extern "C" int mvsdet_plane_sweep_variance_shard_f32(const float* packed, const 
                                                      int D, int H, int W, mvsdet_stream_t stream) {
     return sweep_entry("plane_sweep_variance_shard", packed, nbr, proj, depth, var, scratch, scratch_bytes, M, K, C, D, H,
                        W, stream, 3, N_src, ref_first);
+}
+
+extern "C" int mvsdet_plane_sweep_variance_shard_f16(const float* packed, const int64_t* nbr, const float* proj,
+                                                     const float* depth, void* var_f16, void* scratch,
+                                                     size_t scratch_bytes, int N_src, int ref_first, int M, int K, int C,
+                                                     int D, int H, int W, mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_variance_shard_f16", packed, nbr, proj, depth, var_f16, scratch, scratch_bytes, M, K, C,
+                       D, H, W, stream, 3, N_src, ref_first, true);
 }
 
 extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,

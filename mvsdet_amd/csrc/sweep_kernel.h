@@ -154,10 +154,12 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
 // ---------------------------------------------------------------------------------------------
 // (2) the slab kernel
 // ---------------------------------------------------------------------------------------------
-template <int K, int TW, bool NT, bool STAMP>
+// OutT = float, or __half: the variance is computed in fp32 exactly as before and rounded to nearest-even at the
+// store (BASELINE configs[4], fp16 storage), which halves the dominant write stream.
+template <int K, int TW, bool NT, bool STAMP, typename OutT = float>
 __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
-    const uint4* __restrict__ table, const int4* __restrict__ boxes, float* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
+    const uint4* __restrict__ table, const int4* __restrict__ boxes, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
     int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
@@ -387,18 +389,34 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
                 const int c = slab * kSlab + wave * 8 + 2 * k + sh;
                 const float4 v = *reinterpret_cast<const float4*>(t + 2 * k * kTileStride);
                 if (c < C) {
-                    float* dst = var + (((size_t)n * C + c) * D + d) * HW + st_off;
+                    OutT* dst = var + (((size_t)n * C + c) * D + d) * HW + st_off;
                     // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs
-                    if (st_vec) {
-                        typedef float v4f __attribute__((ext_vector_type(4)));
-                        const v4f vv = {v.x, v.y, v.z, v.w};
-                        if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
-                        else *reinterpret_cast<v4f*>(dst) = vv;
-                    } else {
-                        const float a[4] = {v.x, v.y, v.z, v.w};
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (st_vec) {
+                            typedef float v4f __attribute__((ext_vector_type(4)));
+                            const v4f vv = {v.x, v.y, v.z, v.w};
+                            if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
+                            else *reinterpret_cast<v4f*>(dst) = vv;
+                        } else {
+                            const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (i < st_n) dst[i] = a[i];
+                            for (int i = 0; i < 4; ++i)
+                                if (i < st_n) dst[i] = a[i];
+                        }
+                    } else {
+                        const __half h[4] = {__float2half_rn(v.x), __float2half_rn(v.y), __float2half_rn(v.z),
+                                             __float2half_rn(v.w)};
+                        if (st_vec) {  // 4 pixels x 2 B: the fp32 alignment condition also gives 8-byte alignment
+                            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                            const v2u vv = {(unsigned)__half_as_ushort(h[0]) | ((unsigned)__half_as_ushort(h[1]) << 16),
+                                            (unsigned)__half_as_ushort(h[2]) | ((unsigned)__half_as_ushort(h[3]) << 16)};
+                            if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v2u*>(dst));
+                            else *reinterpret_cast<v2u*>(dst) = vv;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (i < st_n) dst[i] = h[i];
+                        }
                     }
                 }
             }

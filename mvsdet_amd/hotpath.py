@@ -119,6 +119,29 @@ class MVSDetHotPath:
             return ops.plane_sweep_variance_packed(packed, geo.neighbor_ids, geo.proj_rel, geo.depth_values, c, h, w)
         return ops.plane_sweep_variance(feature, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
 
+    def cost_volume_chunks(self, packed: Tensor, geo: SceneGeometry, C: int, H: int, W: int, views_per_chunk: int,
+                           half_out: bool = False, events: Optional[list] = None):
+        """a3+a4 for cost volumes that do not fit HBM whole (BASELINE configs[4]: 503 GB in fp16): yields
+        `(first_view, variance rows (M,C,D,H,W))` chunk by chunk; the consumer (the cost regularisation network)
+        finishes with a chunk and drops it before the next one is produced.  Rows are those of `cost_volume`
+        (bit-identical in fp32; the same values rounded to float16 with `half_out`).  Forward only.
+        `events`: optional list receiving a (start, end) HIP-event pair per launch (bench.py)."""
+        n_src = geo.neighbor_ids.shape[0]
+        if views_per_chunk < 1:
+            raise ValueError("views_per_chunk must be >= 1")
+        for first in range(0, n_src, views_per_chunk):
+            sl = slice(first, min(n_src, first + views_per_chunk))
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            var = ops.plane_sweep_variance_shard(packed, geo.neighbor_ids[sl], geo.proj_rel[sl], geo.depth_values[sl],
+                                                 n_src, first, C, H, W, half_out)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1))
+            yield first, var
+            del var
+
     def depth_distribution(self, cost_logits: Tensor):
         """a5-a7 on the (N,2,D,H,W) output of the cost regularisation network (mvsdet.py:470-482)."""
         cost_reg, off_logit = cost_logits[:, 0], cost_logits[:, 1]
@@ -134,6 +157,19 @@ class MVSDetHotPath:
                                                  float(self.voxel_size[-1]))
         nx, ny, nz = self.n_voxels
         return mean.view(c, nx, ny, nz), count.view(1, nx, ny, nz).long()
+
+    def lift_packed(self, packed: Tensor, geo: SceneGeometry, est_depth: Tensor, est_dens: Tensor, C: int, Hf: int,
+                    Wf: int):
+        """a9+a10 from the packed maps alone (fp16 feature maps have no fp32 NCHW form to hand to `lift`):
+        un-normalised sum over all views + count, then the mvsdet.py:511-515 division.  Forward only."""
+        n_src = geo.neighbor_ids.shape[0]
+        h, w = geo.height, geo.width
+        total, count = ops.backproject_weigh_sum_shard(packed, geo.points, geo.projection, est_depth[:, :, :h, :w],
+                                                       est_dens[:, :, :h, :w], n_src, 0, C, Hf, Wf,
+                                                       float(self.voxel_size[-1]))
+        mean = torch.where(count > 0, total / (count.to(total.dtype) + 1e-8), torch.zeros((), device=total.device))
+        nx, ny, nz = self.n_voxels
+        return mean.view(C, nx, ny, nz), count.view(1, nx, ny, nz).long()
 
     def forward_scene(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor] = None,
                       geo: Optional[SceneGeometry] = None) -> dict:

@@ -33,21 +33,23 @@ def _stream(t: Tensor):
 # ------------------------------------------------------------------------------------------- pack
 @torch.library.custom_op(f"{_NS}::pack_features", mutates_args=(), device_types="cuda")
 def pack_features(feat: Tensor) -> Tensor:
-    """(N,C,H,W) (any strides) -> packed channel-last maps, flat float32 (see include/mvsdet_hip.h)."""
-    _req(feat, "feat", dim=4)
+    """(N,C,H,W) float32 or float16 (any strides) -> packed channel-last maps, flat float32
+    (see include/mvsdet_hip.h; the fp16 -> fp32 conversion is exact)."""
+    half = feat.dtype == torch.float16
+    _req(feat, "feat", dtype=torch.float16 if half else torch.float32, dim=4)
     N, C, H, W = feat.shape
     lib = _lib.load()
     out = torch.empty(lib.mvsdet_packed_bytes(N, C, H, W) // 4, dtype=torch.float32, device=feat.device)
+    fn = lib.mvsdet_pack_features_f16 if half else lib.mvsdet_pack_features_f32
     with torch.cuda.device(feat.device):
-        _lib.check(lib.mvsdet_pack_features_f32(_lib.ptr(feat), _lib.strides4(feat), _lib.ptr(out), N, C, H, W,
-                                                _stream(feat)), "pack_features")
+        _lib.check(fn(_lib.ptr(feat), _lib.strides4(feat), _lib.ptr(out), N, C, H, W, _stream(feat)), "pack_features")
     return out
 
 
 @pack_features.register_fake
 def _(feat):
     N, C, H, W = feat.shape
-    return feat.new_empty(N * H * W * 32 * ((C + 31) // 32))
+    return feat.new_empty(N * H * W * 32 * ((C + 31) // 32), dtype=torch.float32)
 
 
 # ------------------------------------------------------------------------------------------- a3
@@ -124,10 +126,11 @@ def _(packed, nbr, proj, depth, C, H, W):
 
 @torch.library.custom_op(f"{_NS}::plane_sweep_variance_shard", mutates_args=(), device_types="cuda")
 def plane_sweep_variance_shard(packed: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor, n_src: int, ref_first: int,
-                               C: int, H: int, W: int) -> Tensor:
+                               C: int, H: int, W: int, half_out: bool = False) -> Tensor:
     """a3+a4 for the reference views ref_first .. ref_first+M-1 of a scene whose n_src views are all in `packed`
     (intra-scene view sharding).  nbr (M,K) holds global view ids -> (M,C,D,H,W), bit-identical to the
-    same rows of plane_sweep_variance_packed.  Forward only."""
+    same rows of plane_sweep_variance_packed.  half_out=True stores the same fp32 result rounded to float16
+    (BASELINE configs[4]).  Forward only."""
     _req(packed, "packed", dim=1)
     _req(nbr, "nbr", dtype=torch.int64, dim=2)
     _req(proj, "proj", dim=4)
@@ -142,20 +145,21 @@ def plane_sweep_variance_shard(packed: Tensor, nbr: Tensor, proj: Tensor, depth:
     if M < 1 or ref_first < 0 or ref_first + M > n_src:
         raise ValueError(f"plane_sweep_variance_shard: views [{ref_first},{ref_first + M}) outside the {n_src} packed views")
     nbr, proj, depth = nbr.contiguous(), proj.contiguous(), depth.contiguous()
-    out = torch.empty((M, C, D, H, W), dtype=torch.float32, device=packed.device)
+    out = torch.empty((M, C, D, H, W), dtype=torch.float16 if half_out else torch.float32, device=packed.device)
     sbytes = lib.mvsdet_plane_sweep_scratch_bytes(M, K, D, H, W)
     scratch = torch.empty(max(sbytes // 4, 4), dtype=torch.float32, device=packed.device)
+    fn = lib.mvsdet_plane_sweep_variance_shard_f16 if half_out else lib.mvsdet_plane_sweep_variance_shard_f32
     with torch.cuda.device(packed.device):
-        _lib.check(lib.mvsdet_plane_sweep_variance_shard_f32(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(proj),
-                                                             _lib.ptr(depth), _lib.ptr(out), _lib.ptr(scratch), sbytes,
-                                                             n_src, ref_first, M, K, C, D, H, W, _stream(packed)),
+        _lib.check(fn(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(proj),
+                      _lib.ptr(depth), _lib.ptr(out), _lib.ptr(scratch), sbytes,
+                      n_src, ref_first, M, K, C, D, H, W, _stream(packed)),
                    "plane_sweep_variance_shard")
     return out
 
 
 @plane_sweep_variance_shard.register_fake
-def _(packed, nbr, proj, depth, n_src, ref_first, C, H, W):
-    return packed.new_empty((nbr.shape[0], C, depth.shape[1], H, W))
+def _(packed, nbr, proj, depth, n_src, ref_first, C, H, W, half_out=False):
+    return packed.new_empty((nbr.shape[0], C, depth.shape[1], H, W), dtype=torch.float16 if half_out else torch.float32)
 
 
 @torch.library.custom_op(f"{_NS}::plane_sweep_table", mutates_args=(), device_types="cuda")

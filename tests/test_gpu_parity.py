@@ -582,3 +582,44 @@ def test_view_shards_reassemble_the_scene(gpu, oracle):
     np.testing.assert_allclose(one["volume"].cpu().numpy(), full["volume"].cpu().numpy(), rtol=0, atol=2e-6)
     with pytest.raises(ValueError):
         ops.plane_sweep_variance_shard(packed, geo.neighbor_ids[:3], geo.proj_rel[:3], geo.depth_values[:3], N, 5, C, *hw)
+
+
+# --------------------------------------------------------------------------------------------- fp16 storage (configs[4])
+@pytest.mark.parametrize("N,C,D,H,W,chunk", [(5, 40, 6, 24, 32, 2), (3, 32, 4, 33, 47, 3), (4, 256, 3, 20, 28, 1)])
+def test_fp16_storage_and_view_chunks(gpu, oracle, N, C, D, H, W, chunk):
+    """fp16 feature maps in, fp16 cost volume out, produced in chunks of reference views: the arithmetic is the
+    fp32 path's, so the result must equal the oracle's fp32 variance of the (exactly converted) half features,
+    rounded to nearest-even -- bit for bit; fp32 chunks must equal the unchunked rows."""
+    from mvsdet_amd import ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    hp = MVSDetHotPath([8, 8, 4], [.8, .8, .8], [0.2, 5.0], D)
+    meta = synthetic.make_img_meta(N, (H, W), seed=11)
+    feat16 = synthetic.make_features(N, C, (H, W), seed=11).half()
+    feat16[0, 0, 0, 0] = 300.0          # variance of this texel overflows fp16 somewhere -> +inf on both sides
+    geo = hp.prepare_scene(meta, gpu)
+    packed = ops.pack_features(feat16.to(gpu))
+    assert packed.dtype == torch.float32
+    assert torch.equal(packed, ops.pack_features(feat16.float().to(gpu)))          # exact conversion
+    ref32 = oracle.plane_sweep_variance(feat16.float().numpy(), geo.neighbor_ids.cpu().numpy(), geo.proj_rel.cpu().numpy(),
+                                        geo.depth_values.cpu().numpy(), mode=1)
+    with np.errstate(over="ignore"):
+        ref16 = ref32.astype(np.float16)                                            # numpy rounds to nearest-even
+    got16 = torch.empty((N, C, D, H, W), dtype=torch.float16)
+    got32 = torch.empty((N, C, D, H, W), dtype=torch.float32)
+    firsts = []
+    for first, var in hp.cost_volume_chunks(packed, geo, C, H, W, chunk, half_out=True):
+        assert var.dtype == torch.float16
+        got16[first:first + var.shape[0]] = var.cpu()
+        firsts.append(first)
+    for first, var in hp.cost_volume_chunks(packed, geo, C, H, W, chunk):
+        got32[first:first + var.shape[0]] = var.cpu()
+    assert firsts == list(range(0, N, chunk))
+    np.testing.assert_array_equal(got32.numpy(), ref32)
+    np.testing.assert_array_equal(got16.numpy().view(np.uint16), ref16.view(np.uint16))
+    # the lifting from packed maps alone (no fp32 NCHW tensor) equals the fused mean of the fp32 form
+    logits = synthetic.make_cost_logits(N, D, (H, W), seed=11, sharp=2.0).to(gpu)
+    prob, off, ed, en, _, avg = hp.depth_distribution(logits)
+    vol, valid = hp.lift_packed(packed, geo, ed, en, C, H, W)
+    vol2, valid2 = hp.lift(feat16.float().to(gpu), packed, geo, ed, en)
+    assert torch.equal(valid, valid2)
+    np.testing.assert_allclose(vol.cpu().numpy(), vol2.cpu().numpy(), rtol=0, atol=2e-6)
