@@ -23,7 +23,8 @@
 //           P2  LDS-DMA of the box rows (contiguous nc*128-byte runs of the slab image), 1 KiB per wave-instruction
 //           P3  taps = 4 x ds_read_b128 per step; fma chain -> S, Q
 //         P4  variance -> LDS tile [32 channels][128 pixels] (aliases the box storage)
-//         P5  tile rows -> global as 16-byte non-temporal stores, 128 B contiguous per (channel, tile row)
+//         P5  tile rows -> global as 16-byte non-temporal stores, 128 B contiguous per (channel, tile row); each wave
+//             stores the pixels it computed (wave-private transpose, no block barrier between P4 and P5)
 //
 // Why this shape: v1 (all channels per block, taps gathered from global memory) saturated the fabric at a 43 %
 // L2 hit rate (profiles/r01_v1_*); with slabs the kernel became VALU-issue bound (82 % busy), so everything
@@ -202,10 +203,12 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         const int pix = min(y, H - 1) * W + min(x, W - 1);
         f[s] = *reinterpret_cast<const float4*>(ref_img + (size_t)pix * kSlab + 4 * g);
     }
-    // ... and the 4 consecutive output pixels it stores in P5: float4 slot q = lane & 31 of the 128-pixel tile
-    // (TW/4 slots per tile row), for the two channel rows 2*k + (lane >> 5)
-    const int sq = lane & 31, sh = lane >> 5;
-    const int st_x = tx0 + (sq % (TW / 4)) * 4, st_y = ty0 + sq / (TW / 4);
+    // ... and the 4 consecutive output pixels it stores in P5.  A wave stores what it computed itself: its 32
+    // pixels (tile columns 32*wave ..) of all 32 channel rows, so the tile transpose is wave-private and needs no
+    // block barrier.  Lane -> channel row 8*k + (lane >> 3), float4 slot (lane & 7) of the wave's 32 pixels.
+    const int sq = lane & 7, sh = lane >> 3;
+    const int st_p = wave * 32 + 4 * sq;  // first of the 4 pixels, tile-local
+    const int st_x = tx0 + st_p % TW, st_y = ty0 + st_p / TW;
     const int st_off = st_y * W + st_x;
     const int st_n = (st_y < H) ? max(0, min(4, W - st_x)) : 0;        // how many of the 4 pixels are inside the image
     const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);  // 16-byte aligned in every channel row
@@ -379,15 +382,20 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
                 }
             }
         }
-        __syncthreads();
-        MVS_STAMP(6)  // variance -> LDS tile + barrier
-        // ---- P5: wave w stores channel rows 8*w .. 8*w+7, two rows per instruction, 16 bytes per lane
+        // same-wave hand-over through LDS: the LDS queue of a wave is in order, only the compiler must not move
+        // the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MVS_STAMP(6)  // variance -> LDS tile
+        // ---- P5: every wave stores its own 32 pixels: 8 channel rows per instruction, 16 bytes per lane
         {
-            const float* t = s_tile + (wave * 8 + sh) * kTileStride + 4 * sq;
+            const float* t = s_tile + sh * kTileStride + st_p;
+            int c0 = slab * kSlab + sh;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int c = slab * kSlab + wave * 8 + 2 * k + sh;
-                const float4 v = *reinterpret_cast<const float4*>(t + 2 * k * kTileStride);
+                const int c = c0 + 8 * k;
+                const float4 v = *reinterpret_cast<const float4*>(t + 8 * k * kTileStride);
                 if (c < C) {
                     OutT* dst = var + (((size_t)n * C + c) * D + d) * HW + st_off;
                     // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of the plane sweep of TWO builds of libmvsdet_hip.so in one process (cdna guide rule 24):
-   python tools/ab_lib.py A.so B.so [workload] [rounds]
+   python tools/ab_lib.py A.so B.so [C.so ...] [workload] [rounds]
 Only the entry points both builds are certain to share are bound (pack + packed sweep); results must agree bit for bit."""
 import ctypes
 import os
@@ -13,9 +13,10 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from mvsdet_amd.hotpath import MVSDetHotPath  # noqa: E402
 
-paths = sys.argv[1:3]
-name = sys.argv[3] if len(sys.argv) > 3 else "scannet_40v_64d_120x160"
-rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+name = rest[0] if rest else "scannet_40v_64d_120x160"
+rounds = int(rest[1]) if len(rest) > 1 else 6
 vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 libs = []
 for p in paths:
