@@ -80,8 +80,8 @@ int mvsdet_homo_warp_f32(const float* src, const float* proj, const float* depth
  *   proj (N,K,4,4) = nei_proj[n][j] @ inverse(ref_proj[n]);  depth (N,D);
  *   var (N,C,D,H,W) = sum_sq/(K+1) - (sum/(K+1))^2 over {ref, warped_1..K}  (mvsdet.py:467).
  * `scratch` (16-byte aligned, >= mvsdet_plane_sweep_scratch_bytes(N,K,D,H,W)) receives the
- * channel-independent sampling table the sweep builds first: 16 B per (view, neighbour, plane,
- * pixel), about 3 % of the cost volume.
+ * channel-independent sampling table the sweep builds first: 8 B per (view, neighbour, plane,
+ * pixel) = the un-normalised sample position, about 1.5 % of the cost volume.
  * The _f32 form packs `feat` (N,C,H,W dense) into `workspace` first
  * (workspace_bytes >= mvsdet_plane_sweep_workspace_bytes(N,K,C,D,H,W) = packed + scratch).
  * ------------------------------------------------------------------------------------------- */

@@ -88,53 +88,6 @@ __device__ __forceinline__ void compute_taps(const float* __restrict__ P, float 
     w.w = (x1in && y1in) ? wse : wse * 0.0f;
 }
 
-// Same sampling position, in the form the slab kernels use: integer tap origin (x0,y0) clamped to
-// [-1, W-1] x [-1, H-1] (so x0+1 <= W never overflows and NaN/Inf positions become finite indices),
-// the four weights (outside taps: weight*0) and the inclusive range of VALID tap columns / rows of this
-// pixel (lo > hi when the pixel has no valid tap).  For every valid tap (x0+dx, y0+dy) is exactly the tap
-// compute_taps() addresses; invalid taps carry weight 0 and may be read from any finite texel.
-struct TapXY {
-    int x0, y0;
-    float4 w;
-    int xlo, xhi, ylo, yhi;
-};
-
-__device__ __forceinline__ TapXY compute_taps_xy(const float* __restrict__ P, float x, float y, float d, int H, int W) {
-    const float rx = fmaf(P[1], y, P[0] * x) + P[2];
-    const float ry = fmaf(P[5], y, P[4] * x) + P[6];
-    const float rz = fmaf(P[9], y, P[8] * x) + P[10];
-    const float X = rx * d + P[3];
-    const float Y = ry * d + P[7];
-    const float Z = rz * d + P[11];
-    const float px = X / Z;
-    const float py = Y / Z;
-    const float gx = px / ((float)(W - 1) * 0.5f) - 1.0f;
-    const float gy = py / ((float)(H - 1) * 0.5f) - 1.0f;
-    const float ix = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);
-    const float iy = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
-    const float x0 = floorf(ix), y0 = floorf(iy);
-    const float wx = ix - x0, wy = iy - y0;
-    const float ex = 1.0f - wx, sy = 1.0f - wy;
-    const bool x0in = (x0 >= 0.0f) && (x0 <= (float)(W - 1));
-    const bool x1in = (x0 >= -1.0f) && (x0 <= (float)(W - 2));
-    const bool y0in = (y0 >= 0.0f) && (y0 <= (float)(H - 1));
-    const bool y1in = (y0 >= -1.0f) && (y0 <= (float)(H - 2));
-    const float wnw = sy * ex, wne = sy * wx, wsw = wy * ex, wse = wy * wx;
-    TapXY t;
-    t.x0 = (int)fminf(fmaxf(x0, -1.0f), (float)(W - 1));
-    t.y0 = (int)fminf(fmaxf(y0, -1.0f), (float)(H - 1));
-    t.w.x = (x0in && y0in) ? wnw : wnw * 0.0f;
-    t.w.y = (x1in && y0in) ? wne : wne * 0.0f;
-    t.w.z = (x0in && y1in) ? wsw : wsw * 0.0f;
-    t.w.w = (x1in && y1in) ? wse : wse * 0.0f;
-    const bool any = (x0in || x1in) && (y0in || y1in);
-    t.xlo = any ? (x0in ? t.x0 : t.x0 + 1) : INT32_MAX;
-    t.xhi = any ? (x1in ? t.x0 + 1 : t.x0) : INT32_MIN;
-    t.ylo = any ? (y0in ? t.y0 : t.y0 + 1) : INT32_MAX;
-    t.yhi = any ? (y1in ? t.y0 + 1 : t.y0) : INT32_MIN;
-    return t;
-}
-
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // Voxel -> pixel projection of backproject_Weigh (mvsdet.py:1383-1391): q = P @ [p;1] summed in k

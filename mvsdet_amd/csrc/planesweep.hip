@@ -147,7 +147,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     const char* ecap = getenv("MVSDET_SWEEP_BOXCAP");  // tuning knob: 0 forces the global-gather path
     int box_cap = ecap ? atoi(ecap) : kBoxCap;
     box_cap = box_cap < 0 ? 0 : (box_cap > kBoxCap ? kBoxCap : box_cap);
-    uint4* table = reinterpret_cast<uint4*>(scratch);
+    float2* table = reinterpret_cast<float2*>(scratch);
     int4* boxes = reinterpret_cast<int4*>(table + (size_t)N * tiles * D * K * kTilePix);
     dim3 cgrid((unsigned)(N * tiles), (D + d_per_block - 1) / d_per_block);
     dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
@@ -198,10 +198,10 @@ int sweep_tile_width(int W) { return pick_tile_width(W); }  // shared with plane
 
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W) {
     if (N <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    // sampling table (16 B per view, neighbour, plane, tile pixel) + footprint boxes (16 B per view, neighbour,
+    // sampling table (8 B per view, neighbour, plane, tile pixel) + footprint boxes (16 B per view, neighbour,
     // plane, tile); sized for the larger of the two tile shapes so the knob cannot outgrow it
     const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
-    return (size_t)N * tiles * D * K * (kTilePix + 1) * 16;
+    return (size_t)N * tiles * D * K * (kTilePix * sizeof(float2) + sizeof(int4));
 }
 
 static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,

@@ -28,7 +28,7 @@ namespace mvsdet {
 
 template <int K, int TW>
 __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
-    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const uint4* __restrict__ table,
+    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float2* __restrict__ table,
     const int4* __restrict__ boxes, const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S,
     int D, int H, int W, int tiles_x, int tiles) {
     constexpr int KK = K > 0 ? K : 1;
@@ -111,17 +111,10 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
             if (j < K) {
                 const int p = tid % kTilePix;
-                const uint4 e = table[(tbase + j) * kTilePix + p];
-                const float wx = __uint_as_float(e.y), wy = __uint_as_float(e.z);
-                const float ex = 1.0f - wx, sy = 1.0f - wy;
-                const float wnw = sy * ex, wne = sy * wx, wsw = wy * ex, wse = wy * wx;
-                float4 w;
-                w.x = ((e.w & 5u) == 5u) ? wnw : wnw * 0.0f;
-                w.y = ((e.w & 6u) == 6u) ? wne : wne * 0.0f;
-                w.z = ((e.w & 9u) == 9u) ? wsw : wsw * 0.0f;
-                w.w = ((e.w & 10u) == 10u) ? wse : wse * 0.0f;
-                s_w[j][p] = w;
-                s_xy[j][p] = make_int2((int)(e.x & 0xffffu) - 1, (int)(e.x >> 16) - 1);
+                const float2 e = table[(tbase + j) * kTilePix + p];
+                const SampleTaps tp = decode_sample(e.x, e.y, H, W);
+                s_w[j][p] = tap_weights(tp);
+                s_xy[j][p] = make_int2(tp.x0, tp.y0);
             }
         }
         __syncthreads();
@@ -294,7 +287,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     const int tiles_x = (W + tw - 1) / tw, tiles = tiles_x * ((H + th - 1) / th);
     const long long nblocks = (long long)N * tiles * S;
     MVS_REQUIRE(nblocks <= INT32_MAX, "plane_sweep_variance_bwd: grid too large");
-    const uint4* table = reinterpret_cast<const uint4*>(scratch);
+    const float2* table = reinterpret_cast<const float2*>(scratch);
     const int4* boxes = reinterpret_cast<const int4*>(table + (size_t)N * tiles * D * K * kTilePix);
     dim3 grid((unsigned)nblocks);
 #define MVS_BWD_CASE(KV)                                                                                               \

@@ -1,10 +1,10 @@
 // a3+a4 fused: plane-sweep variance (included by planesweep.hip).  Two kernels:
 //
 // (1) plane_sweep_coords_kernel -- everything that depends on (view, neighbour, plane, pixel) but NOT on the
-//     channel: the sampling position of mvs_models/module.py:116-143, reduced to a 16-byte table entry
-//     {tap origin x0,y0; fractional weights wx,wy; validity bits} plus, per (tile, neighbour, plane), the
-//     bounding box of the valid taps.  The reference builds its sampling grid once per plane too.
-//     Cost: N*K*D*H*W entries (1.6 GB at the 64-plane shape, 3 % of the cost volume), written once.
+//     channel: the sampling position of mvs_models/module.py:116-143, reduced to an 8-byte table entry
+//     (the un-normalised sample position ix, iy) plus, per (tile, neighbour, plane), the bounding box of the
+//     valid taps.  The reference builds its sampling grid once per plane too.
+//     Cost: N*K*D*H*W entries (0.8 GB at the 64-plane shape, 1.5 % of the cost volume), written once.
 //
 // (2) plane_sweep_variance_kernel -- the channel work, one 32-channel slab per block:
 //       block   = (reference view n, TWxTH pixel tile (128 pixels), slab s, depth chunk)
@@ -62,10 +62,44 @@ __device__ __forceinline__ int wave_reduce(int v) {
     return kMin ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d));
 }
 
-// Table entry: x = (x0+1) | (y0+1) << 16 with the clamped tap origin of compute_taps_xy(); y, z = bit patterns
-// of wx, wy; w = validity bits (1: column x0 inside, 2: column x0+1 inside, 4: row y0 inside, 8: row y0+1 inside).
-__device__ __forceinline__ uint4 encode_taps(const float* __restrict__ P, float x, float y, float d, int H, int W,
-                                             int& xlo, int& xhi, int& ylo, int& yhi) {
+// Table entry = the un-normalised sample position (ix, iy) of module.py:116-143 (8 bytes); everything bilinear
+// sampling derives from it -- tap origin, fractional weights, which taps are inside -- is decode_sample(), shared
+// by the coords kernel (footprint boxes), the slab kernel and the backward kernel, so all three agree bit for bit.
+struct SampleTaps {
+    int x0, y0;      // clamped tap origin (NaN / Inf positions become finite indices)
+    float wx, wy;    // fractional weights
+    bool x0in, x1in, y0in, y1in;
+};
+
+__device__ __forceinline__ SampleTaps decode_sample(float ix, float iy, int H, int W) {
+    SampleTaps t;
+    const float x0 = floorf(ix), y0 = floorf(iy);
+    t.wx = ix - x0;
+    t.wy = iy - y0;
+    t.x0in = (x0 >= 0.0f) && (x0 <= (float)(W - 1));
+    t.x1in = (x0 >= -1.0f) && (x0 <= (float)(W - 2));
+    t.y0in = (y0 >= 0.0f) && (y0 <= (float)(H - 1));
+    t.y1in = (y0 >= -1.0f) && (y0 <= (float)(H - 2));
+    t.x0 = (int)fminf(fmaxf(x0, -1.0f), (float)(W - 1));
+    t.y0 = (int)fminf(fmaxf(y0, -1.0f), (float)(H - 1));
+    return t;
+}
+
+// the 4 bilinear weights; an outside tap carries weight*0, so Inf/NaN positions give NaN as ATen-CPU does
+__device__ __forceinline__ float4 tap_weights(const SampleTaps& t) {
+    const float ex = 1.0f - t.wx, sy = 1.0f - t.wy;
+    const float wnw = sy * ex, wne = sy * t.wx, wsw = t.wy * ex, wse = t.wy * t.wx;
+    float4 w;
+    w.x = (t.x0in && t.y0in) ? wnw : wnw * 0.0f;
+    w.y = (t.x1in && t.y0in) ? wne : wne * 0.0f;
+    w.z = (t.x0in && t.y1in) ? wsw : wsw * 0.0f;
+    w.w = (t.x1in && t.y1in) ? wse : wse * 0.0f;
+    return w;
+}
+
+constexpr float kNoSample = -2.0f;  // entry of a tile pixel outside the image: no tap inside, all weights +0
+
+__device__ __forceinline__ float2 sample_position(const float* __restrict__ P, float x, float y, float d, int H, int W) {
     const float rx = fmaf(P[1], y, P[0] * x) + P[2];
     const float ry = fmaf(P[5], y, P[4] * x) + P[6];
     const float rz = fmaf(P[9], y, P[8] * x) + P[10];
@@ -76,37 +110,17 @@ __device__ __forceinline__ uint4 encode_taps(const float* __restrict__ P, float 
     const float py = Y / Z;
     const float gx = px / ((float)(W - 1) * 0.5f) - 1.0f;
     const float gy = py / ((float)(H - 1) * 0.5f) - 1.0f;
-    const float ix = fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f);
-    const float iy = fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f);
-    const float x0 = floorf(ix), y0 = floorf(iy);
-    const float wx = ix - x0, wy = iy - y0;
-    const bool x0in = (x0 >= 0.0f) && (x0 <= (float)(W - 1));
-    const bool x1in = (x0 >= -1.0f) && (x0 <= (float)(W - 2));
-    const bool y0in = (y0 >= 0.0f) && (y0 <= (float)(H - 1));
-    const bool y1in = (y0 >= -1.0f) && (y0 <= (float)(H - 2));
-    const int xi = (int)fminf(fmaxf(x0, -1.0f), (float)(W - 1));  // NaN / Inf positions become finite indices
-    const int yi = (int)fminf(fmaxf(y0, -1.0f), (float)(H - 1));
-    const bool any = (x0in || x1in) && (y0in || y1in);
-    xlo = any ? (x0in ? xi : xi + 1) : INT32_MAX;
-    xhi = any ? (x1in ? xi + 1 : xi) : INT32_MIN;
-    ylo = any ? (y0in ? yi : yi + 1) : INT32_MAX;
-    yhi = any ? (y1in ? yi + 1 : yi) : INT32_MIN;
-    uint4 e;
-    e.x = (unsigned)(xi + 1) | ((unsigned)(yi + 1) << 16);
-    e.y = __float_as_uint(wx);
-    e.z = __float_as_uint(wy);
-    e.w = (x0in ? 1u : 0u) | (x1in ? 2u : 0u) | (y0in ? 4u : 0u) | (y1in ? 8u : 0u);
-    return e;
+    return make_float2(fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f), fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f));
 }
 
 // ---------------------------------------------------------------------------------------------
 // (1) sampling table: block = (view, tile); thread = (neighbour, pixel); loops over the planes of its chunk.
-//     table [((n*tiles + tile)*D + d)*K + j][128] uint4;  boxes [((n*tiles + tile)*D + d)*K + j] int4.
+//     table [((n*tiles + tile)*D + d)*K + j][128] float2;  boxes [((n*tiles + tile)*D + d)*K + j] int4.
 // ---------------------------------------------------------------------------------------------
 template <int K, int TW>
 __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const float* __restrict__ proj,
                                                                        const float* __restrict__ depth,
-                                                                       uint4* __restrict__ table, int4* __restrict__ boxes,
+                                                                       float2* __restrict__ table, int4* __restrict__ boxes,
                                                                        int D, int H, int W, int tiles_x, int tiles,
                                                                        int d_per_block) {
     constexpr int TH = kTilePix / TW;
@@ -130,8 +144,17 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
             const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
             if (j < K) {
                 int xlo = INT32_MAX, xhi = INT32_MIN, ylo = INT32_MAX, yhi = INT32_MIN;
-                uint4 e = make_uint4(0x00010001u, 0u, 0u, 0u);  // pixel outside the image: no taps, no footprint
-                if (inside) e = encode_taps(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W, xlo, xhi, ylo, yhi);
+                float2 e = make_float2(kNoSample, kNoSample);  // pixel outside the image: no taps, no footprint
+                if (inside) {
+                    e = sample_position(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W);
+                    const SampleTaps t = decode_sample(e.x, e.y, H, W);
+                    if ((t.x0in || t.x1in) && (t.y0in || t.y1in)) {  // bounding box of the taps that are inside
+                        xlo = t.x0in ? t.x0 : t.x0 + 1;
+                        xhi = t.x1in ? t.x0 + 1 : t.x0;
+                        ylo = t.y0in ? t.y0 : t.y0 + 1;
+                        yhi = t.y1in ? t.y0 + 1 : t.y0;
+                    }
+                }
                 table[(base + j) * kTilePix + p] = e;
                 xlo = wave_reduce<true>(xlo);
                 xhi = wave_reduce<false>(xhi);
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
 template <int K, int TW, bool NT, bool STAMP, typename OutT = float>
 __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
-    const uint4* __restrict__ table, const int4* __restrict__ boxes, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
+    const float2* __restrict__ table, const int4* __restrict__ boxes, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
     int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
@@ -236,11 +259,11 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     // never stalls on them; they are issued BEFORE that plane's result stores, so waiting for them does not wait
     // for store acknowledgements either (vmcnt retires in order).
     int4 bn[KK];
-    uint4 en[ITER];
+    float2 en[ITER];
 #pragma unroll
     for (int j = 0; j < KK; ++j) bn[j] = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN);
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) en[it] = make_uint4(0x00010001u, 0u, 0u, 0u);
+    for (int it = 0; it < ITER; ++it) en[it] = make_float2(kNoSample, kNoSample);
     auto prefetch = [&](int d) {
 #pragma unroll
         for (int j = 0; j < K; ++j) bn[j] = boxes[((size_t)bt * D + d) * K + j];
@@ -269,7 +292,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         bool staged[KK];
         // make sure the prefetched values have landed before the DMA below is queued behind them
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) asm volatile("" ::"v"(en[it].x), "v"(en[it].y), "v"(en[it].z), "v"(en[it].w));
+        for (int it = 0; it < ITER; ++it) asm volatile("" ::"v"(en[it].x), "v"(en[it].y));
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int4 b = bn[j];
@@ -285,23 +308,15 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         if (d != d_begin) __syncthreads();
         MVS_STAMP(0)  // unpack boxes + wait for the prefetch + barrier (previous tile reads)
         if (K > 0 && staged[0]) load_box(0, bx0[0], by0[0], nc[0], nr[0]);  // in flight while the table is decoded
-        // ---- table entry -> weights + tap offsets (float4 units, lane slot g not yet added)
+        // ---- table entry (sample position) -> weights + tap offsets (float4 units, lane slot g not yet added)
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
             if (j < K) {
                 const int p = tid % kTilePix;
-                const uint4 e = en[it];
-                const int x0 = (int)(e.x & 0xffffu) - 1, y0 = (int)(e.x >> 16) - 1;
-                const float wx = __uint_as_float(e.y), wy = __uint_as_float(e.z);
-                const float ex = 1.0f - wx, sy = 1.0f - wy;
-                const float wnw = sy * ex, wne = sy * wx, wsw = wy * ex, wse = wy * wx;
-                float4 w;  // an outside tap carries weight*0, so Inf/NaN positions give NaN as ATen-CPU does
-                w.x = ((e.w & 5u) == 5u) ? wnw : wnw * 0.0f;
-                w.y = ((e.w & 6u) == 6u) ? wne : wne * 0.0f;
-                w.z = ((e.w & 9u) == 9u) ? wsw : wsw * 0.0f;
-                w.w = ((e.w & 10u) == 10u) ? wse : wse * 0.0f;
-                s_w[j][p] = w;
+                const SampleTaps tp = decode_sample(en[it].x, en[it].y, H, W);
+                const int x0 = tp.x0, y0 = tp.y0;
+                s_w[j][p] = tap_weights(tp);
                 int lox = 0, hix = W - 1, loy = 0, hiy = H - 1, pitch = W;
 #pragma unroll
                 for (int jj = 0; jj < K; ++jj)

@@ -108,7 +108,7 @@ def plane_sweep_variance_packed(packed: Tensor, nbr: Tensor, proj: Tensor, depth
         raise ValueError("plane_sweep_variance_packed: proj/depth shape mismatch")
     nbr, proj, depth = nbr.contiguous(), proj.contiguous(), depth.contiguous()
     out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=packed.device)
-    # channel-independent sampling table (16 B per view, neighbour, plane, pixel), built by the op's first kernel
+    # channel-independent sampling table (8 B per view, neighbour, plane, pixel), built by the op's first kernel
     sbytes = lib.mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)
     scratch = torch.empty(max(sbytes // 4, 4), dtype=torch.float32, device=packed.device)
     with torch.cuda.device(packed.device):
@@ -164,7 +164,7 @@ def _(packed, nbr, proj, depth, n_src, ref_first, C, H, W, half_out=False):
 
 @torch.library.custom_op(f"{_NS}::plane_sweep_table", mutates_args=(), device_types="cuda")
 def plane_sweep_table(proj: Tensor, depth: Tensor, H: int, W: int) -> Tensor:
-    """Channel-independent sampling table of a scene (16 B per view, neighbour, plane, pixel): proj (N,K,4,4),
+    """Channel-independent sampling table of a scene (8 B per view, neighbour, plane, pixel): proj (N,K,4,4),
     depth (N,D) -> opaque flat buffer for plane_sweep_variance_tabled."""
     _req(proj, "proj", dim=4)
     _req(depth, "depth", dim=2)
