@@ -40,7 +40,7 @@
 namespace mvsdet {
 
 constexpr int kTilePix = 128;       // pixels per tile
-constexpr int kBoxCap = 224;        // texels (128 B each) of the LDS footprint box: 28 KiB
+constexpr int kBoxCap = 256;        // texels (128 B each) of the LDS footprint box: 32 KiB
 constexpr int kTileStride = 132;    // floats per channel row of the output tile (132 % 32 == 4: conflict-free writes)
 
 // Wave-wide integer min / max: butterfly inside each row of 16 lanes with DPP (4 VALU), then the four row
