@@ -639,12 +639,9 @@ def test_hot_path_is_graph_capturable(gpu):
     feat = synthetic.make_features(N, C, hw, seed=2).to(gpu)
     logits = synthetic.make_cost_logits(N, D, hw, seed=2, sharp=2.0).to(gpu)
 
-    def run(f, lg):
-        packed = ops.pack_features(f)
-        var = hp.cost_volume(f, geo, packed)
-        prob, off, ed, en, _, avg = hp.depth_distribution(lg)
-        vol, valid = hp.lift(f, packed, geo, ed, en)
-        return var, prob, vol, valid
+    def run(f, lg):   # forward_scene forks the sampling-table kernel onto a side stream: captured as a graph branch
+        o = hp.forward_scene(f, meta, cost_logits=lg, geo=geo)
+        return o["variance"], o["prob_volume"], o["volume"], o["valid"]
 
     side = torch.cuda.Stream(device=gpu)
     side.wait_stream(torch.cuda.current_stream(gpu))
