@@ -126,11 +126,23 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             for (int i = 0; i < 4; ++i) go[s][i] = pok[s] ? t[8 * i * kTileStride] : 0.0f;
         }
         // ---- 2. recompute the warped values (taps from the slab images) and S
+        bool skip[KK];  // neighbour entirely outside the source image (and all positions finite): w_j == 0, no gradient
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int4 bx = boxes[tbase + j];
+            skip[j] = (__builtin_amdgcn_readfirstlane(bx.y) < __builtin_amdgcn_readfirstlane(bx.x)) &&
+                      (__builtin_amdgcn_readfirstlane(bx.w) == kBoxSkip);
+        }
         float S_[4][4], wv[KK][4][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { S_[s][0] = f[s].x; S_[s][1] = f[s].y; S_[s][2] = f[s].z; S_[s][3] = f[s].w; }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
+            if (skip[j]) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wv[j][s][0] = wv[j][s][1] = wv[j][s][2] = wv[j][s][3] = 0.0f;
+                continue;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int p = (wave * 4 + s) * 8 + ps;

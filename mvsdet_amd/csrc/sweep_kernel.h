@@ -97,6 +97,8 @@ __device__ __forceinline__ float4 tap_weights(const SampleTaps& t) {
     return w;
 }
 
+constexpr int kBoxSkip = INT32_MIN;       // boxes[].w of an empty footprint whose positions are all finite
+constexpr int kBoxEmpty = INT32_MIN + 1;  // empty footprint with a non-finite position: taps run and give NaN
 constexpr float kNoSample = -2.0f;  // entry of a tile pixel outside the image: no tap inside, all weights +0
 
 __device__ __forceinline__ float2 sample_position(const float* __restrict__ P, float x, float y, float d, int H, int W) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                                                                        int d_per_block) {
     constexpr int TH = kTilePix / TW;
     constexpr int ITER = (K * kTilePix + kThreads - 1) / kThreads;
-    __shared__ int s_red[2][K][2][4];  // [plane parity][neighbour][wave of the neighbour][xlo,xhi,ylo,yhi]
+    __shared__ int s_red[2][K][2][5];  // [plane parity][neighbour][wave of the neighbour][xlo,xhi,ylo,yhi,all finite]
     const int bt = blockIdx.x;  // n*tiles + tile
     const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
@@ -145,8 +147,10 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
             if (j < K) {
                 int xlo = INT32_MAX, xhi = INT32_MIN, ylo = INT32_MAX, yhi = INT32_MIN;
                 float2 e = make_float2(kNoSample, kNoSample);  // pixel outside the image: no taps, no footprint
+                int fin = 1;
                 if (inside) {
                     e = sample_position(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W);
+                    fin = (isfinite(e.x) && isfinite(e.y)) ? 1 : 0;
                     const SampleTaps t = decode_sample(e.x, e.y, H, W);
                     if ((t.x0in || t.x1in) && (t.y0in || t.y1in)) {  // bounding box of the taps that are inside
                         xlo = t.x0in ? t.x0 : t.x0 + 1;
@@ -160,9 +164,10 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                 xhi = wave_reduce<false>(xhi);
                 ylo = wave_reduce<true>(ylo);
                 yhi = wave_reduce<false>(yhi);
+                fin = wave_reduce<true>(fin);
                 if (lane == 0) {
                     int* r = s_red[par][j][(tid >> 6) & 1];
-                    r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi;
+                    r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi; r[4] = fin;
                 }
             }
         }
@@ -170,7 +175,11 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
         if (tid < K) {
             const int* a = s_red[par][tid][0];
             const int* b = s_red[par][tid][1];
-            boxes[base + tid] = make_int4(min(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), max(a[3], b[3]));
+            int4 bx = make_int4(min(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), max(a[3], b[3]));
+            // no tap of the whole tile is inside the source image: the warped values are exactly 0 and the sweep
+            // skips this neighbour (kBoxSkip) -- unless a position is NaN / Inf, whose taps must still produce NaN
+            if (bx.y < bx.x || bx.w < bx.z) bx = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, min(a[4], b[4]) ? kBoxSkip : kBoxEmpty);
+            boxes[base + tid] = bx;
         }
     }
 }
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         MVS_STAMP(-1)
         // ---- P1: footprint boxes (block-uniform scalars, computed once per tile by the coords kernel)
         int bx0[KK], bx1[KK], by0[KK], by1[KK], nc[KK], nr[KK];
-        bool staged[KK];
+        bool staged[KK], skip[KK];
         // make sure the prefetched values have landed before the DMA below is queued behind them
 #pragma unroll
         for (int it = 0; it < ITER; ++it) asm volatile("" ::"v"(en[it].x), "v"(en[it].y));
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
             nc[j] = bx1[j] - bx0[j] + 1;
             nr[j] = by1[j] - by0[j] + 1;
             staged[j] = (bx1[j] >= bx0[j]) && (by1[j] >= by0[j]) && (nc[j] * nr[j] <= box_cap);
+            skip[j] = (bx1[j] < bx0[j]) && (by1[j] == kBoxSkip);  // nothing of this neighbour is visible: w_j == 0
         }
         // the previous plane's tile reads (P5) must be over before the box storage is refilled
         if (d != d_begin) __syncthreads();
@@ -312,7 +322,11 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
-            if (j < K) {
+            bool live = false;
+#pragma unroll
+            for (int jj = 0; jj < K; ++jj)
+                if (jj == j && !skip[jj]) live = true;
+            if (live) {
                 const int p = tid % kTilePix;
                 const SampleTaps tp = decode_sample(en[it].x, en[it].y, H, W);
                 const int x0 = tp.x0, y0 = tp.y0;
@@ -334,12 +348,16 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
             S_[s][0] = f[s].x; S_[s][1] = f[s].y; S_[s][2] = f[s].z; S_[s][3] = f[s].w;
             Q_[s][0] = f[s].x * f[s].x; Q_[s][1] = f[s].y * f[s].y; Q_[s][2] = f[s].z * f[s].z; Q_[s][3] = f[s].w * f[s].w;
         }
+        bool tables_visible = false, prefetched = false;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
+            if (skip[j]) continue;  // S and Q keep their values: the warped features are all zero
             if (j > 0 && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
-            if (staged[j] || j == 0) __syncthreads();  // box (and, for the first neighbour, the tables) visible
+            if (staged[j] || !tables_visible) __syncthreads();  // box (and, the first time, the tables) visible
+            tables_visible = true;
             MVS_STAMP(2 + 2 * (j > 0 ? 1 : 0))  // (DMA issue of neighbour j>0) + wait for the box + barrier
-            if (j == 0 && d + 1 < d_end) prefetch(d + 1);     // lands while the taps below are computed
+            if (!prefetched && d + 1 < d_end) prefetch(d + 1);  // lands while the taps below are computed
+            prefetched = true;
             // ---- P3: taps -> warped value -> running sums
             if (staged[j]) {
 #pragma unroll
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
             if (staged[j]) __syncthreads();  // box fully read before it is overwritten (next neighbour / output tile)
             MVS_STAMP(3 + 2 * (j > 0 ? 1 : 0))  // taps + barrier
         }
+        if (!prefetched && d + 1 < d_end) prefetch(d + 1);  // every neighbour was skipped
         // ---- P4: variance -> output tile [channel row 8*i+g][pixel]
         float* s_tile = reinterpret_cast<float*>(s_box);
         {
