@@ -353,6 +353,12 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         for (int j = 0; j < K; ++j) {
             if (skip[j]) continue;  // S and Q keep their values: the warped features are all zero
             if (j > 0 && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
+            // The LDS-DMA pieces of this wave count on vmcnt, and for a workgroup barrier hipcc only waits for
+            // lgkmcnt: without the explicit wait a wave can pass the barrier while its own pieces are still in flight
+            // and the other waves read stale box texels.  (Found when a variant let some waves skip the decode, whose
+            // scratch reload had been supplying a vmcnt(0) by accident.)  s_waitcnt 0 = vmcnt, expcnt and lgkmcnt all
+            // zero, so the decode's LDS table writes are covered by the same instruction.  Costs nothing measurable.
+            if (staged[j]) __builtin_amdgcn_s_waitcnt(0);
             if (staged[j] || !tables_visible) __syncthreads();  // box (and, the first time, the tables) visible
             tables_visible = true;
             MVS_STAMP(2 + 2 * (j > 0 ? 1 : 0))  // (DMA issue of neighbour j>0) + wait for the box + barrier
