@@ -664,3 +664,47 @@ def test_hot_path_is_graph_capturable(gpu):
         for a, b in zip(outs, eager):
             assert torch.equal(a, b)
     assert int((outs[3] > 0).sum()) > 100
+
+
+# --------------------------------------------------------------------------------------------- randomised sweep cases
+@pytest.mark.parametrize("seed", range(12))
+def test_sweep_randomised_against_oracle(gpu, oracle, seed):
+    """Random shapes and random projective maps (shifts that push whole tiles out of view, shears, scales across the
+    LDS-box limit, planes at and behind the source camera), each run three times: bit-identical to the oracle every
+    time.  Covers the skipped-neighbour / staged / gathered paths in every mixture inside one launch."""
+    from mvsdet_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(2, 7))
+    K = int(rng.integers(1, min(4, N - 1) + 1))
+    C = int(rng.choice([5, 32, 40, 64, 96]))
+    D = int(rng.integers(1, 9))
+    H, W = int(rng.integers(5, 41)), int(rng.integers(6, 81))
+    feat = torch.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32))
+    nbr = np.stack([rng.permutation([j for j in range(N) if j != n] * 4)[:K] for n in range(N)]).astype(np.int64)
+    proj = np.tile(np.eye(4, dtype=np.float32), (N, K, 1, 1))
+    for n in range(N):
+        for j in range(K):
+            kind = rng.integers(0, 6)
+            A = np.eye(3, dtype=np.float32)
+            t = np.zeros(3, dtype=np.float32)
+            if kind == 0:      # ordinary small motion
+                A[:2, :2] += rng.normal(0, 0.05, (2, 2)); t[:2] = rng.normal(0, 3.0, 2)
+            elif kind == 1:    # large shift: most or all of the footprint leaves the image
+                t[:2] = rng.choice([-1, 1], 2) * rng.uniform(0.5, 2.5, 2) * np.array([W, H])
+            elif kind == 2:    # strong scale: footprints across the LDS-box limit
+                A[:2, :2] *= rng.uniform(1.5, 6.0)
+            elif kind == 3:    # perspective: z varies over the image, partly negative
+                A[2, :2] = rng.normal(0, 0.05, 2); t[2] = rng.normal(0, 0.5)
+            elif kind == 4:    # shrink: many pixels share a texel
+                A[:2, :2] *= rng.uniform(0.05, 0.5); t[:2] = rng.uniform(0, 1, 2) * np.array([W, H])
+            else:              # plane through the source camera centre for one depth value
+                A[2, 2] = 0.0; t[2] = 0.0 if rng.random() < 0.5 else 1.0
+            proj[n, j, :3, :3] = A
+            proj[n, j, :3, 3] = t
+    depth = np.sort(rng.uniform(0.2, 5.0, (1, D)).astype(np.float32), axis=1).repeat(N, 0)
+    ref = oracle.plane_sweep_variance(feat, nbr, proj, depth, mode=1)
+    args = (feat.to(gpu), torch.from_numpy(nbr).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(depth).to(gpu))
+    for _ in range(3):
+        out = ops.plane_sweep_variance(*args).cpu().numpy()
+        np.testing.assert_array_equal(np.isnan(out), np.isnan(ref))
+        np.testing.assert_array_equal(out[~np.isnan(ref)], ref[~np.isnan(ref)])
