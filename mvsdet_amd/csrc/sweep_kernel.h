@@ -317,7 +317,19 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
         // the previous plane's tile reads (P5) must be over before the box storage is refilled
         if (d != d_begin) __syncthreads();
         MVS_STAMP(0)  // unpack boxes + wait for the prefetch + barrier (previous tile reads)
-        if (K > 0 && staged[0]) load_box(0, bx0[0], by0[0], nc[0], nr[0]);  // in flight while the table is decoded
+        // the box of the FIRST neighbour that is not skipped is in flight while the table is decoded
+        bool early[KK];
+        {
+            bool taken = false;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                early[j] = !taken && !skip[j];
+                if (early[j]) {
+                    taken = true;
+                    if (staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
+                }
+            }
+        }
         // ---- table entry (sample position) -> weights + tap offsets (float4 units, lane slot g not yet added)
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (skip[j]) continue;  // S and Q keep their values: the warped features are all zero
-            if (j > 0 && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
+            if (!early[j] && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
             // The LDS-DMA pieces of this wave count on vmcnt, and for a workgroup barrier hipcc only waits for
             // lgkmcnt: without the explicit wait a wave can pass the barrier while its own pieces are still in flight
             // and the other waves read stale box texels.  (Found when a variant let some waves skip the decode, whose
