@@ -247,11 +247,13 @@ def main():
         raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU implementation")
     from mvsdet_amd import _lib
     _lib.load()
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for dry runs of the N>1 path on a box with fewer GPUs than ranks
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
         from mvsdet_amd import parallel
-        parallel.init_distributed("nccl", device)
+        # "nccl" is RCCL on ROCm; MVSDET_DIST_BACKEND=gloo lets two ranks share one GPU in a dry run
+        parallel.init_distributed(os.environ.get("MVSDET_DIST_BACKEND", "nccl"), device)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 

@@ -1,0 +1,49 @@
+"""bench.py's contract on the GPU box: one JSON line with the agreed keys at N=1, and the N>1 launch path
+(torch.distributed.run, one process per rank, barrier + max-over-ranks timing) as a two-rank dry run that shares the
+one GPU of the box over gloo -- on the 8-GPU node the same code runs with backend nccl (= RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(600)
+def test_single_gpu_line(gpu):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny_3v_8d_48x64", "--steps", "3",
+                          "--warmup", "1", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["config"]["workload"] == "tiny_3v_8d_48x64" and "model" not in d["config"]
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_launch_dry_run(gpu):
+    env = dict(os.environ, MVSDET_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "tiny_3v_8d_48x64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)                      # rank 0 prints, once
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["config"]["parallelism"].startswith("scene-sharded x2")
