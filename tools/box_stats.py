@@ -38,3 +38,11 @@ for name in sys.argv[1:] or ["scannet_40v_64d_120x160"]:
           f"staged area mean {area[staged].mean():.0f} p90 {np.percentile(area[staged], 90):.0f}; "
           f"DMA pieces/box mean {pieces[staged].mean():.1f} (useful {area[staged].mean() / 8:.1f}); "
           f"fallback area median {np.median(area[fb]) if fb.any() else 0:.0f}")
+    if K == 2:  # per (tile, plane): how the two neighbours combine
+        st = np.where(empty, 0, np.where(staged, 1, 2)).reshape(-1, 2)      # 0 skipped, 1 staged, 2 gathered
+        ar = area.reshape(-1, 2)
+        both_skip = (st == 0).all(1).mean()
+        one_live = ((st == 0).sum(1) == 1).mean()
+        both_staged = (st == 1).all(1)
+        print(f"    planes: both skipped {both_skip:.3f}, one live {one_live:.3f}, both live {1 - both_skip - one_live:.3f}; "
+              f"both staged with area0+area1 <= {CAP}: {(both_staged & (ar.sum(1) <= CAP)).mean():.3f} (of both staged {both_staged.mean():.3f})")
