@@ -161,6 +161,26 @@ def stage_breakdown(w, hp, scene, device, reps=3):
     return {n: round(float(np.median(v)), 4) for n, v in acc.items()}
 
 
+def footprint_stats(w, hp, scene, device):
+    """How the (tile, plane, neighbour) footprints of the first scene split: out of view (skipped by the sweep, exact),
+    staged in the LDS box, or gathered from L2 -- the sweep's speed depends on this mix (tools/box_stats.py)."""
+    from mvsdet_amd import ops
+    geo = hp.prepare_scene(scene.meta, device)
+    N, K, D, H, W = w["N"], geo.neighbor_ids.shape[1], w["D"], w["H"], w["W"]
+    if K == 0:
+        return None
+    tw = 32 if (W % 32 == 0 or W % 16 != 0) else 16
+    tiles = ((W + tw - 1) // tw) * ((H + 128 // tw - 1) // (128 // tw))
+    table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
+    nent = N * tiles * D * K
+    b = table[nent * 256: nent * 256 + nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)
+    nc, nr = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
+    empty = (nc <= 0) | (nr <= 0)
+    area = np.where(empty, 0, nc * nr)
+    return {"out_of_view": round(float(empty.mean()), 4), "staged_in_lds": round(float((~empty & (area <= 256)).mean()), 4),
+            "gathered": round(float((~empty & (area > 256)).mean()), 4)}
+
+
 def hbm_copy_ceiling(device, gib=2.0, reps=5):
     from mvsdet_amd import ops
     n = int(gib * (1 << 30) // 4)
@@ -298,6 +318,7 @@ def main():
         line["config"]["views_per_launch"] = w["chunk"]
     if rank == 0 and world == 1 and not args.no_extras and not w.get("chunk"):
         line["stage_ms"] = stage_breakdown(w, hp, scenes[0], device)
+        line["roofline"]["footprints"] = footprint_stats(w, hp, scenes[0], device)
         del scenes
         torch.cuda.empty_cache()
         line["hbm_copy_ceiling_GBps"] = round(hbm_copy_ceiling(device), 1)
