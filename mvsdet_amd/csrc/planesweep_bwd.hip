@@ -27,7 +27,7 @@
 namespace mvsdet {
 
 template <int K, int TW>
-__global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
+__global__ __launch_bounds__(kThreads, 3) void plane_sweep_variance_bwd_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float2* __restrict__ table,
     const int4* __restrict__ boxes, const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S,
     int D, int H, int W, int tiles_x, int tiles) {
