@@ -161,6 +161,62 @@ def stage_breakdown(w, hp, scene, device, reps=3):
     return {n: round(float(np.median(v)), 4) for n, v in acc.items()}
 
 
+class PointwiseCostReg(torch.nn.Module):
+    """Trainable stand-in for CostRegNet_3DGS: (N,C,D,H,W) -> (N,2,D,H,W) as one thin GEMM per view (2 x C weights), so
+    that neither MIOpen's 3-D convolutions nor their tuning runs are part of the measurement."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(2, channels) / channels ** 0.5)
+        self.bias = torch.nn.Parameter(torch.zeros(2))
+
+    def forward(self, var):
+        n, c, d, h, w = var.shape
+        out = torch.matmul(self.weight, var.reshape(n, c, d * h * w)) + self.bias.view(1, 2, 1)
+        return out.view(n, 2, d, h, w)
+
+
+def run_train(args, w, rank, world, device):
+    """BASELINE.json configs[2]: training step of the hot path -- forward a1..a10, loss, backward through the custom
+    ops' autograd, optimiser step -- with a trainable stand-in for CostRegNet_3DGS (PointwiseCostReg) wrapped in DistributedDataParallel when N > 1: the gradient all-reduce
+    over RCCL/xGMI is the only collective, exactly as in the reference's DDP training."""
+    from mvsdet_amd import parallel
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    torch.manual_seed(0)
+    net = PointwiseCostReg(w["C"]).to(device)
+    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=None) if world > 1 else net
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4)
+    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3, cost_regularization=model)
+    scenes = [SceneInputs(w, seed=rank * 100 + i, device=device) for i in range(args.scene_pool)]
+    geos = [hp.prepare_scene(s.meta, device) for s in scenes]
+
+    def step(i):
+        s = scenes[i % len(scenes)]
+        feat = s.features.detach().requires_grad_(True)   # the 2-D backbone's output: receives dL/dfeat
+        out = hp.forward_scene(feat, s.meta, geo=geos[i % len(scenes)])
+        loss = out["volume"].square().mean() + out["depth_coding"].mean() + out["est_densities"].mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return float(feat.grad.abs().sum().item()) if i == args.steps - 1 else 0.0
+
+    barrier = parallel.barrier if world > 1 else (lambda: None)
+    for i in range(args.warmup):
+        step(-1 - i)
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    checksum = 0.0
+    for i in range(args.steps):
+        checksum += step(i)
+    torch.cuda.synchronize(device)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = parallel.max_over_ranks(elapsed, device)
+    return elapsed, checksum
+
+
 def footprint_stats(w, hp, scene, device):
     """How the (tile, plane, neighbour) footprints of the first scene split: out of view (skipped by the sweep, exact),
     staged in the LDS box, or gathered from L2 -- the sweep's speed depends on this mix (tools/box_stats.py)."""
@@ -258,6 +314,8 @@ def main():
     ap.add_argument("--scene-pool", type=int, default=2, help="distinct resident scenes cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--no-extras", action="store_true", help="skip stage breakdown / copy ceiling / R-shape line")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="train = configs[2]: fwd + bwd + optimiser step with a stand-in cost network under DDP")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -281,6 +339,25 @@ def main():
     if name == "auto":
         free = torch.cuda.mem_get_info(device)[0]
         name = "scannet_40v_64d_120x160" if free > 70 * (1 << 30) else "scannet_ref_40v_12d_60x80"
+    if args.mode == "train":
+        if args.workload == "auto":
+            name = "scannet_ref_40v_12d_60x80"   # what mvsdet_res50_2x_low_res.py trains on
+        w = WORKLOADS[name]
+        elapsed, checksum = run_train(args, w, rank, world, device)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "training scenes/sec through the hot path (fwd a1..a10 + bwd + optimiser step, stand-in cost network)",
+                "value": round(args.steps * world / elapsed, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "train",
+                "config": {"workload": name, "views": w["N"], "channels": w["C"], "depth_planes": w["D"],
+                           "feat_hw": [w["H"], w["W"]], "scenes_per_step_per_gpu": 1,
+                           "parallelism": f"ddp x{world}, gradient all-reduce only"},
+                "roofline": None, "checksum": checksum}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     w = WORKLOADS[name]
 
     elapsed, sweep_ms, checksum, hp, scenes = run_gpu(args, w, rank, world, device)

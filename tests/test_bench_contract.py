@@ -47,3 +47,18 @@ def test_two_rank_launch_dry_run(gpu):
     d = _last_json(out.stdout)                      # rank 0 prints, once
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["parallelism"].startswith("scene-sharded x2")
+
+
+@pytest.mark.timeout(600)
+def test_training_mode_two_rank_ddp_dry_run(gpu):
+    """configs[2]: fwd + bwd + optimiser step of the hot path with a trainable stand-in network under
+    DistributedDataParallel, two ranks sharing the GPU over gloo (nccl = RCCL on the 8-GPU node)."""
+    env = dict(os.environ, MVSDET_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2",
+           "--warmup", "1", "--workload", "tiny_3v_8d_48x64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["mode"] == "train" and d["n_gpus"] == 2 and d["value"] > 0 and d["checksum"] > 0
+    assert d["config"]["parallelism"].startswith("ddp x2")
