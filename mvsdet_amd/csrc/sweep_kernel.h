@@ -16,11 +16,14 @@
 //                 128 B; each wave owns 32 pixels = 4 steps; the reference features of those pixels stay in
 //                 registers across the depth loop.
 //       per depth plane
-//         P1  scalar-load the footprint boxes; start the LDS-DMA of neighbour 0's box; one thread per (pixel,
-//             neighbour) decodes its table entry into 4 weights + 4 tap offsets inside the box (or inside the
+//         P1  scalar-load the footprint boxes; a neighbour with NO tap of the whole tile inside its image is dropped
+//             for this plane (its warped values are exactly 0; a third of all (tile, plane, neighbour) triples at
+//             ScanNet-like geometry); start the LDS-DMA of the first live neighbour's box; one thread per (pixel,
+//             live neighbour) decodes its table entry into 4 weights + 4 tap offsets inside the box (or inside the
 //             slab image when the footprint does not fit in LDS and that neighbour gathers from global memory)
-//         per neighbour j
-//           P2  LDS-DMA of the box rows (contiguous nc*128-byte runs of the slab image), 1 KiB per wave-instruction
+//         per live neighbour j
+//           P2  LDS-DMA of the box rows (contiguous nc*128-byte runs of the slab image), 1 KiB per wave-instruction;
+//               explicit s_waitcnt 0 before the barrier that publishes the box (hipcc waits for lgkmcnt only)
 //           P3  taps = 4 x ds_read_b128 per step; fma chain -> S, Q
 //         P4  variance -> LDS tile [32 channels][128 pixels] (aliases the box storage)
 //         P5  tile rows -> global as 16-byte non-temporal stores, 128 B contiguous per (channel, tile row); each wave
