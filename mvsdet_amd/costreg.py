@@ -1,0 +1,69 @@
+"""The cost regularisation network that sits between a4 and a5 ("next"):
+`CostRegNet_3DGS` of mvs_models/mvsnet.py:73-113 -- a three-level 3-D U-Net, (N,256,D,H,W) variance ->
+(N,2,D,H,W) {cost logits, offset logits}.
+
+This is plain PyTorch (MIOpen convolutions), not a HIP kernel of ours: it exists so that `MVSDetHotPath.forward_scene`
+can run the reference's whole stage chain with real weights.  Parameter names and shapes equal the reference's
+(`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,
+`prob.weight/bias`), so a reference checkpoint's `cost_regularization.*` entries load with `load_state_dict`
+(tests/test_integration.py compares the outputs with the reference module itself).  D, H, W must be divisible by 4
+(two stride-2 levels), as in the reference.
+
+At the reference-true shape the network is ~2.8 TFLOP per scene against ~1 ms for the whole hot path around it:
+on the GPU it, not the plane sweep, is what a scene costs.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+class _ConvBnReLU3d(nn.Module):
+    """Conv3d(no bias) -> BatchNorm3d -> ReLU, with the reference's sub-module names `conv` and `bn` (module.py:26)."""
+
+    def __init__(self, cin: int, cout: int, stride: int = 1):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False)
+        self.bn = nn.BatchNorm3d(cout)
+
+    def forward(self, x):
+        return torch.relu_(self.bn(self.conv(x)))
+
+
+def _up(cin: int, cout: int) -> nn.Sequential:
+    # indices 0 / 1 / 2 of the Sequential are the reference's parameter names (mvsnet.py:92-100)
+    return nn.Sequential(nn.ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False),
+                         nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+
+class CostRegNet3DGS(nn.Module):
+    def __init__(self, in_channels: int = 256, base: int = 64):
+        super().__init__()
+        self.conv0 = _ConvBnReLU3d(in_channels, base)
+        self.conv1 = _ConvBnReLU3d(base, 2 * base, stride=2)
+        self.conv2 = _ConvBnReLU3d(2 * base, 2 * base)
+        self.conv3 = _ConvBnReLU3d(2 * base, 4 * base, stride=2)
+        self.conv4 = _ConvBnReLU3d(4 * base, 4 * base)
+        self.conv9 = _up(4 * base, 2 * base)
+        self.conv11 = _up(2 * base, base)
+        self.prob = nn.Conv3d(base, 2, 3, stride=1, padding=1)
+
+    def forward(self, x):
+        if any(s % 4 for s in x.shape[2:]):
+            raise ValueError(f"CostRegNet3DGS: D, H, W must be divisible by 4, got {tuple(x.shape[2:])}")
+        full = self.conv0(x)                          # (N, 64, D, H, W)
+        half = self.conv2(self.conv1(full))           # (N, 128, D/2, H/2, W/2)
+        quarter = self.conv4(self.conv3(half))        # (N, 256, D/4, H/4, W/4)
+        half = half + self.conv9(quarter)
+        full = full + self.conv11(half)
+        return self.prob(full)                        # (N, 2, D, H, W)
+
+    @staticmethod
+    def flops(n: int, d: int, h: int, w: int, in_channels: int = 256, base: int = 64) -> float:
+        """Multiply-add count x2 of one forward pass (for the MFMA roofline of this network)."""
+        v = n * d * h * w
+        k = 27 * 2
+        full, half, quarter = v, v / 8, v / 64
+        return k * (in_channels * base * full + base * 2 * base * half + (2 * base) ** 2 * half +
+                    2 * base * 4 * base * quarter + (4 * base) ** 2 * quarter +
+                    4 * base * 2 * base * quarter + 2 * base * base * half + base * 2 * full)

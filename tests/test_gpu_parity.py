@@ -708,3 +708,32 @@ def test_sweep_randomised_against_oracle(gpu, oracle, seed):
         out = ops.plane_sweep_variance(*args).cpu().numpy()
         np.testing.assert_array_equal(np.isnan(out), np.isnan(ref))
         np.testing.assert_array_equal(out[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+# --------------------------------------------------------------------------------------------- with the real cost network
+def test_forward_scene_with_cost_regularisation_network(gpu, oracle):
+    """a1..a10 with the 3-D U-Net between a4 and a5 (mvsdet_amd.costreg, MIOpen): forward_scene feeds the variance
+    volume to the module and its logits to the a5-a7 kernel; the stages after the network equal the oracle's on the
+    network's own output, and gradients reach both the features and the network."""
+    from mvsdet_amd import synthetic
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw = 3, 32, 8, (24, 32)
+    torch.manual_seed(0)
+    net = CostRegNet3DGS(C, base=8).to(gpu)
+    hp = MVSDetHotPath([16, 16, 8], [.4, .4, .4], [0.2, 5.0], D, cost_regularization=net)
+    meta = synthetic.make_img_meta(N, hw, seed=6)
+    feat = synthetic.make_features(N, C, hw, seed=6).to(gpu).requires_grad_(True)
+    out = hp.forward_scene(feat, meta)
+    logits = net(out["variance"].detach()).detach()
+    r = oracle.depth_prob_topk(logits[:, 0].cpu().numpy(), logits[:, 1].cpu().numpy(), 0.2, hp.depth_interval, 3)
+    np.testing.assert_allclose(out["prob_volume"].detach().cpu().numpy(), r["prob"], rtol=0, atol=2e-6)
+    sep = np.sort(r["prob"], axis=1)
+    clear = (sep[:, -1] - sep[:, -2] > 1e-4) & (sep[:, -2] - sep[:, -3] > 1e-4) & (sep[:, -3] - sep[:, -4] > 1e-4)
+    h, w = out["geometry"].height, out["geometry"].width
+    got = out["est_depth"].detach().cpu().numpy()
+    np.testing.assert_allclose(got[np.broadcast_to(clear[:, None, :h, :w], got.shape)],
+                               r["est_depth"][:, :, :h, :w][np.broadcast_to(clear[:, None, :h, :w], got.shape)], rtol=0, atol=1e-5)
+    (out["volume"].square().mean() + out["depth_coding"].mean()).backward()
+    assert feat.grad is not None and torch.isfinite(feat.grad).all() and float(feat.grad.abs().sum()) > 0
+    assert all(p.grad is not None for p in net.parameters())

@@ -49,3 +49,31 @@ def test_patch_and_unpatch(reference):
     finally:
         integration.unpatch_reference(ref, orig)
     assert ref.homo_warping is orig["homo_warping"]
+
+
+def test_cost_regularisation_network_matches_the_reference_module(reference):
+    """mvsdet_amd.costreg.CostRegNet3DGS against mvs_models/mvsnet.py:CostRegNet_3DGS: same parameter names and
+    shapes (a reference checkpoint loads), same outputs in eval and in train mode (CPU, fp32)."""
+    import torch
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    ref_net = sys.modules["refpkg.mvs_models.mvsnet"].CostRegNet_3DGS()
+    torch.manual_seed(0)
+    for m in ref_net.modules():            # non-trivial BatchNorm statistics and affine parameters
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    ours = CostRegNet3DGS()
+    sd = ref_net.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    ours.load_state_dict(sd)
+    x = torch.rand(1, 256, 8, 12, 16)
+    for mode in ("eval", "train"):
+        getattr(ref_net, mode)(); getattr(ours, mode)()
+        with torch.no_grad():
+            a, b = ref_net(x.clone()), ours(x.clone())
+        assert a.shape == (1, 2, 8, 12, 16)
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5)
+    # 2.8 TFLOP per scene at the reference-true shape (SURVEY.md 8 f-1)
+    assert 2.5e12 < CostRegNet3DGS.flops(40, 12, 60, 80) < 3.2e12
+    with pytest.raises(ValueError):
+        ours(torch.rand(1, 256, 6, 12, 16))
