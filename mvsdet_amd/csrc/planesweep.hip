@@ -150,7 +150,13 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     float2* table = reinterpret_cast<float2*>(scratch);
     int4* boxes = reinterpret_cast<int4*>(table + (size_t)N * tiles * D * K * kTilePix);
     dim3 cgrid((unsigned)(N * tiles), (D + d_per_block - 1) / d_per_block);
-    dim3 grid((unsigned)nblocks, (D + d_per_block - 1) / d_per_block);
+    // XCD-aware id -> (slab, tile) map for fewer than 8 slabs (see the kernel); MVSDET_SWEEP_XCD=0 switches it off
+    const char* excd = getenv("MVSDET_SWEEP_XCD");
+    const int n_bt = N * tiles;
+    int xcd_parts = (S < 8 && 8 % S == 0 && !(excd && atoi(excd) == 0)) ? 8 / S : 1;
+    long long grid_x = nblocks;
+    if (xcd_parts > 1) grid_x = 8LL * ((n_bt + xcd_parts - 1) / xcd_parts);
+    dim3 grid((unsigned)grid_x, (D + d_per_block - 1) / d_per_block);
     const float* ref_packed = packed ? packed + (size_t)ref_first * S * H * W * kSlab : nullptr;
 #define MVS_SWEEP_CASE(KV)                                                                                            \
     case KV:                                                                                                          \
@@ -160,22 +166,22 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         if (!(phases & 2)) break;                                                                                     \
         if (half_out)                                                                                                 \
             hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, true, false, __half>), grid, dim3(kThreads), 0, stream, packed, \
-                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
+                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts); \
         else if (g_stamps)                                                                                                 \
             hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, true>), grid, dim3(kThreads), 0, stream, packed, \
-                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
+                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts); \
         else                                                                                                          \
             hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, \
-                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps); \
+                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts); \
         break;
     switch (K) {
         case 0:
             if ((phases & 2) && half_out)
                 hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, true, false, __half>), grid, dim3(kThreads), 0, stream, packed,
-                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
+                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts);
             else if (phases & 2)
                 hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, ref_packed, nbr,
-                               table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps);
+                               table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts);
             break;
         MVS_SWEEP_CASE(1)
         MVS_SWEEP_CASE(2)

@@ -196,7 +196,7 @@ template <int K, int TW, bool NT, bool STAMP, typename OutT = float>
 __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
     const float2* __restrict__ table, const int4* __restrict__ boxes, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps) {
+    int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps, int n_bt, int xcd_parts) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
     constexpr int ITER = (KK * kTilePix + kThreads - 1) / kThreads;
@@ -207,8 +207,17 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
 
     const int HW = H * W;
     const int id = blockIdx.x;
-    const int slab = id % S;
-    const int bt = id / S;  // n*tiles + tile
+    int slab = id % S;
+    int bt = id / S;  // n*tiles + tile
+    if (xcd_parts > 1) {
+        // fewer than 8 slabs (C < 256): the 8/S XCDs that share a slab each take one contiguous range of
+        // (view, tile) pairs, so an XCD's L2 sees a compact set of source rows instead of every 8th tile's
+        const int xcd = id & 7, k = id >> 3;
+        const int per_part = (n_bt + xcd_parts - 1) / xcd_parts;
+        slab = xcd % S;
+        bt = (xcd / S) * per_part + k;
+        if (k >= per_part || bt >= n_bt) return;  // padding blocks of the rounded-up grid (whole block, before any barrier)
+    }
     const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int d_begin = blockIdx.y * d_per_block;
