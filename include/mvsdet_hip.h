@@ -154,6 +154,15 @@ int mvsdet_depth_prob_topk_bwd_f32(const float* prob, const float* off, const in
                                    int H, int W, int topk, float near, float interval, mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Head of the cost regularisation network (first step): mvs_models/mvsnet.py:102,112
+ *   self.prob = nn.Conv3d(64, 2, 3, stride=1, padding=1);  x = self.prob(x)
+ * x (N,Cin,D,H,W) dense fp32, weight (2,Cin,3,3,3), bias (2) or NULL -> out (N,2,D,H,W): the (cost, offset)
+ * logits that mvsdet_depth_prob_topk_f32 consumes.  Forward only (training keeps the framework's convolution).
+ * ------------------------------------------------------------------------------------------- */
+int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
+                               int D, int H, int W, mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a9  backproject_Weigh -- mvsdet.py:1372-1492 (gt_depth=None).
  *   feat + feat_strides: (N,C,h,w) view of the 2-D features (crop allowed, see pack above)
  *   points (3,V) voxel coordinates from get_points (mvsdet.py:1316); projection (N,3,4)

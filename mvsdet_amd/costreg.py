@@ -56,7 +56,15 @@ class CostRegNet3DGS(nn.Module):
         quarter = self.conv4(self.conv3(half))        # (N, 256, D/4, H/4, W/4)
         half = half + self.conv9(quarter)
         full = full + self.conv11(half)
-        return self.prob(full)                        # (N, 2, D, H, W)
+        return self._head(full)                       # (N, 2, D, H, W)
+
+    def _head(self, full):
+        """mvsnet.py:112.  Two output channels make a poor GEMM (MIOpen: 8.2 ms at the reference-true shape); without
+        autograd the streaming HIP kernel of csrc/costreg_head.hip does it in a fraction of that."""
+        if full.is_cuda and full.dtype == torch.float32 and not torch.is_grad_enabled():
+            from . import ops
+            return ops.conv3d_k3_cout2(full, self.prob.weight.detach(), self.prob.bias.detach())
+        return self.prob(full)
 
     @staticmethod
     def flops(n: int, d: int, h: int, w: int, in_channels: int = 256, base: int = 64) -> float:

@@ -1,0 +1,133 @@
+// Last layer of the cost regularisation network (mvs_models/mvsnet.py:102,112): Conv3d(Cin -> 2, kernel 3, padding 1,
+// bias) on the full-resolution (N,Cin,D,H,W) feature volume -> (N,2,D,H,W) {cost logits, offset logits}.
+//
+// Two output channels make a poor GEMM (MIOpen: 8.2 ms for 8 GFLOP at the reference-true shape) but a trivial
+// streaming kernel: every input value is read once per tile (+ halo) and used for 54 fused multiply-adds.
+//
+//   block  = (view n, TD x TH x TW = 4 x 8 x 32 output voxels); thread = one (h, w) column of TD = 4 voxels
+//   loop over input channels in chunks of CC = 4: the chunk's halo tile (6 x 10 x 34 floats per channel) is staged
+//   in LDS with zero padding; per channel and (kh, kw) a thread reads its 6 values along d once and feeds the
+//   3 kd x 4 voxels x 2 outputs = 24 FMAs; the 54 weights of a channel are wave-uniform scalar loads.
+//   The next chunk's halo values are fetched into registers while the current chunk is computed.
+//   Bound: VALU issue (4 FMA per LDS dword read; 8 GFMA = 0.2-0.25 ms of fp32 FMA issue) + the 0.6 GB input stream
+//   (x2 with halos, from L2).  Measured 0.44 ms at (40,64,12,60,80) against 8.2 ms for MIOpen's convolution.
+//
+// Accumulation order: channels ascending, then kh, kw, kd -- fp32 FMA chain; differs from MIOpen's / ATen's order by
+// rounding only (tests compare against ATen-CPU conv3d within 1e-5 of the output scale).
+#include "common.h"
+
+namespace mvsdet {
+
+constexpr int kTD = 4, kTH = 8, kTW = 32, kCC = 4;
+constexpr int kHD = kTD + 2, kHH = kTH + 2, kHW = kTW + 2;  // halo tile 6 x 10 x 34
+constexpr int kHaloVox = kHD * kHH * kHW;                  // 2040 floats per channel
+
+__global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    int Cin, int D, int H, int W, int tiles_w, int tiles_h) {
+    __shared__ float s_in[kCC][kHaloVox];
+    const int tid = threadIdx.x;
+    const int tw = tid % kTW, th = tid / kTW;  // 32 x 8 threads
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int w0 = bw * kTW, h0 = bh * kTH, d0 = blockIdx.y * kTD, n = blockIdx.z;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    const float* xn = x + (size_t)n * Cin * vol;
+
+    float acc[2][kTD];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < kTD; ++t) acc[o][t] = bias ? bias[o] : 0.0f;
+
+    // staging plan of this thread, the same for every channel: halo elements r = tid + 256*k -> offset inside a
+    // channel volume (or -1 outside the volume: zero padding)
+    constexpr int kStage = (kHaloVox + kThreads - 1) / kThreads;  // 8
+    int s_off[kStage];
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+        const int r = tid + k * kThreads;
+        const int dz = r / (kHH * kHW), r2 = r - dz * (kHH * kHW);
+        const int hy = r2 / kHW, wx = r2 - hy * kHW;
+        const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
+        const bool ok = r < kHaloVox && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
+        s_off[k] = ok ? (int)((size_t)d * plane + (size_t)h * W + w) : -1;
+    }
+
+    // software pipeline: the next chunk's halo values travel global -> registers while this chunk is computed
+    float nxt[kCC][kStage];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int cc = 0; cc < kCC; ++cc) {
+            const float* xc = xn + (size_t)(c0 + cc) * vol;
+            const bool cok = c0 + cc < Cin;
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) nxt[cc][k] = (cok && s_off[k] >= 0) ? xc[s_off[k]] : 0.0f;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < Cin; c0 += kCC) {
+        __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+        for (int cc = 0; cc < kCC; ++cc)
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) {
+                const int r = tid + k * kThreads;
+                if (r < kHaloVox) s_in[cc][r] = nxt[cc][k];
+            }
+        __syncthreads();
+        if (c0 + kCC < Cin) fetch(c0 + kCC);
+#pragma unroll
+        for (int cc = 0; cc < kCC; ++cc) {
+            const int c = c0 + cc;
+            if (c >= Cin) break;
+            const float* w0p = wgt + (size_t)c * 27;                   // weight[0][c][kd][kh][kw]
+            const float* w1p = wgt + ((size_t)Cin + c) * 27;           // weight[1][c][...]
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* col = &s_in[cc][(th + kh) * kHW + (tw + kw)];
+                    float v[kHD];
+#pragma unroll
+                    for (int dz = 0; dz < kHD; ++dz) v[dz] = col[dz * (kHH * kHW)];
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd) {
+                        const float a = w0p[(kd * 3 + kh) * 3 + kw], b = w1p[(kd * 3 + kh) * 3 + kw];  // wave-uniform
+#pragma unroll
+                        for (int t = 0; t < kTD; ++t) {
+                            acc[0][t] = fmaf(v[t + kd], a, acc[0][t]);
+                            acc[1][t] = fmaf(v[t + kd], b, acc[1][t]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int h = h0 + th, w = w0 + tw;
+    if (h < H && w < W) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int t = 0; t < kTD; ++t)
+                if (d0 + t < D) out[((size_t)n * 2 + o) * vol + (size_t)(d0 + t) * plane + (size_t)h * W + w] = acc[o][t];
+    }
+}
+
+}  // namespace mvsdet
+
+using namespace mvsdet;
+
+extern "C" int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N,
+                                          int Cin, int D, int H, int W, mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && weight && out, "conv3d_k3_cout2: NULL pointer");
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_cout2: bad shape N=%d Cin=%d D=%d H=%d W=%d", N, Cin, D,
+                H, W);
+    const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH, tiles_d = (D + kTD - 1) / kTD;
+    MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_cout2: N or D too large");
+    MVS_REQUIRE((size_t)D * H * W < (size_t)INT32_MAX, "conv3d_k3_cout2: one channel volume exceeds 2^31 elements");
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
+    hipLaunchKernelGGL(conv3d_k3_cout2_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, weight, bias, out, Cin, D, H,
+                       W, tiles_w, tiles_h);
+    MVS_LAUNCH_CHECK("conv3d_k3_cout2");
+    return MVSDET_OK;
+}

@@ -6,7 +6,7 @@ their inputs are not float32 tensors on a ROCm device -- there is no CPU impleme
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -598,3 +598,31 @@ def device_copy(src: Tensor, dst: Tensor):
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     with torch.cuda.device(src.device):
         _lib.check(_lib.load().mvsdet_copy_f32(_lib.ptr(src), _lib.ptr(dst), src.numel(), _stream(src)), "copy")
+
+
+# ------------------------------------------------------------------------------------------- cost network head (f-1)
+@torch.library.custom_op(f"{_NS}::conv3d_k3_cout2", mutates_args=(), device_types="cuda")
+def conv3d_k3_cout2(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """Conv3d(Cin -> 2, kernel 3, stride 1, padding 1) of mvs_models/mvsnet.py:102 on (N,Cin,D,H,W) -> (N,2,D,H,W).
+    Forward only: under autograd use torch's convolution (mvsdet_amd.costreg does)."""
+    _req(x, "x", dim=5)
+    _req(weight, "weight", dim=5)
+    N, Cin, D, H, W = x.shape
+    if tuple(weight.shape) != (2, Cin, 3, 3, 3):
+        raise ValueError(f"conv3d_k3_cout2: weight {tuple(weight.shape)} != (2,{Cin},3,3,3)")
+    if bias is not None:
+        _req(bias, "bias", dim=1)
+        if bias.numel() != 2:
+            raise ValueError("conv3d_k3_cout2: bias must have 2 elements")
+        bias = bias.contiguous()
+    x, weight = x.contiguous(), weight.contiguous()
+    out = torch.empty((N, 2, D, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_conv3d_k3_cout2_f32(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), N, Cin,
+                                                          D, H, W, _stream(x)), "conv3d_k3_cout2")
+    return out
+
+
+@conv3d_k3_cout2.register_fake
+def _(x, weight, bias):
+    return x.new_empty((x.shape[0], 2) + tuple(x.shape[2:]))

@@ -737,3 +737,22 @@ def test_forward_scene_with_cost_regularisation_network(gpu, oracle):
     (out["volume"].square().mean() + out["depth_coding"].mean()).backward()
     assert feat.grad is not None and torch.isfinite(feat.grad).all() and float(feat.grad.abs().sum()) > 0
     assert all(p.grad is not None for p in net.parameters())
+
+
+@pytest.mark.parametrize("N,Cin,D,H,W", [(2, 64, 12, 60, 80), (1, 64, 5, 7, 33), (3, 6, 4, 9, 40), (1, 10, 1, 1, 1)])
+def test_cost_network_head_conv(gpu, N, Cin, D, H, W):
+    """csrc/costreg_head.hip (Conv3d Cin -> 2, k=3, pad=1, bias) against ATen-CPU conv3d: same sums in a different
+    order, so within 1e-5 of the output scale; ragged tiles in d, h and w, Cin not a multiple of the channel chunk."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    wgt = torch.randn(2, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b = torch.randn(2, generator=g)
+    ref = torch.nn.functional.conv3d(x, wgt, b, padding=1)
+    out = ops.conv3d_k3_cout2(x.to(gpu), wgt.to(gpu), b.to(gpu)).cpu()
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out, ref, rtol=0, atol=1e-5 * float(ref.abs().max()))
+    out0 = ops.conv3d_k3_cout2(x.to(gpu), wgt.to(gpu), None).cpu()
+    torch.testing.assert_close(out0, ref - b.view(1, 2, 1, 1, 1), rtol=0, atol=1e-5 * float(ref.abs().max()))
+    with pytest.raises(ValueError):
+        ops.conv3d_k3_cout2(x.to(gpu), wgt[:, :, :2].contiguous().to(gpu), None)
