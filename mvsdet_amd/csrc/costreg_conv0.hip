@@ -1,0 +1,166 @@
+// First layer of the cost regularisation network (mvs_models/mvsnet.py:76,105): Conv3d(Cin -> 64, kernel 3, padding 1,
+// no bias) on the variance volume (N,Cin,D,H,W), optionally followed by a per-channel affine (eval-mode BatchNorm
+// folded) and ReLU -- 72 % of the network's 2.8 TFLOP.  Implicit GEMM on the fp32 matrix cores:
+//
+//   D[o][w] += sum over (channel pair, tap) of A[o][k] * B[k][w]          v_mfma_f32_32x32x2_f32, k = channel in pair
+//     A = weights, pre-permuted by the caller to [c][kd][kh][kw][o] so that a channel pair's 2 x 27 x 64 block is one
+//         contiguous 13.8 KB run;   B = input row of 32 voxels along w, shifted by the tap
+//   block = (view, tile of 2 x 4 x 32 voxels (d,h,w)) x all 64 output channels; wave = 2 rows of 32 voxels x 2 blocks of
+//           32 channels = 4 accumulators of 32x32 (64 VGPRs); per channel pair and tap 2 A reads + 2 B reads
+//           (ds_read_b32, conflict-free) feed 4 MFMAs (256 matrix-core cycles)
+//   per channel pair the halo tile (2 x 4x6x34 floats) and the weight block are staged in LDS; the next pair's values
+//   travel global -> registers while the current pair is multiplied.
+//   Numerics: an fp32 MFMA is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md), so the result is an fp32
+//   FMA sum in (channel, tap) order -- the same products as ATen's convolution in another order.
+// Bound: fp32 MFMA, 64 FLOP/clk/SIMD = 157 TFLOP/s; 2.04 TFLOP at (40,256,12,60,80) = 13 ms at peak (15.5 ms with
+// the w-padding of 80 -> 96).
+#include "common.h"
+
+namespace mvsdet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kC0D = 2, kC0H = 4, kC0W = 32;
+constexpr int kC0HD = kC0D + 2, kC0HH = kC0H + 2, kC0HW = kC0W + 2;   // halo 4 x 6 x 34
+constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // 816 floats per channel
+constexpr int kC0Out = 64;
+constexpr int kC0WPair = 2 * 27 * kC0Out;                            // 3456 floats of weights per channel pair
+constexpr int kC0InStage = (2 * kC0Halo + kThreads - 1) / kThreads;  // 7 input values per thread and pair
+constexpr int kC0WStage = (kC0WPair / 4 + kThreads - 1) / kThreads;  // 4 float4 of weights per thread and pair
+
+__global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
+    const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int Cin, int D, int H, int W, int tiles_w, int tiles_h,
+    int relu) {
+    __shared__ float s_in[2 * kC0Halo];
+    __shared__ float4 s_w4[kC0WPair / 4];
+    const float* s_w = reinterpret_cast<const float*>(s_w4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * kC0D, n = blockIdx.z;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    const float* xn = x + (size_t)n * Cin * vol;
+    const int npairs = (Cin + 1) / 2;
+
+    // this wave's two voxel rows: row r = dz*4 + hy, r in {2*wave, 2*wave+1}
+    const int dz0 = wave >> 1, hy0 = (wave & 1) * 2;
+    const int col = lane & 31, kk = lane >> 5;  // MFMA operand lane map: A[i=col][k=kk], B[k=kk][j=col]
+
+    // staging plan (identical for every channel pair): input element e = tid + 256*k of the 2 x 816 halo values
+    int in_off[kC0InStage];
+#pragma unroll
+    for (int k = 0; k < kC0InStage; ++k) {
+        const int e = tid + k * kThreads;
+        const int kc = e / kC0Halo, r = e - kc * kC0Halo;
+        const int dz = r / (kC0HH * kC0HW), r2 = r - dz * (kC0HH * kC0HW);
+        const int hy = r2 / kC0HW, wx = r2 - hy * kC0HW;
+        const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
+        const bool ok = e < 2 * kC0Halo && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
+        // bit 30 carries the channel of the pair; offsets stay below 2^30 (checked by the launcher)
+        in_off[k] = ok ? (int)((size_t)d * plane + (size_t)h * W + w) | (kc << 30) : -1;
+    }
+
+    float in_reg[kC0InStage];
+    float4 w_reg[kC0WStage];
+    auto fetch = [&](int cp) {
+        const float* x0 = xn + (size_t)(2 * cp) * vol;
+        const bool has1 = 2 * cp + 1 < Cin;
+#pragma unroll
+        for (int k = 0; k < kC0InStage; ++k) {
+            const int o = in_off[k];
+            const int kc = (o >> 30) & 1;
+            float v = 0.0f;
+            if (o >= 0 && (kc == 0 || has1)) v = x0[(size_t)kc * vol + (o & 0x3fffffff)];
+            in_reg[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < kC0WStage; ++k) {
+            const int e = tid + k * kThreads;
+            w_reg[k] = e < kC0WPair / 4 ? wperm[(size_t)cp * (kC0WPair / 4) + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    f32x16 acc[2][2];  // [output-channel block][voxel row]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    fetch(0);
+    for (int cp = 0; cp < npairs; ++cp) {
+        __syncthreads();  // previous pair fully consumed
+#pragma unroll
+        for (int k = 0; k < kC0InStage; ++k) {
+            const int e = tid + k * kThreads;
+            if (e < 2 * kC0Halo) s_in[e] = in_reg[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kC0WStage; ++k) {
+            const int e = tid + k * kThreads;
+            if (e < kC0WPair / 4) s_w4[e] = w_reg[k];
+        }
+        __syncthreads();
+        if (cp + 1 < npairs) fetch(cp + 1);
+
+        const float* bin = s_in + kk * kC0Halo + (dz0 * kC0HH + hy0) * kC0HW + col;
+        const float* ain = s_w + kk * 27 * kC0Out + col;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+                    const float a0 = ain[tap * kC0Out], a1 = ain[tap * kC0Out + 32];
+                    const float b0 = bin[(kd * kC0HH + kh) * kC0HW + kw];
+                    const float b1 = bin[(kd * kC0HH + kh + 1) * kC0HW + kw];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (voxel along w), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    const int w = w0 + col;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int d = d0 + dz0, h = h0 + hy0 + rb;
+        if (d >= D || h >= H || w >= W) continue;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                float v = acc[ob][rb][r];
+                if (scale) v = fmaf(v, scale[o], shift[o]);
+                if (relu) v = fmaxf(v, 0.0f);
+                out[((size_t)n * kC0Out + o) * vol + (size_t)d * plane + (size_t)h * W + w] = v;
+            }
+    }
+}
+
+}  // namespace mvsdet
+
+using namespace mvsdet;
+
+extern "C" int mvsdet_conv3d_k3_c64_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                        float* out, int N, int Cin, int D, int H, int W, int relu, mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && weight_perm && out, "conv3d_k3_c64: NULL pointer");
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3d_k3_c64: scale and shift come together");
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_c64: bad shape N=%d Cin=%d D=%d H=%d W=%d", N, Cin, D, H,
+                W);
+    MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "conv3d_k3_c64: weights must be 16-byte aligned");
+    MVS_REQUIRE((size_t)D * H * W < ((size_t)1 << 30), "conv3d_k3_c64: one channel volume exceeds 2^30 elements");
+    const int tiles_w = (W + kC0W - 1) / kC0W, tiles_h = (H + kC0H - 1) / kC0H, tiles_d = (D + kC0D - 1) / kC0D;
+    MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_c64: N or D too large");
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
+    hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, D, H, W, tiles_w, tiles_h, relu);
+    MVS_LAUNCH_CHECK("conv3d_k3_c64");
+    return MVSDET_OK;
+}

@@ -626,3 +626,45 @@ def conv3d_k3_cout2(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor
 @conv3d_k3_cout2.register_fake
 def _(x, weight, bias):
     return x.new_empty((x.shape[0], 2) + tuple(x.shape[2:]))
+
+
+def permute_conv0_weight(weight: Tensor) -> Tensor:
+    """(64,Cin,3,3,3) -> the [c][kd][kh][kw][o] layout conv3d_k3_c64 reads (Cin padded to even with zeros)."""
+    cout, cin = weight.shape[:2]
+    if cout != 64 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"conv3d_k3_c64: weight {tuple(weight.shape)} != (64,Cin,3,3,3)")
+    w = weight.detach().permute(1, 2, 3, 4, 0).contiguous()
+    if cin % 2:
+        w = torch.cat([w, w.new_zeros((1, 3, 3, 3, 64))], 0)
+    return w
+
+
+@torch.library.custom_op(f"{_NS}::conv3d_k3_c64", mutates_args=(), device_types="cuda")
+def conv3d_k3_c64(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool) -> Tensor:
+    """Conv3d(Cin -> 64, kernel 3, padding 1, no bias) [+ per-channel affine + ReLU] of mvs_models/mvsnet.py:76 on the
+    fp32 matrix cores: x (N,Cin,D,H,W), weight_perm = permute_conv0_weight(weight) -> (N,64,D,H,W).  Forward only."""
+    _req(x, "x", dim=5)
+    _req(weight_perm, "weight_perm", dim=5)
+    N, Cin, D, H, W = x.shape
+    if tuple(weight_perm.shape) != (Cin + Cin % 2, 3, 3, 3, 64):
+        raise ValueError(f"conv3d_k3_c64: weight_perm {tuple(weight_perm.shape)} does not match Cin={Cin}")
+    if (scale is None) != (shift is None):
+        raise ValueError("conv3d_k3_c64: scale and shift come together")
+    if scale is not None:
+        _req(scale, "scale", dim=1)
+        _req(shift, "shift", dim=1)
+        if scale.numel() != 64 or shift.numel() != 64:
+            raise ValueError("conv3d_k3_c64: scale / shift must have 64 elements")
+        scale, shift = scale.contiguous(), shift.contiguous()
+    x, weight_perm = x.contiguous(), weight_perm.contiguous()
+    out = torch.empty((N, 64, D, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_conv3d_k3_c64_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
+                                                        _lib.ptr(out), N, Cin, D, H, W, int(relu), _stream(x)),
+                   "conv3d_k3_c64")
+    return out
+
+
+@conv3d_k3_c64.register_fake
+def _(x, weight_perm, scale, shift, relu):
+    return x.new_empty((x.shape[0], 64) + tuple(x.shape[2:]))

@@ -756,3 +756,48 @@ def test_cost_network_head_conv(gpu, N, Cin, D, H, W):
     torch.testing.assert_close(out0, ref - b.view(1, 2, 1, 1, 1), rtol=0, atol=1e-5 * float(ref.abs().max()))
     with pytest.raises(ValueError):
         ops.conv3d_k3_cout2(x.to(gpu), wgt[:, :, :2].contiguous().to(gpu), None)
+
+
+@pytest.mark.parametrize("N,Cin,D,H,W", [(1, 256, 4, 8, 32), (2, 32, 5, 7, 33), (1, 7, 3, 5, 80), (1, 2, 1, 1, 1)])
+def test_cost_network_first_conv_mfma(gpu, N, Cin, D, H, W):
+    """csrc/costreg_conv0.hip (Conv3d Cin -> 64, k=3, pad=1 on the fp32 matrix cores) against ATen-CPU conv3d, with and
+    without the folded BatchNorm + ReLU epilogue; ragged tiles in d, h, w and an odd channel count."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    wgt = torch.randn(64, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    ref = torch.nn.functional.conv3d(x, wgt, None, padding=1)
+    tol = 2e-6 * float(ref.abs().max()) * max(1.0, (27 * Cin) ** 0.5 / 8)
+    wp = ops.permute_conv0_weight(wgt.to(gpu))
+    out = ops.conv3d_k3_c64(x.to(gpu), wp, None, None, False).cpu()
+    assert out.shape == ref.shape
+    torch.testing.assert_close(out, ref, rtol=0, atol=tol)
+    out2 = ops.conv3d_k3_c64(x.to(gpu), wp, scale.to(gpu), shift.to(gpu), True).cpu()
+    ref2 = torch.relu(ref * scale.view(1, 64, 1, 1, 1) + shift.view(1, 64, 1, 1, 1))
+    torch.testing.assert_close(out2, ref2, rtol=0, atol=2 * tol)
+    with pytest.raises(ValueError):
+        ops.conv3d_k3_c64(x.to(gpu), wp, scale.to(gpu), None, True)
+
+
+def test_cost_network_hip_layers_match_torch_layers(gpu):
+    """CostRegNet3DGS in eval mode without autograd (HIP first conv + folded BN + ReLU, HIP head) against the same
+    module evaluated with torch's own layers (autograd on), on the GPU: same network, two execution routes."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    torch.manual_seed(1)
+    net = CostRegNet3DGS(256).to(gpu).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    x = torch.rand(2, 256, 8, 12, 32, device=gpu)
+    with torch.no_grad():
+        fast = net(x)
+    slow = net(x.clone().requires_grad_(True)).detach()      # autograd on: torch layers throughout
+    torch.testing.assert_close(fast, slow, rtol=0, atol=2e-5 * float(slow.abs().max()))
+    net.conv0.conv.weight.data.mul_(0.5)                      # the kernel reads the current weights on every call
+    with torch.no_grad():
+        fast2 = net(x)
+    slow2 = net(x.clone().requires_grad_(True)).detach()
+    torch.testing.assert_close(fast2, slow2, rtol=0, atol=2e-5 * float(slow2.abs().max()))
+    assert float((fast2 - fast).abs().max()) > 1e-4
