@@ -12,26 +12,31 @@
 //   travel global -> registers while the current pair is multiplied.
 //   Numerics: an fp32 MFMA is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md), so the result is an fp32
 //   FMA sum in (channel, tap) order -- the same products as ATen's convolution in another order.
-// Bound: fp32 MFMA, 64 FLOP/clk/SIMD = 157 TFLOP/s; 2.04 TFLOP at (40,256,12,60,80) = 13 ms at peak (15.5 ms with
-// the w-padding of 80 -> 96).
+// Bound: fp32 MFMA, 64 FLOP/clk/SIMD = 157 TFLOP/s; 2.04 TFLOP at (40,256,12,60,80) = 13 ms at peak.
+// Measured 15.7 ms = 130 TFLOP/s (MIOpen: 33.6 ms).
 #include "common.h"
 
 namespace mvsdet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kC0D = 2, kC0H = 4, kC0W = 32;
-constexpr int kC0HD = kC0D + 2, kC0HH = kC0H + 2, kC0HW = kC0W + 2;   // halo 4 x 6 x 34
-constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // 816 floats per channel
+// The 32 B-columns of an MFMA are 32 voxels along w (TWC = 32: tile 2 x 4 x 32) or two h-rows of 16 (TWC = 16: tile
+// 2 x 8 x 16): the launcher picks the one that pads W less (W = 80: 96 vs 80).
+constexpr int kC0D = 2;
 constexpr int kC0Out = 64;
 constexpr int kC0WPair = 2 * 27 * kC0Out;                            // 3456 floats of weights per channel pair
-constexpr int kC0InStage = (2 * kC0Halo + kThreads - 1) / kThreads;  // 7 input values per thread and pair
 constexpr int kC0WStage = (kC0WPair / 4 + kThreads - 1) / kThreads;  // 4 float4 of weights per thread and pair
 
+template <int TWC>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int Cin, int D, int H, int W, int tiles_w, int tiles_h,
     int relu) {
+    constexpr int kC0W = TWC, kC0H = 4 * (32 / TWC);
+    constexpr int kC0HD = kC0D + 2, kC0HH = kC0H + 2, kC0HW = kC0W + 2;   // halo 4 x 6 x 34 or 4 x 10 x 18
+    constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // 816 / 720 floats per channel
+    constexpr int kC0InStage = (2 * kC0Halo + kThreads - 1) / kThreads;  // input values per thread and pair
+    constexpr int kRowsPerCol = 32 / TWC;                                // h-rows covered by the 32 MFMA columns
     __shared__ float s_in[2 * kC0Halo];
     __shared__ float4 s_w4[kC0WPair / 4];
     const float* s_w = reinterpret_cast<const float*>(s_w4);
@@ -44,9 +49,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     const float* xn = x + (size_t)n * Cin * vol;
     const int npairs = (Cin + 1) / 2;
 
-    // this wave's two voxel rows: row r = dz*4 + hy, r in {2*wave, 2*wave+1}
-    const int dz0 = wave >> 1, hy0 = (wave & 1) * 2;
+    // this wave's two MFMA column groups g = 2*wave, 2*wave+1 of the tile's 8: plane dz0 = g / 4, h-rows
+    // (g % 4)*kRowsPerCol .. ; inside a group column c is voxel (h-row c / TWC, w = c % TWC)
+    const int dz0 = wave >> 1, hy0 = (wave & 1) * 2 * kRowsPerCol;
     const int col = lane & 31, kk = lane >> 5;  // MFMA operand lane map: A[i=col][k=kk], B[k=kk][j=col]
+    const int chy = col / TWC, cw = col % TWC;
 
     // staging plan (identical for every channel pair): input element e = tid + 256*k of the 2 x 816 halo values
     int in_off[kC0InStage];
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
         __syncthreads();
         if (cp + 1 < npairs) fetch(cp + 1);
 
-        const float* bin = s_in + kk * kC0Halo + (dz0 * kC0HH + hy0) * kC0HW + col;
+        const float* bin = s_in + kk * kC0Halo + (dz0 * kC0HH + hy0 + chy) * kC0HW + cw;
         const float* ain = s_w + kk * 27 * kC0Out + col;
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
                     const int tap = (kd * 3 + kh) * 3 + kw;
                     const float a0 = ain[tap * kC0Out], a1 = ain[tap * kC0Out + 32];
                     const float b0 = bin[(kd * kC0HH + kh) * kC0HW + kw];
-                    const float b1 = bin[(kd * kC0HH + kh + 1) * kC0HW + kw];
+                    const float b1 = bin[(kd * kC0HH + kh + kRowsPerCol) * kC0HW + kw];
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -126,10 +133,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     }
 
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (voxel along w), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    const int w = w0 + col;
+    const int w = w0 + cw;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-        const int d = d0 + dz0, h = h0 + hy0 + rb;
+        const int d = d0 + dz0, h = h0 + hy0 + rb * kRowsPerCol + chy;
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
@@ -156,11 +163,22 @@ extern "C" int mvsdet_conv3d_k3_c64_f32(const float* x, const float* weight_perm
                 W);
     MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "conv3d_k3_c64: weights must be 16-byte aligned");
     MVS_REQUIRE((size_t)D * H * W < ((size_t)1 << 30), "conv3d_k3_c64: one channel volume exceeds 2^30 elements");
-    const int tiles_w = (W + kC0W - 1) / kC0W, tiles_h = (H + kC0H - 1) / kC0H, tiles_d = (D + kC0D - 1) / kC0D;
+    // 32 voxels along w per MFMA column group, or 2 h-rows of 16: whichever covers (H, W) with less padding
+    const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 3) / 4 * 4);
+    const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 7) / 8 * 8);
+    const int twc = pad16 < pad32 ? 16 : 32;
+    const int th = 4 * (32 / twc);
+    const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + kC0D - 1) / kC0D;
     MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_c64: N or D too large");
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
-    hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
-                       reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, D, H, W, tiles_w, tiles_h, relu);
+    if (twc == 16)
+        hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
+                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, D, H, W, tiles_w, tiles_h,
+                           relu);
+    else
+        hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel<32>, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
+                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, D, H, W, tiles_w, tiles_h,
+                           relu);
     MVS_LAUNCH_CHECK("conv3d_k3_c64");
     return MVSDET_OK;
 }
