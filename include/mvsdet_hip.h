@@ -159,13 +159,14 @@ int mvsdet_depth_prob_topk_bwd_f32(const float* prob, const float* off, const in
  * x (N,Cin,D,H,W) dense fp32, weight (2,Cin,3,3,3), bias (2) or NULL -> out (N,2,D,H,W): the (cost, offset)
  * logits that mvsdet_depth_prob_topk_f32 consumes.  Forward only (training keeps the framework's convolution).
  * ------------------------------------------------------------------------------------------- */
-/* First layer of the same network, mvs_models/mvsnet.py:76,105 (ConvBnReLU3D(256, 64): Conv3d k=3, padding 1, no bias):
- *   x (N,Cin,D,H,W) dense fp32 -> out (N,64,D,H,W) on the fp32 matrix cores (exact fp32 FMA sums).
- *   weight_perm: the (64,Cin,3,3,3) weight permuted to [c][kd][kh][kw][o] (Cin rounded up to even, zero padded),
- *   16-byte aligned.  scale / shift (64 each, or both NULL): out = v*scale[o] + shift[o] -- eval-mode BatchNorm folded;
+/* The stride-1 ConvBnReLU3D layers of the same network, mvs_models/mvsnet.py:76,79,82 (Conv3d k=3, padding 1, no bias;
+ * conv0 256->64, conv2 128->128, conv4 256->256):
+ *   x (N,Cin,D,H,W) dense fp32 -> out (N,Cout,D,H,W), Cout a multiple of 64, on the fp32 matrix cores (exact fp32 FMA sums).
+ *   weight_perm: the (Cout,Cin,3,3,3) weight permuted to [c][kd][kh][kw][o] (Cin rounded up to even, zero padded),
+ *   16-byte aligned.  scale / shift (Cout each, or both NULL): out = v*scale[o] + shift[o] -- eval-mode BatchNorm folded;
  *   relu != 0 clamps at 0.  Forward only. */
-int mvsdet_conv3d_k3_c64_f32(const float* x, const float* weight_perm, const float* scale, const float* shift, float* out,
-                             int N, int Cin, int D, int H, int W, int relu, mvsdet_stream_t stream);
+int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift, float* out,
+                              int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                                int D, int H, int W, mvsdet_stream_t stream);
 

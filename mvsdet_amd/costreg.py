@@ -51,27 +51,27 @@ class CostRegNet3DGS(nn.Module):
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
             raise ValueError(f"CostRegNet3DGS: D, H, W must be divisible by 4, got {tuple(x.shape[2:])}")
-        full = self._conv0(x)                         # (N, 64, D, H, W)
-        half = self.conv2(self.conv1(full))           # (N, 128, D/2, H/2, W/2)
-        quarter = self.conv4(self.conv3(half))        # (N, 256, D/4, H/4, W/4)
+        full = self._cbr(self.conv0, x)                           # (N, 64, D, H, W)
+        half = self._cbr(self.conv2, self.conv1(full))            # (N, 128, D/2, H/2, W/2)
+        quarter = self._cbr(self.conv4, self.conv3(half))         # (N, 256, D/4, H/4, W/4)
         half = half + self.conv9(quarter)
         full = full + self.conv11(half)
         return self._head(full)                       # (N, 2, D, H, W)
 
-    def _conv0(self, x):
-        """mvsnet.py:105.  72 % of the network's FLOPs.  Without autograd and in eval mode (BatchNorm = per-channel
-        affine) the fp32-MFMA kernel of csrc/costreg_conv0.hip runs conv + BN + ReLU in one pass: 15.7 ms (130 TFLOP/s)
-        instead of 33.6 + 0.5 ms for MIOpen at the reference-true shape, same fp32 FMA sums."""
-        c0 = self.conv0
+    def _cbr(self, layer, x):
+        """A stride-1 ConvBnReLU3D layer (mvsnet.py:76,79,82: conv0, conv2, conv4).  Without autograd and in eval mode
+        (BatchNorm = per-channel affine) the fp32-MFMA kernel of csrc/costreg_conv0.hip runs conv + BN + ReLU in one
+        pass -- conv0 at the reference-true shape: 15.7 ms (130 TFLOP/s) instead of 33.6 + 0.5 ms for MIOpen, the same
+        fp32 FMA sums."""
+        conv, bn = layer.conv, layer.bn
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not self.training
-                and c0.conv.out_channels == 64):
+                and conv.out_channels % 64 == 0 and conv.stride == (1, 1, 1)):
             from . import ops
-            wperm = ops.permute_conv0_weight(c0.conv.weight)   # 1.8 MB, negligible next to the convolution
-            bn = c0.bn
+            wperm = ops.permute_conv_weight(conv.weight)   # a few MB at most, negligible next to the convolution
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
             shift = (bn.bias - bn.running_mean * scale).detach()
-            return ops.conv3d_k3_c64(x, wperm, scale, shift, True)
-        return c0(x)
+            return ops.conv3d_k3_mfma(x, wperm, scale, shift, True)
+        return layer(x)
 
     def _head(self, full):
         """mvsnet.py:112.  Two output channels make a poor GEMM (MIOpen: 8.2 ms at the reference-true shape); without

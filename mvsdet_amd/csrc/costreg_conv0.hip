@@ -30,8 +30,8 @@ constexpr int kC0WStage = (kC0WPair / 4 + kThreads - 1) / kThreads;  // 4 float4
 template <int TWC>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ out, int Cin, int D, int H, int W, int tiles_w, int tiles_h,
-    int relu) {
+    const float* __restrict__ shift, float* __restrict__ out, int Cin, int Cout, int D, int H, int W, int tiles_w,
+    int tiles_h, int relu) {
     constexpr int kC0W = TWC, kC0H = 4 * (32 / TWC);
     constexpr int kC0HD = kC0D + 2, kC0HH = kC0H + 2, kC0HW = kC0W + 2;   // halo 4 x 6 x 34 or 4 x 10 x 18
     constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // 816 / 720 floats per channel
@@ -44,7 +44,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
-    const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * kC0D, n = blockIdx.z;
+    // blockIdx.z = (view, block of 64 output channels): Cout > 64 runs as Cout/64 independent slices of the weights
+    const int nob = Cout / kC0Out;
+    const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * kC0D, n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
     const float* xn = x + (size_t)n * Cin * vol;
     const int npairs = (Cin + 1) / 2;
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < kC0WStage; ++k) {
             const int e = tid + k * kThreads;
-            w_reg[k] = e < kC0WPair / 4 ? wperm[(size_t)cp * (kC0WPair / 4) + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // row = (channel of the pair, tap), 16 float4 = this block's 64 of the Cout output channels
+            w_reg[k] = e < kC0WPair / 4 ? wperm[((size_t)cp * 54 + (e >> 4)) * (Cout / 4) + ob64 * 16 + (e & 15)]
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -142,11 +146,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
         for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 float v = acc[ob][rb][r];
                 if (scale) v = fmaf(v, scale[o], shift[o]);
                 if (relu) v = fmaxf(v, 0.0f);
-                out[((size_t)n * kC0Out + o) * vol + (size_t)d * plane + (size_t)h * W + w] = v;
+                out[((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w] = v;
             }
     }
 }
@@ -155,30 +159,32 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
 
 using namespace mvsdet;
 
-extern "C" int mvsdet_conv3d_k3_c64_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
-                                        float* out, int N, int Cin, int D, int H, int W, int relu, mvsdet_stream_t stream) {
-    MVS_REQUIRE(x && weight_perm && out, "conv3d_k3_c64: NULL pointer");
-    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3d_k3_c64: scale and shift come together");
-    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_c64: bad shape N=%d Cin=%d D=%d H=%d W=%d", N, Cin, D, H,
+extern "C" int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                         float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                         mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && weight_perm && out, "conv3d_k3_mfma: NULL pointer");
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3d_k3_mfma: scale and shift come together");
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_mfma: bad shape N=%d Cin=%d D=%d H=%d W=%d", N, Cin, D, H,
                 W);
-    MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "conv3d_k3_c64: weights must be 16-byte aligned");
-    MVS_REQUIRE((size_t)D * H * W < ((size_t)1 << 30), "conv3d_k3_c64: one channel volume exceeds 2^30 elements");
+    MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "conv3d_k3_mfma: weights must be 16-byte aligned");
+    MVS_REQUIRE((size_t)D * H * W < ((size_t)1 << 30), "conv3d_k3_mfma: one channel volume exceeds 2^30 elements");
     // 32 voxels along w per MFMA column group, or 2 h-rows of 16: whichever covers (H, W) with less padding
     const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 3) / 4 * 4);
     const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 7) / 8 * 8);
     const int twc = pad16 < pad32 ? 16 : 32;
     const int th = 4 * (32 / twc);
     const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + kC0D - 1) / kC0D;
-    MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_c64: N or D too large");
-    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
+    MVS_REQUIRE(Cout > 0 && Cout % kC0Out == 0, "conv3d_k3_mfma: Cout=%d must be a multiple of 64", Cout);
+    MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "conv3d_k3_mfma: N*Cout/64 or D too large");
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out)));
     if (twc == 16)
         hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
-                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, D, H, W, tiles_w, tiles_h,
-                           relu);
+                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, Cout, D, H, W, tiles_w,
+                           tiles_h, relu);
     else
         hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel<32>, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
-                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, D, H, W, tiles_w, tiles_h,
-                           relu);
-    MVS_LAUNCH_CHECK("conv3d_k3_c64");
+                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, Cout, D, H, W, tiles_w,
+                           tiles_h, relu);
+    MVS_LAUNCH_CHECK("conv3d_k3_mfma");
     return MVSDET_OK;
 }

@@ -628,43 +628,51 @@ def _(x, weight, bias):
     return x.new_empty((x.shape[0], 2) + tuple(x.shape[2:]))
 
 
-def permute_conv0_weight(weight: Tensor) -> Tensor:
-    """(64,Cin,3,3,3) -> the [c][kd][kh][kw][o] layout conv3d_k3_c64 reads (Cin padded to even with zeros)."""
+def permute_conv_weight(weight: Tensor) -> Tensor:
+    """(Cout,Cin,3,3,3) -> the [c][kd][kh][kw][o] layout conv3d_k3_mfma reads (Cin padded to even with zeros)."""
     cout, cin = weight.shape[:2]
-    if cout != 64 or tuple(weight.shape[2:]) != (3, 3, 3):
-        raise ValueError(f"conv3d_k3_c64: weight {tuple(weight.shape)} != (64,Cin,3,3,3)")
+    if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"conv3d_k3_mfma: weight {tuple(weight.shape)} != (64*m,Cin,3,3,3)")
     w = weight.detach().permute(1, 2, 3, 4, 0).contiguous()
     if cin % 2:
-        w = torch.cat([w, w.new_zeros((1, 3, 3, 3, 64))], 0)
+        w = torch.cat([w, w.new_zeros((1, 3, 3, 3, cout))], 0)
     return w
 
 
-@torch.library.custom_op(f"{_NS}::conv3d_k3_c64", mutates_args=(), device_types="cuda")
-def conv3d_k3_c64(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool) -> Tensor:
-    """Conv3d(Cin -> 64, kernel 3, padding 1, no bias) [+ per-channel affine + ReLU] of mvs_models/mvsnet.py:76 on the
-    fp32 matrix cores: x (N,Cin,D,H,W), weight_perm = permute_conv0_weight(weight) -> (N,64,D,H,W).  Forward only."""
+permute_conv0_weight = permute_conv_weight
+
+
+@torch.library.custom_op(f"{_NS}::conv3d_k3_mfma", mutates_args=(), device_types="cuda")
+def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool) -> Tensor:
+    """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ per-channel affine + ReLU] of
+    mvs_models/mvsnet.py:76-82 on the fp32 matrix cores: x (N,Cin,D,H,W), weight_perm = permute_conv_weight(weight)
+    -> (N,Cout,D,H,W).  Forward only."""
     _req(x, "x", dim=5)
     _req(weight_perm, "weight_perm", dim=5)
     N, Cin, D, H, W = x.shape
-    if tuple(weight_perm.shape) != (Cin + Cin % 2, 3, 3, 3, 64):
-        raise ValueError(f"conv3d_k3_c64: weight_perm {tuple(weight_perm.shape)} does not match Cin={Cin}")
+    Cout = weight_perm.shape[4]
+    if tuple(weight_perm.shape[:4]) != (Cin + Cin % 2, 3, 3, 3) or Cout % 64:
+        raise ValueError(f"conv3d_k3_mfma: weight_perm {tuple(weight_perm.shape)} does not match Cin={Cin}")
     if (scale is None) != (shift is None):
-        raise ValueError("conv3d_k3_c64: scale and shift come together")
+        raise ValueError("conv3d_k3_mfma: scale and shift come together")
     if scale is not None:
         _req(scale, "scale", dim=1)
         _req(shift, "shift", dim=1)
-        if scale.numel() != 64 or shift.numel() != 64:
-            raise ValueError("conv3d_k3_c64: scale / shift must have 64 elements")
+        if scale.numel() != Cout or shift.numel() != Cout:
+            raise ValueError(f"conv3d_k3_mfma: scale / shift must have {Cout} elements")
         scale, shift = scale.contiguous(), shift.contiguous()
     x, weight_perm = x.contiguous(), weight_perm.contiguous()
-    out = torch.empty((N, 64, D, H, W), dtype=torch.float32, device=x.device)
+    out = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mvsdet_conv3d_k3_c64_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
-                                                        _lib.ptr(out), N, Cin, D, H, W, int(relu), _stream(x)),
-                   "conv3d_k3_c64")
+        _lib.check(_lib.load().mvsdet_conv3d_k3_mfma_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
+                                                         _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu), _stream(x)),
+                   "conv3d_k3_mfma")
     return out
 
 
-@conv3d_k3_c64.register_fake
+@conv3d_k3_mfma.register_fake
 def _(x, weight_perm, scale, shift, relu):
-    return x.new_empty((x.shape[0], 64) + tuple(x.shape[2:]))
+    return x.new_empty((x.shape[0], weight_perm.shape[4]) + tuple(x.shape[2:]))
+
+
+conv3d_k3_c64 = conv3d_k3_mfma

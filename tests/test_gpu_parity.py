@@ -778,6 +778,11 @@ def test_cost_network_first_conv_mfma(gpu, N, Cin, D, H, W):
     torch.testing.assert_close(out2, ref2, rtol=0, atol=2 * tol)
     with pytest.raises(ValueError):
         ops.conv3d_k3_c64(x.to(gpu), wp, scale.to(gpu), None, True)
+    # Cout = 128: two independent 64-channel slices of the weights (conv2 / conv4 of the network)
+    wgt2 = torch.randn(128, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    ref3 = torch.nn.functional.conv3d(x, wgt2, None, padding=1)
+    out3 = ops.conv3d_k3_mfma(x.to(gpu), ops.permute_conv_weight(wgt2.to(gpu)), None, None, False).cpu()
+    torch.testing.assert_close(out3, ref3, rtol=0, atol=2e-6 * float(ref3.abs().max()) * max(1.0, (27 * Cin) ** 0.5 / 8))
 
 
 def test_cost_network_hip_layers_match_torch_layers(gpu):
