@@ -217,6 +217,30 @@ def run_train(args, w, rank, world, device):
     return elapsed, checksum
 
 
+def full_chain_rate(device, steps=10):
+    """a1..a10 with the real CostRegNet_3DGS (random weights, eval mode, no autograd) between a4 and a5 at the shape the
+    shipped config runs: what a scene costs end to end on the GPU (the network is ~30x the hot path around it)."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    wr = WORKLOADS["scannet_ref_40v_12d_60x80"]
+    torch.manual_seed(0)
+    net = CostRegNet3DGS(wr["C"]).to(device).eval()
+    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(wr["near_far"]), wr["D"], topk=3, cost_regularization=net)
+    scene = SceneInputs(wr, seed=0, device=device)
+    with torch.no_grad():
+        for _ in range(2):
+            out = hp.forward_scene(scene.features, scene.meta)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = hp.forward_scene(scene.features, scene.meta)
+        torch.cuda.synchronize(device)
+    el = time.perf_counter() - t0
+    return {"workload": "scannet_ref_40v_12d_60x80", "scenes_per_sec": round(steps / el, 3),
+            "ms_per_scene": round(el / steps * 1e3, 3), "cost_network_tflop": round(CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12, 3),
+            "non_empty_voxels": int((out["valid"] > 0).sum().item())}
+
+
 def footprint_stats(w, hp, scene, device):
     """How the (tile, plane, neighbour) footprints of the first scene split: out of view (skipped by the sweep, exact),
     staged in the LDS box, or gathered from L2 -- the sweep's speed depends on this mix (tools/box_stats.py)."""
@@ -314,6 +338,9 @@ def main():
     ap.add_argument("--scene-pool", type=int, default=2, help="distinct resident scenes cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--no-extras", action="store_true", help="skip stage breakdown / copy ceiling / R-shape line")
+    ap.add_argument("--with-cost-network", action="store_true",
+                    help="extra: scenes/s of a1..a10 with the real cost regularisation network in between (reference-true shape; "
+                         "the first run spends about a minute in MIOpen's kernel search)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="train = configs[2]: fwd + bwd + optimiser step with a stand-in cost network under DDP")
     args = ap.parse_args()
@@ -412,6 +439,8 @@ def main():
                                             "sweep_GBps": round(br / (sm * 1e-3) / 1e9, 1),
                                             "stage_ms": stage_breakdown(wr, hp_r, sc_r[0], device)}
             del sc_r
+    if rank == 0 and world == 1 and args.with_cost_network:
+        line["with_cost_network"] = full_chain_rate(device)
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and not w.get("half"):
         line["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
