@@ -167,6 +167,10 @@ int mvsdet_depth_prob_topk_bwd_f32(const float* prob, const float* off, const in
  *   relu != 0 clamps at 0.  Forward only. */
 int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift, float* out,
                               int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* The stride-2 layers (mvsnet.py:78,81: conv1 64->128, conv3 128->256): same arguments, x (N,Cin,D,H,W) ->
+ * out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1). */
+int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                 float* out, int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                                int D, int H, int W, mvsdet_stream_t stream);
 

@@ -52,25 +52,25 @@ class CostRegNet3DGS(nn.Module):
         if any(s % 4 for s in x.shape[2:]):
             raise ValueError(f"CostRegNet3DGS: D, H, W must be divisible by 4, got {tuple(x.shape[2:])}")
         full = self._cbr(self.conv0, x)                           # (N, 64, D, H, W)
-        half = self._cbr(self.conv2, self.conv1(full))            # (N, 128, D/2, H/2, W/2)
-        quarter = self._cbr(self.conv4, self.conv3(half))         # (N, 256, D/4, H/4, W/4)
+        half = self._cbr(self.conv2, self._cbr(self.conv1, full))         # (N, 128, D/2, H/2, W/2)
+        quarter = self._cbr(self.conv4, self._cbr(self.conv3, half))      # (N, 256, D/4, H/4, W/4)
         half = half + self.conv9(quarter)
         full = full + self.conv11(half)
         return self._head(full)                       # (N, 2, D, H, W)
 
     def _cbr(self, layer, x):
-        """A stride-1 ConvBnReLU3D layer (mvsnet.py:76,79,82: conv0, conv2, conv4).  Without autograd and in eval mode
+        """A ConvBnReLU3D layer (mvsnet.py:76-82: conv0..conv4, stride 1 or 2).  Without autograd and in eval mode
         (BatchNorm = per-channel affine) the fp32-MFMA kernel of csrc/costreg_conv0.hip runs conv + BN + ReLU in one
         pass -- conv0 at the reference-true shape: 15.7 ms (130 TFLOP/s) instead of 33.6 + 0.5 ms for MIOpen, the same
         fp32 FMA sums."""
         conv, bn = layer.conv, layer.bn
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not self.training
-                and conv.out_channels % 64 == 0 and conv.stride == (1, 1, 1)):
+                and conv.out_channels % 64 == 0 and conv.stride in ((1, 1, 1), (2, 2, 2))):
             from . import ops
             wperm = ops.permute_conv_weight(conv.weight)   # a few MB at most, negligible next to the convolution
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
             shift = (bn.bias - bn.running_mean * scale).detach()
-            return ops.conv3d_k3_mfma(x, wperm, scale, shift, True)
+            return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
         return layer(x)
 
     def _head(self, full):

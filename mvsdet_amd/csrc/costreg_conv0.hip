@@ -27,14 +27,16 @@ constexpr int kC0Out = 64;
 constexpr int kC0WPair = 2 * 27 * kC0Out;                            // 3456 floats of weights per channel pair
 constexpr int kC0WStage = (kC0WPair / 4 + kThreads - 1) / kThreads;  // 4 float4 of weights per thread and pair
 
-template <int TWC>
+// ST = stride (1 or 2, padding 1): input voxel = ST * output voxel - 1 + tap; (Di,Hi,Wi) input, (D,H,W) output extents.
+template <int TWC, int ST>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ out, int Cin, int Cout, int D, int H, int W, int tiles_w,
-    int tiles_h, int relu) {
+    const float* __restrict__ shift, float* __restrict__ out, int Cin, int Cout, int Di, int Hi, int Wi, int D, int H,
+    int W, int tiles_w, int tiles_h, int relu) {
     constexpr int kC0W = TWC, kC0H = 4 * (32 / TWC);
-    constexpr int kC0HD = kC0D + 2, kC0HH = kC0H + 2, kC0HW = kC0W + 2;   // halo 4 x 6 x 34 or 4 x 10 x 18
-    constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // 816 / 720 floats per channel
+    // halo of the input tile: ST*(T-1) + 3 per dimension (stride 1: 4 x 6 x 34 or 4 x 10 x 18)
+    constexpr int kC0HD = ST * (kC0D - 1) + 3, kC0HH = ST * (kC0H - 1) + 3, kC0HW = ST * (kC0W - 1) + 3;
+    constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // floats per channel
     constexpr int kC0InStage = (2 * kC0Halo + kThreads - 1) / kThreads;  // input values per thread and pair
     constexpr int kRowsPerCol = 32 / TWC;                                // h-rows covered by the 32 MFMA columns
     __shared__ float s_in[2 * kC0Halo];
@@ -47,8 +49,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     // blockIdx.z = (view, block of 64 output channels): Cout > 64 runs as Cout/64 independent slices of the weights
     const int nob = Cout / kC0Out;
     const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * kC0D, n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
-    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
-    const float* xn = x + (size_t)n * Cin * vol;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;        // output
+    const size_t iplane = (size_t)Hi * Wi, ivol = (size_t)Di * iplane;  // input
+    const float* xn = x + (size_t)n * Cin * ivol;
     const int npairs = (Cin + 1) / 2;
 
     // this wave's two MFMA column groups g = 2*wave, 2*wave+1 of the tile's 8: plane dz0 = g / 4, h-rows
@@ -65,23 +68,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
         const int kc = e / kC0Halo, r = e - kc * kC0Halo;
         const int dz = r / (kC0HH * kC0HW), r2 = r - dz * (kC0HH * kC0HW);
         const int hy = r2 / kC0HW, wx = r2 - hy * kC0HW;
-        const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
-        const bool ok = e < 2 * kC0Halo && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
+        const int d = ST * d0 + dz - 1, h = ST * h0 + hy - 1, w = ST * w0 + wx - 1;
+        const bool ok = e < 2 * kC0Halo && d >= 0 && d < Di && h >= 0 && h < Hi && w >= 0 && w < Wi;
         // bit 30 carries the channel of the pair; offsets stay below 2^30 (checked by the launcher)
-        in_off[k] = ok ? (int)((size_t)d * plane + (size_t)h * W + w) | (kc << 30) : -1;
+        in_off[k] = ok ? (int)((size_t)d * iplane + (size_t)h * Wi + w) | (kc << 30) : -1;
     }
 
     float in_reg[kC0InStage];
     float4 w_reg[kC0WStage];
     auto fetch = [&](int cp) {
-        const float* x0 = xn + (size_t)(2 * cp) * vol;
+        const float* x0 = xn + (size_t)(2 * cp) * ivol;
         const bool has1 = 2 * cp + 1 < Cin;
 #pragma unroll
         for (int k = 0; k < kC0InStage; ++k) {
             const int o = in_off[k];
             const int kc = (o >> 30) & 1;
             float v = 0.0f;
-            if (o >= 0 && (kc == 0 || has1)) v = x0[(size_t)kc * vol + (o & 0x3fffffff)];
+            if (o >= 0 && (kc == 0 || has1)) v = x0[(size_t)kc * ivol + (o & 0x3fffffff)];
             in_reg[k] = v;
         }
 #pragma unroll
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
         __syncthreads();
         if (cp + 1 < npairs) fetch(cp + 1);
 
-        const float* bin = s_in + kk * kC0Halo + (dz0 * kC0HH + hy0 + chy) * kC0HW + cw;
+        const float* bin = s_in + kk * kC0Halo + (ST * dz0 * kC0HH + ST * (hy0 + chy)) * kC0HW + ST * cw;
         const float* ain = s_w + kk * 27 * kC0Out + col;
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
                     const int tap = (kd * 3 + kh) * 3 + kw;
                     const float a0 = ain[tap * kC0Out], a1 = ain[tap * kC0Out + 32];
                     const float b0 = bin[(kd * kC0HH + kh) * kC0HW + kw];
-                    const float b1 = bin[(kd * kC0HH + kh + kRowsPerCol) * kC0HW + kw];
+                    const float b1 = bin[(kd * kC0HH + kh + ST * kRowsPerCol) * kC0HW + kw];
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -159,32 +162,50 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
 
 using namespace mvsdet;
 
-extern "C" int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
-                                         float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
-                                         mvsdet_stream_t stream) {
-    MVS_REQUIRE(x && weight_perm && out, "conv3d_k3_mfma: NULL pointer");
-    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3d_k3_mfma: scale and shift come together");
-    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_mfma: bad shape N=%d Cin=%d D=%d H=%d W=%d", N, Cin, D, H,
-                W);
-    MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "conv3d_k3_mfma: weights must be 16-byte aligned");
-    MVS_REQUIRE((size_t)D * H * W < ((size_t)1 << 30), "conv3d_k3_mfma: one channel volume exceeds 2^30 elements");
+static int launch_conv_mfma(const char* name, const float* x, const float* weight_perm, const float* scale,
+                            const float* shift, float* out, int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
+                            int relu, mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && weight_perm && out, "%s: NULL pointer", name);
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
+    MVS_REQUIRE(N > 0 && Cin > 0 && Di > 0 && Hi > 0 && Wi > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, Di, Hi,
+                Wi);
+    MVS_REQUIRE(stride == 1 || stride == 2, "%s: stride %d not in {1,2}", name, stride);
+    MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "%s: weights must be 16-byte aligned", name);
+    MVS_REQUIRE((size_t)Di * Hi * Wi < ((size_t)1 << 30), "%s: one channel volume exceeds 2^30 elements", name);
+    MVS_REQUIRE(Cout > 0 && Cout % kC0Out == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
+    // output extent of kernel 3, padding 1: floor((in - 1) / stride) + 1
+    const int D = (Di - 1) / stride + 1, H = (Hi - 1) / stride + 1, W = (Wi - 1) / stride + 1;
     // 32 voxels along w per MFMA column group, or 2 h-rows of 16: whichever covers (H, W) with less padding
     const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 3) / 4 * 4);
     const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 7) / 8 * 8);
     const int twc = pad16 < pad32 ? 16 : 32;
     const int th = 4 * (32 / twc);
     const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + kC0D - 1) / kC0D;
-    MVS_REQUIRE(Cout > 0 && Cout % kC0Out == 0, "conv3d_k3_mfma: Cout=%d must be a multiple of 64", Cout);
-    MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "conv3d_k3_mfma: N*Cout/64 or D too large");
+    MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out)));
-    if (twc == 16)
-        hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
-                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, Cout, D, H, W, tiles_w,
-                           tiles_h, relu);
-    else
-        hipLaunchKernelGGL(conv3d_k3_c64_mfma_kernel<32>, grid, dim3(kThreads), 0, (hipStream_t)stream, x,
-                           reinterpret_cast<const float4*>(weight_perm), scale, shift, out, Cin, Cout, D, H, W, tiles_w,
-                           tiles_h, relu);
-    MVS_LAUNCH_CHECK("conv3d_k3_mfma");
+    const float4* w4 = reinterpret_cast<const float4*>(weight_perm);
+    hipStream_t st = (hipStream_t)stream;
+#define MVS_CONV_CASE(TW_, ST_)                                                                                          \
+    hipLaunchKernelGGL((conv3d_k3_c64_mfma_kernel<TW_, ST_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift, out, Cin, \
+                       Cout, Di, Hi, Wi, D, H, W, tiles_w, tiles_h, relu)
+    if (stride == 1) {
+        if (twc == 16) MVS_CONV_CASE(16, 1); else MVS_CONV_CASE(32, 1);
+    } else {
+        if (twc == 16) MVS_CONV_CASE(16, 2); else MVS_CONV_CASE(32, 2);
+    }
+#undef MVS_CONV_CASE
+    MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
+}
+
+extern "C" int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                         float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                         mvsdet_stream_t stream) {
+    return launch_conv_mfma("conv3d_k3_mfma", x, weight_perm, scale, shift, out, N, Cin, Cout, D, H, W, 1, relu, stream);
+}
+
+extern "C" int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale,
+                                            const float* shift, float* out, int N, int Cin, int Cout, int D, int H, int W,
+                                            int relu, mvsdet_stream_t stream) {
+    return launch_conv_mfma("conv3d_k3_s2_mfma", x, weight_perm, scale, shift, out, N, Cin, Cout, D, H, W, 2, relu, stream);
 }

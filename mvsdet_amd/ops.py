@@ -643,10 +643,11 @@ permute_conv0_weight = permute_conv_weight
 
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_mfma", mutates_args=(), device_types="cuda")
-def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool) -> Tensor:
-    """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ per-channel affine + ReLU] of
+def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
+                   stride: int = 1) -> Tensor:
+    """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1 or 2, padding 1, no bias) [+ per-channel affine + ReLU] of
     mvs_models/mvsnet.py:76-82 on the fp32 matrix cores: x (N,Cin,D,H,W), weight_perm = permute_conv_weight(weight)
-    -> (N,Cout,D,H,W).  Forward only."""
+    -> (N,Cout,D',H',W').  Forward only."""
     _req(x, "x", dim=5)
     _req(weight_perm, "weight_perm", dim=5)
     N, Cin, D, H, W = x.shape
@@ -661,18 +662,22 @@ def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shif
         if scale.numel() != Cout or shift.numel() != Cout:
             raise ValueError(f"conv3d_k3_mfma: scale / shift must have {Cout} elements")
         scale, shift = scale.contiguous(), shift.contiguous()
+    if stride not in (1, 2):
+        raise ValueError("conv3d_k3_mfma: stride must be 1 or 2")
     x, weight_perm = x.contiguous(), weight_perm.contiguous()
-    out = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=x.device)
+    od, oh, ow = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((N, Cout, od, oh, ow), dtype=torch.float32, device=x.device)
+    fn = _lib.load().mvsdet_conv3d_k3_mfma_f32 if stride == 1 else _lib.load().mvsdet_conv3d_k3_s2_mfma_f32
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mvsdet_conv3d_k3_mfma_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
                                                          _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu), _stream(x)),
                    "conv3d_k3_mfma")
     return out
 
 
 @conv3d_k3_mfma.register_fake
-def _(x, weight_perm, scale, shift, relu):
-    return x.new_empty((x.shape[0], weight_perm.shape[4]) + tuple(x.shape[2:]))
+def _(x, weight_perm, scale, shift, relu, stride=1):
+    return x.new_empty((x.shape[0], weight_perm.shape[4]) + tuple((s - 1) // stride + 1 for s in x.shape[2:]))
 
 
 conv3d_k3_c64 = conv3d_k3_mfma

@@ -783,6 +783,11 @@ def test_cost_network_first_conv_mfma(gpu, N, Cin, D, H, W):
     ref3 = torch.nn.functional.conv3d(x, wgt2, None, padding=1)
     out3 = ops.conv3d_k3_mfma(x.to(gpu), ops.permute_conv_weight(wgt2.to(gpu)), None, None, False).cpu()
     torch.testing.assert_close(out3, ref3, rtol=0, atol=2e-6 * float(ref3.abs().max()) * max(1.0, (27 * Cin) ** 0.5 / 8))
+    # stride 2 (conv1 / conv3 of the network)
+    ref4 = torch.nn.functional.conv3d(x, wgt, None, padding=1, stride=2)
+    out4 = ops.conv3d_k3_mfma(x.to(gpu), wp, None, None, False, 2).cpu()
+    assert out4.shape == ref4.shape
+    torch.testing.assert_close(out4, ref4, rtol=0, atol=tol)
 
 
 def test_cost_network_hip_layers_match_torch_layers(gpu):
