@@ -171,6 +171,13 @@ int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const fl
  * out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1). */
 int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
                                  float* out, int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* The up-sampling layers (mvsnet.py:92-100,110-111: conv9 256->128, conv11 128->64): ConvTranspose3d(kernel 3, stride 2,
+ * padding 1, output_padding 1, no bias) [+ affine + ReLU] [+ residual]: x (N,Cin,D,H,W) -> out (N,Cout,2D,2H,2W);
+ * weight_perm: the (Cin,Cout,3,3,3) weight permuted to [c][kd][kh][kw][o]; residual (shape of out, or NULL) is added
+ * AFTER the affine + ReLU (x = skip + conv(x)).  Eight launches, one per output parity class. */
+int mvsdet_convT3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                  const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                  mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                                int D, int H, int W, mvsdet_stream_t stream);
 

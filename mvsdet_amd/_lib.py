@@ -42,6 +42,7 @@ SIGNATURES = {
     "mvsdet_sample_depth_prob_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "mvsdet_depth_prob_topk_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "mvsdet_conv3d_k3_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_convT3d_k3_s2_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_s2_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_backproject_weigh_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp,

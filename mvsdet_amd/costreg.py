@@ -2,8 +2,9 @@
 `CostRegNet_3DGS` of mvs_models/mvsnet.py:73-113 -- a three-level 3-D U-Net, (N,256,D,H,W) variance ->
 (N,2,D,H,W) {cost logits, offset logits}.
 
-This is plain PyTorch (MIOpen convolutions), not a HIP kernel of ours: it exists so that `MVSDetHotPath.forward_scene`
-can run the reference's whole stage chain with real weights.  Parameter names and shapes equal the reference's
+The module is plain PyTorch (so autograd and training work through MIOpen as in the reference); in eval mode without
+autograd every layer is routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
+csrc/costreg_head.hip (28.9 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
 (`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,
 `prob.weight/bias`), so a reference checkpoint's `cost_regularization.*` entries load with `load_state_dict`
 (tests/test_integration.py compares the outputs with the reference module itself).  D, H, W must be divisible by 4
@@ -54,8 +55,8 @@ class CostRegNet3DGS(nn.Module):
         full = self._cbr(self.conv0, x)                           # (N, 64, D, H, W)
         half = self._cbr(self.conv2, self._cbr(self.conv1, full))         # (N, 128, D/2, H/2, W/2)
         quarter = self._cbr(self.conv4, self._cbr(self.conv3, half))      # (N, 256, D/4, H/4, W/4)
-        half = half + self.conv9(quarter)
-        full = full + self.conv11(half)
+        half = self._up(self.conv9, quarter, half)        # half + relu(bn(deconv(quarter)))
+        full = self._up(self.conv11, half, full)
         return self._head(full)                       # (N, 2, D, H, W)
 
     def _cbr(self, layer, x):
@@ -72,6 +73,19 @@ class CostRegNet3DGS(nn.Module):
             shift = (bn.bias - bn.running_mean * scale).detach()
             return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
         return layer(x)
+
+    def _up(self, seq, x, skip):
+        """mvsnet.py:110-111: skip + Sequential(ConvTranspose3d, BatchNorm3d, ReLU)(x); one fp32-MFMA kernel per output
+        parity class (csrc/costreg_conv0.hip) without autograd in eval mode."""
+        deconv, bn = seq[0], seq[1]
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not self.training
+                and deconv.out_channels % 64 == 0):
+            from . import ops
+            wperm = ops.permute_convT_weight(deconv.weight)
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+            shift = (bn.bias - bn.running_mean * scale).detach()
+            return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)
+        return skip + seq(x)
 
     def _head(self, full):
         """mvsnet.py:112.  Two output channels make a poor GEMM (MIOpen: 8.2 ms at the reference-true shape); without

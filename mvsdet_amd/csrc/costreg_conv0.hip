@@ -209,3 +209,176 @@ extern "C" int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_
                                             int relu, mvsdet_stream_t stream) {
     return launch_conv_mfma("conv3d_k3_s2_mfma", x, weight_perm, scale, shift, out, N, Cin, Cout, D, H, W, 2, relu, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two up-sampling layers (mvsnet.py:92-100,110-111): ConvTranspose3d(kernel 3, stride 2, padding 1,
+// output_padding 1, no bias) + BatchNorm + ReLU, then the skip connection is added.  out[2i + p] per dimension only
+// sees tap k = 1 (input i) when p = 0 and taps k = 0 (input i + 1), k = 2 (input i) when p = 1, so each of the 8 output
+// parity classes (PD,PH,PW) is a small stride-1 convolution over the INPUT grid with 1, 2, 4 or 8 taps: the same
+// implicit GEMM as above, B rows contiguous in the input, results written to the strided output positions.
+// weight_perm: the (Cin,Cout,3,3,3) ConvTranspose3d weight permuted to [c][kd][kh][kw][o].
+// ---------------------------------------------------------------------------------------------------------------
+namespace mvsdet {
+
+template <int TWC, int PD, int PH, int PW>
+__global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
+    const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ out, int Cin, int Cout,
+    int Di, int Hi, int Wi, int tiles_w, int tiles_h, int relu) {
+    constexpr int kTW = TWC, kTH = 4 * (32 / TWC);
+    constexpr int kHD = kC0D + 1, kHH = kTH + 1, kHW = kTW + 1;   // +1 on the high side: input i + 1 for tap 0
+    constexpr int kHalo = kHD * kHH * kHW;
+    constexpr int kInStage = (2 * kHalo + kThreads - 1) / kThreads;
+    constexpr int kRowsPerCol = 32 / TWC;
+    __shared__ float s_in[2 * kHalo];
+    __shared__ float4 s_w4[kC0WPair / 4];
+    const float* s_w = reinterpret_cast<const float*>(s_w4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int nob = Cout / kC0Out;
+    const int w0 = bw * kTW, h0 = bh * kTH, d0 = blockIdx.y * kC0D, n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    const size_t iplane = (size_t)Hi * Wi, ivol = (size_t)Di * iplane;
+    const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+    const float* xn = x + (size_t)n * Cin * ivol;
+    const int npairs = (Cin + 1) / 2;
+
+    const int dz0 = wave >> 1, hy0 = (wave & 1) * 2 * kRowsPerCol;
+    const int col = lane & 31, kk = lane >> 5;
+    const int chy = col / TWC, cw = col % TWC;
+
+    int in_off[kInStage];
+#pragma unroll
+    for (int k = 0; k < kInStage; ++k) {
+        const int e = tid + k * kThreads;
+        const int kc = e / kHalo, r = e - kc * kHalo;
+        const int dz = r / (kHH * kHW), r2 = r - dz * (kHH * kHW);
+        const int hy = r2 / kHW, wx = r2 - hy * kHW;
+        const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
+        const bool ok = e < 2 * kHalo && d < Di && h < Hi && w < Wi;
+        in_off[k] = ok ? (int)((size_t)d * iplane + (size_t)h * Wi + w) | (kc << 30) : -1;
+    }
+    float in_reg[kInStage];
+    float4 w_reg[kC0WStage];
+    auto fetch = [&](int cp) {
+        const float* x0 = xn + (size_t)(2 * cp) * ivol;
+        const bool has1 = 2 * cp + 1 < Cin;
+#pragma unroll
+        for (int k = 0; k < kInStage; ++k) {
+            const int o = in_off[k];
+            const int kc = (o >> 30) & 1;
+            float v = 0.0f;
+            if (o >= 0 && (kc == 0 || has1)) v = x0[(size_t)kc * ivol + (o & 0x3fffffff)];
+            in_reg[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < kC0WStage; ++k) {
+            const int e = tid + k * kThreads;
+            w_reg[k] = e < kC0WPair / 4 ? wperm[((size_t)cp * 54 + (e >> 4)) * (Cout / 4) + ob64 * 16 + (e & 15)]
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    fetch(0);
+    for (int cp = 0; cp < npairs; ++cp) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kInStage; ++k) {
+            const int e = tid + k * kThreads;
+            if (e < 2 * kHalo) s_in[e] = in_reg[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kC0WStage; ++k) {
+            const int e = tid + k * kThreads;
+            if (e < kC0WPair / 4) s_w4[e] = w_reg[k];
+        }
+        __syncthreads();
+        if (cp + 1 < npairs) fetch(cp + 1);
+
+        const float* bin = s_in + kk * kHalo + (dz0 * kHH + hy0 + chy) * kHW + cw;
+        const float* ain = s_w + kk * 27 * kC0Out + col;
+        // parity 0: tap 1 at input offset 0; parity 1: tap 0 at offset +1 and tap 2 at offset 0
+#pragma unroll
+        for (int td = 0; td < (PD ? 2 : 1); ++td)
+#pragma unroll
+            for (int th = 0; th < (PH ? 2 : 1); ++th)
+#pragma unroll
+                for (int tw = 0; tw < (PW ? 2 : 1); ++tw) {
+                    const int kd = PD ? (td ? 2 : 0) : 1, od = PD ? (td ? 0 : 1) : 0;
+                    const int kh = PH ? (th ? 2 : 0) : 1, oh = PH ? (th ? 0 : 1) : 0;
+                    const int kw = PW ? (tw ? 2 : 0) : 1, ow = PW ? (tw ? 0 : 1) : 0;
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+                    const float a0 = ain[tap * kC0Out], a1 = ain[tap * kC0Out + 32];
+                    const float b0 = bin[(od * kHH + oh) * kHW + ow];
+                    const float b1 = bin[(od * kHH + oh + kRowsPerCol) * kHW + ow];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+    }
+
+    const int wi = w0 + cw;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int di = d0 + dz0, hi = h0 + hy0 + rb * kRowsPerCol + chy;
+        if (di >= Di || hi >= Hi || wi >= Wi) continue;
+        const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + (2 * wi + PW);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                float v = acc[ob][rb][r];
+                if (scale) v = fmaf(v, scale[o], shift[o]);
+                if (relu) v = fmaxf(v, 0.0f);
+                const size_t idx = ((size_t)n * Cout + o) * ovol + pos;
+                if (residual) v = residual[idx] + v;
+                out[idx] = v;
+            }
+    }
+}
+
+}  // namespace mvsdet
+
+extern "C" int mvsdet_convT3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                             const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W,
+                                             int relu, mvsdet_stream_t stream) {
+    const char* name = "convT3d_k3_s2_mfma";
+    MVS_REQUIRE(x && weight_perm && out, "%s: NULL pointer", name);
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
+    MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "%s: weights must be 16-byte aligned", name);
+    MVS_REQUIRE((size_t)D * H * W < ((size_t)1 << 27), "%s: one input channel volume exceeds 2^27 elements", name);
+    MVS_REQUIRE(Cout > 0 && Cout % kC0Out == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
+    const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 3) / 4 * 4);
+    const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 7) / 8 * 8);
+    const int twc = pad16 < pad32 ? 16 : 32;
+    const int th = 4 * (32 / twc);
+    const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + kC0D - 1) / kC0D;
+    MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out)));
+    const float4* w4 = reinterpret_cast<const float4*>(weight_perm);
+    hipStream_t st = (hipStream_t)stream;
+#define MVS_CT_CASE(TW_, PD_, PH_, PW_)                                                                                     \
+    hipLaunchKernelGGL((convT3d_k3_s2_mfma_kernel<TW_, PD_, PH_, PW_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift,   \
+                       residual, out, Cin, Cout, D, H, W, tiles_w, tiles_h, relu)
+#define MVS_CT_ALL(TW_)                                                                                                     \
+    MVS_CT_CASE(TW_, 0, 0, 0); MVS_CT_CASE(TW_, 0, 0, 1); MVS_CT_CASE(TW_, 0, 1, 0); MVS_CT_CASE(TW_, 0, 1, 1);             \
+    MVS_CT_CASE(TW_, 1, 0, 0); MVS_CT_CASE(TW_, 1, 0, 1); MVS_CT_CASE(TW_, 1, 1, 0); MVS_CT_CASE(TW_, 1, 1, 1)
+    if (twc == 16) { MVS_CT_ALL(16); } else { MVS_CT_ALL(32); }
+#undef MVS_CT_ALL
+#undef MVS_CT_CASE
+    MVS_LAUNCH_CHECK(name);
+    return MVSDET_OK;
+}

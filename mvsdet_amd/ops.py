@@ -681,3 +681,53 @@ def _(x, weight_perm, scale, shift, relu, stride=1):
 
 
 conv3d_k3_c64 = conv3d_k3_mfma
+
+
+def permute_convT_weight(weight: Tensor) -> Tensor:
+    """ConvTranspose3d weight (Cin,Cout,3,3,3) -> the [c][kd][kh][kw][o] layout convT3d_k3_s2_mfma reads."""
+    cin, cout = weight.shape[:2]
+    if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"convT3d_k3_s2_mfma: weight {tuple(weight.shape)} != (Cin,64*m,3,3,3)")
+    w = weight.detach().permute(0, 2, 3, 4, 1).contiguous()
+    if cin % 2:
+        w = torch.cat([w, w.new_zeros((1, 3, 3, 3, cout))], 0)
+    return w
+
+
+@torch.library.custom_op(f"{_NS}::convT3d_k3_s2_mfma", mutates_args=(), device_types="cuda")
+def convT3d_k3_s2_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor],
+                       residual: Optional[Tensor], relu: bool) -> Tensor:
+    """ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine + ReLU] [+ residual] of
+    mvs_models/mvsnet.py:92-100 on the fp32 matrix cores: x (N,Cin,D,H,W) -> (N,Cout,2D,2H,2W).  Forward only."""
+    _req(x, "x", dim=5)
+    _req(weight_perm, "weight_perm", dim=5)
+    N, Cin, D, H, W = x.shape
+    Cout = weight_perm.shape[4]
+    if tuple(weight_perm.shape[:4]) != (Cin + Cin % 2, 3, 3, 3) or Cout % 64:
+        raise ValueError(f"convT3d_k3_s2_mfma: weight_perm {tuple(weight_perm.shape)} does not match Cin={Cin}")
+    if (scale is None) != (shift is None):
+        raise ValueError("convT3d_k3_s2_mfma: scale and shift come together")
+    if scale is not None:
+        _req(scale, "scale", dim=1)
+        _req(shift, "shift", dim=1)
+        if scale.numel() != Cout or shift.numel() != Cout:
+            raise ValueError(f"convT3d_k3_s2_mfma: scale / shift must have {Cout} elements")
+        scale, shift = scale.contiguous(), shift.contiguous()
+    oshape = (N, Cout, 2 * D, 2 * H, 2 * W)
+    if residual is not None:
+        _req(residual, "residual", dim=5)
+        if tuple(residual.shape) != oshape:
+            raise ValueError(f"convT3d_k3_s2_mfma: residual {tuple(residual.shape)} != {oshape}")
+        residual = residual.contiguous()
+    x, weight_perm = x.contiguous(), weight_perm.contiguous()
+    out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_convT3d_k3_s2_mfma_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale),
+                                                             _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout,
+                                                             D, H, W, int(relu), _stream(x)), "convT3d_k3_s2_mfma")
+    return out
+
+
+@convT3d_k3_s2_mfma.register_fake
+def _(x, weight_perm, scale, shift, residual, relu):
+    return x.new_empty((x.shape[0], weight_perm.shape[4]) + tuple(2 * s for s in x.shape[2:]))

@@ -12,7 +12,7 @@ from conftest import ROOT
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "mvsdet_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mvsdet_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(mvsdet_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")

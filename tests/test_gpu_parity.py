@@ -811,3 +811,24 @@ def test_cost_network_hip_layers_match_torch_layers(gpu):
     slow2 = net(x.clone().requires_grad_(True)).detach()
     torch.testing.assert_close(fast2, slow2, rtol=0, atol=2e-5 * float(slow2.abs().max()))
     assert float((fast2 - fast).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 256, 128, 3, 15, 20), (2, 6, 64, 2, 5, 33), (1, 3, 64, 1, 1, 1)])
+def test_cost_network_transposed_conv_mfma(gpu, N, Cin, Cout, D, H, W):
+    """ConvTranspose3d(k=3, s=2, p=1, output_padding=1) [+ affine + ReLU + residual] on the fp32 matrix cores (eight
+    output parity classes) against ATen-CPU conv_transpose3d."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    wgt = torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (27 * Cin / 8) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv_transpose3d(x, wgt, None, stride=2, padding=1, output_padding=1)
+    res = torch.randn(ref.shape, generator=g)
+    tol = 4e-6 * float(ref.abs().max()) * max(1.0, Cin ** 0.5 / 4)
+    wp = ops.permute_convT_weight(wgt.to(gpu))
+    out = ops.convT3d_k3_s2_mfma(x.to(gpu), wp, None, None, None, False).cpu()
+    assert out.shape == ref.shape == (N, Cout, 2 * D, 2 * H, 2 * W)
+    torch.testing.assert_close(out, ref, rtol=0, atol=tol)
+    out2 = ops.convT3d_k3_s2_mfma(x.to(gpu), wp, scale.to(gpu), shift.to(gpu), res.to(gpu), True).cpu()
+    ref2 = res + torch.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+    torch.testing.assert_close(out2, ref2, rtol=0, atol=2 * tol)
