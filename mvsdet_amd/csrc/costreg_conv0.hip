@@ -28,14 +28,15 @@ constexpr int kC0WPair = 2 * 27 * kC0Out;                            // 3456 flo
 constexpr int kC0WStage = (kC0WPair / 4 + kThreads - 1) / kThreads;  // 4 float4 of weights per thread and pair
 
 // ST = stride (1 or 2, padding 1): input voxel = ST * output voxel - 1 + tap; (Di,Hi,Wi) input, (D,H,W) output extents.
-template <int TWC, int ST>
+// TD = tile planes (2 or 4): the 256 output voxels of a block are TD x (256 / (TD * TWC)) x TWC.
+template <int TWC, int ST, int TD>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int Cin, int Cout, int Di, int Hi, int Wi, int D, int H,
     int W, int tiles_w, int tiles_h, int relu) {
-    constexpr int kC0W = TWC, kC0H = 4 * (32 / TWC);
-    // halo of the input tile: ST*(T-1) + 3 per dimension (stride 1: 4 x 6 x 34 or 4 x 10 x 18)
-    constexpr int kC0HD = ST * (kC0D - 1) + 3, kC0HH = ST * (kC0H - 1) + 3, kC0HW = ST * (kC0W - 1) + 3;
+    constexpr int kC0W = TWC, kC0H = 256 / (TD * TWC);
+    // halo of the input tile: ST*(T-1) + 3 per dimension (stride 1, TD = 2: 4 x 6 x 34 or 4 x 10 x 18)
+    constexpr int kC0HD = ST * (TD - 1) + 3, kC0HH = ST * (kC0H - 1) + 3, kC0HW = ST * (kC0W - 1) + 3;
     constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // floats per channel
     constexpr int kC0InStage = (2 * kC0Halo + kThreads - 1) / kThreads;  // input values per thread and pair
     constexpr int kRowsPerCol = 32 / TWC;                                // h-rows covered by the 32 MFMA columns
@@ -48,19 +49,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
     // blockIdx.z = (view, block of 64 output channels): Cout > 64 runs as Cout/64 independent slices of the weights
     const int nob = Cout / kC0Out;
-    const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * kC0D, n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * TD, n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;        // output
     const size_t iplane = (size_t)Hi * Wi, ivol = (size_t)Di * iplane;  // input
     const float* xn = x + (size_t)n * Cin * ivol;
     const int npairs = (Cin + 1) / 2;
 
-    // this wave's two MFMA column groups g = 2*wave, 2*wave+1 of the tile's 8: plane dz0 = g / 4, h-rows
-    // (g % 4)*kRowsPerCol .. ; inside a group column c is voxel (h-row c / TWC, w = c % TWC)
-    const int dz0 = wave >> 1, hy0 = (wave & 1) * 2 * kRowsPerCol;
+    // this wave's two MFMA column groups g = 2*wave, 2*wave+1 of the tile's 8 (8/TD per plane, both in one plane):
+    // plane dz0 = g / (8/TD), h-rows (g % (8/TD))*kRowsPerCol .. ; inside a group column c is voxel
+    // (h-row c / TWC, w = c % TWC)
+    constexpr int kGroupsPerPlane = 8 / TD;  // 4 or 2
+    const int dz0 = (2 * wave) / kGroupsPerPlane, hy0 = ((2 * wave) % kGroupsPerPlane) * kRowsPerCol;
     const int col = lane & 31, kk = lane >> 5;  // MFMA operand lane map: A[i=col][k=kk], B[k=kk][j=col]
     const int chy = col / TWC, cw = col % TWC;
 
-    // staging plan (identical for every channel pair): input element e = tid + 256*k of the 2 x 816 halo values
+    // staging plan (identical for every channel pair): input element e = tid + 256*k of the 2 x halo values
     int in_off[kC0InStage];
 #pragma unroll
     for (int k = 0; k < kC0InStage; ++k) {
@@ -175,23 +178,31 @@ static int launch_conv_mfma(const char* name, const float* x, const float* weigh
     MVS_REQUIRE(Cout > 0 && Cout % kC0Out == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
     // output extent of kernel 3, padding 1: floor((in - 1) / stride) + 1
     const int D = (Di - 1) / stride + 1, H = (Hi - 1) / stride + 1, W = (Wi - 1) / stride + 1;
-    // 32 voxels along w per MFMA column group, or 2 h-rows of 16: whichever covers (H, W) with less padding
-    const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 3) / 4 * 4);
-    const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 7) / 8 * 8);
-    const int twc = pad16 < pad32 ? 16 : 32;
-    const int th = 4 * (32 / twc);
-    const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + kC0D - 1) / kC0D;
+    // tile shapes (TWC along w, TD planes, 256/(TD*TWC) rows): the one that pads (D, H, W) least; the 4-plane tile only
+    // exists for stride 1 and 16-wide column groups
+    auto padded = [&](int twc_, int td_) {
+        const int th_ = 256 / (td_ * twc_);
+        return (long long)((W + twc_ - 1) / twc_ * twc_) * ((H + th_ - 1) / th_ * th_) * ((D + td_ - 1) / td_ * td_);
+    };
+    int twc = 32, td = 2;
+    long long best = padded(32, 2);
+    if (padded(16, 2) < best) { best = padded(16, 2); twc = 16; td = 2; }
+    if (stride == 1 && padded(16, 4) < best) { best = padded(16, 4); twc = 16; td = 4; }
+    const int th = 256 / (td * twc);
+    const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + td - 1) / td;
     MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out)));
     const float4* w4 = reinterpret_cast<const float4*>(weight_perm);
     hipStream_t st = (hipStream_t)stream;
-#define MVS_CONV_CASE(TW_, ST_)                                                                                          \
-    hipLaunchKernelGGL((conv3d_k3_c64_mfma_kernel<TW_, ST_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift, out, Cin, \
+#define MVS_CONV_CASE(TW_, ST_, TD_)                                                                                          \
+    hipLaunchKernelGGL((conv3d_k3_c64_mfma_kernel<TW_, ST_, TD_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift, out, Cin, \
                        Cout, Di, Hi, Wi, D, H, W, tiles_w, tiles_h, relu)
     if (stride == 1) {
-        if (twc == 16) MVS_CONV_CASE(16, 1); else MVS_CONV_CASE(32, 1);
+        if (td == 4) MVS_CONV_CASE(16, 1, 4);
+        else if (twc == 16) MVS_CONV_CASE(16, 1, 2);
+        else MVS_CONV_CASE(32, 1, 2);
     } else {
-        if (twc == 16) MVS_CONV_CASE(16, 2); else MVS_CONV_CASE(32, 2);
+        if (twc == 16) MVS_CONV_CASE(16, 2, 2); else MVS_CONV_CASE(32, 2, 2);
     }
 #undef MVS_CONV_CASE
     MVS_LAUNCH_CHECK(name);

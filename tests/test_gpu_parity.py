@@ -758,7 +758,8 @@ def test_cost_network_head_conv(gpu, N, Cin, D, H, W):
         ops.conv3d_k3_cout2(x.to(gpu), wgt[:, :, :2].contiguous().to(gpu), None)
 
 
-@pytest.mark.parametrize("N,Cin,D,H,W", [(1, 256, 4, 8, 32), (2, 32, 5, 7, 33), (1, 7, 3, 5, 80), (1, 2, 1, 1, 1)])
+@pytest.mark.parametrize("N,Cin,D,H,W", [(1, 256, 4, 8, 32), (2, 32, 5, 7, 33), (1, 7, 3, 5, 80), (1, 2, 1, 1, 1),
+                                         (1, 8, 4, 4, 16), (1, 6, 8, 12, 48)])   # the last two pick the 4-plane tile
 def test_cost_network_first_conv_mfma(gpu, N, Cin, D, H, W):
     """csrc/costreg_conv0.hip (Conv3d Cin -> 64, k=3, pad=1 on the fp32 matrix cores) against ATen-CPU conv3d, with and
     without the folded BatchNorm + ReLU epilogue; ragged tiles in d, h, w and an odd channel count."""
