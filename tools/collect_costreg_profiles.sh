@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 kernel trace + one PMC pass (matrix-core counters) of the cost network on our kernels (GPU box, gpurun).
+tag=${1:-costreg}
+root=${GRAFT_REPO_ROOT:-$PWD}
+out=$root/gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+cd $root
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o costreg -- python3 tools/costreg_layers_hip.py > $out/kt.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc -o pmc -- python3 tools/costreg_layers_hip.py > $out/pmc.log 2>&1
+find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt 2>&1
+find $out -name "*.csv" -size +2000k -delete
+tail -3 $out/pmc.log | cut -c1-200
+head -12 $out/kernel_stats.csv | cut -c1-110,280-400
+grep -i "conv" $out/pmc_summary.txt | head -20 | cut -c1-160
