@@ -40,9 +40,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
     constexpr int kC0Halo = kC0HD * kC0HH * kC0HW;                       // floats per channel
     constexpr int kC0InStage = (2 * kC0Halo + kThreads - 1) / kThreads;  // input values per thread and pair
     constexpr int kRowsPerCol = 32 / TWC;                                // h-rows covered by the 32 MFMA columns
-    __shared__ float s_in[2 * kC0Halo];
-    __shared__ float4 s_w4[kC0WPair / 4];
-    const float* s_w = reinterpret_cast<const float*>(s_w4);
+    // two LDS stages: the next channel pair is written while the current one is multiplied, one barrier per pair
+    __shared__ float s_in2[2][2 * kC0Halo];
+    __shared__ float4 s_w42[2][kC0WPair / 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,24 +107,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    fetch(0);
-    for (int cp = 0; cp < npairs; ++cp) {
-        __syncthreads();  // previous pair fully consumed
+    auto stage = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < kC0InStage; ++k) {
             const int e = tid + k * kThreads;
-            if (e < 2 * kC0Halo) s_in[e] = in_reg[k];
+            if (e < 2 * kC0Halo) s_in2[buf][e] = in_reg[k];
         }
 #pragma unroll
         for (int k = 0; k < kC0WStage; ++k) {
             const int e = tid + k * kThreads;
-            if (e < kC0WPair / 4) s_w4[e] = w_reg[k];
+            if (e < kC0WPair / 4) s_w42[buf][e] = w_reg[k];
         }
-        __syncthreads();
-        if (cp + 1 < npairs) fetch(cp + 1);
-
-        const float* bin = s_in + kk * kC0Halo + (ST * dz0 * kC0HH + ST * (hy0 + chy)) * kC0HW + ST * cw;
-        const float* ain = s_w + kk * 27 * kC0Out + col;
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    if (npairs > 1) fetch(1);
+    for (int cp = 0; cp < npairs; ++cp) {
+        const int buf = cp & 1;
+        const float* bin = s_in2[buf] + kk * kC0Halo + (ST * dz0 * kC0HH + ST * (hy0 + chy)) * kC0HW + ST * cw;
+        const float* ain = reinterpret_cast<const float*>(s_w42[buf]) + kk * 27 * kC0Out + col;
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
@@ -140,6 +142,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                 }
+        if (cp + 1 < npairs) {
+            // the other stage was last read in iteration cp - 1, which every wave left through the barrier below
+            stage(buf ^ 1);
+            __syncthreads();
+            if (cp + 2 < npairs) fetch(cp + 2);
+        }
     }
 
     // epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (voxel along w), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
