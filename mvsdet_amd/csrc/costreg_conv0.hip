@@ -13,7 +13,7 @@
 //   Numerics: an fp32 MFMA is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md), so the result is an fp32
 //   FMA sum in (channel, tap) order -- the same products as ATen's convolution in another order.
 // Bound: fp32 MFMA, 64 FLOP/clk/SIMD = 157 TFLOP/s; 2.04 TFLOP at (40,256,12,60,80) = 13 ms at peak.
-// Measured 15.7 ms = 130 TFLOP/s (MIOpen: 33.6 ms).
+// Measured 15.1 ms = 135 TFLOP/s (MIOpen: 33.6 ms).
 #include "common.h"
 
 namespace mvsdet {
