@@ -236,7 +236,21 @@ def full_chain_rate(device, steps=10):
             out = hp.forward_scene(scene.features, scene.meta)
         torch.cuda.synchronize(device)
     el = time.perf_counter() - t0
-    return {"workload": "scannet_ref_40v_12d_60x80", "scenes_per_sec": round(steps / el, 3),
+    # the network alone on the variance volume of the last scene: fp32 matrix-core roofline (157.3 TFLOP/s dense)
+    with torch.no_grad():
+        var = out["variance"]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            net(var)
+        e1.record()
+        torch.cuda.synchronize(device)
+    net_ms = e0.elapsed_time(e1) / 3
+    tfl = CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12
+    roof = {"bound": "mfma", "achieved": round(tfl / net_ms * 1e3, 1), "peak": 157.3, "unit": "TFLOP/s",
+            "frac": round(tfl / net_ms * 1e3 / 157.3, 4), "kernel": "cost network forward (8 layers, fp32 MFMA)",
+            "kernel_ms": round(net_ms, 3)}
+    return {"workload": "scannet_ref_40v_12d_60x80", "scenes_per_sec": round(steps / el, 3), "cost_network_roofline": roof,
             "ms_per_scene": round(el / steps * 1e3, 3), "cost_network_tflop": round(CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12, 3),
             "non_empty_voxels": int((out["valid"] > 0).sum().item())}
 
