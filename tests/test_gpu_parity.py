@@ -833,3 +833,27 @@ def test_cost_network_transposed_conv_mfma(gpu, N, Cin, Cout, D, H, W):
     out2 = ops.convT3d_k3_s2_mfma(x.to(gpu), wp, scale.to(gpu), shift.to(gpu), res.to(gpu), True).cpu()
     ref2 = res + torch.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
     torch.testing.assert_close(out2, ref2, rtol=0, atol=2 * tol)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cost_network_convs_randomised(gpu, seed):
+    """Random shapes through the three matrix-core convolution entry points (stride 1, stride 2, transposed) against
+    ATen-CPU: every tile variant, ragged edges in all three dimensions, odd channel counts, Cout = 64 / 128."""
+    from mvsdet_amd import ops
+    rng = np.random.default_rng(500 + seed)
+    N, Cin = int(rng.integers(1, 3)), int(rng.integers(1, 40))
+    Cout = int(rng.choice([64, 128]))
+    D, H, W = int(rng.integers(1, 10)), int(rng.integers(1, 21)), int(rng.integers(1, 70))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    wgt = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    wp = ops.permute_conv_weight(wgt.to(gpu))
+    for stride in (1, 2):
+        ref = torch.nn.functional.conv3d(x, wgt, None, padding=1, stride=stride)
+        out = ops.conv3d_k3_mfma(x.to(gpu), wp, None, None, False, stride).cpu()
+        assert out.shape == ref.shape
+        torch.testing.assert_close(out, ref, rtol=0, atol=3e-6 * max(1.0, float(ref.abs().max())) * max(1.0, Cin ** 0.5))
+    wt = torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (27 * Cin / 8) ** 0.5
+    ref = torch.nn.functional.conv_transpose3d(x, wt, None, stride=2, padding=1, output_padding=1)
+    out = ops.convT3d_k3_s2_mfma(x.to(gpu), ops.permute_convT_weight(wt.to(gpu)), None, None, None, False).cpu()
+    torch.testing.assert_close(out, ref, rtol=0, atol=3e-6 * max(1.0, float(ref.abs().max())) * max(1.0, Cin ** 0.5))
