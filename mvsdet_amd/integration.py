@@ -10,6 +10,7 @@ projects/NeRF-Det/configs/mvsdet_res50_2x_low_res.py:
     get_nearest_pose_ids   (mvsdet.py:67)      -- same ATen ops, kept for completeness
     get_points             (mvsdet.py:1316)
     MVSDet.sample_depth_prob / MVSDet.compute_avg_depth / MVSDet.collect_proj  (mvsdet.py:266, 298, 249)
+    CostRegNet_3DGS        (imported at mvsdet.py:32, instantiated at :228) -> mvsdet_amd.costreg.CostRegNet3DGS
 
 With mmengine the patch is applied by adding this module to the config's `custom_imports` AFTER the reference
 module; `apply_on_import()` then finds the already imported reference module in sys.modules.
@@ -50,6 +51,17 @@ PATCHED_FUNCTIONS = {
     "knn": F_.knn,
     "get_points": F_.get_points,
 }
+def _cost_network():
+    from .costreg import CostRegNet3DGS
+    return CostRegNet3DGS
+
+
+# names the reference module looks up when it builds the model (mvsdet.py:32,228: `self.cost_regularization =
+# CostRegNet_3DGS()`): the replacement has the same parameter names, so checkpoints load, and routes every layer to
+# the fp32-MFMA kernels in eval mode without autograd (28 ms instead of 59 ms per scene)
+PATCHED_CLASSES = {
+    "CostRegNet_3DGS": _cost_network,
+}
 PATCHED_METHODS = {
     "sample_depth_prob": _sample_depth_prob,
     "compute_avg_depth": _compute_avg_depth,
@@ -64,6 +76,10 @@ def patch_reference(mvsdet_module) -> dict:
         if hasattr(mvsdet_module, name):
             originals[name] = getattr(mvsdet_module, name)
             setattr(mvsdet_module, name, fn)
+    for name, factory in PATCHED_CLASSES.items():
+        if hasattr(mvsdet_module, name):
+            originals[name] = getattr(mvsdet_module, name)
+            setattr(mvsdet_module, name, factory())
     cls = getattr(mvsdet_module, "MVSDet", None)
     if cls is not None:
         for name, fn in PATCHED_METHODS.items():

@@ -44,6 +44,8 @@ def test_patch_and_unpatch(reference):
     try:
         assert ref.homo_warping is F_.homo_warping and ref.backproject_Weigh is F_.backproject_Weigh
         assert ref.MVSDet.sample_depth_prob is integration.PATCHED_METHODS["sample_depth_prob"]
+        from mvsdet_amd.costreg import CostRegNet3DGS
+        assert ref.CostRegNet_3DGS is CostRegNet3DGS          # MVSDet.__init__ builds the HIP-routed network
         assert set(orig) >= {"homo_warping", "backproject_Weigh", "MVSDet.sample_depth_prob", "MVSDet.compute_avg_depth"}
         assert not integration.apply_on_import()  # already patched: nothing left to do
     finally:
