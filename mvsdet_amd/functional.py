@@ -22,6 +22,11 @@ from . import ops
 
 
 # ------------------------------------------------------------------------------------------- geometry (host)
+# Set by integration.patch_reference: homo_warping then returns a deferred volume (lazywarp.LazyVolume) instead of
+# launching the warp kernel.  Off for direct callers of this module.
+LAZY_WARP = False
+
+
 def relative_projection(src_proj: Tensor, ref_proj: Tensor) -> Tensor:
     """module.py:116  proj = src_proj @ inverse(ref_proj), fp32, evaluated with ATen-CPU; result on CPU."""
     return torch.matmul(src_proj.detach().float().cpu(), torch.inverse(ref_proj.detach().float().cpu()))
@@ -50,7 +55,11 @@ def get_nearest_pose_ids(tar_pose: Tensor, ref_poses: Tensor, num_select: int, m
     num_select = min(num_select, len(ref_poses) - 1)
     tar = tar_pose[:, :3, 3].unsqueeze(0).transpose(2, 1)
     ref = ref_poses[:, :3, 3].unsqueeze(0).transpose(2, 1)
-    return knn(tar, ref, k=num_select, maskself=maskself)[0]
+    ids = knn(tar, ref, k=num_select, maskself=maskself)[0]
+    if LAZY_WARP:
+        from . import lazywarp
+        lazywarp.note_neighbor_ids(ids)
+    return ids
 
 
 def collect_proj(w2c: Tensor, intr: Tensor, neighbor_ids: Tensor):
@@ -95,7 +104,12 @@ def homo_warping(src_fea: Tensor, src_proj: Tensor, ref_proj: Tensor, depth_valu
     if depth_values.dim() != 2:
         raise NotImplementedError("per-pixel depth_values (B,D,H,W) (module.py:130-133) is unused by MVSDet")
     proj = relative_projection(src_proj, ref_proj).to(src_fea.device)
-    return ops.homo_warp(src_fea, proj, depth_values.to(src_fea.device))
+    depth_values = depth_values.to(src_fea.device)
+    if LAZY_WARP and src_fea.is_cuda and src_fea.dtype == torch.float32:
+        # inside the patched reference: defer, so that its variance loop collapses into the fused kernel (lazywarp.py)
+        from . import lazywarp
+        return lazywarp.lazy_homo_warp(src_fea, proj, depth_values)
+    return ops.homo_warp(src_fea, proj, depth_values)
 
 
 # ------------------------------------------------------------------------------------------- a9

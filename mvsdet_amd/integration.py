@@ -69,9 +69,13 @@ PATCHED_METHODS = {
 }
 
 
-def patch_reference(mvsdet_module) -> dict:
-    """Rebind the hot-path functions of an imported reference `mvsdet` module; returns {name: original}."""
+def patch_reference(mvsdet_module, lazy_variance: bool = True) -> dict:
+    """Rebind the hot-path functions of an imported reference `mvsdet` module; returns {name: original}.
+    `lazy_variance`: `homo_warping` returns deferred volumes so that the reference's own variance loop
+    (mvsdet.py:453-467) collapses into ONE fused plane-sweep launch (lazywarp.py); anything unexpected falls back to
+    the eager kernels."""
     originals = {}
+    F_.LAZY_WARP = bool(lazy_variance)
     for name, fn in PATCHED_FUNCTIONS.items():
         if hasattr(mvsdet_module, name):
             originals[name] = getattr(mvsdet_module, name)
@@ -90,6 +94,7 @@ def patch_reference(mvsdet_module) -> dict:
 
 
 def unpatch_reference(mvsdet_module, originals: dict) -> None:
+    F_.LAZY_WARP = False
     for name, fn in originals.items():
         if name.startswith("MVSDet."):
             setattr(mvsdet_module.MVSDet, name.split(".", 1)[1], fn)

@@ -1,0 +1,171 @@
+"""Deferred evaluation of the reference's own variance loop, so that an UNMODIFIED `MVSDet.extract_feat` reaches the
+fused plane-sweep kernel.
+
+mvsdet.py:439-467 calls `homo_warping` once per neighbour and folds the results into a sum, a sum of squares and a
+variance with ordinary tensor arithmetic -- k materialised (N,C,D,H,W) volumes and eight elementwise passes (14.4 ms per
+scene at the reference-true shape against 1.1 ms fused, tools/route_timing.py).  With the function-level patch
+(`integration.patch_reference`) `homo_warping` returns a `LazyVolume` instead: a tensor subclass without storage that
+records the call.  The few operations of the loop (`+`, `+=`, `** 2`, `.pow_(2)`, `.div_(n)`, `.sub_`) build a small
+expression; when the last one, `sq_sum.div_(n).sub_(sum.div_(n).pow_(2))`, arrives and the expression is exactly the
+variance of {reference, warped_1..k}, ONE call of `ops.plane_sweep_variance` (with its autograd) produces the result.
+Anything else that touches a `LazyVolume` -- another operation, another order, a print -- materialises it with the eager
+kernels first, so the semantics never depend on the pattern being recognised; `stats` counts which way each call went.
+"""
+from __future__ import annotations
+
+import threading
+
+import torch
+from torch import Tensor
+
+_tls = threading.local()
+stats = {"fused": 0, "materialized": 0}
+
+
+def note_neighbor_ids(ids: Tensor) -> None:
+    """Called by the patched `get_nearest_pose_ids`: the fused kernel needs the neighbour view ids, the reference only
+    hands `homo_warping` the already gathered feature maps (checked against these ids before they are trusted)."""
+    _tls.neighbor_ids = ids
+
+
+_META = {"size", "dim", "numel", "stride", "is_contiguous", "data_ptr", "__len__", "__repr__", "__str__", "__format__",
+         "element_size", "nelement", "ndimension", "is_floating_point", "is_complex", "type", "get_device"}
+
+
+class LazyVolume(Tensor):
+    """kind: 'warp' (src, proj, depth) | 'sq' (warp) | 'sum' / 'sqsum' (base, warps) | 'scaled' (inner, n) |
+    'scaled_sq' (inner 'scaled' of a 'sum')."""
+
+    @staticmethod
+    def __new__(cls, kind, payload, like_shape, dtype, device):
+        t = Tensor._make_wrapper_subclass(cls, like_shape, dtype=dtype, device=device, requires_grad=False)
+        t.kind, t.payload = kind, payload
+        return t
+
+    # ---- eager evaluation ---------------------------------------------------------------------------------
+    def materialize(self) -> Tensor:
+        from . import ops
+        stats["materialized"] += 1
+        k, p = self.kind, self.payload
+        if k == "warp":
+            return ops.homo_warp(p["src"], p["proj"], p["depth"])
+        if k == "sq":
+            return p["warp"].materialize() ** 2
+        if k == "sum":
+            out = p["base"]
+            for w in p["warps"]:
+                out = out + w.materialize()
+            return out
+        if k == "sqsum":
+            out = p["base"]
+            for w in p["warps"]:
+                out = out + w.materialize() ** 2
+            return out
+        if k == "scaled":
+            return _eager(p["inner"]) / p["n"]
+        if k == "scaled_sq":
+            return _eager(p["inner"]) ** 2
+        raise RuntimeError(f"LazyVolume: unknown kind {k}")
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # last resort (an ATen call that bypassed __torch_function__): evaluate eagerly and run it on real tensors
+        kwargs = kwargs or {}
+        return func(*_tree_eager(args), **{k: _tree_eager(v) for k, v in kwargs.items()})
+
+    # ---- the pattern ----------------------------------------------------------------------------------------
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name == "__get__" or name in _META:  # shape / dtype / device / size(): the wrapper's own metadata
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        if not kwargs and len(args) == 2:
+            a, b = args
+            la, lb = isinstance(a, LazyVolume), isinstance(b, LazyVolume)
+            if name in ("pow", "__pow__", "pow_") and la and isinstance(b, (int, float)) and b == 2:
+                if a.kind == "warp":
+                    return _like(a, "sq", {"warp": a})
+                if a.kind == "scaled" and a.payload["inner"].kind == "sum":
+                    return _like(a, "scaled_sq", {"inner": a})
+            if name in ("add", "__add__", "__iadd__", "add_", "__radd__"):
+                if name == "__radd__":
+                    a, b, la, lb = b, a, lb, la
+                if lb and b.kind == "warp":
+                    if not la and isinstance(a, Tensor) and tuple(a.shape) == tuple(b.shape):
+                        return _like(b, "sum", {"base": a, "warps": [b]})
+                    if la and a.kind == "sum":
+                        return _like(b, "sum", {"base": a.payload["base"], "warps": a.payload["warps"] + [b]})
+                if lb and b.kind == "sq":
+                    if not la and isinstance(a, Tensor) and tuple(a.shape) == tuple(b.shape):
+                        return _like(b, "sqsum", {"base": a, "warps": [b.payload["warp"]]})
+                    if la and a.kind == "sqsum":
+                        return _like(b, "sqsum", {"base": a.payload["base"], "warps": a.payload["warps"] + [b.payload["warp"]]})
+            if name in ("div_", "div", "__truediv__", "__itruediv__", "true_divide") and la and a.kind in ("sum", "sqsum") \
+                    and isinstance(b, (int, float)):
+                return _like(a, "scaled", {"inner": a, "n": b})
+            if name in ("sub_", "sub", "__sub__", "__isub__") and la and lb and a.kind == "scaled" and b.kind == "scaled_sq":
+                out = _try_fused(a, b)
+                if out is not None:
+                    return out
+        # anything else: evaluate eagerly, then run the operation on real tensors
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*_tree_eager(args), **{k: _tree_eager(v) for k, v in kwargs.items()})
+
+
+def _like(t: LazyVolume, kind: str, payload: dict) -> LazyVolume:
+    with torch._C.DisableTorchFunctionSubclass():
+        return LazyVolume(kind, payload, tuple(t.shape), t.dtype, t.device)
+
+
+def _eager(x):
+    return x.materialize() if isinstance(x, LazyVolume) else x
+
+
+def _tree_eager(x):
+    if isinstance(x, LazyVolume):
+        return x.materialize()
+    if isinstance(x, (tuple, list)):
+        return type(x)(_tree_eager(v) for v in x)
+    return x
+
+
+def _try_fused(sq_scaled: LazyVolume, sum_scaled_sq: LazyVolume):
+    """variance = sqsum/n - (sum/n)^2 with sum = ref + w_1..k, sqsum = ref^2 + w_1^2..k^2, n = k + 1 -> fused op."""
+    from . import ops
+    sqsum, n1 = sq_scaled.payload["inner"], sq_scaled.payload["n"]
+    inner = sum_scaled_sq.payload["inner"]
+    s, n2 = inner.payload["inner"], inner.payload["n"]
+    if sqsum.kind != "sqsum" or s.kind != "sum":
+        return None
+    warps = s.payload["warps"]
+    if n1 != n2 or n1 != len(warps) + 1 or len(sqsum.payload["warps"]) != len(warps):
+        return None
+    if any(a is not b for a, b in zip(warps, sqsum.payload["warps"])):
+        return None
+    base, base_sq = s.payload["base"], sqsum.payload["base"]
+    ids = getattr(_tls, "neighbor_ids", None)
+    with torch._C.DisableTorchFunctionSubclass():
+        feat = base[:, :, 0]
+        n = feat.shape[0]
+        if ids is None or tuple(ids.shape) != (n, len(warps)):
+            return None
+        ids = ids.to(feat.device)
+        # the recorded calls must be exactly this scene's: reference volume = features repeated over the planes, its
+        # square, and the neighbour maps = features gathered with the noted ids
+        if not (torch.equal(base[:, :, -1], feat) and torch.equal(base_sq[:, :, 0], feat * feat)):
+            return None
+        depth = warps[0].payload["depth"]
+        for j, w in enumerate(warps):
+            if not (torch.equal(w.payload["src"], feat[ids[:, j]]) and w.payload["depth"] is depth):
+                return None
+        proj = torch.stack([w.payload["proj"] for w in warps], dim=1)
+        stats["fused"] += 1
+        return ops.plane_sweep_variance(feat, ids, proj, depth)
+
+
+def lazy_homo_warp(src_fea: Tensor, proj_rel: Tensor, depth_values: Tensor) -> LazyVolume:
+    b, c, h, w = src_fea.shape
+    return LazyVolume("warp", {"src": src_fea, "proj": proj_rel, "depth": depth_values}, (b, c, depth_values.shape[1], h, w),
+                      src_fea.dtype, src_fea.device)

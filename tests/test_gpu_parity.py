@@ -857,3 +857,73 @@ def test_cost_network_convs_randomised(gpu, seed):
     ref = torch.nn.functional.conv_transpose3d(x, wt, None, stride=2, padding=1, output_padding=1)
     out = ops.convT3d_k3_s2_mfma(x.to(gpu), ops.permute_convT_weight(wt.to(gpu)), None, None, None, False).cpu()
     torch.testing.assert_close(out, ref, rtol=0, atol=3e-6 * max(1.0, float(ref.abs().max())) * max(1.0, Cin ** 0.5))
+
+
+# --------------------------------------------------------------------------------------------- unmodified variance loop
+def _reference_style_variance(F_, feature, c2w, w2c, K_feat, depth_values, training):
+    """The operation sequence of mvsdet.py:430-467 (restated), on the patched functions."""
+    num_src = feature.shape[0]
+    k = min(2, num_src - 1)
+    neighbor_ids = F_.get_nearest_pose_ids(c2w, c2w, k, maskself=True)
+    num_depth = depth_values.shape[1]
+    ref_volume = feature.unsqueeze(2).repeat(1, 1, num_depth, 1, 1)
+    volume_sum = ref_volume
+    volume_sq_sum = ref_volume ** 2
+    del ref_volume
+    nei_features = feature[neighbor_ids.view(-1)].view(num_src, k, *feature.shape[1:])
+    nei_features = torch.unbind(nei_features, dim=1)
+    ref_proj, nei_projs = F_.collect_proj(w2c, K_feat, neighbor_ids)
+    for nei_fea, nei_proj in zip(nei_features, nei_projs):
+        warped_volume = F_.homo_warping(nei_fea, nei_proj, ref_proj, depth_values)
+        if training:
+            volume_sum = volume_sum + warped_volume
+            volume_sq_sum = volume_sq_sum + warped_volume ** 2
+        else:
+            volume_sum += warped_volume
+            volume_sq_sum += warped_volume.pow_(2)
+        del warped_volume
+    return volume_sq_sum.div_(k + 1).sub_(volume_sum.div_(k + 1).pow_(2)), neighbor_ids
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_unmodified_variance_loop_collapses_into_the_fused_kernel(gpu, oracle, training):
+    """With the function-level patch `homo_warping` returns deferred volumes (mvsdet_amd/lazywarp.py): the reference's
+    own loop then costs ONE fused plane-sweep launch and gives the fused kernel's bits; a loop that does something
+    else with the volumes falls back to the eager kernels and still gives the right values."""
+    from mvsdet_amd import functional as F_, lazywarp, ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw = 5, 32, 8, (24, 32)
+    hp = MVSDetHotPath([8, 8, 4], [.8, .8, .8], [0.2, 5.0], D)
+    meta = synthetic.make_img_meta(N, hw, seed=8)
+    geo = hp.prepare_scene(meta, gpu)
+    w2c = torch.tensor(np.array(meta["lidar2img"]["extrinsic"]))
+    K_feat = torch.tensor(oracle.feat_intrinsics(meta["lidar2img"]["intrinsic"], meta["img_shape"], meta["ori_shape"]))
+    c2w = w2c.inverse()
+    feature = synthetic.make_features(N, C, hw, seed=8).to(gpu).requires_grad_(training)
+    expected = ops.plane_sweep_variance(feature.detach(), geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+    old = F_.LAZY_WARP
+    F_.LAZY_WARP = True
+    try:
+        before = dict(lazywarp.stats)
+        var, ids = _reference_style_variance(F_, feature, c2w, w2c, K_feat, geo.depth_values, training)
+        assert type(var) is torch.Tensor and lazywarp.stats["fused"] == before["fused"] + 1
+        assert lazywarp.stats["materialized"] == before["materialized"]            # no volume was ever materialised
+        assert torch.equal(ids.to(gpu), geo.neighbor_ids) and torch.equal(var, expected)
+        if training:
+            var.square().mean().backward()
+            g_lazy = feature.grad.clone()
+            feature.grad = None
+            ops.plane_sweep_variance(feature, geo.neighbor_ids, geo.proj_rel, geo.depth_values).square().mean().backward()
+            torch.testing.assert_close(g_lazy, feature.grad, rtol=1e-4, atol=1e-7)
+        # a different loop: the volume is inspected, then combined in another order -> eager kernels, same values
+        nb = F_.get_nearest_pose_ids(c2w, c2w, 2, maskself=True)
+        ref_proj, nei_projs = F_.collect_proj(w2c, K_feat, nb)
+        w0 = F_.homo_warping(feature.detach()[nb[:, 0]], nei_projs[0], ref_proj, geo.depth_values)
+        assert isinstance(w0, lazywarp.LazyVolume) and tuple(w0.shape) == (N, C, D) + hw and w0.device.type == "cuda"
+        m = float(w0.mean())                                                         # materialises
+        eager = ops.homo_warp(feature.detach()[nb[:, 0]], geo.proj_rel[:, 0].contiguous(), geo.depth_values)
+        assert abs(m - float(eager.mean())) < 1e-6 and lazywarp.stats["materialized"] > before["materialized"]
+        mixed = (w0 * 2.0 + 1.0)
+        assert type(mixed) is torch.Tensor and torch.equal(mixed, eager * 2.0 + 1.0)
+    finally:
+        F_.LAZY_WARP = old
