@@ -125,6 +125,12 @@ def backproject_Weigh(features: Tensor, points: Tensor, projection: Tensor, dept
     # (N, h*w, 1, J) is a view of (N,J,h,w): hand the kernel that view, no copy (mvsdet.py:1393-1395)
     est_depth = depth.reshape(n, h, w, j).permute(0, 3, 1, 2)
     est_dens = prob.reshape(n, h, w, j).permute(0, 3, 1, 2)
+    if LAZY_WARP and features.is_cuda and features.dtype == torch.float32:
+        # inside the patched reference: `volume.sum(dim=0)` / `valid.sum(dim=0)` (mvsdet.py:509-511) then cost one launch
+        # of the fused lifting kernel instead of a (N,C,X,Y,Z) volume and a reduction over it (lazywarp.py)
+        from . import lazywarp
+        volume, valid = lazywarp.lazy_backproject(features, points, projection, est_depth, est_dens, float(voxel_size[-1]))
+        return volume, valid, torch.tensor(1.), torch.tensor(1.)
     volume, valid = ops.backproject_weigh(features, points, projection, est_depth, est_dens, float(voxel_size[-1]))
     volume = volume.view(n, c, nx, ny, nz)
     valid = valid.view(n, 1, nx, ny, nz)

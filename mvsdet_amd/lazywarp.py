@@ -65,6 +65,13 @@ class LazyVolume(Tensor):
             return _eager(p["inner"]) / p["n"]
         if k == "scaled_sq":
             return _eager(p["inner"]) ** 2
+        if k in ("lift", "lift_valid"):
+            if "eager" not in p:
+                volume, valid = ops.backproject_weigh(p["features"], p["points"], p["projection"], p["est_depth"],
+                                                      p["est_dens"], p["vz"])
+                n, c = p["features"].shape[:2]
+                p["eager"] = (volume.view((n, c) + p["grid"]), valid.view((n, 1) + p["grid"]))
+            return p["eager"][0 if k == "lift" else 1]
         raise RuntimeError(f"LazyVolume: unknown kind {k}")
 
     @classmethod
@@ -81,6 +88,12 @@ class LazyVolume(Tensor):
         if name == "__get__" or name in _META:  # shape / dtype / device / size(): the wrapper's own metadata
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
+        if name == "sum" and isinstance(args[0], LazyVolume) and args[0].kind in ("lift", "lift_valid") and \
+                (tuple(args[1:]) == (0,) or (len(args) == 1 and kwargs == {"dim": 0})):
+            # mvsdet.py:509-511: volume.sum(dim=0) / valid.sum(dim=0) -> the fused lifting kernel, un-normalised
+            out = _lift_sum(args[0])
+            if out is not None:
+                return out
         if not kwargs and len(args) == 2:
             a, b = args
             la, lb = isinstance(a, LazyVolume), isinstance(b, LazyVolume)
@@ -169,3 +182,33 @@ def lazy_homo_warp(src_fea: Tensor, proj_rel: Tensor, depth_values: Tensor) -> L
     b, c, h, w = src_fea.shape
     return LazyVolume("warp", {"src": src_fea, "proj": proj_rel, "depth": depth_values}, (b, c, depth_values.shape[1], h, w),
                       src_fea.dtype, src_fea.device)
+
+
+def _lift_sum(t: LazyVolume):
+    """Sum over the views of a deferred `backproject_Weigh` result: one launch of the fused lifting kernel (forward only;
+    under autograd the eager per-view operator and torch's sum keep the gradient path)."""
+    from . import ops
+    p = t.payload
+    if torch.is_grad_enabled() and (p["features"].requires_grad or p["est_dens"].requires_grad):
+        return None
+    if "sums" not in p:
+        with torch._C.DisableTorchFunctionSubclass():
+            feats = p["features"]
+            n, c, h, w = feats.shape
+            packed = ops.pack_features(feats)
+            total, count = ops.backproject_weigh_sum_shard(packed, p["points"], p["projection"], p["est_depth"], p["est_dens"],
+                                                           n, 0, c, h, w, p["vz"])
+            p["sums"] = (total.view((c,) + p["grid"]), count.view((1,) + p["grid"]).long())
+            stats["fused"] += 1
+    return p["sums"][0 if t.kind == "lift" else 1]
+
+
+def lazy_backproject(features: Tensor, points: Tensor, projection: Tensor, est_depth: Tensor, est_dens: Tensor, vz: float):
+    """(volume, valid) of backproject_Weigh as deferred volumes sharing one payload."""
+    n, c = features.shape[:2]
+    grid = tuple(points.shape[-3:])
+    payload = {"features": features, "points": points, "projection": projection, "est_depth": est_depth,
+               "est_dens": est_dens, "vz": vz, "grid": grid}
+    volume = LazyVolume("lift", payload, (n, c) + grid, features.dtype, features.device)
+    valid = LazyVolume("lift_valid", payload, (n, 1) + grid, torch.bool, features.device)
+    return volume, valid

@@ -927,3 +927,42 @@ def test_unmodified_variance_loop_collapses_into_the_fused_kernel(gpu, oracle, t
         assert type(mixed) is torch.Tensor and torch.equal(mixed, eager * 2.0 + 1.0)
     finally:
         F_.LAZY_WARP = old
+
+
+def test_unmodified_lifting_block_uses_the_fused_kernel(gpu, oracle):
+    """mvsdet.py:497-513 on the patched backproject_Weigh: `volume.sum(dim=0)` and `valid.sum(dim=0)` of the deferred
+    volumes run ONE fused lifting launch; indexing the volume instead materialises the per-view result."""
+    from mvsdet_amd import functional as F_, lazywarp, ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw = 6, 32, 12, (24, 32)
+    hp = MVSDetHotPath([16, 16, 8], [.4, .4, .4], [0.2, 5.0], D)
+    meta = synthetic.make_img_meta(N, hw, seed=12)
+    feat = synthetic.make_features(N, C, hw, seed=12).to(gpu)
+    logits = synthetic.make_cost_logits(N, D, hw, seed=12, sharp=2.0).to(gpu)
+    out = hp.forward_scene(feat, meta, cost_logits=logits)
+    geo = out["geometry"]
+    h, w = geo.height, geo.width
+    # the reference's argument layout: (N, h*w, 1, J)
+    est_depth = out["est_depth"].reshape(N, 3, -1).transpose(2, 1).unsqueeze(2)
+    est_dens = out["est_densities"].reshape(N, 3, -1).transpose(2, 1).unsqueeze(2)
+    old = F_.LAZY_WARP
+    F_.LAZY_WARP = True
+    try:
+        before = dict(lazywarp.stats)
+        volume, valid, _, _ = F_.backproject_Weigh(feat[:, :, :h, :w], geo.points, geo.projection, est_depth, hp.voxel_size,
+                                                   est_dens)
+        assert isinstance(volume, lazywarp.LazyVolume) and tuple(volume.shape) == (N, C, 16, 16, 8)
+        volume_sum = volume.sum(dim=0)
+        valid_cnt = valid.sum(dim=0)
+        volume_mean = volume_sum / (valid_cnt + 1e-8)
+        volume_mean[:, valid_cnt[0] == 0] = .0
+        assert lazywarp.stats["fused"] == before["fused"] + 1 and lazywarp.stats["materialized"] == before["materialized"]
+        assert torch.equal(valid_cnt, out["valid"])
+        np.testing.assert_allclose(volume_mean.cpu().numpy(), out["volume"].cpu().numpy(), rtol=0, atol=2e-6)
+        # another use of the volume: per-view slices -> the eager operator
+        eager_vol, eager_valid = ops.backproject_weigh(feat[:, :, :h, :w], geo.points, geo.projection,
+                                                       out["est_depth"], out["est_densities"], hp.voxel_size[-1])
+        assert torch.equal(volume[2], eager_vol.view(N, C, 16, 16, 8)[2])
+        assert torch.equal(valid.float().sum(), eager_valid.float().sum())
+    finally:
+        F_.LAZY_WARP = old
