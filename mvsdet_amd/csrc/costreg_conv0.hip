@@ -239,19 +239,25 @@ extern "C" int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_
 // ---------------------------------------------------------------------------------------------------------------
 namespace mvsdet {
 
+// A class with T = 1, 2, 4 or 8 taps stages P = 8 / T channel pairs at once (and only its own taps' weights), so every
+// stage carries the same 8 tap-pairs = 32 MFMAs per wave behind one barrier pair, whatever the class.
 template <int TWC, int PD, int PH, int PW>
 __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
-    const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
+    const float* __restrict__ x, const float* __restrict__ wperm, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ out, int Cin, int Cout,
     int Di, int Hi, int Wi, int tiles_w, int tiles_h, int relu) {
     constexpr int kTW = TWC, kTH = 4 * (32 / TWC);
     constexpr int kHD = kC0D + 1, kHH = kTH + 1, kHW = kTW + 1;   // +1 on the high side: input i + 1 for tap 0
-    constexpr int kHalo = kHD * kHH * kHW;
-    constexpr int kInStage = (2 * kHalo + kThreads - 1) / kThreads;
+    constexpr int kHalo = kHD * kHH * kHW;                         // per channel
     constexpr int kRowsPerCol = 32 / TWC;
-    __shared__ float s_in[2 * kHalo];
-    __shared__ float4 s_w4[kC0WPair / 4];
-    const float* s_w = reinterpret_cast<const float*>(s_w4);
+    constexpr int ND = PD ? 2 : 1, NH = PH ? 2 : 1, NW = PW ? 2 : 1, T = ND * NH * NW;
+    constexpr int P = 8 / T;                                       // channel pairs per stage
+    constexpr int kInFloats = P * 2 * kHalo;                       // staged input values
+    constexpr int kInStage = (kInFloats + kThreads - 1) / kThreads;
+    constexpr int kWFloats = P * 2 * T * kC0Out;                   // staged weights: [pair][k][tap of the class][64] = 1024
+    constexpr int kWStage = (kWFloats + kThreads - 1) / kThreads;  // 4
+    __shared__ float s_in[kInFloats];
+    __shared__ float s_w[kWFloats];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,40 +269,49 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
     const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
     const float* xn = x + (size_t)n * Cin * ivol;
     const int npairs = (Cin + 1) / 2;
+    const int nstages = (npairs + P - 1) / P;
 
     const int dz0 = wave >> 1, hy0 = (wave & 1) * 2 * kRowsPerCol;
     const int col = lane & 31, kk = lane >> 5;
     const int chy = col / TWC, cw = col % TWC;
 
+    // staging plans.  Input element e -> (channel q of the stage's 2P, halo position); weight element e ->
+    // (pair p, channel k of the pair, class tap t, output channel o)
     int in_off[kInStage];
 #pragma unroll
     for (int k = 0; k < kInStage; ++k) {
         const int e = tid + k * kThreads;
-        const int kc = e / kHalo, r = e - kc * kHalo;
+        const int q = e / kHalo, r = e - q * kHalo;
         const int dz = r / (kHH * kHW), r2 = r - dz * (kHH * kHW);
         const int hy = r2 / kHW, wx = r2 - hy * kHW;
         const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
-        const bool ok = e < 2 * kHalo && d < Di && h < Hi && w < Wi;
-        in_off[k] = ok ? (int)((size_t)d * iplane + (size_t)h * Wi + w) | (kc << 30) : -1;
+        const bool ok = e < kInFloats && d < Di && h < Hi && w < Wi;
+        in_off[k] = ok ? (int)((size_t)d * iplane + (size_t)h * Wi + w) : -1;   // channel q = e / kHalo recomputed below
     }
-    float in_reg[kInStage];
-    float4 w_reg[kC0WStage];
-    auto fetch = [&](int cp) {
-        const float* x0 = xn + (size_t)(2 * cp) * ivol;
-        const bool has1 = 2 * cp + 1 < Cin;
+    int w_off[kWStage];  // offset inside wperm relative to the stage's first channel: (q * 27 + tap27) * Cout + o
+#pragma unroll
+    for (int k = 0; k < kWStage; ++k) {
+        const int e = tid + k * kThreads;
+        const int o = e % kC0Out, t = (e / kC0Out) % T, q = e / (kC0Out * T);   // q = 2*p + k
+        const int tw = t % NW, th = (t / NW) % NH, td = t / (NW * NH);
+        const int kd = PD ? (td ? 2 : 0) : 1, kh = PH ? (th ? 2 : 0) : 1, kw = PW ? (tw ? 2 : 0) : 1;
+        w_off[k] = e < kWFloats ? (q * 27 + (kd * 3 + kh) * 3 + kw) * Cout + ob64 * kC0Out + o : -1;
+    }
+    float in_reg[kInStage], w_reg[kWStage];
+    auto fetch = [&](int sidx) {
+        const int c0 = sidx * 2 * P;  // first channel of the stage
 #pragma unroll
         for (int k = 0; k < kInStage; ++k) {
-            const int o = in_off[k];
-            const int kc = (o >> 30) & 1;
+            const int q = (tid + k * kThreads) / kHalo;
             float v = 0.0f;
-            if (o >= 0 && (kc == 0 || has1)) v = x0[(size_t)kc * ivol + (o & 0x3fffffff)];
+            if (in_off[k] >= 0 && c0 + q < Cin) v = xn[(size_t)(c0 + q) * ivol + in_off[k]];
             in_reg[k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < kC0WStage; ++k) {
-            const int e = tid + k * kThreads;
-            w_reg[k] = e < kC0WPair / 4 ? wperm[((size_t)cp * 54 + (e >> 4)) * (Cout / 4) + ob64 * 16 + (e & 15)]
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < kWStage; ++k) {
+            const int q = (tid + k * kThreads) / (kC0Out * T);
+            // wperm is zero padded to an even channel count by the caller; beyond that, zero here
+            w_reg[k] = (w_off[k] >= 0 && c0 + q < ((Cin + 1) & ~1)) ? wperm[(size_t)c0 * 27 * Cout + w_off[k]] : 0.0f;
         }
     };
 
@@ -309,42 +324,43 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     fetch(0);
-    for (int cp = 0; cp < npairs; ++cp) {
+    for (int sidx = 0; sidx < nstages; ++sidx) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kInStage; ++k) {
             const int e = tid + k * kThreads;
-            if (e < 2 * kHalo) s_in[e] = in_reg[k];
+            if (e < kInFloats) s_in[e] = in_reg[k];
         }
 #pragma unroll
-        for (int k = 0; k < kC0WStage; ++k) {
+        for (int k = 0; k < kWStage; ++k) {
             const int e = tid + k * kThreads;
-            if (e < kC0WPair / 4) s_w4[e] = w_reg[k];
+            if (e < kWFloats) s_w[e] = w_reg[k];
         }
         __syncthreads();
-        if (cp + 1 < npairs) fetch(cp + 1);
+        if (sidx + 1 < nstages) fetch(sidx + 1);
 
-        const float* bin = s_in + kk * kHalo + (dz0 * kHH + hy0 + chy) * kHW + cw;
-        const float* ain = s_w + kk * 27 * kC0Out + col;
-        // parity 0: tap 1 at input offset 0; parity 1: tap 0 at offset +1 and tap 2 at offset 0
 #pragma unroll
-        for (int td = 0; td < (PD ? 2 : 1); ++td)
+        for (int p = 0; p < P; ++p) {
+            const float* bin = s_in + (2 * p + kk) * kHalo + (dz0 * kHH + hy0 + chy) * kHW + cw;
+            const float* ain = s_w + (2 * p + kk) * T * kC0Out + col;
+            // parity 0: tap 1 at input offset 0; parity 1: tap 0 at offset +1 and tap 2 at offset 0
 #pragma unroll
-            for (int th = 0; th < (PH ? 2 : 1); ++th)
+            for (int td = 0; td < ND; ++td)
 #pragma unroll
-                for (int tw = 0; tw < (PW ? 2 : 1); ++tw) {
-                    const int kd = PD ? (td ? 2 : 0) : 1, od = PD ? (td ? 0 : 1) : 0;
-                    const int kh = PH ? (th ? 2 : 0) : 1, oh = PH ? (th ? 0 : 1) : 0;
-                    const int kw = PW ? (tw ? 2 : 0) : 1, ow = PW ? (tw ? 0 : 1) : 0;
-                    const int tap = (kd * 3 + kh) * 3 + kw;
-                    const float a0 = ain[tap * kC0Out], a1 = ain[tap * kC0Out + 32];
-                    const float b0 = bin[(od * kHH + oh) * kHW + ow];
-                    const float b1 = bin[(od * kHH + oh + kRowsPerCol) * kHW + ow];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                }
+                for (int th = 0; th < NH; ++th)
+#pragma unroll
+                    for (int tw = 0; tw < NW; ++tw) {
+                        const int od = PD ? (td ? 0 : 1) : 0, oh = PH ? (th ? 0 : 1) : 0, ow = PW ? (tw ? 0 : 1) : 0;
+                        const int t = (td * NH + th) * NW + tw;
+                        const float a0 = ain[t * kC0Out], a1 = ain[t * kC0Out + 32];
+                        const float b0 = bin[(od * kHH + oh) * kHW + ow];
+                        const float b1 = bin[(od * kHH + oh + kRowsPerCol) * kHW + ow];
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    }
+        }
     }
 
     const int wi = w0 + cw;
@@ -387,10 +403,9 @@ extern "C" int mvsdet_convT3d_k3_s2_mfma_f32(const float* x, const float* weight
     const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + kC0D - 1) / kC0D;
     MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out)));
-    const float4* w4 = reinterpret_cast<const float4*>(weight_perm);
     hipStream_t st = (hipStream_t)stream;
 #define MVS_CT_CASE(TW_, PD_, PH_, PW_)                                                                                     \
-    hipLaunchKernelGGL((convT3d_k3_s2_mfma_kernel<TW_, PD_, PH_, PW_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift,   \
+    hipLaunchKernelGGL((convT3d_k3_s2_mfma_kernel<TW_, PD_, PH_, PW_>), grid, dim3(kThreads), 0, st, x, weight_perm, scale, shift, \
                        residual, out, Cin, Cout, D, H, W, tiles_w, tiles_h, relu)
 #define MVS_CT_ALL(TW_)                                                                                                     \
     MVS_CT_CASE(TW_, 0, 0, 0); MVS_CT_CASE(TW_, 0, 0, 1); MVS_CT_CASE(TW_, 0, 1, 0); MVS_CT_CASE(TW_, 0, 1, 1);             \
