@@ -30,7 +30,7 @@ constexpr int kC0WStage = (kC0WPair / 4 + kThreads - 1) / kThreads;  // 4 float4
 // ST = stride (1 or 2, padding 1): input voxel = ST * output voxel - 1 + tap; (Di,Hi,Wi) input, (D,H,W) output extents.
 // TD = tile planes (2 or 4): the 256 output voxels of a block are TD x (256 / (TD * TWC)) x TWC.
 template <int TWC, int ST, int TD>
-__global__ __launch_bounds__(kThreads, 2) void conv3d_k3_c64_mfma_kernel(
+__global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
     const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int Cin, int Cout, int Di, int Hi, int Wi, int D, int H,
     int W, int tiles_w, int tiles_h, int relu) {
@@ -203,7 +203,7 @@ static int launch_conv_mfma(const char* name, const float* x, const float* weigh
     const float4* w4 = reinterpret_cast<const float4*>(weight_perm);
     hipStream_t st = (hipStream_t)stream;
 #define MVS_CONV_CASE(TW_, ST_, TD_)                                                                                          \
-    hipLaunchKernelGGL((conv3d_k3_c64_mfma_kernel<TW_, ST_, TD_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift, out, Cin, \
+    hipLaunchKernelGGL((conv3d_k3_mfma_kernel<TW_, ST_, TD_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift, out, Cin, \
                        Cout, Di, Hi, Wi, D, H, W, tiles_w, tiles_h, relu)
     if (stride == 1) {
         if (td == 4) MVS_CONV_CASE(16, 1, 4);

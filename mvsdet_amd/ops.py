@@ -639,8 +639,6 @@ def permute_conv_weight(weight: Tensor) -> Tensor:
     return w
 
 
-permute_conv0_weight = permute_conv_weight
-
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_mfma", mutates_args=(), device_types="cuda")
 def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
@@ -679,8 +677,6 @@ def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shif
 def _(x, weight_perm, scale, shift, relu, stride=1):
     return x.new_empty((x.shape[0], weight_perm.shape[4]) + tuple((s - 1) // stride + 1 for s in x.shape[2:]))
 
-
-conv3d_k3_c64 = conv3d_k3_mfma
 
 
 def permute_convT_weight(weight: Tensor) -> Tensor:

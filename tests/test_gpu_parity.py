@@ -770,15 +770,15 @@ def test_cost_network_first_conv_mfma(gpu, N, Cin, D, H, W):
     scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
     ref = torch.nn.functional.conv3d(x, wgt, None, padding=1)
     tol = 2e-6 * float(ref.abs().max()) * max(1.0, (27 * Cin) ** 0.5 / 8)
-    wp = ops.permute_conv0_weight(wgt.to(gpu))
-    out = ops.conv3d_k3_c64(x.to(gpu), wp, None, None, False).cpu()
+    wp = ops.permute_conv_weight(wgt.to(gpu))
+    out = ops.conv3d_k3_mfma(x.to(gpu), wp, None, None, False).cpu()
     assert out.shape == ref.shape
     torch.testing.assert_close(out, ref, rtol=0, atol=tol)
-    out2 = ops.conv3d_k3_c64(x.to(gpu), wp, scale.to(gpu), shift.to(gpu), True).cpu()
+    out2 = ops.conv3d_k3_mfma(x.to(gpu), wp, scale.to(gpu), shift.to(gpu), True).cpu()
     ref2 = torch.relu(ref * scale.view(1, 64, 1, 1, 1) + shift.view(1, 64, 1, 1, 1))
     torch.testing.assert_close(out2, ref2, rtol=0, atol=2 * tol)
     with pytest.raises(ValueError):
-        ops.conv3d_k3_c64(x.to(gpu), wp, scale.to(gpu), None, True)
+        ops.conv3d_k3_mfma(x.to(gpu), wp, scale.to(gpu), None, True)
     # Cout = 128: two independent 64-channel slices of the weights (conv2 / conv4 of the network)
     wgt2 = torch.randn(128, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
     ref3 = torch.nn.functional.conv3d(x, wgt2, None, padding=1)
