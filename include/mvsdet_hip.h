@@ -178,6 +178,13 @@ int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const
 int mvsdet_convT3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
                                   const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
                                   mvsdet_stream_t stream);
+/* Weight gradient of the stride-1 layers (training): dW[o][c][tap] = sum_voxels grad_out[n][o][v] * x[n][c][v + tap - 1]
+ * on the fp32 matrix cores.  partial (nsplit,Cout,Cin,27) fp32 receives one partial sum per voxel split
+ * (mvsdet_conv3d_k3_dw_partial_bytes); the caller adds them up (deterministic, no atomics).  The input gradient of
+ * these layers is mvsdet_conv3d_k3_mfma_f32 on grad_out with the weights transposed and flipped. */
+size_t mvsdet_conv3d_k3_dw_partial_bytes(int Cin, int Cout, int nsplit);
+int mvsdet_conv3d_k3_dw_mfma_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
+                                 int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                                int D, int H, int W, mvsdet_stream_t stream);
 

@@ -19,6 +19,32 @@ import torch
 from torch import nn
 
 
+class _ConvK3S1(torch.autograd.Function):
+    """Conv3d(kernel 3, stride 1, padding 1, no bias) with all three passes on the fp32 matrix cores: forward and input
+    gradient through `ops.conv3d_k3_mfma` (the input gradient is the same convolution of grad_out with the weights
+    transposed and flipped), weight gradient through `ops.conv3d_k3_dw`.  MIOpen needs 34 + 42 + 360 ms for conv0 at the
+    reference-true shape, these kernels 15 + 15 + 37 ms."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import ops
+        ctx.save_for_backward(x, weight)
+        return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(weight), None, None, False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wflip = weight.detach().transpose(0, 1).flip(2, 3, 4).contiguous()      # (Cin, Cout, 3,3,3)
+            gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(wflip), None, None, False)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv3d_k3_dw(x, gy)
+        return gx, gw
+
+
 class _ConvBnReLU3d(nn.Module):
     """Conv3d(no bias) -> BatchNorm3d -> ReLU, with the reference's sub-module names `conv` and `bn` (module.py:26)."""
 
@@ -48,6 +74,8 @@ class CostRegNet3DGS(nn.Module):
         self.conv9 = _up(4 * base, 2 * base)
         self.conv11 = _up(2 * base, base)
         self.prob = nn.Conv3d(base, 2, 3, stride=1, padding=1)
+        # under autograd the stride-1 ConvBnReLU layers (conv0, conv2, conv4) use our forward / dX / dW kernels
+        self.hip_backward = True
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
@@ -72,6 +100,10 @@ class CostRegNet3DGS(nn.Module):
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
             shift = (bn.bias - bn.running_mean * scale).detach()
             return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
+        if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and conv.stride == (1, 1, 1) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
+            # training: convolution forward / backward on our kernels, BatchNorm (batch statistics) and ReLU stay torch's
+            return torch.relu_(bn(_ConvK3S1.apply(x, conv.weight)))
         return layer(x)
 
     def _up(self, seq, x, skip):

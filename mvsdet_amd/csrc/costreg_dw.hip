@@ -1,0 +1,139 @@
+// Weight gradient of the stride-1 3x3x3 convolutions of the cost regularisation network (conv0 256->64 above all:
+// MIOpen needs 360 ms for it at the reference-true shape, 42 % of a whole training step of the network):
+//
+//   dW[o][c][kd][kh][kw] = sum over (n, d, h, w) of dY[n][o][d][h][w] * X[n][c][d+kd-1][h+kh-1][w+kw-1]
+//
+// As a GEMM the reduction runs over the voxels: D[o][c] += A[o][k] * B[k][c] with k = voxel, one 32x32 accumulator per
+// tap, on v_mfma_f32_32x32x2_f32 (two voxels per instruction; exact fp32 FMA sums).
+//   block  = (32 input channels, 32 output channels, one of S voxel splits); wave w owns the taps w, w+4, ... (7,7,7,6)
+//            = 7 accumulators (112 VGPRs)
+//   tile   = 1 x 4 x 16 voxels: dY[32][64] and the X halo [32][3 x 6 x 18] staged in LDS (odd row strides: the operand
+//            reads vary the channel across lanes), 32 voxel pairs x 7 taps = 224 MFMAs per wave and tile
+//   output = partial[s][o][c][27] per split, summed by the caller (deterministic, no atomics)
+// Bound: fp32 MFMA (same 2.04 TFLOP as the forward of conv0).
+#include "common.h"
+
+namespace mvsdet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kDwTH = 4, kDwTW = 16, kDwVox = kDwTH * kDwTW;        // 64 voxels per tile
+constexpr int kDwHD = 3, kDwHH = kDwTH + 2, kDwHW = kDwTW + 2;      // halo 3 x 6 x 18
+constexpr int kDwHalo = kDwHD * kDwHH * kDwHW;                      // 324
+constexpr int kDwXStride = kDwHalo + 1;                             // 325: odd, conflict-free across channels
+constexpr int kDwYStride = kDwVox + 1;                              // 65
+constexpr int kDwTapsPerWave = 7;
+
+__global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                      float* __restrict__ partial, int N, int Cin, int Cout,
+                                                                      int D, int H, int W, int tiles_w, int tiles_h,
+                                                                      int ntiles, int nsplit) {
+    __shared__ float s_x[32 * kDwXStride];
+    __shared__ float s_y[32 * kDwYStride];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x, c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    const int col = lane & 31, kk = lane >> 5;
+
+    // this wave's taps and their offsets inside the halo
+    int tapoff[kDwTapsPerWave];
+    int ntap = 0;
+#pragma unroll
+    for (int i = 0; i < kDwTapsPerWave; ++i) {
+        const int t = wave + 4 * i;
+        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+        tapoff[i] = (kd * kDwHH + kh) * kDwHW + kw;
+        if (t < 27) ntap = i + 1;
+    }
+
+    f32x16 acc[kDwTapsPerWave];
+#pragma unroll
+    for (int i = 0; i < kDwTapsPerWave; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int tiles_per_view = D * tiles_h * tiles_w;
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        const int n = tile / tiles_per_view, tv = tile - n * tiles_per_view;
+        const int d = tv / (tiles_h * tiles_w), t2 = tv - d * (tiles_h * tiles_w);
+        const int h0 = (t2 / tiles_w) * kDwTH, w0 = (t2 % tiles_w) * kDwTW;
+        __syncthreads();  // previous tile fully consumed
+        // X halo: 32 channels x 324 positions, zero outside the volume / beyond Cin
+        for (int e = tid; e < 32 * kDwHalo; e += kThreads) {
+            const int c = e / kDwHalo, r = e - c * kDwHalo;
+            const int dz = r / (kDwHH * kDwHW), r2 = r - dz * (kDwHH * kDwHW);
+            const int hy = r2 / kDwHW, wx = r2 - hy * kDwHW;
+            const int dd = d + dz - 1, hh = h0 + hy - 1, ww = w0 + wx - 1;
+            float v = 0.0f;
+            if (c0 + c < Cin && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W)
+                v = x[((size_t)n * Cin + c0 + c) * vol + (size_t)dd * plane + (size_t)hh * W + ww];
+            s_x[c * kDwXStride + r] = v;
+        }
+        // dY: 32 output channels x 64 voxels, zero outside the volume / beyond Cout
+        for (int e = tid; e < 32 * kDwVox; e += kThreads) {
+            const int o = e / kDwVox, q = e - o * kDwVox;
+            const int hh = h0 + q / kDwTW, ww = w0 + q % kDwTW;
+            float v = 0.0f;
+            if (o0 + o < Cout && hh < H && ww < W) v = gy[((size_t)n * Cout + o0 + o) * vol + (size_t)d * plane + (size_t)hh * W + ww];
+            s_y[o * kDwYStride + q] = v;
+        }
+        __syncthreads();
+        const float* ay = s_y + col * kDwYStride + kk;   // A[i = o][k = voxel parity]
+        const float* bx = s_x + col * kDwXStride;        // B[k][j = c]
+#pragma unroll 4
+        for (int vp = 0; vp < kDwVox / 2; ++vp) {
+            const int q = 2 * vp + kk;                   // this lane's voxel of the pair
+            const int base = (q / kDwTW) * kDwHW + (q % kDwTW);
+            const float a = ay[2 * vp];
+#pragma unroll
+            for (int i = 0; i < kDwTapsPerWave; ++i) {
+                if (i < ntap) {
+                    const float b = bx[base + tapoff[i]];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial[split][o][c][tap]; C/D map: column = lane & 31 (c), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (o)
+#pragma unroll
+    for (int i = 0; i < kDwTapsPerWave; ++i) {
+        const int t = wave + 4 * i;
+        if (t >= 27) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * kk, c = c0 + col;
+            if (o < Cout && c < Cin) partial[(((size_t)split * Cout + o) * Cin + c) * 27 + t] = acc[i][r];
+        }
+    }
+}
+
+}  // namespace mvsdet
+
+using namespace mvsdet;
+
+extern "C" size_t mvsdet_conv3d_k3_dw_partial_bytes(int Cin, int Cout, int nsplit) {
+    if (Cin <= 0 || Cout <= 0 || nsplit <= 0) return 0;
+    return (size_t)nsplit * Cout * Cin * 27 * sizeof(float);
+}
+
+extern "C" int mvsdet_conv3d_k3_dw_mfma_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes,
+                                            int nsplit, int N, int Cin, int Cout, int D, int H, int W,
+                                            mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && grad_out && partial, "conv3d_k3_dw: NULL pointer");
+    MVS_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_dw: bad shape");
+    MVS_REQUIRE(nsplit > 0 && nsplit <= 65535, "conv3d_k3_dw: nsplit=%d outside [1,65535]", nsplit);
+    if (partial_bytes < mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)) {
+        set_error("conv3d_k3_dw: partial buffer %zu B < %zu B", partial_bytes, mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit));
+        return MVSDET_ERR_WORKSPACE;
+    }
+    const int tiles_w = (W + kDwTW - 1) / kDwTW, tiles_h = (H + kDwTH - 1) / kDwTH;
+    const long long ntiles = (long long)N * D * tiles_h * tiles_w;
+    MVS_REQUIRE(ntiles < INT32_MAX, "conv3d_k3_dw: too many tiles");
+    dim3 grid((unsigned)nsplit, (unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
+    MVS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "conv3d_k3_dw: too many channel blocks");
+    hipLaunchKernelGGL(conv3d_k3_dw_mfma_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, grad_out, partial, N, Cin,
+                       Cout, D, H, W, tiles_w, tiles_h, (int)ntiles, nsplit);
+    MVS_LAUNCH_CHECK("conv3d_k3_dw");
+    return MVSDET_OK;
+}

@@ -727,3 +727,28 @@ def convT3d_k3_s2_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], 
 @convT3d_k3_s2_mfma.register_fake
 def _(x, weight_perm, scale, shift, residual, relu):
     return x.new_empty((x.shape[0], weight_perm.shape[4]) + tuple(2 * s for s in x.shape[2:]))
+
+
+@torch.library.custom_op(f"{_NS}::conv3d_k3_dw", mutates_args=(), device_types="cuda")
+def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 128) -> Tensor:
+    """Weight gradient of Conv3d(kernel 3, stride 1, padding 1): x (N,Cin,D,H,W), grad_out (N,Cout,D,H,W) ->
+    (Cout,Cin,3,3,3), on the fp32 matrix cores; `nsplit` voxel splits are accumulated separately and summed."""
+    _req(x, "x", dim=5)
+    _req(grad_out, "grad_out", dim=5)
+    N, Cin, D, H, W = x.shape
+    Cout = grad_out.shape[1]
+    if tuple(grad_out.shape) != (N, Cout, D, H, W):
+        raise ValueError(f"conv3d_k3_dw: grad_out {tuple(grad_out.shape)} does not match x {tuple(x.shape)}")
+    x, grad_out = x.contiguous(), grad_out.contiguous()
+    lib = _lib.load()
+    pbytes = lib.mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)
+    partial = torch.empty((nsplit, Cout, Cin, 27), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mvsdet_conv3d_k3_dw_mfma_f32(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), pbytes, nsplit, N, Cin,
+                                                    Cout, D, H, W, _stream(x)), "conv3d_k3_dw")
+    return partial.sum(0).view(Cout, Cin, 3, 3, 3)
+
+
+@conv3d_k3_dw.register_fake
+def _(x, grad_out, nsplit=128):
+    return x.new_empty((grad_out.shape[1], x.shape[1], 3, 3, 3))

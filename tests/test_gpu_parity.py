@@ -966,3 +966,53 @@ def test_unmodified_lifting_block_uses_the_fused_kernel(gpu, oracle):
         assert torch.equal(valid.float().sum(), eager_valid.float().sum())
     finally:
         F_.LAZY_WARP = old
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,nsplit", [(2, 32, 64, 3, 8, 16, 4), (1, 40, 70, 2, 5, 19, 3), (2, 5, 3, 1, 1, 1, 2),
+                                                     (1, 64, 32, 4, 9, 33, 200)])
+def test_cost_network_weight_gradient_mfma(gpu, N, Cin, Cout, D, H, W, nsplit):
+    """dW of Conv3d(k=3, s=1, p=1) on the fp32 matrix cores (csrc/costreg_dw.hip) against ATen-CPU's conv3d_weight;
+    the input gradient through the forward kernel with transposed, flipped weights against conv3d_input."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    gy = torch.randn(N, Cout, D, H, W, generator=g)
+    wgt = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    ref_w = torch.nn.grad.conv3d_weight(x, wgt.shape, gy, padding=1)
+    got_w = ops.conv3d_k3_dw(x.to(gpu), gy.to(gpu), nsplit).cpu()
+    assert got_w.shape == ref_w.shape
+    torch.testing.assert_close(got_w, ref_w, rtol=0, atol=3e-6 * float(ref_w.abs().max()) * max(1.0, (N * D * H * W) ** 0.5 / 8))
+    if Cin % 64 == 0:   # dX = conv(dY, W^T flipped): the output channel count of that convolution is Cin
+        ref_x = torch.nn.grad.conv3d_input(x.shape, wgt, gy, padding=1)
+        wflip = wgt.transpose(0, 1).flip(2, 3, 4).contiguous()
+        got_x = ops.conv3d_k3_mfma(gy.to(gpu), ops.permute_conv_weight(wflip.to(gpu)), None, None, False).cpu()
+        torch.testing.assert_close(got_x, ref_x, rtol=0, atol=3e-6 * float(ref_x.abs().max()) * max(1.0, (27 * Cout) ** 0.5 / 8))
+
+
+def test_cost_network_training_gradients_hip_vs_torch(gpu):
+    """CostRegNet3DGS under autograd: with `hip_backward` the stride-1 convolutions run forward, dX and dW on our kernels;
+    outputs and every parameter / input gradient agree with the all-torch route."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    torch.manual_seed(3)
+    # BatchNorm on its running statistics: with batch statistics over the few quarter-resolution voxels of this small
+    # volume the summation-order noise of two correct convolutions is amplified beyond any useful tolerance
+    net = CostRegNet3DGS(256).to(gpu).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(2, 256, 8, 12, 32, device=gpu)
+    target = torch.randn(2, 2, 8, 12, 32, device=gpu)
+    grads = {}
+    for flag in (True, False):
+        net.hip_backward = flag
+        net.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        out = net(xin)
+        ((out - target) ** 2).mean().backward()
+        grads[flag] = (out.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+    o1, gx1, gp1 = grads[True]
+    o0, gx0, gp0 = grads[False]
+    torch.testing.assert_close(o1, o0, rtol=0, atol=2e-5 * float(o0.abs().max()))
+    torch.testing.assert_close(gx1, gx0, rtol=0, atol=1e-4 * float(gx0.abs().max()))
+    for k in gp0:
+        torch.testing.assert_close(gp1[k], gp0[k], rtol=0, atol=1e-4 * max(float(gp0[k].abs().max()), 1e-12), msg=k)
