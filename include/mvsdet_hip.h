@@ -188,6 +188,13 @@ int mvsdet_conv3d_k3_dw_mfma_f32(const float* x, const float* grad_out, float* p
 int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                                int D, int H, int W, mvsdet_stream_t stream);
 
+/* Backward of the head (training): grad_x (N,Cin,D,H,W) from grad_out (N,2,D,H,W) and weight (2,Cin,3,3,3); and the
+ * weight gradient as partial (nsplit,2,Cin,27) sums (one per voxel split, added up by the caller). */
+int mvsdet_conv3d_k3_cout2_dx_f32(const float* grad_out, const float* weight, float* grad_x, int N, int Cin, int D, int H,
+                                  int W, mvsdet_stream_t stream);
+int mvsdet_conv3d_k3_cout2_dw_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
+                                  int N, int Cin, int D, int H, int W, mvsdet_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a9  backproject_Weigh -- mvsdet.py:1372-1492 (gt_depth=None).
  *   feat + feat_strides: (N,C,h,w) view of the 2-D features (crop allowed, see pack above)

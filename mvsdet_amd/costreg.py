@@ -2,8 +2,9 @@
 `CostRegNet_3DGS` of mvs_models/mvsnet.py:73-113 -- a three-level 3-D U-Net, (N,256,D,H,W) variance ->
 (N,2,D,H,W) {cost logits, offset logits}.
 
-The module is plain PyTorch (so autograd and training work through MIOpen as in the reference); in eval mode without
-autograd every layer is routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
+The module is plain PyTorch; under autograd the stride-1 convolutions and the head use our forward / input-gradient /
+weight-gradient kernels (training step 127 ms instead of 859 ms on MIOpen), in eval mode without autograd every layer is
+routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
 csrc/costreg_head.hip (27.9 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
 (`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,
 `prob.weight/bias`), so a reference checkpoint's `cost_regularization.*` entries load with `load_state_dict`
@@ -43,6 +44,25 @@ class _ConvK3S1(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_k3_dw(x, gy)
         return gx, gw
+
+
+class _HeadConv(torch.autograd.Function):
+    """The head Conv3d(64 -> 2, k=3, p=1, bias) with forward and both gradients on the streaming kernels of
+    csrc/costreg_head.hip (MIOpen: 363 ms for one forward + backward at the reference-true shape; here about 2 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import ops
+        ctx.save_for_backward(x, weight)
+        return ops.conv3d_k3_cout2(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        gx, gw = ops.conv3d_k3_cout2_backward(x, weight.detach(), gy.contiguous())
+        gb = gy.sum(dim=(0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
+        return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), gb
 
 
 class _ConvBnReLU3d(nn.Module):
@@ -125,6 +145,8 @@ class CostRegNet3DGS(nn.Module):
         if full.is_cuda and full.dtype == torch.float32 and not torch.is_grad_enabled():
             from . import ops
             return ops.conv3d_k3_cout2(full, self.prob.weight.detach(), self.prob.bias.detach())
+        if self.hip_backward and full.is_cuda and full.dtype == torch.float32 and torch.is_grad_enabled():
+            return _HeadConv.apply(full, self.prob.weight, self.prob.bias)
         return self.prob(full)
 
     @staticmethod

@@ -131,3 +131,172 @@ extern "C" int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, c
     MVS_LAUNCH_CHECK("conv3d_k3_cout2");
     return MVSDET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the head (training).  MIOpen needs 363 ms for forward + backward of this 64 -> 2 convolution at the
+// reference-true shape -- two output channels make its GEMM formulations degenerate -- while both gradients are
+// streaming problems of 8 GFMA each:
+//   dX[n][c][v]       = sum over (o, tap) of gy[n][o][v - tap + 1] * W[o][c][tap]        (gy: 2 channels, staged once)
+//   dW[o][c][tap]     = sum over (n, v)   of gy[n][o][v] * X[n][c][v + tap - 1]          (54 sums per channel)
+// Same tile and thread layout as the forward kernel: 4 x 8 x 32 voxels per block, one (h, w) column of 4 voxels per
+// thread, values along d read once from LDS and reused for the three kd.
+// ---------------------------------------------------------------------------------------------------------------
+namespace mvsdet {
+
+__global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dx_kernel(const float* __restrict__ gy, const float* __restrict__ wgt,
+                                                                       float* __restrict__ gx, int Cin, int D, int H, int W,
+                                                                       int tiles_w, int tiles_h) {
+    __shared__ float s_g[2][kHaloVox];
+    const int tid = threadIdx.x;
+    const int tw = tid % kTW, th = tid / kTW;
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int w0 = bw * kTW, h0 = bh * kTH, d0 = blockIdx.y * kTD, n = blockIdx.z;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    for (int e = tid; e < 2 * kHaloVox; e += kThreads) {
+        const int o = e / kHaloVox, r = e - o * kHaloVox;
+        const int dz = r / (kHH * kHW), r2 = r - dz * (kHH * kHW);
+        const int hy = r2 / kHW, wx = r2 - hy * kHW;
+        const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
+        float v = 0.0f;
+        if (d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W) v = gy[((size_t)n * 2 + o) * vol + (size_t)d * plane + (size_t)h * W + w];
+        s_g[o][r] = v;
+    }
+    __syncthreads();
+    const int h = h0 + th, w = w0 + tw;
+    const bool inside = h < H && w < W;
+    for (int c = 0; c < Cin; ++c) {
+        float acc[kTD] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float* wp = wgt + ((size_t)o * Cin + c) * 27;   // wave-uniform
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // gy at (v - tap + 1): halo index of voxel t for tap k is t + 2 - k per dimension
+                    const float* colp = &s_g[o][(th + 2 - kh) * kHW + (tw + 2 - kw)];
+                    float v[kHD];
+#pragma unroll
+                    for (int dz = 0; dz < kHD; ++dz) v[dz] = colp[dz * (kHH * kHW)];
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd) {
+                        const float a = wp[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+                        for (int t = 0; t < kTD; ++t) acc[t] = fmaf(v[t + 2 - kd], a, acc[t]);
+                    }
+                }
+        }
+        if (inside) {
+#pragma unroll
+            for (int t = 0; t < kTD; ++t)
+                if (d0 + t < D) gx[((size_t)n * Cin + c) * vol + (size_t)(d0 + t) * plane + (size_t)h * W + w] = acc[t];
+        }
+    }
+}
+
+// block = (input channel c, voxel split); 54 running sums per thread over all its tiles, one block reduction at the end
+__global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dw_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                       float* __restrict__ partial, int N, int Cin, int D,
+                                                                       int H, int W, int tiles_w, int tiles_h, int tiles_d,
+                                                                       int nsplit) {
+    __shared__ float s_x[kHaloVox];
+    __shared__ float s_red[4][54];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tw = tid % kTW, th = tid / kTW;
+    const int c = blockIdx.x, split = blockIdx.y;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    float acc[2][27];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[o][k] = 0.0f;
+    const int tiles_per_view = tiles_d * tiles_h * tiles_w;
+    const int ntiles = N * tiles_per_view;
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        const int n = tile / tiles_per_view, tv = tile - n * tiles_per_view;
+        const int d0 = (tv / (tiles_h * tiles_w)) * kTD, t2 = tv % (tiles_h * tiles_w);
+        const int h0 = (t2 / tiles_w) * kTH, w0 = (t2 % tiles_w) * kTW;
+        __syncthreads();
+        for (int r = tid; r < kHaloVox; r += kThreads) {
+            const int dz = r / (kHH * kHW), r2 = r - dz * (kHH * kHW);
+            const int hy = r2 / kHW, wx = r2 - hy * kHW;
+            const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
+            float v = 0.0f;
+            if (d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W) v = x[((size_t)n * Cin + c) * vol + (size_t)d * plane + (size_t)h * W + w];
+            s_x[r] = v;
+        }
+        __syncthreads();
+        const int h = h0 + th, w = w0 + tw;
+        float g[2][kTD];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int t = 0; t < kTD; ++t)
+                g[o][t] = (h < H && w < W && d0 + t < D) ? gy[((size_t)n * 2 + o) * vol + (size_t)(d0 + t) * plane + (size_t)h * W + w] : 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* colp = &s_x[(th + kh) * kHW + (tw + kw)];
+                float v[kHD];
+#pragma unroll
+                for (int dz = 0; dz < kHD; ++dz) v[dz] = colp[dz * (kHH * kHW)];
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int t = 0; t < kTD; ++t) {
+                        acc[0][(kd * 3 + kh) * 3 + kw] = fmaf(g[0][t], v[t + kd], acc[0][(kd * 3 + kh) * 3 + kw]);
+                        acc[1][(kd * 3 + kh) * 3 + kw] = fmaf(g[1][t], v[t + kd], acc[1][(kd * 3 + kh) * 3 + kw]);
+                    }
+            }
+    }
+    // block reduction of the 54 sums: butterfly inside each wave, then the four waves through LDS
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            float v = acc[o][k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) s_red[wave][o * 27 + k] = v;
+        }
+    __syncthreads();
+    if (tid < 54) {
+        const float v = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        const int o = tid / 27, k = tid % 27;
+        partial[(((size_t)split * 2 + o) * Cin + c) * 27 + k] = v;
+    }
+}
+
+}  // namespace mvsdet
+
+extern "C" int mvsdet_conv3d_k3_cout2_dx_f32(const float* grad_out, const float* weight, float* grad_x, int N, int Cin, int D,
+                                             int H, int W, mvsdet_stream_t stream) {
+    MVS_REQUIRE(grad_out && weight && grad_x, "conv3d_k3_cout2_dx: NULL pointer");
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_cout2_dx: bad shape");
+    const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH, tiles_d = (D + kTD - 1) / kTD;
+    MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_cout2_dx: N or D too large");
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
+    hipLaunchKernelGGL(conv3d_k3_cout2_dx_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out, weight, grad_x, Cin,
+                       D, H, W, tiles_w, tiles_h);
+    MVS_LAUNCH_CHECK("conv3d_k3_cout2_dx");
+    return MVSDET_OK;
+}
+
+extern "C" int mvsdet_conv3d_k3_cout2_dw_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes,
+                                             int nsplit, int N, int Cin, int D, int H, int W, mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && grad_out && partial, "conv3d_k3_cout2_dw: NULL pointer");
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_cout2_dw: bad shape");
+    MVS_REQUIRE(nsplit > 0 && nsplit <= 65535 && Cin <= 65535, "conv3d_k3_cout2_dw: nsplit or Cin too large");
+    if (partial_bytes < (size_t)nsplit * 2 * Cin * 27 * sizeof(float)) {
+        set_error("conv3d_k3_cout2_dw: partial buffer %zu B too small", partial_bytes);
+        return MVSDET_ERR_WORKSPACE;
+    }
+    const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH, tiles_d = (D + kTD - 1) / kTD;
+    MVS_REQUIRE((long long)N * tiles_d * tiles_h * tiles_w < INT32_MAX, "conv3d_k3_cout2_dw: too many tiles");
+    dim3 grid((unsigned)Cin, (unsigned)nsplit);
+    hipLaunchKernelGGL(conv3d_k3_cout2_dw_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, grad_out, partial, N, Cin, D,
+                       H, W, tiles_w, tiles_h, tiles_d, nsplit);
+    MVS_LAUNCH_CHECK("conv3d_k3_cout2_dw");
+    return MVSDET_OK;
+}

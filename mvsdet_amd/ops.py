@@ -752,3 +752,29 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 128) -> Tensor:
 @conv3d_k3_dw.register_fake
 def _(x, grad_out, nsplit=128):
     return x.new_empty((grad_out.shape[1], x.shape[1], 3, 3, 3))
+
+
+@torch.library.custom_op(f"{_NS}::conv3d_k3_cout2_backward", mutates_args=(), device_types="cuda")
+def conv3d_k3_cout2_backward(x: Tensor, weight: Tensor, grad_out: Tensor, nsplit: int = 32) -> Tuple[Tensor, Tensor]:
+    """Gradients of conv3d_k3_cout2 w.r.t. x (N,Cin,D,H,W) and weight (2,Cin,3,3,3) from grad_out (N,2,D,H,W)."""
+    _req(x, "x", dim=5)
+    _req(weight, "weight", dim=5)
+    _req(grad_out, "grad_out", dim=5)
+    N, Cin, D, H, W = x.shape
+    if tuple(weight.shape) != (2, Cin, 3, 3, 3) or tuple(grad_out.shape) != (N, 2, D, H, W):
+        raise ValueError("conv3d_k3_cout2_backward: shape mismatch")
+    x, weight, grad_out = x.contiguous(), weight.contiguous(), grad_out.contiguous()
+    lib = _lib.load()
+    gx = torch.empty_like(x)
+    partial = torch.empty((nsplit, 2, Cin, 27), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mvsdet_conv3d_k3_cout2_dx_f32(_lib.ptr(grad_out), _lib.ptr(weight), _lib.ptr(gx), N, Cin, D, H, W,
+                                                     _stream(x)), "conv3d_k3_cout2_dx")
+        _lib.check(lib.mvsdet_conv3d_k3_cout2_dw_f32(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), partial.numel() * 4,
+                                                     nsplit, N, Cin, D, H, W, _stream(x)), "conv3d_k3_cout2_dw")
+    return gx, partial.sum(0).view(2, Cin, 3, 3, 3)
+
+
+@conv3d_k3_cout2_backward.register_fake
+def _(x, weight, grad_out, nsplit=32):
+    return torch.empty_like(x), torch.empty_like(weight)

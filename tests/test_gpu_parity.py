@@ -1016,3 +1016,19 @@ def test_cost_network_training_gradients_hip_vs_torch(gpu):
     torch.testing.assert_close(gx1, gx0, rtol=0, atol=1e-4 * float(gx0.abs().max()))
     for k in gp0:
         torch.testing.assert_close(gp1[k], gp0[k], rtol=0, atol=1e-4 * max(float(gp0[k].abs().max()), 1e-12), msg=k)
+
+
+@pytest.mark.parametrize("N,Cin,D,H,W", [(2, 64, 12, 20, 40), (1, 6, 5, 7, 33), (1, 3, 1, 1, 1)])
+def test_cost_network_head_backward(gpu, N, Cin, D, H, W):
+    """Gradients of the head convolution (64 -> 2) from the streaming kernels against ATen-CPU's conv3d_input /
+    conv3d_weight."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 10 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    wgt = torch.randn(2, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    gy = torch.randn(N, 2, D, H, W, generator=g)
+    ref_x = torch.nn.grad.conv3d_input(x.shape, wgt, gy, padding=1)
+    ref_w = torch.nn.grad.conv3d_weight(x, wgt.shape, gy, padding=1)
+    gx, gw = ops.conv3d_k3_cout2_backward(x.to(gpu), wgt.to(gpu), gy.to(gpu), 5)
+    torch.testing.assert_close(gx.cpu(), ref_x, rtol=0, atol=1e-5 * float(ref_x.abs().max()))
+    torch.testing.assert_close(gw.cpu(), ref_w, rtol=0, atol=3e-6 * float(ref_w.abs().max()) * max(1.0, (N * D * H * W) ** 0.5 / 8))
