@@ -183,7 +183,11 @@ def run_train(args, w, rank, world, device):
     from mvsdet_amd import parallel
     from mvsdet_amd.hotpath import MVSDetHotPath
     torch.manual_seed(0)
-    net = PointwiseCostReg(w["C"]).to(device)
+    if args.with_cost_network:   # the real 3-D U-Net (forward / dX / dW of its big layers on our kernels) instead of the stand-in
+        from mvsdet_amd.costreg import CostRegNet3DGS
+        net = CostRegNet3DGS(w["C"]).to(device).train()
+    else:
+        net = PointwiseCostReg(w["C"]).to(device)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=None) if world > 1 else net
     opt = torch.optim.SGD(net.parameters(), lr=1e-4)
     hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3, cost_regularization=model)
@@ -387,7 +391,8 @@ def main():
         elapsed, checksum = run_train(args, w, rank, world, device)
         if rank == 0:
             print(json.dumps({
-                "metric": "training scenes/sec through the hot path (fwd a1..a10 + bwd + optimiser step, stand-in cost network)",
+                "metric": "training scenes/sec through the hot path (fwd a1..a10 + bwd + optimiser step, "
+                          + ("real cost network)" if args.with_cost_network else "stand-in cost network)"),
                 "value": round(args.steps * world / elapsed, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "train",
