@@ -8,7 +8,9 @@
 //   block  = (32 input channels, 32 output channels, one of S voxel splits); wave w owns the taps w, w+4, ... (7,7,7,6)
 //            = 7 accumulators (112 VGPRs)
 //   tile   = 1 x 4 x 16 voxels: dY[32][64] and the X halo [32][3 x 6 x 18] staged in LDS (odd row strides: the operand
-//            reads vary the channel across lanes), 32 voxel pairs x 7 taps = 224 MFMAs per wave and tile
+//            reads vary the channel across lanes), 32 voxel pairs x 7 taps = 224 MFMAs per wave and tile; a block walks
+//            (view, h-tile, w-tile) columns along d with the halo as a ring of three planes, so each tile loads one new
+//            plane of X instead of three
 //   output = partial[s][o][c][27] per split, summed by the caller (deterministic, no atomics)
 // Bound: fp32 MFMA (same 2.04 TFLOP as the forward of conv0).
 #include "common.h"
@@ -27,7 +29,10 @@ constexpr int kDwTapsPerWave = 7;
 __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                       float* __restrict__ partial, int N, int Cin, int Cout,
                                                                       int D, int H, int W, int tiles_w, int tiles_h,
-                                                                      int ntiles, int nsplit) {
+                                                                      int ncols, int nsplit) {
+    // X halo as a ring of three planes per channel: walking a (view, h-tile, w-tile) column along d, only ONE new
+    // plane (6 x 18 values per channel) is loaded per tile instead of three
+    constexpr int kPlane = kDwHH * kDwHW;  // 108
     __shared__ float s_x[32 * kDwXStride];
     __shared__ float s_y[32 * kDwYStride];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -36,14 +41,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const fl
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
     const int col = lane & 31, kk = lane >> 5;
 
-    // this wave's taps and their offsets inside the halo
-    int tapoff[kDwTapsPerWave];
+    // this wave's taps: (kd, in-plane offset)
+    int tap_kd[kDwTapsPerWave], tap_in[kDwTapsPerWave];
     int ntap = 0;
 #pragma unroll
     for (int i = 0; i < kDwTapsPerWave; ++i) {
         const int t = wave + 4 * i;
-        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
-        tapoff[i] = (kd * kDwHH + kh) * kDwHW + kw;
+        tap_kd[i] = t / 9;
+        tap_in[i] = ((t / 3) % 3) * kDwHW + (t % 3);
         if (t < 27) ntap = i + 1;
     }
 
@@ -53,44 +58,55 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const int tiles_per_view = D * tiles_h * tiles_w;
-    for (int tile = split; tile < ntiles; tile += nsplit) {
-        const int n = tile / tiles_per_view, tv = tile - n * tiles_per_view;
-        const int d = tv / (tiles_h * tiles_w), t2 = tv - d * (tiles_h * tiles_w);
-        const int h0 = (t2 / tiles_w) * kDwTH, w0 = (t2 % tiles_w) * kDwTW;
-        __syncthreads();  // previous tile fully consumed
-        // X halo: 32 channels x 324 positions, zero outside the volume / beyond Cin
-        for (int e = tid; e < 32 * kDwHalo; e += kThreads) {
-            const int c = e / kDwHalo, r = e - c * kDwHalo;
-            const int dz = r / (kDwHH * kDwHW), r2 = r - dz * (kDwHH * kDwHW);
-            const int hy = r2 / kDwHW, wx = r2 - hy * kDwHW;
-            const int dd = d + dz - 1, hh = h0 + hy - 1, ww = w0 + wx - 1;
+    // loads input plane dd (may be outside [0, D): zeros) of the column into ring slot dd mod 3
+    auto load_plane = [&](int n, int h0, int w0, int dd) {
+        const int slot = ((dd % 3) + 3) % 3;
+        for (int e = tid; e < 32 * kPlane; e += kThreads) {
+            const int c = e / kPlane, r = e - c * kPlane;
+            const int hy = r / kDwHW, wx = r - hy * kDwHW;
+            const int hh = h0 + hy - 1, ww = w0 + wx - 1;
             float v = 0.0f;
             if (c0 + c < Cin && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W)
                 v = x[((size_t)n * Cin + c0 + c) * vol + (size_t)dd * plane + (size_t)hh * W + ww];
-            s_x[c * kDwXStride + r] = v;
+            s_x[c * kDwXStride + slot * kPlane + r] = v;
         }
-        // dY: 32 output channels x 64 voxels, zero outside the volume / beyond Cout
-        for (int e = tid; e < 32 * kDwVox; e += kThreads) {
-            const int o = e / kDwVox, q = e - o * kDwVox;
-            const int hh = h0 + q / kDwTW, ww = w0 + q % kDwTW;
-            float v = 0.0f;
-            if (o0 + o < Cout && hh < H && ww < W) v = gy[((size_t)n * Cout + o0 + o) * vol + (size_t)d * plane + (size_t)hh * W + ww];
-            s_y[o * kDwYStride + q] = v;
-        }
-        __syncthreads();
-        const float* ay = s_y + col * kDwYStride + kk;   // A[i = o][k = voxel parity]
-        const float* bx = s_x + col * kDwXStride;        // B[k][j = c]
-#pragma unroll 4
-        for (int vp = 0; vp < kDwVox / 2; ++vp) {
-            const int q = 2 * vp + kk;                   // this lane's voxel of the pair
-            const int base = (q / kDwTW) * kDwHW + (q % kDwTW);
-            const float a = ay[2 * vp];
+    };
+
+    const int cols_per_view = tiles_h * tiles_w;
+    for (int cidx = split; cidx < ncols; cidx += nsplit) {
+        const int n = cidx / cols_per_view, t2 = cidx - n * cols_per_view;
+        const int h0 = (t2 / tiles_w) * kDwTH, w0 = (t2 % tiles_w) * kDwTW;
+        __syncthreads();  // previous column fully consumed
+        load_plane(n, h0, w0, -1);
+        load_plane(n, h0, w0, 0);
+        for (int d = 0; d < D; ++d) {
+            if (d > 0) __syncthreads();  // tile d-1 fully consumed: its oldest plane and s_y may be replaced
+            load_plane(n, h0, w0, d + 1);
+            for (int e = tid; e < 32 * kDwVox; e += kThreads) {
+                const int o = e / kDwVox, q = e - o * kDwVox;
+                const int hh = h0 + q / kDwTW, ww = w0 + q % kDwTW;
+                float v = 0.0f;
+                if (o0 + o < Cout && hh < H && ww < W)
+                    v = gy[((size_t)n * Cout + o0 + o) * vol + (size_t)d * plane + (size_t)hh * W + ww];
+                s_y[o * kDwYStride + q] = v;
+            }
+            __syncthreads();
+            int tapoff[kDwTapsPerWave];
 #pragma unroll
-            for (int i = 0; i < kDwTapsPerWave; ++i) {
-                if (i < ntap) {
-                    const float b = bx[base + tapoff[i]];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < kDwTapsPerWave; ++i) tapoff[i] = ((d + tap_kd[i] - 1 + 3) % 3) * kPlane + tap_in[i];
+            const float* ay = s_y + col * kDwYStride + kk;   // A[i = o][k = voxel parity]
+            const float* bx = s_x + col * kDwXStride;        // B[k][j = c]
+#pragma unroll 4
+            for (int vp = 0; vp < kDwVox / 2; ++vp) {
+                const int q = 2 * vp + kk;                   // this lane's voxel of the pair
+                const int base = (q / kDwTW) * kDwHW + (q % kDwTW);
+                const float a = ay[2 * vp];
+#pragma unroll
+                for (int i = 0; i < kDwTapsPerWave; ++i) {
+                    if (i < ntap) {
+                        const float b = bx[base + tapoff[i]];
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -128,12 +144,12 @@ extern "C" int mvsdet_conv3d_k3_dw_mfma_f32(const float* x, const float* grad_ou
         return MVSDET_ERR_WORKSPACE;
     }
     const int tiles_w = (W + kDwTW - 1) / kDwTW, tiles_h = (H + kDwTH - 1) / kDwTH;
-    const long long ntiles = (long long)N * D * tiles_h * tiles_w;
-    MVS_REQUIRE(ntiles < INT32_MAX, "conv3d_k3_dw: too many tiles");
+    const long long ncols = (long long)N * tiles_h * tiles_w;  // (view, h-tile, w-tile) columns, walked along d
+    MVS_REQUIRE(ncols < INT32_MAX, "conv3d_k3_dw: too many tiles");
     dim3 grid((unsigned)nsplit, (unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
     MVS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "conv3d_k3_dw: too many channel blocks");
     hipLaunchKernelGGL(conv3d_k3_dw_mfma_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, grad_out, partial, N, Cin,
-                       Cout, D, H, W, tiles_w, tiles_h, (int)ntiles, nsplit);
+                       Cout, D, H, W, tiles_w, tiles_h, (int)ncols, nsplit);
     MVS_LAUNCH_CHECK("conv3d_k3_dw");
     return MVSDET_OK;
 }
