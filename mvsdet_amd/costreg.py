@@ -24,7 +24,7 @@ class _ConvK3S1(torch.autograd.Function):
     """Conv3d(kernel 3, stride 1, padding 1, no bias) with all three passes on the fp32 matrix cores: forward and input
     gradient through `ops.conv3d_k3_mfma` (the input gradient is the same convolution of grad_out with the weights
     transposed and flipped), weight gradient through `ops.conv3d_k3_dw`.  MIOpen needs 34 + 42 + 360 ms for conv0 at the
-    reference-true shape, these kernels 15 + 15 + 27 ms."""
+    reference-true shape, these kernels 15 + 15 + 22 ms."""
 
     @staticmethod
     def forward(ctx, x, weight):

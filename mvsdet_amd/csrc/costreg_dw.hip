@@ -43,13 +43,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const fl
 
     // this wave's taps: (kd, in-plane offset)
     int tap_kd[kDwTapsPerWave], tap_in[kDwTapsPerWave];
-    int ntap = 0;
 #pragma unroll
     for (int i = 0; i < kDwTapsPerWave; ++i) {
-        const int t = wave + 4 * i;
+        const int t = wave + 4 * i < 27 ? wave + 4 * i : wave;   // the 28th slot repeats a valid tap; its result is dropped
         tap_kd[i] = t / 9;
         tap_in[i] = ((t / 3) % 3) * kDwHW + (t % 3);
-        if (t < 27) ntap = i + 1;
     }
 
     f32x16 acc[kDwTapsPerWave];
@@ -96,18 +94,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const fl
             for (int i = 0; i < kDwTapsPerWave; ++i) tapoff[i] = ((d + tap_kd[i] - 1 + 3) % 3) * kPlane + tap_in[i];
             const float* ay = s_y + col * kDwYStride + kk;   // A[i = o][k = voxel parity]
             const float* bx = s_x + col * kDwXStride;        // B[k][j = c]
-#pragma unroll 4
+            // all operand reads of a voxel pair are issued before its MFMAs (no branch in between): the reads of
+            // the next pair overlap the matrix instructions of this one.  A wave with 6 taps multiplies a seventh,
+            // unused accumulator (1/28 of the work) rather than branch.
+#pragma unroll 2
             for (int vp = 0; vp < kDwVox / 2; ++vp) {
                 const int q = 2 * vp + kk;                   // this lane's voxel of the pair
                 const int base = (q / kDwTW) * kDwHW + (q % kDwTW);
                 const float a = ay[2 * vp];
+                float b[kDwTapsPerWave];
 #pragma unroll
-                for (int i = 0; i < kDwTapsPerWave; ++i) {
-                    if (i < ntap) {
-                        const float b = bx[base + tapoff[i]];
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-                    }
-                }
+                for (int i = 0; i < kDwTapsPerWave; ++i) b[i] = bx[base + tapoff[i]];
+#pragma unroll
+                for (int i = 0; i < kDwTapsPerWave; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i], acc[i], 0, 0, 0);
             }
         }
     }
