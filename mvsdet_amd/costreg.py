@@ -3,7 +3,7 @@
 (N,2,D,H,W) {cost logits, offset logits}.
 
 The module is plain PyTorch; under autograd the stride-1 convolutions and the head use our forward / input-gradient /
-weight-gradient kernels (training step 114 ms instead of 859 ms on MIOpen), in eval mode without autograd every layer is
+weight-gradient kernels (training step 108 ms instead of 859 ms on MIOpen), in eval mode without autograd every layer is
 routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
 csrc/costreg_head.hip (27.9 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
 (`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,
