@@ -730,9 +730,10 @@ def _(x, weight_perm, scale, shift, residual, relu):
 
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_dw", mutates_args=(), device_types="cuda")
-def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 128) -> Tensor:
+def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0) -> Tensor:
     """Weight gradient of Conv3d(kernel 3, stride 1, padding 1): x (N,Cin,D,H,W), grad_out (N,Cout,D,H,W) ->
-    (Cout,Cin,3,3,3), on the fp32 matrix cores; `nsplit` voxel splits are accumulated separately and summed."""
+    (Cout,Cin,3,3,3), on the fp32 matrix cores; `nsplit` voxel splits are accumulated separately and summed
+    (0 = automatic: up to 128 splits, fewer when Cin*Cout is large so that the partial sums stay below 256 MB)."""
     _req(x, "x", dim=5)
     _req(grad_out, "grad_out", dim=5)
     N, Cin, D, H, W = x.shape
@@ -741,6 +742,8 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 128) -> Tensor:
         raise ValueError(f"conv3d_k3_dw: grad_out {tuple(grad_out.shape)} does not match x {tuple(x.shape)}")
     x, grad_out = x.contiguous(), grad_out.contiguous()
     lib = _lib.load()
+    if nsplit <= 0:
+        nsplit = max(8, min(128, (256 << 20) // (Cout * Cin * 108)))
     pbytes = lib.mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)
     partial = torch.empty((nsplit, Cout, Cin, 27), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
@@ -750,7 +753,7 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 128) -> Tensor:
 
 
 @conv3d_k3_dw.register_fake
-def _(x, grad_out, nsplit=128):
+def _(x, grad_out, nsplit=0):
     return x.new_empty((grad_out.shape[1], x.shape[1], 3, 3, 3))
 
 
