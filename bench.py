@@ -35,7 +35,9 @@ WORKLOADS = {
     # what the shipped config mvsdet_res50_2x_low_res.py really runs: "R"
     "scannet_ref_40v_12d_60x80": dict(N=40, C=256, D=12, H=60, W=80, near_far=(0.2, 5.0), per_view_K=False),
     # BASELINE.json configs[3]
-    "arkit_50v_96d_60x80": dict(N=50, C=256, D=96, H=60, W=80, near_far=(0.5, 5.5), per_view_K=True),
+    # BASELINE.json configs[3]: per-view intrinsics and the larger voxel grid of SURVEY 8d C4 (the shipped ARKit
+    # config keeps 40x40x16: SURVEY D6; 64x64x24 is the builder-defined "larger grid" the config line asks for)
+    "arkit_50v_96d_60x80": dict(N=50, C=256, D=96, H=60, W=80, near_far=(0.5, 5.5), per_view_K=True, voxels=[64, 64, 24]),
     # BASELINE.json configs[4] at C=32 (fp32, unchunked: 126 GB cost volume; the C=256 fp16 form needs view chunks)
     "stress_100v_128d_240x320_c32": dict(N=100, C=32, D=128, H=240, W=320, near_far=(0.2, 5.0), per_view_K=False),
     # BASELINE.json configs[4] as worded: C=256, fp16 features and fp16 cost volume (503 GB) produced in chunks of
@@ -46,6 +48,7 @@ WORKLOADS = {
     "tiny_3v_8d_48x64": dict(N=3, C=32, D=8, H=48, W=64, near_far=(0.2, 5.0), per_view_K=False),
 }
 N_VOXELS, VOXEL_SIZE = [40, 40, 16], [0.16, 0.16, 0.2]
+SWEEP_KERNEL_NAME = "plane_sweep_variance_kernel<2,TW,NT>"
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -70,7 +73,7 @@ def run_gpu(args, w, rank, world, device):
     from mvsdet_amd import ops, parallel
     from mvsdet_amd.hotpath import MVSDetHotPath
 
-    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3)
+    hp = MVSDetHotPath(w.get("voxels", N_VOXELS), VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3)
     scenes = [SceneInputs(w, seed=rank * 100 + i, device=device) for i in range(args.scene_pool)]
     torch.cuda.synchronize(device)
     ev = []
@@ -96,14 +99,16 @@ def run_gpu(args, w, rank, world, device):
         feat = s.features
         geo = hp.prepare_scene(s.meta, device)
         packed = ops.pack_features(feat)
-        table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, w["H"], w["W"])
-        if timed:  # HIP events around the dominant kernel only (launched on torch's current stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if timed:  # HIP events on torch's current stream (where the ops launch): stage 1 = table + slab kernel
+            e0, em, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
+        table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, w["H"], w["W"])
+        if timed:
+            em.record()
         var = ops.plane_sweep_variance_tabled(packed, geo.neighbor_ids, table, w["C"], w["D"], w["H"], w["W"])
         if timed:
             e1.record()
-            ev.append((e0, e1))
+            ev.append((e0, em, e1))
         prob, off, est_depth, est_dens, est_idx, avg = hp.depth_distribution(s.cost_logits)
         vol, valid = hp.lift(feat, packed, geo, est_depth, est_dens)
         return var, vol, valid
@@ -127,7 +132,13 @@ def run_gpu(args, w, rank, world, device):
     elapsed = time.perf_counter() - t0
     checksum = float(out[1].abs().sum().item()) + float(out[0][0, 0, 0].abs().sum().item())
     del out
-    sweep_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    # (table ms, slab-kernel ms) per launch; the chunked workload's shard entry point enqueues both behind one pair
+    if ev and len(ev[0]) == 3:
+        sweep_ms = (float(np.mean([a.elapsed_time(m) for a, m, b in ev])), float(np.mean([m.elapsed_time(b) for a, m, b in ev])))
+    elif ev:
+        sweep_ms = (0.0, float(np.mean([a.elapsed_time(b) for a, b in ev])))
+    else:
+        sweep_ms = (float("nan"), float("nan"))
     if world > 1:
         elapsed = parallel.max_over_ranks(elapsed, device)
     return elapsed, sweep_ms, checksum, hp, scenes
@@ -347,6 +358,88 @@ def cpu_baseline(w, budget_s):
                 variants={k: round(v["value"], 4) for k, v in res.items()})
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside a torchrun environment: start the N ranks ourselves.  The parent has not touched
+    the GPU (no HIP call, no `torch.cuda.is_available()`), starts `torch.distributed.run` as a CHILD process (never an
+    exec: MI355X boxes refuse an exec from a process that initialised the GPU, and we keep the habit), one rank per
+    GPU over RCCL, relays rank 0's single JSON line and returns non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as so:   # a free rendezvous port on the loop-back interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    for ln in proc.stdout.splitlines():
+        (lines.append(ln) if ln.startswith("{") else print(ln, file=sys.stderr))
+    if proc.returncode != 0:
+        print(f"bench.py: the {n}-rank launch failed with exit code {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if len(lines) != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def launch_check(args, rank, world):
+    """--launch-check: the rendezvous, barrier and max-over-ranks plumbing of the N-rank launch WITHOUT device work, so
+    that the spawn path can be tested on a machine without a GPU (tests/test_bench_launch.py, gloo)."""
+    from mvsdet_amd import parallel
+    if world > 1:
+        parallel.init_distributed(os.environ.get("MVSDET_DIST_BACKEND", "gloo"), None)
+    if os.environ.get("MVSDET_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    parallel.barrier()
+    t = parallel.max_over_ranks(float(rank + 1))
+    total = parallel.sum_over_ranks(1.0)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_arg": args.gpus, "max_over_ranks": t,
+                          "ranks_seen": int(total)}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def side_workload(name, device, steps=3, warmup=1):
+    """Compact line of another BASELINE configuration through the same code (parity-test cases, not the headline)."""
+    w = WORKLOADS[name]
+    a = argparse.Namespace(steps=steps, warmup=warmup, scene_pool=1)
+    el, (tab_ms, slab_ms), _, hp, sc = run_gpu(a, w, 0, 1, device)
+    del sc, hp
+    torch.cuda.empty_cache()
+    nbytes = sweep_bytes_per_cv(w) * (w.get("chunk") or w["N"])
+    out = {"sweep_kernel_ms": round(slab_ms, 4), "table_kernel_ms": round(tab_ms, 4),
+           "sweep_GBps": round(nbytes / (slab_ms * 1e-3) / 1e9, 1),
+           "frac": round(nbytes / (slab_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "stage1_frac": round(nbytes / ((slab_ms + tab_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "scenes_per_sec": round(steps / el, 3), "cost_volumes_per_sec": round(w["N"] * steps / el, 2),
+           "voxels": w.get("voxels", N_VOXELS), "dtype": "f32 (f16 storage)" if w.get("half") else "f32"}
+    if w.get("chunk"):
+        out["views_per_launch"] = w["chunk"]
+        out["note"] = "one launch = table + slab kernel of one view chunk"
+    return out
+
+
+def committed_traffic(name):
+    """HBM-side bytes per launch of the sweep kernel from the committed rocprofv3 PMC passes (bench.py cannot collect
+    counters itself).  Only quoted when the profile was taken from THIS library version and workload, else None."""
+    from mvsdet_amd import _lib
+    try:
+        with open(os.path.join(ROOT, "profiles", "sweep_traffic.json")) as fh:
+            prof = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if prof.get("lib_version") != int(_lib.load().mvsdet_version()):
+        return None
+    ent = prof.get("workloads", {}).get(name)
+    return None if ent is None else {"bytes": ent["traffic_bytes"], "source": prof.get("source"), "measured_in_run": False}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,17 +448,28 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto"] + list(WORKLOADS))
     ap.add_argument("--scene-pool", type=int, default=2, help="distinct resident scenes cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget (0 disables)")
-    ap.add_argument("--no-extras", action="store_true", help="skip stage breakdown / copy ceiling / R-shape line")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip stage breakdown / copy ceiling / R-shape line / other workloads / cost-network chain")
     ap.add_argument("--with-cost-network", action="store_true",
-                    help="extra: scenes/s of a1..a10 with the real cost regularisation network in between (reference-true shape; "
-                         "the first run spends about a minute in MIOpen's kernel search)")
+                    help="(default on at N=1 unless --no-extras) scenes/s of a1..a10 with the real cost regularisation "
+                         "network in between, reference-true shape, eval mode: our kernels only")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="train = configs[2]: fwd + bwd + optimiser step with a stand-in cost network under DDP")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # decided before anything touches the GPU: the parent only launches and relays
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank number "
+                         f"as a {args.gpus}-GPU one")
+    if args.launch_check:
+        return launch_check(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU implementation")
     from mvsdet_amd import _lib
@@ -377,8 +481,6 @@ def main():
         from mvsdet_amd import parallel
         # "nccl" is RCCL on ROCm; MVSDET_DIST_BACKEND=gloo lets two ranks share one GPU in a dry run
         parallel.init_distributed(os.environ.get("MVSDET_DIST_BACKEND", "nccl"), device)
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     name = args.workload
     if name == "auto":
@@ -406,59 +508,64 @@ def main():
         return
     w = WORKLOADS[name]
 
-    elapsed, sweep_ms, checksum, hp, scenes = run_gpu(args, w, rank, world, device)
+    elapsed, (table_ms, sweep_ms), checksum, hp, scenes = run_gpu(args, w, rank, world, device)
     n_cv = w["N"] * args.steps * world
     value = n_cv / elapsed
     # one launch = the reference views of one scene, or of one view chunk for the chunked workload (there the
     # events bracket the table kernel too: the shard entry point enqueues both)
     bytes_launch = sweep_bytes_per_cv(w) * (w.get("chunk") or w["N"])
     achieved = bytes_launch / (sweep_ms * 1e-3) / 1e9
-    # HBM-side bytes per launch from the committed rocprofv3 PMC passes of the same kernel and workload
-    # (profiles/r01_final_sweep_pmc.txt; bench.py cannot collect counters itself)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")) as fh:
-            traffic = json.load(fh).get(name, {}).get("traffic_bytes")
-    except OSError:
-        pass
+    stage1 = bytes_launch / ((sweep_ms + table_ms) * 1e-3) / 1e9
     line = {
         "metric": "cost volumes/sec (plane-sweep variance, one per reference view) through the full hot path",
         "value": round(value, 3), "unit": "cost volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (f16 storage)" if w.get("half") else "f32", "data": "synthetic",
         "config": {"workload": name, "views": w["N"], "neighbors": 2, "channels": w["C"], "depth_planes": w["D"],
-                   "feat_hw": [w["H"], w["W"]], "voxels": N_VOXELS, "scenes_per_step_per_gpu": 1,
+                   "feat_hw": [w["H"], w["W"]], "voxels": w.get("voxels", N_VOXELS), "scenes_per_step_per_gpu": 1,
                    "parallelism": f"scene-sharded x{world}, no data-path collective"},
         "scenes_per_sec": round(args.steps * world / elapsed, 4),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "kernel": "plane_sweep_variance_kernel<2,TW,NT>",
-                     "kernel_ms": round(sweep_ms, 4),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": committed_traffic(name),
+                     "kernel": SWEEP_KERNEL_NAME,
+                     "kernel_ms": round(sweep_ms, 4), "table_kernel_ms": round(table_ms, 4),
+                     "stage1_frac_incl_table": round(stage1 / HBM_PEAK_GBPS, 4),
                      "algorithmic_bytes_per_launch": bytes_launch},
         "checksum": checksum,
     }
     if w.get("chunk"):
         line["config"]["views_per_launch"] = w["chunk"]
-    if rank == 0 and world == 1 and not args.no_extras and not w.get("chunk"):
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras and not w.get("chunk"):
         line["stage_ms"] = stage_breakdown(w, hp, scenes[0], device)
         line["roofline"]["footprints"] = footprint_stats(w, hp, scenes[0], device)
-        del scenes
-        torch.cuda.empty_cache()
+    del scenes, hp
+    torch.cuda.empty_cache()
+    if extras:
         line["hbm_copy_ceiling_GBps"] = round(hbm_copy_ceiling(device), 1)
         line["roofline"]["frac_of_copy_ceiling"] = round(achieved / line["hbm_copy_ceiling_GBps"], 4)
         if name != "scannet_ref_40v_12d_60x80":
             # the shape the shipped config really runs, reported beside the headline
             wr = WORKLOADS["scannet_ref_40v_12d_60x80"]
             a2 = argparse.Namespace(steps=20, warmup=3, scene_pool=2)
-            el, sm, _, hp_r, sc_r = run_gpu(a2, wr, 0, 1, device)
+            el, (tm, sm), _, hp_r, sc_r = run_gpu(a2, wr, 0, 1, device)
             br = sweep_bytes_per_cv(wr) * wr["N"]
             line["reference_true_shape"] = {"workload": "scannet_ref_40v_12d_60x80",
                                             "cost_volumes_per_sec": round(wr["N"] * 20 / el, 2),
                                             "scenes_per_sec": round(20 / el, 3), "sweep_kernel_ms": round(sm, 4),
+                                            "table_kernel_ms": round(tm, 4),
                                             "sweep_GBps": round(br / (sm * 1e-3) / 1e9, 1),
+                                            "frac": round(br / (sm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                             "stage_ms": stage_breakdown(wr, hp_r, sc_r[0], device)}
-            del sc_r
-    if rank == 0 and world == 1 and args.with_cost_network:
+            del sc_r, hp_r
+            torch.cuda.empty_cache()
+        if name == "scannet_40v_64d_120x160":
+            # the other BASELINE configurations through the same code: configs[3], configs[4] (fp32 at C=32; as worded
+            # in fp16 storage, chunked)
+            line["other_workloads"] = {n: side_workload(n, device) for n in
+                                       ("arkit_50v_96d_60x80", "stress_100v_128d_240x320_c32",
+                                        "stress_100v_128d_240x320_c256_f16")}
+    if rank == 0 and world == 1 and (args.with_cost_network or extras):
         line["with_cost_network"] = full_chain_rate(device)
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and not w.get("half"):
         line["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)

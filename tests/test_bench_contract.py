@@ -31,6 +31,7 @@ def test_single_gpu_line(gpu):
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["table_kernel_ms"] >= 0 and (r["traffic"] is None or r["traffic"]["measured_in_run"] is False)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["config"]["workload"] == "tiny_3v_8d_48x64" and "model" not in d["config"]
@@ -38,9 +39,10 @@ def test_single_gpu_line(gpu):
 
 @pytest.mark.timeout(600)
 def test_two_rank_launch_dry_run(gpu):
-    env = dict(os.environ, MVSDET_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    # `bench.py --gpus 2` alone: the parent starts the two ranks itself (no torchrun on the command line)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MVSDET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--workload", "tiny_3v_8d_48x64"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
