@@ -41,6 +41,22 @@ typedef void* mvsdet_stream_t; /* hipStream_t */
 int mvsdet_version(void);
 /* HOST, thread-local message of the last failing call on this thread ("" if none). */
 const char* mvsdet_last_error(void);
+/* Tuning options (schedule only: results are bit-identical under every setting).  Read ONCE from the environment
+ * (MVSDET_SWEEP_TW, MVSDET_SWEEP_BOXCAP, MVSDET_SWEEP_XCD, MVSDET_SWEEP_GROUPS) when the library first needs them,
+ * afterwards changed only through mvsdet_set_option -- the launch path never calls getenv.  HOST, process-global:
+ * set them before launching from several threads.
+ *   "sweep_tw"      0 (by the map width) | 16 | 32   pixel-tile shape of the sweep (16x8 / 32x4)
+ *   "sweep_boxcap"  texels of one LDS footprint box (default 256; 0 = gather every tap from global memory)
+ *   "sweep_xcd"     0 | 1   XCD-aware block map for fewer than 8 channel slabs
+ *   "sweep_groups"  1 | 2   wave groups per block (2 = eight waves, even / odd planes share the resident boxes)
+ * "sweep_tw" decides the layout of the sampling table: consume a table (mvsdet_plane_sweep_variance_tabled_f32, the
+ * backward pass) under the "sweep_tw" it was built with; the other options may change between the two calls. */
+int mvsdet_set_option(const char* name /*HOST*/, int value);
+int mvsdet_get_option(const char* name /*HOST*/, int* value /*HOST*/);
+/* HOST check of neighbour view ids before they are uploaded (mvsdet.py:434 feeds them to an index gather, where an
+ * id outside [0, n_src) raises): MVSDET_ERR_INVALID_ARG names the first offending entry.  The kernels additionally
+ * clamp ids, so a tensor that never passed through this check cannot make them read outside the packed maps. */
+int mvsdet_validate_neighbors(const int64_t* nbr /*HOST (M,K)*/, int M, int K, int n_src);
 
 /* ---------------------------------------------------------------------------------------------
  * Packed feature maps.
@@ -81,7 +97,9 @@ int mvsdet_homo_warp_f32(const float* src, const float* proj, const float* depth
  *   var (N,C,D,H,W) = sum_sq/(K+1) - (sum/(K+1))^2 over {ref, warped_1..K}  (mvsdet.py:467).
  * `scratch` (16-byte aligned, >= mvsdet_plane_sweep_scratch_bytes(N,K,D,H,W)) receives the
  * channel-independent sampling table the sweep builds first: 8 B per (view, neighbour, plane,
- * pixel) = the un-normalised sample position, about 1.5 % of the cost volume.
+ * pixel) = the un-normalised sample position (about 1.5 % of the cost volume), and per (view, tile,
+ * plane, neighbour) the footprint box that the sweep keeps resident in LDS -- shared by runs of
+ * consecutive planes (sweep_kernel.h).
  * The _f32 form packs `feat` (N,C,H,W dense) into `workspace` first
  * (workspace_bytes >= mvsdet_plane_sweep_workspace_bytes(N,K,C,D,H,W) = packed + scratch).
  * ------------------------------------------------------------------------------------------- */

@@ -24,6 +24,9 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 SIGNATURES = {
     "mvsdet_version": [],
     "mvsdet_last_error": [],
+    "mvsdet_set_option": [ctypes.c_char_p, _i],
+    "mvsdet_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
+    "mvsdet_validate_neighbors": [_i64p, _i, _i, _i],
     "mvsdet_packed_bytes": [_i, _i, _i, _i],
     "mvsdet_pack_features_f32": [_vp, _i64p, _vp, _i, _i, _i, _i, _vp],
     "mvsdet_pack_features_f16": [_vp, _i64p, _vp, _i, _i, _i, _i, _vp],
@@ -90,6 +93,17 @@ def load():
         fn.restype = _RESTYPE.get(name, ctypes.c_int)
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int):
+    """Schedule-only tuning option of the library (include/mvsdet_hip.h: mvsdet_set_option)."""
+    check(load().mvsdet_set_option(name.encode(), int(value)), f"set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    check(load().mvsdet_get_option(name.encode(), ctypes.byref(v)), f"get_option({name})")
+    return int(v.value)
 
 
 def check(rc: int, what: str):

@@ -1,6 +1,7 @@
 // Library-level entry points: version, error string, HBM-ceiling copy kernel.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace mvsdet {
@@ -12,6 +13,28 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+Options& options() {
+    static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 256), env_int("MVSDET_SWEEP_XCD", 1),
+                        env_int("MVSDET_SWEEP_GROUPS", 1), 0};
+    return o;
+}
+
+static int* option_slot(const char* name) {
+    Options& o = options();
+    if (!name) return nullptr;
+    if (!strcmp(name, "sweep_tw")) return &o.sweep_tw;
+    if (!strcmp(name, "sweep_boxcap")) return &o.sweep_boxcap;
+    if (!strcmp(name, "sweep_xcd")) return &o.sweep_xcd;
+    if (!strcmp(name, "sweep_groups")) return &o.sweep_groups;
+    if (!strcmp(name, "sweep_debug")) return &o.sweep_debug;
+    return nullptr;
 }
 
 // float4 grid-stride copy: the achievable-HBM yardstick of bench.py (MI355X_MICROARCH: 6.29 TB/s measured).
@@ -38,7 +61,32 @@ __global__ void copy_tail_kernel(const float* __restrict__ src, float* __restric
 
 using namespace mvsdet;
 
-extern "C" int mvsdet_version(void) { return 1000; }
+extern "C" int mvsdet_version(void) { return 2000; }
+
+extern "C" int mvsdet_set_option(const char* name, int value) {
+    int* slot = option_slot(name);
+    MVS_REQUIRE(slot, "set_option: unknown option '%s'", name ? name : "(null)");
+    *slot = value;
+    return MVSDET_OK;
+}
+
+extern "C" int mvsdet_validate_neighbors(const int64_t* nbr, int M, int K, int n_src) {
+    MVS_REQUIRE(M >= 0 && K >= 0 && n_src > 0, "validate_neighbors: bad shape M=%d K=%d n_src=%d", M, K, n_src);
+    MVS_REQUIRE(K == 0 || M == 0 || nbr, "validate_neighbors: NULL pointer");
+    for (int m = 0; m < M; ++m)
+        for (int j = 0; j < K; ++j) {
+            const int64_t v = nbr[(size_t)m * K + j];
+            MVS_REQUIRE(v >= 0 && v < n_src, "neighbour id %lld of view %d (slot %d) outside [0, %d)", (long long)v, m, j, n_src);
+        }
+    return MVSDET_OK;
+}
+
+extern "C" int mvsdet_get_option(const char* name, int* value) {
+    int* slot = option_slot(name);
+    MVS_REQUIRE(slot && value, "get_option: unknown option '%s'", name ? name : "(null)");
+    *value = *slot;
+    return MVSDET_OK;
+}
 
 extern "C" const char* mvsdet_last_error(void) { return g_err; }
 

@@ -107,9 +107,7 @@ extern "C" int mvsdet_homo_warp_f32(const float* src, const float* proj, const f
 
 namespace {
 int pick_tile_width(int W) {
-    // tuning knob, read per call so A/B runs can flip it inside one process
-    const char* e = getenv("MVSDET_SWEEP_TW");
-    const int tw = e ? atoi(e) : 0;
+    const int tw = options().sweep_tw;  // tuning knob (mvsdet_set_option "sweep_tw"); 0 = by the map width
     if (tw == 16 || tw == 32) return tw;
     return (W % 32 == 0 || W % 16 != 0) ? 32 : 16;
 }
@@ -119,9 +117,39 @@ int num_tiles(int H, int W, int tw) {
     return ((W + tw - 1) / tw) * ((H + th - 1) / th);
 }
 
-unsigned long long* g_stamps = nullptr;  // diagnostic runs only (mvsdet_debug_set_stamp_buffer)
+// texels of one LDS footprint box: K resident boxes of 128-byte texels, two blocks per CU (80 KiB each)
+int effective_box_cap(int K, int G) {
+    if (K <= 0) return 0;
+    int cap = options().sweep_boxcap;
+    const int fit = (int)((80 * 1024 - sweep_lds_bytes(K, G, 0)) / 128) / K;  // sweep_lds_bytes(.., 0) = pads + loader ring
+    cap = cap < 0 ? 0 : (cap > fit ? fit : cap);
+    return cap > 512 ? 512 : cap;
+}
 
-template <int TW, bool NT>
+template <typename F>
+int allow_dynamic_lds(F* kernel, size_t bytes) {
+    // above 64 KiB of dynamic LDS the launch needs the function attribute; set once per kernel (host-side state,
+    // nothing is enqueued: safe under stream capture)
+    if (bytes <= 48 * 1024) return MVSDET_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+        set_error("plane_sweep_variance: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        return MVSDET_ERR_HIP;
+    }
+    return MVSDET_OK;
+}
+
+template <int KV, int TW, int G, typename OutT>
+int launch_slab(dim3 grid, hipStream_t stream, size_t lds, const float* packed, const float* ref_packed, const int64_t* nbr,
+                const float2* table, const int4* boxes, const unsigned* flags, OutT* var, int n_src, int C, int S, int D, int H, int W, int tiles_x,
+                int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
+    auto* k = plane_sweep_variance_kernel<KV, TW, G, true, OutT>;
+    if (int rc = allow_dynamic_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, grid, dim3(kThreads * G), lds, stream, packed, ref_packed, nbr, table, boxes, flags, var, n_src, C, S, D,
+                       H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts, options().sweep_debug);
+    return MVSDET_OK;
+}
+
+template <int TW>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, void* var_any,
                  void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
                  int ref_first, bool half_out) {
@@ -139,49 +167,49 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         set_error("plane_sweep_variance: grid too large");
         return MVSDET_ERR_INVALID_ARG;
     }
-    // every block sweeps all its planes (reference features stay in registers, neighbouring planes reuse
-    // source rows) unless the grid would be too small to fill 256 CUs
+    const int G = options().sweep_groups == 2 ? 2 : 1;
+    const int box_cap = effective_box_cap(K, G);
+    // every block sweeps all its planes (reference features stay in registers, a resident footprint box serves a run
+    // of planes) unless the grid would be too small to fill 256 CUs x 2 blocks
     int dsplit = 1;
-    while (nblocks * dsplit < 2048 && dsplit < D) dsplit *= 2;
+    while (nblocks * dsplit < 1024 && D / (dsplit * 2) >= 2 * G) dsplit *= 2;
     const int d_per_block = (D + dsplit - 1) / dsplit;
-    const char* ecap = getenv("MVSDET_SWEEP_BOXCAP");  // tuning knob: 0 forces the global-gather path
-    int box_cap = ecap ? atoi(ecap) : kBoxCap;
-    box_cap = box_cap < 0 ? 0 : (box_cap > kBoxCap ? kBoxCap : box_cap);
     float2* table = reinterpret_cast<float2*>(scratch);
     int4* boxes = reinterpret_cast<int4*>(table + (size_t)N * tiles * D * K * kTilePix);
-    dim3 cgrid((unsigned)(N * tiles), (D + d_per_block - 1) / d_per_block);
-    // XCD-aware id -> (slab, tile) map for fewer than 8 slabs (see the kernel); MVSDET_SWEEP_XCD=0 switches it off
-    const char* excd = getenv("MVSDET_SWEEP_XCD");
+    unsigned* flags = reinterpret_cast<unsigned*>(boxes + (size_t)N * tiles * D * K);
+    dim3 cgrid((unsigned)(N * tiles));
+    // XCD-aware id -> (slab, tile) map for fewer than 8 slabs (see the kernel); option "sweep_xcd" = 0 switches it off
     const int n_bt = N * tiles;
-    int xcd_parts = (S < 8 && 8 % S == 0 && !(excd && atoi(excd) == 0)) ? 8 / S : 1;
+    // option "sweep_xcd": 0 = slab = id % S; 1 = slab-major (an XCD owns a slab; compacted for fewer than 8 slabs);
+    // 2 = tile-major (an XCD owns (view, tile) pairs and runs all their slabs: the table is read once per XCD)
+    int xcd_parts = 1;
     long long grid_x = nblocks;
-    if (xcd_parts > 1) grid_x = 8LL * ((n_bt + xcd_parts - 1) / xcd_parts);
+    if (options().sweep_xcd == 2 && S > 1) {
+        xcd_parts = -1;
+        grid_x = 8LL * ((n_bt + 7) / 8) * S;
+    } else if (S < 8 && 8 % S == 0 && options().sweep_xcd != 0) {
+        xcd_parts = 8 / S;
+        grid_x = 8LL * ((n_bt + xcd_parts - 1) / xcd_parts);
+    }
     dim3 grid((unsigned)grid_x, (D + d_per_block - 1) / d_per_block);
     const float* ref_packed = packed ? packed + (size_t)ref_first * S * H * W * kSlab : nullptr;
+    const size_t lds = sweep_lds_bytes(K, G, box_cap);
+    int rc = MVSDET_OK;
+#define MVS_SLAB(KV, GV)                                                                                               \
+    (half_out ? launch_slab<KV, TW, GV, __half>(grid, stream, lds, packed, ref_packed, nbr, table, boxes, flags, var16, n_src, C, S, \
+                                                D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts)       \
+              : launch_slab<KV, TW, GV, float>(grid, stream, lds, packed, ref_packed, nbr, table, boxes, flags, var, n_src, C, S, D, \
+                                               H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts))
 #define MVS_SWEEP_CASE(KV)                                                                                            \
     case KV:                                                                                                          \
         if (phases & 1)                                                                                               \
             hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads), 0, stream, proj, depth,    \
-                               table, boxes, D, H, W, tiles_x, tiles, d_per_block);                                   \
-        if (!(phases & 2)) break;                                                                                     \
-        if (half_out)                                                                                                 \
-            hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, true, false, __half>), grid, dim3(kThreads), 0, stream, packed, \
-                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts); \
-        else if (g_stamps)                                                                                                 \
-            hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, true>), grid, dim3(kThreads), 0, stream, packed, \
-                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts); \
-        else                                                                                                          \
-            hipLaunchKernelGGL((plane_sweep_variance_kernel<KV, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, \
-                               ref_packed, nbr, table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts); \
+                               table, boxes, flags, D, H, W, tiles_x, tiles, box_cap);                                       \
+        if (phases & 2) rc = (G == 1) ? MVS_SLAB(KV, 1) : MVS_SLAB(KV, 2);                                            \
         break;
     switch (K) {
         case 0:
-            if ((phases & 2) && half_out)
-                hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, true, false, __half>), grid, dim3(kThreads), 0, stream, packed,
-                               ref_packed, nbr, table, boxes, var16, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts);
-            else if (phases & 2)
-                hipLaunchKernelGGL((plane_sweep_variance_kernel<0, TW, NT, false>), grid, dim3(kThreads), 0, stream, packed, ref_packed, nbr,
-                               table, boxes, var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, g_stamps, n_bt, xcd_parts);
+            if (phases & 2) rc = MVS_SLAB(0, 1);
             break;
         MVS_SWEEP_CASE(1)
         MVS_SWEEP_CASE(2)
@@ -189,17 +217,16 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         MVS_SWEEP_CASE(4)
     }
 #undef MVS_SWEEP_CASE
+#undef MVS_SLAB
+    if (rc) return rc;
     MVS_LAUNCH_CHECK("plane_sweep_variance");
     return MVSDET_OK;
 }
 }  // namespace
 
-// Diagnostic hook (not part of include/mvsdet_hip.h): a device buffer of 65536*4*8 u64 makes the next sweeps run the
-// instrumented instantiation, which adds up the cycles each wave spends per loop segment.  NULL switches it off.
-extern "C" void mvsdet_debug_set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
-
 namespace mvsdet {
 int sweep_tile_width(int W) { return pick_tile_width(W); }  // shared with planesweep_bwd.hip
+int sweep_box_cap(int K) { return effective_box_cap(K, options().sweep_groups == 2 ? 2 : 1); }
 }
 
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W) {
@@ -207,7 +234,8 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
     // sampling table (8 B per view, neighbour, plane, tile pixel) + footprint boxes (16 B per view, neighbour,
     // plane, tile); sized for the larger of the two tile shapes so the knob cannot outgrow it
     const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
-    return (size_t)N * tiles * D * K * (kTilePix * sizeof(float2) + sizeof(int4));
+    // + one flags word per (view, tile, plane)
+    return (size_t)N * tiles * D * K * (kTilePix * sizeof(float2) + sizeof(int4)) + (((size_t)N * tiles * D * 4 + 15) & ~(size_t)15);
 }
 
 static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,
@@ -223,6 +251,7 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "%s: bad shape N=%d C=%d D=%d H=%d W=%d", name, N, C, D, H, W);
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "%s: K=%d outside [0,%d]", name, K, MVSDET_MAX_NEIGHBORS);
     MVS_REQUIRE(D <= 65535 && H < 65535 && W < 65535, "%s: D, H or W > 65534", name);
+    MVS_REQUIRE((size_t)8 * D * H * W * sizeof(float) < ((size_t)1 << 32), "%s: 8 channel rows of the cost volume (8*D*H*W floats) exceed 4 GiB", name);
     MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "%s: one slab image exceeds 2^31 elements", name);
     if (scratch_bytes < mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)) {
         set_error("%s: scratch %zu B < %zu B", name, scratch_bytes, mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W));
@@ -230,13 +259,9 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     }
     MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "%s: scratch must be 16-byte aligned", name);
     const int tw = pick_tile_width(W);
-    const char* ent = getenv("MVSDET_SWEEP_NT");
-    const bool nt = ent ? atoi(ent) != 0 : true;
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return nt ? launch_sweep<16, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out)
-                            : launch_sweep<16, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
-    return nt ? launch_sweep<32, true>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out)
-              : launch_sweep<32, false>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,

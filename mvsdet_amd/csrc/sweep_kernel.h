@@ -1,38 +1,30 @@
-// a3+a4 fused: plane-sweep variance (included by planesweep.hip).  Two kernels:
+// a3+a4 fused: plane-sweep variance (included by planesweep.hip and planesweep_bwd.hip).  Two kernels:
 //
 // (1) plane_sweep_coords_kernel -- everything that depends on (view, neighbour, plane, pixel) but NOT on the
-//     channel: the sampling position of mvs_models/module.py:116-143, reduced to an 8-byte table entry
-//     (the un-normalised sample position ix, iy) plus, per (tile, neighbour, plane), the bounding box of the
-//     valid taps.  The reference builds its sampling grid once per plane too.
-//     Cost: N*K*D*H*W entries (0.8 GB at the 64-plane shape, 1.5 % of the cost volume), written once.
+//     channel: the sampling position of mvs_models/module.py:116-143 as an 8-byte table entry (the un-normalised
+//     sample position ix, iy) plus, per (tile, neighbour, plane), a footprint box.  Consecutive planes whose tap
+//     bounding boxes have a UNION of at most `box_cap` texels form a run and all carry that union box: beyond
+//     ~1.2 m the footprints of neighbouring planes move by less than a texel per plane, so a 256-texel box serves
+//     ~9 planes on the ScanNet-like geometry and ~35 on the ARKit-like one (tools/box_runs.py).
 //
 // (2) plane_sweep_variance_kernel -- the channel work, one 32-channel slab per block:
-//       block   = (reference view n, TWxTH pixel tile (128 pixels), slab s, depth chunk)
-//                 logical id = (n*tiles + tile)*S + s: consecutive blocks are the S slabs of one tile and the
-//                 round-robin block->XCD dispatch sends slab s of every tile to the same XCD when S == 8, so
-//                 an XCD only ever touches ONE 128-byte slab of each source texel and its live working set
-//                 fits its 4 MiB L2 (rocprofv3: 2*FETCH_SIZE + WRITE_SIZE == algorithmic bytes).
-//       lanes   = (pixel slot ps = lane>>3, channel group g = lane&7); a wave-instruction covers 8 pixels x
-//                 128 B; each wave owns 32 pixels = 4 steps; the reference features of those pixels stay in
-//                 registers across the depth loop.
-//       per depth plane
-//         P1  scalar-load the footprint boxes; a neighbour with NO tap of the whole tile inside its image is dropped
-//             for this plane (its warped values are exactly 0; a third of all (tile, plane, neighbour) triples at
-//             ScanNet-like geometry); start the LDS-DMA of the first live neighbour's box; one thread per (pixel,
-//             live neighbour) decodes its table entry into 4 weights + 4 tap offsets inside the box (or inside the
-//             slab image when the footprint does not fit in LDS and that neighbour gathers from global memory)
-//         per live neighbour j
-//           P2  LDS-DMA of the box rows (contiguous nc*128-byte runs of the slab image), 1 KiB per wave-instruction;
-//               explicit s_waitcnt 0 before the barrier that publishes the box (hipcc waits for lgkmcnt only)
-//           P3  taps = 4 x ds_read_b128 per step; fma chain -> S, Q
-//         P4  variance -> LDS tile [32 channels][128 pixels] (aliases the box storage)
-//         P5  tile rows -> global as 16-byte non-temporal stores, 128 B contiguous per (channel, tile row); each wave
-//             stores the pixels it computed (wave-private transpose, no block barrier between P4 and P5)
+//       block   = (reference view n, TWxTH pixel tile (128 pixels), slab s, depth chunk), 4*G waves
+//       LDS     = ONE resident footprint box per neighbour (K slots of box_cap 128-byte texels).  A slot is
+//                 refilled (LDS-DMA, two block barriers) only when the run's union box changes: ~10 % of the live
+//                 (tile, plane, neighbour) triples.  All other planes run without any block-level synchronisation:
+//                 table entry -> decode -> taps from LDS -> variance -> stores, wave-private from end to end.
+//       lanes   = (pixel slot ps = lane>>3, channel group g = lane&7); the lane owns the 4 CONSECUTIVE pixels
+//                 4*ps .. 4*ps+3 of its wave's 32 (one per step) x 4 channels (8*i+g), so a variance value is stored
+//                 straight from registers as 16 bytes per lane = 8 channel rows x 128 contiguous bytes per
+//                 wave-instruction -- no LDS transpose.
+//       decode  = lane (ps, g) decodes the table entry of pixel-step g&3 once per neighbour and plane (tap origin,
+//                 4 weights, 4 LDS offsets); the four steps read it from their quad-lane with DPP quad_perm
+//                 broadcasts -- no LDS tables, no barrier between decode and taps.
+//       G = 2   = eight waves share the boxes of one tile: waves 0-3 take the even planes of the block's depth
+//                 range and waves 4-7 the odd ones, which doubles the waves per CU for the same LDS.
 //
-// Why this shape: v1 (all channels per block, taps gathered from global memory) saturated the fabric at a 43 %
-// L2 hit rate (profiles/r01_v1_*); with slabs the kernel became VALU-issue bound (82 % busy), so everything
-// that is not per-channel arithmetic was moved out of the per-slab loop (the table), made scalar (row bases,
-// boxes) or turned into immediates (LDS addresses).
+// Design history: v1 gathered from global memory (fabric-bound, L2 hit 43 %), v3-v5 staged one box
+// per (plane, neighbour) with 5 barriers and 2 exposed DMA latencies per plane (wave wait 57 %, 3.4 TB/s).
 //
 // Arithmetic (device rounding, oracle mode 1): warped = fma chain over the 4 taps; S = f + w1 + ..;
 // Q = fma(w,w,Q); var = fma(-m, m, Q*r) with m = S*r, r = 1/(K+1).
@@ -43,8 +35,9 @@
 namespace mvsdet {
 
 constexpr int kTilePix = 128;       // pixels per tile
-constexpr int kBoxCap = 256;        // texels (128 B each) of the LDS footprint box: 32 KiB
-constexpr int kTileStride = 132;    // floats per channel row of the output tile (132 % 32 == 4: conflict-free writes)
+constexpr int kBoxCap = 256;        // default texels (128 B each) of one LDS footprint box: 32 KiB per neighbour
+constexpr int kBoxCapMax = 320;     // 2 neighbours x 320 texels x 2 blocks = the CU's 160 KiB
+constexpr int kTileStride = 132;    // floats per channel row of the backward kernel's gradient tile
 
 // Wave-wide integer min / max: butterfly inside each row of 16 lanes with DPP (4 VALU), then the four row
 // results are combined on the scalar unit.  The result is wave-uniform (an SGPR).
@@ -100,6 +93,8 @@ __device__ __forceinline__ float4 tap_weights(const SampleTaps& t) {
     return w;
 }
 
+constexpr unsigned kFlagLive = 1u, kFlagStaged = 2u, kFlagRefill = 4u;  // per-neighbour nibble of a plane's flags word
+constexpr int kBoxPad = 8;                // texels of slack per LDS slot (the bank swizzle may use slot index ntex)
 constexpr int kBoxSkip = INT32_MIN;       // boxes[].w of an empty footprint whose positions are all finite
 constexpr int kBoxEmpty = INT32_MIN + 1;  // empty footprint with a non-finite position: taps run and give NaN
 constexpr float kNoSample = -2.0f;  // entry of a tile pixel outside the image: no tap inside, all weights +0
@@ -119,15 +114,18 @@ __device__ __forceinline__ float2 sample_position(const float* __restrict__ P, f
 }
 
 // ---------------------------------------------------------------------------------------------
-// (1) sampling table: block = (view, tile); thread = (neighbour, pixel); loops over the planes of its chunk.
+// (1) sampling table: block = (view, tile); thread = (neighbour, pixel); loops over all planes.
 //     table [((n*tiles + tile)*D + d)*K + j][128] float2;  boxes [((n*tiles + tile)*D + d)*K + j] int4.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool box_nonempty(const int4& b) { return b.y >= b.x && b.w >= b.z; }
+__device__ __forceinline__ int box_area(const int4& b) { return (b.y - b.x + 1) * (b.w - b.z + 1); }
+
 template <int K, int TW>
 __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const float* __restrict__ proj,
                                                                        const float* __restrict__ depth,
                                                                        float2* __restrict__ table, int4* __restrict__ boxes,
-                                                                       int D, int H, int W, int tiles_x, int tiles,
-                                                                       int d_per_block) {
+                                                                       unsigned* __restrict__ flags, int D, int H, int W,
+                                                                       int tiles_x, int tiles, int box_cap) {
     constexpr int TH = kTilePix / TW;
     constexpr int ITER = (K * kTilePix + kThreads - 1) / kThreads;
     __shared__ int s_red[2][K][2][5];  // [plane parity][neighbour][wave of the neighbour][xlo,xhi,ylo,yhi,all finite]
@@ -138,9 +136,9 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     const int p = tid % kTilePix;
     const int x = tx0 + (p % TW), y = ty0 + (p / TW);
     const bool inside = (x < W) && (y < H);
-    const int d_begin = blockIdx.y * d_per_block, d_end = min(D, d_begin + d_per_block);
-    for (int d = d_begin; d < d_end; ++d) {
-        const int par = (d - d_begin) & 1;
+    for (int d = tid; d < D; d += kThreads) flags[(size_t)bt * D + d] = 0u;  // nibbles are OR-ed in below
+    for (int d = 0; d < D; ++d) {
+        const int par = d & 1;
         const float dval = depth[(size_t)n * D + d];
         const size_t base = ((size_t)bt * D + d) * K;
 #pragma unroll
@@ -185,31 +183,131 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
             boxes[base + tid] = bx;
         }
     }
+    // Runs: consecutive live planes of one neighbour whose union box holds at most box_cap texels all get that union
+    // box (greedy; out-of-view planes in between do not break a run -- the resident box stays valid across them -- a
+    // footprint larger than the cap does).  Thread j reads back what it wrote itself above, then publishes per plane
+    // its nibble of the flags word: kFlagLive (taps run), kFlagStaged (from the LDS box), kFlagRefill (the box differs
+    // from the one the previous staged plane of this neighbour left resident).
+    __syncthreads();  // the zeroed flags words
+    if (tid < K) {
+        int4* bj = boxes + (size_t)bt * D * K + tid;
+        int run_first = -1;
+        int4 u = make_int4(0, 0, 0, 0);
+        for (int d = 0; d <= D && box_cap > 0; ++d) {
+            bool close = (d == D);
+            int4 b = make_int4(0, -1, 0, -1);
+            if (d < D) {
+                b = bj[(size_t)d * K];
+                if (!box_nonempty(b)) continue;
+                if (box_area(b) > box_cap) {
+                    close = true;
+                } else if (run_first >= 0) {
+                    const int4 c = make_int4(min(u.x, b.x), max(u.y, b.y), min(u.z, b.z), max(u.w, b.w));
+                    if (box_area(c) <= box_cap) { u = c; continue; }
+                    close = true;
+                }
+            }
+            if (close && run_first >= 0) {
+                for (int e = run_first; e < d; ++e) {
+                    const int4 o = bj[(size_t)e * K];
+                    if (box_nonempty(o) && box_area(o) <= box_cap) bj[(size_t)e * K] = u;
+                }
+                run_first = -1;
+            }
+            if (d < D && box_area(b) <= box_cap) { run_first = d; u = b; }
+        }
+        int4 res = make_int4(0, -1, 0, -1);  // what the sweep holds resident in this neighbour's slot
+        for (int d = 0; d < D; ++d) {
+            const int4 b = bj[(size_t)d * K];
+            unsigned f = 0;
+            if (box_nonempty(b)) {
+                f = kFlagLive;
+                if (box_area(b) <= box_cap) {
+                    f |= kFlagStaged;
+                    if (b.x != res.x || b.y != res.y || b.z != res.z || b.w != res.w) f |= kFlagRefill;
+                    res = b;
+                }
+            } else if (b.w != kBoxSkip) {
+                f = kFlagLive;  // empty footprint with a non-finite position: the taps run (from global memory) and give NaN
+            }
+            if (f) atomicOr(flags + (size_t)bt * D + d, f << (4 * tid));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // (2) the slab kernel
 // ---------------------------------------------------------------------------------------------
+// quad broadcast: every lane reads the value of lane (lane & ~3) + S of its quad
+template <int S>
+__device__ __forceinline__ int quad_bcast(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xf, 0xf, true);
+}
+template <int S>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), S * 0x55, 0xf, 0xf, true));
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));  // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 operands
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+
+// what one lane holds of a decoded table entry: 4 tap offsets (float4 units inside the LDS slots, or inside the slab
+// image for a gathered footprint) and the 4 bilinear weights
+struct DecodedTaps {
+    int o0, o1, o2, o3;
+    float w0, w1, w2, w3;
+};
+
+// LDS bank swizzle of a staged box: box texel t (row-major) is kept in texel slot t ^ bit2(t).  The 8 pixel slots of a
+// wave-instruction read texels about 4 apart (each lane owns 4 consecutive pixels); unswizzled they would all start in
+// the same 128-byte half of the 64 banks (2-way conflicts on every tap), swizzled texels 4 apart alternate halves.
+// An involution; the largest slot index of an n-texel box is n (hence kBoxPad).
+__device__ __forceinline__ int box_slot(int t) { return t ^ ((t >> 2) & 1); }
+
 // OutT = float, or __half: the variance is computed in fp32 exactly as before and rounded to nearest-even at the
 // store (BASELINE configs[4], fp16 storage), which halves the dominant write stream.
-template <int K, int TW, bool NT, bool STAMP, typename OutT = float>
-__global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
+constexpr int kRingPlanes = 4;  // own planes of table entries a wave keeps in its private LDS ring (K x 256 B each)
+__host__ __device__ constexpr size_t sweep_lds_bytes(int K, int G, int box_cap) {
+    return (size_t)K * (box_cap + kBoxPad) * 128 + (size_t)(4 * G) * kRingPlanes * K * 256;
+}
+
+// s_waitcnt vmcnt(n) with a run-time n <= 15 (the instruction takes an immediate): expcnt / lgkmcnt not waited for
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define MVS_W(N) case N: __builtin_amdgcn_s_waitcnt(0x0F70 | N); break;
+        MVS_W(1) MVS_W(2) MVS_W(3) MVS_W(4) MVS_W(5) MVS_W(6) MVS_W(7) MVS_W(8) MVS_W(9) MVS_W(10) MVS_W(11) MVS_W(12)
+        MVS_W(13) MVS_W(14) MVS_W(15)
+#undef MVS_W
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;  // vmcnt(0)
+    }
+}
+
+template <int K, int TW, int G, bool NT, typename OutT = float>
+__global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
-    const float2* __restrict__ table, const int4* __restrict__ boxes, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int d_per_block, int box_cap, unsigned long long* __restrict__ stamps, int n_bt, int xcd_parts) {
+    const float2* __restrict__ table, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
+    OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
+    int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts, int dbg) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int TH = kTilePix / TW;
-    constexpr int ITER = (KK * kTilePix + kThreads - 1) / kThreads;
-    static_assert(kBoxCap * 8 >= 32 * kTileStride / 4, "output tile must fit in the box storage");
-    __shared__ float4 s_box[kBoxCap * 8];       // footprint box of one neighbour; later the output tile
-    __shared__ int4 s_off[KK][kTilePix];        // float4 index of the 4 taps (inside s_box or the slab image)
-    __shared__ float4 s_w[KK][kTilePix];        // tap weights
+    constexpr int R = kRingPlanes;
+    extern __shared__ float4 s_box[];  // K slots of (box_cap + kBoxPad) texels (8 float4 each), then the waves' entry rings
 
     const int HW = H * W;
     const int id = blockIdx.x;
     int slab = id % S;
     int bt = id / S;  // n*tiles + tile
-    if (xcd_parts > 1) {
+    if (xcd_parts < 0) {
+        // tile-major: blocks b and b + 8 share an XCD (round-robin dispatch), so XCD x takes the (view, tile) pairs
+        // 8*q + x and runs their S slabs back to back: the slabs of a tile read the SAME sampling-table rows, which now
+        // come out of that XCD's L2 for all but the first of them (with slab = id % S they sat on 8 different XCDs and
+        // the table crossed the fabric 8 times: 2.9 of 14 ms at the 64-plane shape).  Speed only, never correctness.
+        const int xcd = id & 7, k = id >> 3;
+        slab = k % S;
+        bt = (k / S) * 8 + xcd;
+        if (bt >= n_bt) return;  // padding blocks of the rounded-up grid (whole block, before any barrier)
+    } else if (xcd_parts > 1) {
         // fewer than 8 slabs (C < 256): the 8/S XCDs that share a slab each take one contiguous range of
         // (view, tile) pairs, so an XCD's L2 sees a compact set of source rows instead of every 8th tile's
         const int xcd = id & 7, k = id >> 3;
@@ -225,6 +323,7 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it scalar
+    const int sub = wave & 3, grp = wave >> 2;                  // pixel quarter of the tile, plane parity group
     const int g = lane & 7, ps = lane >> 3;
     const size_t slab_stride = (size_t)HW * kSlab;       // floats per (view, slab) image
     // ref_packed = packed + first reference view of this launch (a view shard); N bounds the NEIGHBOUR ids
@@ -233,273 +332,264 @@ __global__ __launch_bounds__(kThreads, 4) void plane_sweep_variance_kernel(
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         int64_t v = nbr[(size_t)n * K + j];
-        v = v < 0 ? 0 : (v >= N ? N - 1 : v);  // never read outside the packed maps
+        v = v < 0 ? 0 : (v >= N ? N - 1 : v);  // never read outside the packed maps (ids are validated on the host)
         nb_img[j] = reinterpret_cast<const float4*>(packed + ((size_t)v * S + slab) * slab_stride);
     }
     const float rcp = 1.0f / (float)(K + 1);
+    const int slot_f4 = (box_cap + kBoxPad) * 8;  // float4 per LDS slot
+    // this wave's ring of table entries: [R own planes][K][32 pixels] float2
+    float2* s_ring = reinterpret_cast<float2*>(s_box + (size_t)KK * slot_f4) + (size_t)wave * R * KK * 32;
 
-    // loop invariants of this lane: reference features of its 4 pixels (one per step) ...
-    float4 f[4];
+    // the lane's 4 consecutive pixels: tile-local p0 .. p0+3 (4 | TW, so they share a row)
+    const int p0 = 32 * sub + 4 * ps;
+    const int px0 = tx0 + p0 % TW, py = ty0 + p0 / TW;
+    f2 f[4][2];  // loop invariant: their reference features (channels 8*i + g; [s][0] = i 0,1; [s][1] = i 2,3)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int p = (wave * 4 + s) * 8 + ps;
-        const int x = tx0 + (p % TW), y = ty0 + (p / TW);
-        const int pix = min(y, H - 1) * W + min(x, W - 1);
-        f[s] = *reinterpret_cast<const float4*>(ref_img + (size_t)pix * kSlab + 4 * g);
+        const int pix = min(py, H - 1) * W + min(px0 + s, W - 1);
+        const float4 v = *reinterpret_cast<const float4*>(ref_img + (size_t)pix * kSlab + 4 * g);
+        f[s][0] = (f2){v.x, v.y};
+        f[s][1] = (f2){v.z, v.w};
     }
-    // ... and the 4 consecutive output pixels it stores in P5.  A wave stores what it computed itself: its 32
-    // pixels (tile columns 32*wave ..) of all 32 channel rows, so the tile transpose is wave-private and needs no
-    // block barrier.  Lane -> channel row 8*k + (lane >> 3), float4 slot (lane & 7) of the wave's 32 pixels.
-    const int sq = lane & 7, sh = lane >> 3;
-    const int st_p = wave * 32 + 4 * sq;  // first of the 4 pixels, tile-local
-    const int st_x = tx0 + st_p % TW, st_y = ty0 + st_p / TW;
-    const int st_off = st_y * W + st_x;
-    const int st_n = (st_y < H) ? max(0, min(4, W - st_x)) : 0;        // how many of the 4 pixels are inside the image
+    // stores: uniform base of (channel 8*i of the slab, plane d) + one 32-bit lane offset (channel g, the pixels)
+    // (bytes; the entry point checks that 8 channel rows of the volume stay below 4 GiB)
+    const unsigned st_off = ((unsigned)g * (unsigned)D * (unsigned)HW + (unsigned)(py * W + px0)) * (unsigned)sizeof(OutT);
+    const int st_n = (py < H) ? max(0, min(4, W - px0)) : 0;               // how many of the 4 pixels are inside the image
     const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);  // 16-byte aligned in every channel row
 
+    // LDS-DMA of one footprint box into its slot: each wave-instruction fills 8 texel slots = 1 KiB without touching
+    // VGPRs (LDS address = wave-uniform base + 16*lane, global address per lane: the texel that belongs in the lane's
+    // slot).  Pieces are dealt round-robin to the block's waves.
     auto load_box = [&](int j, int bx0, int by0, int nc, int nr) {
-        // LDS-DMA: each wave-instruction moves 1 KiB global -> LDS without touching VGPRs; the LDS address is the
-        // wave-uniform base + 16*lane, the global address is per lane.  The DMA counts on vmcnt, which the next
-        // __syncthreads() drains.  Every wave copies whole rows: one contiguous nc*128-byte run each.
-        const int row_f4 = nc * 8;
-        const int cpr = (row_f4 + 63) >> 6;  // 1-KiB chunks per row; units (row, chunk) are dealt round-robin to the waves
-        int row = 0, chunk = wave;
-        while (chunk >= cpr) { chunk -= cpr; ++row; }
-        while (row < nr) {
-            const float4* src = nb_img[j] + ((size_t)(by0 + row) * W + bx0) * 8 + chunk * 64;  // wave-uniform
-            float4* dst = s_box + row * row_f4 + chunk * 64;
-            if (chunk * 64 + lane < row_f4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane),
+        const int ntex = nc * nr;
+        const float inv_nc = 1.0f / (float)nc;
+        for (int q = wave; q * 8 <= ntex; q += 4 * G) {
+            const int t = box_slot(q * 8 + ps);                 // the box texel kept in slot q*8 + ps
+            const int row = (int)(((float)t + 0.5f) * inv_nc);  // t / nc for t < 2^11 (never within rounding of an integer)
+            const int col = t - row * nc;
+            const float4* src = nb_img[j] + ((size_t)(by0 + row) * W + (bx0 + col)) * 8 + g;
+            float4* dst = s_box + (size_t)j * slot_f4 + q * 64;  // wave-uniform
+            if (t < ntex)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            chunk += 4;
-            while (chunk >= cpr) { chunk -= cpr; ++row; }
         }
     };
 
-    // Boxes and table entries are requested one plane ahead (during the taps of the previous plane), so the loop
-    // never stalls on them; they are issued BEFORE that plane's result stores, so waiting for them does not wait
-    // for store acknowledgements either (vmcnt retires in order).
-    int4 bn[KK];
-    float2 en[ITER];
+    const unsigned* fl_bt = flags + (size_t)bt * D;
+    unsigned fl_next = (K > 0 && d_begin < d_end) ? fl_bt[d_begin] : 0u;
+    // the box resident in slot j: origin, last column / row (block-uniform scalars)
+    int rx0[KK], ry0[KK], rx1[KK], ry1[KK];
+    bool have[KK];
 #pragma unroll
-    for (int j = 0; j < KK; ++j) bn[j] = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN);
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) en[it] = make_float2(kNoSample, kNoSample);
-    auto prefetch = [&](int d) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) bn[j] = boxes[((size_t)bt * D + d) * K + j];
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
-            if (j < K) en[it] = table[(((size_t)bt * D + d) * K + j) * kTilePix + (tid % kTilePix)];
-        }
-    };
-    if (K > 0 && d_begin < d_end) prefetch(d_begin);
+    for (int j = 0; j < KK; ++j) { rx0[j] = 0; ry0[j] = 0; rx1[j] = -1; ry1[j] = -1; have[j] = false; }
 
-    // diagnostic instantiation only (STAMP, tools/stamp_sweep.py): cycles per loop segment, summed per wave
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-#define MVS_STAMP(IDX)                                                           \
-    if (STAMP) {                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();             \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-        if ((IDX) >= 0) tacc[(IDX) < 0 ? 0 : (IDX)] += tn_ - tprev;              \
-        tprev = tn_;                                                             \
+    // ---- table entries.  gfx950 has ONE in-order counter (vmcnt) for loads, stores and LDS-DMA, and under a 3+ TB/s
+    // write stream a store takes thousands of cycles to be acknowledged: a wave that waits for a table entry with the
+    // compiler's conservative vmcnt also waits for the stores of its previous plane (measured: 3.7 of 15.5 ms).  So the
+    // entries travel by LDS-DMA into a wave-private ring, kRingPlanes - 1 own planes ahead, and the wave waits for them
+    // with an EXACT vmcnt(n): n = the vector-memory instructions it has issued since that DMA (one DMA per own plane +
+    // the stores of the planes in between, counted below), which are all younger and may stay in flight.
+    // One DMA instruction per own plane: lane l < 16*K fetches 16 B = the entries of pixels 2*(l&15), +1 of neighbour l>>4.
+    const int n_own = (d_end - d_begin - grp + G - 1) / G;  // own planes: d = d_begin + grp + m*G
+    const char* tab_wave = reinterpret_cast<const char*>(table + (size_t)bt * D * K * kTilePix + 32 * sub) +
+                           (size_t)(lane >> 4) * (kTilePix * sizeof(float2)) + 16 * (lane & 15);
+    // The DMA is issued from inline assembly on purpose: hipcc's wait-count pass puts an s_waitcnt vmcnt(0) in front of
+    // every LDS read that may alias a pending LDS-DMA it knows of -- exactly the wait (for all stores in flight) this
+    // scheme exists to avoid.  M0 = LDS byte address of the ring slot (one wait state between the write of M0 and its use).
+    auto request = [&](int m) {  // own plane m -> ring slot m % R
+        const char* src = tab_wave + (size_t)(d_begin + grp + ((dbg & 64) ? 0 : m) * G) * K * (kTilePix * sizeof(float2));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(s_ring + (size_t)(m % R) * KK * 32));
+        if (lane < 16 * K)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
+    };
+    // stores this wave issues per computed plane, counted only where the count is exact (whole float4 stores: lanes are
+    // all-in or all-out, a channel row is skipped by the whole wave or by none); otherwise 0 = "assume none in flight"
+    int n_st = 0;
+    {
+        const bool exact = ((W & 3) == 0) && ((HW & 3) == 0);
+        const bool any_lane = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(st_n == 4))) != 0;
+        if (exact && any_lane && !(dbg & 1))
+            for (int i = 0; i < 4; ++i) n_st += (slab * kSlab + 8 * i < C) ? 1 : 0;
     }
-    for (int d = d_begin; d < d_end; ++d) {
-        MVS_STAMP(-1)
-        // ---- P1: footprint boxes (block-uniform scalars, computed once per tile by the coords kernel)
-        int bx0[KK], bx1[KK], by0[KK], by1[KK], nc[KK], nr[KK];
-        bool staged[KK], skip[KK];
-        // make sure the prefetched values have landed before the DMA below is queued behind them
+    int issued = 0;                  // vector-memory instructions issued so far that are certainly counted in vmcnt
+    int mark0 = 0, mark1 = 0, mark2 = 0;  // `issued` right after the DMA of own plane m, m+1, m+2
+    if (K > 0) {
+        asm volatile("" ::: "memory");
+        if (0 < n_own) { request(0); ++issued; } mark0 = issued;
+        if (1 < n_own) { request(1); ++issued; } mark1 = issued;
+        if (2 < n_own) { request(2); ++issued; } mark2 = issued;
+        asm volatile("" ::: "memory");
+    }
+    const int pdec = 4 * ps + (g & 3);  // the wave-local pixel whose entry this lane decodes
+    int m_own = 0;
+    float2 en[KK];
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) asm volatile("" ::"v"(en[it].x), "v"(en[it].y));
+    for (int j = 0; j < KK; ++j) en[j] = make_float2(kNoSample, kNoSample);
+
+    // results of the last computed plane, and the stores that send them out: straight from registers, 16 bytes per lane =
+    // 8 channel rows x 128 contiguous bytes per wave-instruction
+    float vout[4][4];
+    int d_pending = -1;
+    auto flush = [&](int d) {
+        OutT* plane_base = var + (((size_t)n * C + slab * kSlab) * D + d) * HW;  // block-uniform
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int4 b = bn[j];
-            bx0[j] = __builtin_amdgcn_readfirstlane(b.x);
-            bx1[j] = __builtin_amdgcn_readfirstlane(b.y);
-            by0[j] = __builtin_amdgcn_readfirstlane(b.z);
-            by1[j] = __builtin_amdgcn_readfirstlane(b.w);
-            nc[j] = bx1[j] - bx0[j] + 1;
-            nr[j] = by1[j] - by0[j] + 1;
-            staged[j] = (bx1[j] >= bx0[j]) && (by1[j] >= by0[j]) && (nc[j] * nr[j] <= box_cap);
-            skip[j] = (bx1[j] < bx0[j]) && (by1[j] == kBoxSkip);  // nothing of this neighbour is visible: w_j == 0
+        for (int i = 0; i < 4; ++i) {
+            const float* v = vout[i];
+            const int c = slab * kSlab + g + 8 * i;
+            if (c < C && !((dbg & 1) && v[0] != 12345.678f)) {
+                OutT* dst = reinterpret_cast<OutT*>(reinterpret_cast<char*>(plane_base + (size_t)(8 * i) * D * HW) + st_off);
+                // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs
+                if constexpr (sizeof(OutT) == 4) {
+                    if (st_vec) {
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        const v4f vv = {v[0], v[1], v[2], v[3]};
+                        if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
+                        else *reinterpret_cast<v4f*>(dst) = vv;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (s < st_n) dst[s] = v[s];
+                    }
+                } else {
+                    const __half h[4] = {__float2half_rn(v[0]), __float2half_rn(v[1]), __float2half_rn(v[2]), __float2half_rn(v[3])};
+                    if (st_vec) {  // 4 pixels x 2 B: the fp32 alignment condition also gives 8-byte alignment
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        const v2u vv = {(unsigned)__half_as_ushort(h[0]) | ((unsigned)__half_as_ushort(h[1]) << 16),
+                                        (unsigned)__half_as_ushort(h[2]) | ((unsigned)__half_as_ushort(h[3]) << 16)};
+                        if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v2u*>(dst));
+                        else *reinterpret_cast<v2u*>(dst) = vv;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (s < st_n) dst[s] = h[s];
+                    }
+                }
+            }
         }
-        // the previous plane's tile reads (P5) must be over before the box storage is refilled
-        if (d != d_begin) __syncthreads();
-        MVS_STAMP(0)  // unpack boxes + wait for the prefetch + barrier (previous tile reads)
-        // the box of the FIRST neighbour that is not skipped is in flight while the table is decoded
-        bool early[KK];
-        {
-            bool taken = false;
+        asm volatile("" ::: "memory");
+        issued += n_st;
+    };
+
+    for (int d = d_begin; d < d_end; ++d) {
+        // ---- this plane's flags (one scalar word, requested a plane ahead); every wave follows every plane so that all
+        //      of them take the same refill decisions, whichever planes they compute
+        const unsigned fl = __builtin_amdgcn_readfirstlane(fl_next);
+        if (K > 0 && d + 1 < d_end) fl_next = fl_bt[d + 1];
+        bool refill = false;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if ((fl >> (4 * j)) & kFlagStaged)
+                if (((fl >> (4 * j)) & kFlagRefill) || !have[j]) refill = true;
+        if (refill && !(dbg & 8)) {
+            __syncthreads();  // every wave is done with the planes that read the old boxes
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                early[j] = !taken && !skip[j];
-                if (early[j]) {
-                    taken = true;
-                    if (staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
+                if (((fl >> (4 * j)) & kFlagStaged) && (((fl >> (4 * j)) & kFlagRefill) || !have[j])) {
+                    const int4 b = boxes[((size_t)bt * D + d) * K + j];
+                    rx0[j] = __builtin_amdgcn_readfirstlane(b.x);
+                    rx1[j] = __builtin_amdgcn_readfirstlane(b.y);
+                    ry0[j] = __builtin_amdgcn_readfirstlane(b.z);
+                    ry1[j] = __builtin_amdgcn_readfirstlane(b.w);
+                    have[j] = true;
+                    if (!(dbg & 4)) load_box(j, rx0[j], ry0[j], rx1[j] - rx0[j] + 1, ry1[j] - ry0[j] + 1);
                 }
             }
+            // The LDS-DMA pieces of this wave count on vmcnt, and for a workgroup barrier hipcc only waits for lgkmcnt:
+            // without the explicit wait a wave can pass the barrier while its own pieces are still in flight and the
+            // other waves read stale box texels.  (Everything this wave has in flight is older than its pieces.)
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
         }
-        // ---- table entry (sample position) -> weights + tap offsets (float4 units, lane slot g not yet added)
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
-            bool live = false;
-#pragma unroll
-            for (int jj = 0; jj < K; ++jj)
-                if (jj == j && !skip[jj]) live = true;
-            if (live) {
-                const int p = tid % kTilePix;
-                const SampleTaps tp = decode_sample(en[it].x, en[it].y, H, W);
-                const int x0 = tp.x0, y0 = tp.y0;
-                s_w[j][p] = tap_weights(tp);
-                int lox = 0, hix = W - 1, loy = 0, hiy = H - 1, pitch = W;
-#pragma unroll
-                for (int jj = 0; jj < K; ++jj)
-                    if (jj == j && staged[jj]) { lox = bx0[jj]; hix = bx1[jj]; loy = by0[jj]; hiy = by1[jj]; pitch = nc[jj]; }
-                const int xa = clampi(x0, lox, hix) - lox, xb = clampi(x0 + 1, lox, hix) - lox;
-                const int ya = (clampi(y0, loy, hiy) - loy) * pitch, yb = (clampi(y0 + 1, loy, hiy) - loy) * pitch;
-                s_off[j][p] = make_int4((ya + xa) * 8, (ya + xb) * 8, (yb + xa) * 8, (yb + xb) * 8);
-            }
-        }
+        if (d_pending >= 0) { flush(d_pending); d_pending = -1; }
+        if (G > 1 && ((d - d_begin) & (G - 1)) != grp) continue;  // the other wave group's plane
 
-        MVS_STAMP(1)  // DMA issue of neighbour 0 + decode
-        float S_[4][4], Q_[4][4];
+        if (K > 0 && !(dbg & 2)) {
+            // this plane's entries: everything issued since their DMA may stay in flight
+            asm volatile("" ::: "memory");
+            if (!(dbg & 16)) wait_vmcnt(min(issued - mark0, 15));
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < K; ++j) en[j] = s_ring[((size_t)(m_own % R) * K + j) * 32 + pdec];
+            asm volatile("" ::: "memory");
+        }
+        f2 S_[4][2], Q_[4][2];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            S_[s][0] = f[s].x; S_[s][1] = f[s].y; S_[s][2] = f[s].z; S_[s][3] = f[s].w;
-            Q_[s][0] = f[s].x * f[s].x; Q_[s][1] = f[s].y * f[s].y; Q_[s][2] = f[s].z * f[s].z; Q_[s][3] = f[s].w * f[s].w;
+            S_[s][0] = f[s][0]; S_[s][1] = f[s][1];
+            // eight waves per block live on 128 VGPRs: keep f*f inside the loop (hoisted, it costs 16 of them and spills)
+            if (G > 1) asm volatile("" : "+v"(S_[s][0]), "+v"(S_[s][1]));
+            Q_[s][0] = S_[s][0] * S_[s][0]; Q_[s][1] = S_[s][1] * S_[s][1];
         }
-        bool tables_visible = false, prefetched = false;
+#define MVS_TAP_STEP(SS, LOADER)                                                                                      \
+        {                                                                                                             \
+            const int o0 = quad_bcast<SS>(dt.o0), o1 = quad_bcast<SS>(dt.o1);                                         \
+            const int o2 = quad_bcast<SS>(dt.o2), o3 = quad_bcast<SS>(dt.o3);                                         \
+            const f2 w0 = splat(quad_bcast<SS>(dt.w0)), w1 = splat(quad_bcast<SS>(dt.w1));                            \
+            const f2 w2 = splat(quad_bcast<SS>(dt.w2)), w3 = splat(quad_bcast<SS>(dt.w3));                            \
+            const float4 t0 = LOADER(o0), t1 = LOADER(o1), t2 = LOADER(o2), t3 = LOADER(o3);                          \
+            f2 va = (f2){t0.x, t0.y} * w0, vb = (f2){t0.z, t0.w} * w0;                                                \
+            va = pk_fma((f2){t1.x, t1.y}, w1, va); vb = pk_fma((f2){t1.z, t1.w}, w1, vb);                             \
+            va = pk_fma((f2){t2.x, t2.y}, w2, va); vb = pk_fma((f2){t2.z, t2.w}, w2, vb);                             \
+            va = pk_fma((f2){t3.x, t3.y}, w3, va); vb = pk_fma((f2){t3.z, t3.w}, w3, vb);                             \
+            S_[SS][0] = S_[SS][0] + va; S_[SS][1] = S_[SS][1] + vb;                                                   \
+            Q_[SS][0] = pk_fma(va, va, Q_[SS][0]); Q_[SS][1] = pk_fma(vb, vb, Q_[SS][1]);                             \
+            if (G > 1) __builtin_amdgcn_sched_barrier(0); /* 128-VGPR budget: keep the steps' live ranges apart */  \
+        }
+#define MVS_LDS_TAP(O) s_box[(O) + g]
+#define MVS_GLB_TAP(O) nb_img[j][(O) + g]
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            if (skip[j]) continue;  // S and Q keep their values: the warped features are all zero
-            if (!early[j] && staged[j]) load_box(j, bx0[j], by0[j], nc[j], nr[j]);
-            // The LDS-DMA pieces of this wave count on vmcnt, and for a workgroup barrier hipcc only waits for
-            // lgkmcnt: without the explicit wait a wave can pass the barrier while its own pieces are still in flight
-            // and the other waves read stale box texels.  (Found when a variant let some waves skip the decode, whose
-            // scratch reload had been supplying a vmcnt(0) by accident.)  s_waitcnt 0 = vmcnt, expcnt and lgkmcnt all
-            // zero, so the decode's LDS table writes are covered by the same instruction.  Costs nothing measurable.
-            if (staged[j]) __builtin_amdgcn_s_waitcnt(0);
-            if (staged[j] || !tables_visible) __syncthreads();  // box (and, the first time, the tables) visible
-            tables_visible = true;
-            MVS_STAMP(2 + 2 * (j > 0 ? 1 : 0))  // (DMA issue of neighbour j>0) + wait for the box + barrier
-            if (!prefetched && d + 1 < d_end) prefetch(d + 1);  // lands while the taps below are computed
-            prefetched = true;
-            // ---- P3: taps -> warped value -> running sums
-            if (staged[j]) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int p = (wave * 4 + s) * 8 + ps;
-                    const int4 o = s_off[j][p];
-                    const float4 w = s_w[j][p];
-                    const float4 t0 = s_box[o.x + g], t1 = s_box[o.y + g], t2 = s_box[o.z + g], t3 = s_box[o.w + g];
-                    const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};
-                    const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = a0[i] * w.x;
-                        v = fmaf(a1[i], w.y, v);
-                        v = fmaf(a2[i], w.z, v);
-                        v = fmaf(a3[i], w.w, v);
-                        S_[s][i] = S_[s][i] + v;
-                        Q_[s][i] = fmaf(v, v, Q_[s][i]);
-                    }
-                }
-            } else {  // fallback: footprint too large (or empty): taps straight from the slab image
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int p = (wave * 4 + s) * 8 + ps;
-                    const int4 o = s_off[j][p];
-                    const float4 w = s_w[j][p];
-                    const float4* b = nb_img[j] + g;
-                    const float4 t0 = b[o.x], t1 = b[o.y], t2 = b[o.z], t3 = b[o.w];
-                    const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};
-                    const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float v = a0[i] * w.x;
-                        v = fmaf(a1[i], w.y, v);
-                        v = fmaf(a2[i], w.z, v);
-                        v = fmaf(a3[i], w.w, v);
-                        S_[s][i] = S_[s][i] + v;
-                        Q_[s][i] = fmaf(v, v, Q_[s][i]);
-                    }
-                }
+            const unsigned fj = fl >> (4 * j);
+            if (!(fj & kFlagLive)) continue;  // nothing of this neighbour is visible: its warped features are all zero
+            // ---- decode this plane's table entry of the lane's pixel-step (tap origin, weights, tap offsets)
+            const SampleTaps tp = decode_sample(en[j].x, en[j].y, H, W);
+            const float4 w = tap_weights(tp);
+            DecodedTaps dt;
+            dt.w0 = w.x; dt.w1 = w.y; dt.w2 = w.z; dt.w3 = w.w;
+            if (fj & kFlagStaged) {  // taps from the resident box
+                const int pitch = rx1[j] - rx0[j] + 1;
+                const int xa = clampi(tp.x0, rx0[j], rx1[j]) - rx0[j], xb = clampi(tp.x0 + 1, rx0[j], rx1[j]) - rx0[j];
+                const int ya = (clampi(tp.y0, ry0[j], ry1[j]) - ry0[j]) * pitch, yb = (clampi(tp.y0 + 1, ry0[j], ry1[j]) - ry0[j]) * pitch;
+                dt.o0 = box_slot(ya + xa) * 8 + j * slot_f4; dt.o1 = box_slot(ya + xb) * 8 + j * slot_f4;
+                dt.o2 = box_slot(yb + xa) * 8 + j * slot_f4; dt.o3 = box_slot(yb + xb) * 8 + j * slot_f4;
+                MVS_TAP_STEP(0, MVS_LDS_TAP) MVS_TAP_STEP(1, MVS_LDS_TAP) MVS_TAP_STEP(2, MVS_LDS_TAP) MVS_TAP_STEP(3, MVS_LDS_TAP)
+            } else {                 // footprint too large (or empty with non-finite positions): taps from the slab image
+                const int xa = clampi(tp.x0, 0, W - 1), xb = clampi(tp.x0 + 1, 0, W - 1);
+                const int ya = clampi(tp.y0, 0, H - 1) * W, yb = clampi(tp.y0 + 1, 0, H - 1) * W;
+                dt.o0 = (ya + xa) * 8; dt.o1 = (ya + xb) * 8; dt.o2 = (yb + xa) * 8; dt.o3 = (yb + xb) * 8;
+                MVS_TAP_STEP(0, MVS_GLB_TAP) MVS_TAP_STEP(1, MVS_GLB_TAP) MVS_TAP_STEP(2, MVS_GLB_TAP) MVS_TAP_STEP(3, MVS_GLB_TAP)
             }
-            if (staged[j]) __syncthreads();  // box fully read before it is overwritten (next neighbour / output tile)
-            MVS_STAMP(3 + 2 * (j > 0 ? 1 : 0))  // taps + barrier
         }
-        if (!prefetched && d + 1 < d_end) prefetch(d + 1);  // every neighbour was skipped
-        // ---- P4: variance -> output tile [channel row 8*i+g][pixel]
-        float* s_tile = reinterpret_cast<float*>(s_box);
-        {
-            float* t = s_tile + g * kTileStride + wave * 32 + ps;
+#undef MVS_TAP_STEP
+#undef MVS_LDS_TAP
+#undef MVS_GLB_TAP
+        if (K > 0 && !(dbg & 2)) {
+            // request the entries of own plane m + 3 (into the ring slot read one own plane ago).  Placed here, a whole
+            // tap phase after this wave's last stores: a vector-memory instruction issued right behind a burst of stores
+            // waits at issue until the store path has taken them.
+            asm volatile("" ::: "memory");
+            mark0 = mark1; mark1 = mark2;
+            if (m_own + 3 < n_own && !(dbg & 32)) { request(m_own + 3); ++issued; }
+            mark2 = issued;
+            asm volatile("" ::: "memory");
+        }
+        ++m_own;
+        // ---- variance (channel 8*i + g, the lane's 4 consecutive pixels): kept in registers, stored at the top of the
+        //      next iteration (after a possible box refill, whose vmcnt(0) then only meets stores a whole plane old)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float m = S_[s][i] * rcp;
-                    t[8 * i * kTileStride + s * 8] = fmaf(-m, m, Q_[s][i] * rcp);
-                }
+                const float sv = (i & 1) ? S_[s][i >> 1].y : S_[s][i >> 1].x;
+                const float qv = (i & 1) ? Q_[s][i >> 1].y : Q_[s][i >> 1].x;
+                const float m = sv * rcp;
+                vout[i][s] = fmaf(-m, m, qv * rcp);
             }
         }
-        // same-wave hand-over through LDS: the LDS queue of a wave is in order, only the compiler must not move
-        // the reads above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        MVS_STAMP(6)  // variance -> LDS tile
-        // ---- P5: every wave stores its own 32 pixels: 8 channel rows per instruction, 16 bytes per lane
-        {
-            const float* t = s_tile + sh * kTileStride + st_p;
-            int c0 = slab * kSlab + sh;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = c0 + 8 * k;
-                const float4 v = *reinterpret_cast<const float4*>(t + 8 * k * kTileStride);
-                if (c < C) {
-                    OutT* dst = var + (((size_t)n * C + c) * D + d) * HW + st_off;
-                    // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs
-                    if constexpr (sizeof(OutT) == 4) {
-                        if (st_vec) {
-                            typedef float v4f __attribute__((ext_vector_type(4)));
-                            const v4f vv = {v.x, v.y, v.z, v.w};
-                            if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
-                            else *reinterpret_cast<v4f*>(dst) = vv;
-                        } else {
-                            const float a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (i < st_n) dst[i] = a[i];
-                        }
-                    } else {
-                        const __half h[4] = {__float2half_rn(v.x), __float2half_rn(v.y), __float2half_rn(v.z),
-                                             __float2half_rn(v.w)};
-                        if (st_vec) {  // 4 pixels x 2 B: the fp32 alignment condition also gives 8-byte alignment
-                            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                            const v2u vv = {(unsigned)__half_as_ushort(h[0]) | ((unsigned)__half_as_ushort(h[1]) << 16),
-                                            (unsigned)__half_as_ushort(h[2]) | ((unsigned)__half_as_ushort(h[3]) << 16)};
-                            if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v2u*>(dst));
-                            else *reinterpret_cast<v2u*>(dst) = vv;
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (i < st_n) dst[i] = h[i];
-                        }
-                    }
-                }
-            }
-        }
-        MVS_STAMP(7)  // tile -> global stores
+        d_pending = d;
     }
-    if (STAMP && stamps && lane == 0 && blockIdx.x < 65536) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) stamps[((size_t)blockIdx.x * 4 + wave) * 8 + kk] = tacc[kk];
-    }
-#undef MVS_STAMP
+    if (d_pending >= 0) flush(d_pending);
 }
 
 }  // namespace mvsdet

@@ -182,7 +182,9 @@ def plane_sweep_table(proj: Tensor, depth: Tensor, H: int, W: int) -> Tensor:
 
 @plane_sweep_table.register_fake
 def _(proj, depth, H, W):
-    return proj.new_empty(4)
+    # same size as the real op: the scratch-size query is a host-only function of the shape
+    sbytes = _lib.load().mvsdet_plane_sweep_scratch_bytes(proj.shape[0], proj.shape[1], depth.shape[1], H, W)
+    return proj.new_empty(max(sbytes // 4, 4))
 
 
 @torch.library.custom_op(f"{_NS}::plane_sweep_variance_tabled", mutates_args=(), device_types="cuda")

@@ -461,23 +461,29 @@ def test_training_step_through_forward_scene(gpu):
     assert abs(fd.item() - an.item()) <= 2e-2 * max(abs(an.item()), 1e-6) + 1e-7, (fd.item(), an.item())
 
 
-def test_sweep_variants_are_bit_identical(gpu, monkeypatch):
-    """The tuning knobs only change the schedule: tile shape 16x8 vs 32x4, LDS-staged boxes vs the global-gather
-    fallback (what a footprint larger than the LDS box takes) and plain vs non-temporal stores give the same bits."""
-    from mvsdet_amd import ops
+def test_sweep_variants_are_bit_identical(gpu):
+    """The tuning options only change the schedule: tile shape 16x8 vs 32x4, four or eight waves per block, resident
+    LDS boxes of several capacities (runs of planes per box) vs the global-gather fallback give the same bits."""
+    from mvsdet_amd import _lib, ops
     g = load_golden("g2_variance_n3_d8")
     feat = dev(g["feature"], gpu)
     N, C, H, W = feat.shape
     args = (ops.pack_features(feat), dev(g["neighbor_ids"], gpu), dev(g["proj_rel"], gpu), dev(g["depth_values"], gpu), C, H, W)
     ref = ops.plane_sweep_variance_packed(*args)
-    for env in ({"MVSDET_SWEEP_TW": "16"}, {"MVSDET_SWEEP_TW": "32"}, {"MVSDET_SWEEP_BOXCAP": "0"},
-                {"MVSDET_SWEEP_BOXCAP": "40"}, {"MVSDET_SWEEP_NT": "0"}, {"MVSDET_SWEEP_TW": "16", "MVSDET_SWEEP_BOXCAP": "0"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        out = ops.plane_sweep_variance_packed(*args)
-        for k in env:
-            monkeypatch.delenv(k)
-        assert torch.equal(out, ref), env
+    saved = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap", "sweep_groups", "sweep_xcd")}
+    try:
+        for opts in ({"sweep_tw": 16}, {"sweep_tw": 32}, {"sweep_boxcap": 0}, {"sweep_boxcap": 40}, {"sweep_boxcap": 320},
+                     {"sweep_groups": 1}, {"sweep_groups": 2}, {"sweep_tw": 16, "sweep_boxcap": 0, "sweep_groups": 1},
+                     {"sweep_tw": 32, "sweep_boxcap": 96, "sweep_groups": 2, "sweep_xcd": 0}):
+            for k, v in {**saved, **opts}.items():
+                _lib.set_option(k, v)
+            out = ops.plane_sweep_variance_packed(*args)
+            assert torch.equal(out, ref), opts
+    finally:
+        for k, v in saved.items():
+            _lib.set_option(k, v)
+    with pytest.raises(ValueError):
+        _lib.set_option("no_such_option", 1)
 
 
 def test_sweep_degenerate_geometry(gpu, oracle):
