@@ -282,7 +282,7 @@ def footprint_stats(w, hp, scene, device):
     tiles = ((W + tw - 1) // tw) * ((H + 128 // tw - 1) // (128 // tw))
     table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
     nent = N * tiles * D * K
-    b = table[nent * 256: nent * 256 + nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)
+    b = table[:nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)  # boxes lead the scratch buffer
     nc, nr = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
     empty = (nc <= 0) | (nr <= 0)
     area = np.where(empty, 0, nc * nr)

@@ -33,7 +33,7 @@ extern "C" {
 
 #define MVSDET_MAX_NEIGHBORS 4 /* k source views per reference view (reference: k = min(2, N-1)) */
 #define MVSDET_MAX_TOPK 8      /* depth candidates per pixel (reference: topk = 3) */
-#define MVSDET_MAX_DEPTH 512   /* depth planes (reference: 12) */
+#define MVSDET_MAX_DEPTH 512   /* depth planes (reference: 12; BASELINE configs go to 128) */
 
 typedef void* mvsdet_stream_t; /* hipStream_t */
 
@@ -96,10 +96,11 @@ int mvsdet_homo_warp_f32(const float* src, const float* proj, const float* depth
  *   proj (N,K,4,4) = nei_proj[n][j] @ inverse(ref_proj[n]);  depth (N,D);
  *   var (N,C,D,H,W) = sum_sq/(K+1) - (sum/(K+1))^2 over {ref, warped_1..K}  (mvsdet.py:467).
  * `scratch` (16-byte aligned, >= mvsdet_plane_sweep_scratch_bytes(N,K,D,H,W)) receives the
- * channel-independent sampling table the sweep builds first: 8 B per (view, neighbour, plane,
- * pixel) = the un-normalised sample position (about 1.5 % of the cost volume), and per (view, tile,
- * plane, neighbour) the footprint box that the sweep keeps resident in LDS -- shared by runs of
- * consecutive planes (sweep_kernel.h).
+ * channel-independent sweep geometry the sweep builds first: per (view, 128-pixel tile, plane,
+ * neighbour) the footprint box that the sweep keeps resident in LDS -- shared by runs of
+ * consecutive planes (sweep_kernel.h) --, one flags word per (view, tile, plane), and copies of
+ * proj / depth: 20 B per (view, tile, plane) and neighbour, 0.03 % of the cost volume.  The sample
+ * positions themselves are recomputed by the sweep (the reference builds its grid per plane too).
  * The _f32 form packs `feat` (N,C,H,W dense) into `workspace` first
  * (workspace_bytes >= mvsdet_plane_sweep_workspace_bytes(N,K,C,D,H,W) = packed + scratch).
  * ------------------------------------------------------------------------------------------- */
@@ -124,9 +125,10 @@ int mvsdet_plane_sweep_variance_shard_f16(const float* packed, const int64_t* nb
                                           const float* depth, void* var_f16, void* scratch, size_t scratch_bytes,
                                           int N_src, int ref_first, int M, int K, int C, int D, int H, int W,
                                           mvsdet_stream_t stream);
-/* The two halves of the call above, for callers that want to time / overlap / reuse them:
- *   mvsdet_plane_sweep_table_f32           builds the sampling table of a scene's geometry into `scratch`;
- *   mvsdet_plane_sweep_variance_tabled_f32 runs the per-channel sweep on a table built by it for the SAME
+/* The two halves of the call above, for callers that want to time / overlap / reuse them (the geometry of a scene can
+ * be built once and swept with any number of feature sets):
+ *   mvsdet_plane_sweep_table_f32           builds the sweep geometry of a scene's cameras into `scratch`;
+ *   mvsdet_plane_sweep_variance_tabled_f32 runs the per-channel sweep on a geometry built by it for the SAME
  *                                          (N,K,D,H,W) (table_bytes = the scratch size passed there). */
 int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,
                                  int N, int K, int D, int H, int W, mvsdet_stream_t stream);
@@ -139,7 +141,8 @@ int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const
 /* backward of the above w.r.t. feat (the sampling grid carries no gradient, module.py:115).
  *   g (N,C,D,H,W) = dL/dvar;  gfeat (N,C,H,W) is OVERWRITTEN with dL/dfeat.
  *   workspace_bytes >= mvsdet_plane_sweep_bwd_workspace_bytes(N,K,C,D,H,W)
- *   (packed features + packed gradient + sampling table). */
+ *   (packed features + packed gradient + sweep geometry + the sampling positions, 8 B per view, pixel, plane and
+ *   neighbour, which the backward pass reads instead of recomputing). */
 size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, int D, int H, int W);
 int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, const float* proj,
                                         const float* depth, const float* g, float* gfeat, void* workspace,

@@ -21,7 +21,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 Options& options() {
-    static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 256), env_int("MVSDET_SWEEP_XCD", 1),
+    static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1),
                         env_int("MVSDET_SWEEP_GROUPS", 1), 0};
     return o;
 }

@@ -23,6 +23,15 @@ struct Options {
 };
 Options& options();
 
+// where plane_sweep_coords_kernel leaves the sweep geometry inside the scratch buffer (planesweep.hip)
+struct SweepGeometry {
+    int4* boxes;
+    unsigned* flags;
+    float* proj;
+    float* depth;
+};
+SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles);
+
 constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kThreads = 256;   // 4 waves, one per SIMD
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, blocks are dealt round-robin over them

@@ -118,17 +118,17 @@ int num_tiles(int H, int W, int tw) {
 }
 
 // texels of one LDS footprint box: K resident boxes of 128-byte texels, two blocks per CU (80 KiB each)
-int effective_box_cap(int K, int G) {
+int effective_box_cap(int K) {
     if (K <= 0) return 0;
     int cap = options().sweep_boxcap;
-    const int fit = (int)((80 * 1024 - sweep_lds_bytes(K, G, 0)) / 128) / K;  // sweep_lds_bytes(.., 0) = pads + loader ring
+    const int fit = (80 * 1024 / 128) / K - kBoxPad;
     cap = cap < 0 ? 0 : (cap > fit ? fit : cap);
     return cap > 512 ? 512 : cap;
 }
 
 template <typename F>
 int allow_dynamic_lds(F* kernel, size_t bytes) {
-    // above 64 KiB of dynamic LDS the launch needs the function attribute; set once per kernel (host-side state,
+    // above 48 KiB of dynamic LDS the launch needs the function attribute; set once per kernel (host-side state,
     // nothing is enqueued: safe under stream capture)
     if (bytes <= 48 * 1024) return MVSDET_OK;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
@@ -138,26 +138,49 @@ int allow_dynamic_lds(F* kernel, size_t bytes) {
     return MVSDET_OK;
 }
 
+size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+}  // namespace
+
+namespace mvsdet {
+// Sweep geometry in the scratch buffer (built by plane_sweep_coords_kernel, consumed by the slab kernels):
+//   boxes [N*tiles*D*K] int4 | flags [N*tiles*D] u32 | proj copy [N*K*16] f32 | depth copy [N*D] f32
+// `tiles` is that of the tile width in force; the size query assumes the larger of the two tile shapes.
+SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles) {
+    SweepGeometry g;
+    char* p = static_cast<char*>(scratch);
+    g.boxes = reinterpret_cast<int4*>(p);
+    p += (size_t)N * tiles * D * K * sizeof(int4);
+    g.flags = reinterpret_cast<unsigned*>(p);
+    p += align16((size_t)N * tiles * D * sizeof(unsigned));
+    g.proj = reinterpret_cast<float*>(p);
+    p += align16((size_t)N * K * 16 * sizeof(float));
+    g.depth = reinterpret_cast<float*>(p);
+    return g;
+}
+}  // namespace mvsdet
+
+namespace {
 template <int KV, int TW, int G, typename OutT>
 int launch_slab(dim3 grid, hipStream_t stream, size_t lds, const float* packed, const float* ref_packed, const int64_t* nbr,
-                const float2* table, const int4* boxes, const unsigned* flags, OutT* var, int n_src, int C, int S, int D, int H, int W, int tiles_x,
+                const SweepGeometry& geo, OutT* var, int n_src, int C, int S, int D, int H, int W, int tiles_x,
                 int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
     auto* k = plane_sweep_variance_kernel<KV, TW, G, true, OutT>;
     if (int rc = allow_dynamic_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(kThreads * G), lds, stream, packed, ref_packed, nbr, table, boxes, flags, var, n_src, C, S, D,
-                       H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts, options().sweep_debug);
+    hipLaunchKernelGGL(k, grid, dim3(kThreads * G), lds, stream, packed, ref_packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags,
+                       var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts, options().sweep_debug);
     return MVSDET_OK;
 }
 
 template <int TW>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, void* var_any,
-                 void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
+                 void* scratch, void* table, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
                  int ref_first, bool half_out) {
     float* var = static_cast<float*>(var_any);
     __half* var16 = static_cast<__half*>(var_any);  // half_out: same kernel, variance rounded to fp16 at the store
-    // phases: bit 0 = build the sampling table (coords kernel), bit 1 = run the slab kernel
-    // N reference views starting at view ref_first of the n_src packed source views (a view shard; N == n_src
-    // and ref_first == 0 for a whole scene); nbr / proj / depth / var / scratch are indexed by the LOCAL view
+    // phases: bit 0 = build the sweep geometry (coords kernel; + the sampling table when `table` is given), bit 1 = run
+    // the slab kernel.  N reference views starting at view ref_first of the n_src packed source views (a view shard;
+    // N == n_src and ref_first == 0 for a whole scene); nbr / proj / depth / var / scratch are indexed by the LOCAL view
     constexpr int TH = kTilePix / TW;
     const int S = num_slabs(C);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -168,43 +191,38 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         return MVSDET_ERR_INVALID_ARG;
     }
     const int G = options().sweep_groups == 2 ? 2 : 1;
-    const int box_cap = effective_box_cap(K, G);
+    const int box_cap = effective_box_cap(K);
     // every block sweeps all its planes (reference features stay in registers, a resident footprint box serves a run
     // of planes) unless the grid would be too small to fill 256 CUs x 2 blocks
     int dsplit = 1;
     while (nblocks * dsplit < 1024 && D / (dsplit * 2) >= 2 * G) dsplit *= 2;
     const int d_per_block = (D + dsplit - 1) / dsplit;
-    float2* table = reinterpret_cast<float2*>(scratch);
-    int4* boxes = reinterpret_cast<int4*>(table + (size_t)N * tiles * D * K * kTilePix);
-    unsigned* flags = reinterpret_cast<unsigned*>(boxes + (size_t)N * tiles * D * K);
+    const SweepGeometry geo = sweep_geometry(scratch, N, K, D, tiles);
     dim3 cgrid((unsigned)(N * tiles));
-    // XCD-aware id -> (slab, tile) map for fewer than 8 slabs (see the kernel); option "sweep_xcd" = 0 switches it off
     const int n_bt = N * tiles;
-    // option "sweep_xcd": 0 = slab = id % S; 1 = slab-major (an XCD owns a slab; compacted for fewer than 8 slabs);
-    // 2 = tile-major (an XCD owns (view, tile) pairs and runs all their slabs: the table is read once per XCD)
+    // option "sweep_xcd": 0 = slab = id % S; 1 = an XCD owns a slab (compacted for fewer than 8 slabs)
     int xcd_parts = 1;
     long long grid_x = nblocks;
-    if (options().sweep_xcd == 2 && S > 1) {
-        xcd_parts = -1;
-        grid_x = 8LL * ((n_bt + 7) / 8) * S;
-    } else if (S < 8 && 8 % S == 0 && options().sweep_xcd != 0) {
+    if (S < 8 && 8 % S == 0 && options().sweep_xcd != 0) {
         xcd_parts = 8 / S;
         grid_x = 8LL * ((n_bt + xcd_parts - 1) / xcd_parts);
     }
     dim3 grid((unsigned)grid_x, (D + d_per_block - 1) / d_per_block);
     const float* ref_packed = packed ? packed + (size_t)ref_first * S * H * W * kSlab : nullptr;
-    const size_t lds = sweep_lds_bytes(K, G, box_cap);
+    const size_t lds = sweep_lds_bytes(K, box_cap);
     int rc = MVSDET_OK;
 #define MVS_SLAB(KV, GV)                                                                                               \
-    (half_out ? launch_slab<KV, TW, GV, __half>(grid, stream, lds, packed, ref_packed, nbr, table, boxes, flags, var16, n_src, C, S, \
+    (half_out ? launch_slab<KV, TW, GV, __half>(grid, stream, lds, packed, ref_packed, nbr, geo, var16, n_src, C, S,   \
                                                 D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts)       \
-              : launch_slab<KV, TW, GV, float>(grid, stream, lds, packed, ref_packed, nbr, table, boxes, flags, var, n_src, C, S, D, \
+              : launch_slab<KV, TW, GV, float>(grid, stream, lds, packed, ref_packed, nbr, geo, var, n_src, C, S, D,   \
                                                H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts))
 #define MVS_SWEEP_CASE(KV)                                                                                            \
     case KV:                                                                                                          \
         if (phases & 1)                                                                                               \
-            hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads), 0, stream, proj, depth,    \
-                               table, boxes, flags, D, H, W, tiles_x, tiles, box_cap);                                       \
+            hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads),                            \
+                               (size_t)D * (KV * sizeof(int4) + sizeof(unsigned)), stream, proj, depth,               \
+                               static_cast<float2*>(table), geo.boxes, geo.flags, geo.proj, geo.depth, D, H, W,       \
+                               tiles_x, tiles, box_cap);                                                              \
         if (phases & 2) rc = (G == 1) ? MVS_SLAB(KV, 1) : MVS_SLAB(KV, 2);                                            \
         break;
     switch (K) {
@@ -226,21 +244,32 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
 
 namespace mvsdet {
 int sweep_tile_width(int W) { return pick_tile_width(W); }  // shared with planesweep_bwd.hip
-int sweep_box_cap(int K) { return effective_box_cap(K, options().sweep_groups == 2 ? 2 : 1); }
+int sweep_box_cap(int K) { return effective_box_cap(K); }
+int sweep_num_tiles(int H, int W) { return num_tiles(H, W, pick_tile_width(W)); }
 }
 
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W) {
     if (N <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    // sampling table (8 B per view, neighbour, plane, tile pixel) + footprint boxes (16 B per view, neighbour,
-    // plane, tile); sized for the larger of the two tile shapes so the knob cannot outgrow it
+    // footprint boxes (16 B per view, tile, plane, neighbour) + flags (4 B per view, tile, plane) + copies of the camera
+    // data; sized for the larger of the two tile shapes so the "sweep_tw" option cannot outgrow it
     const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
-    // + one flags word per (view, tile, plane)
-    return (size_t)N * tiles * D * K * (kTilePix * sizeof(float2) + sizeof(int4)) + (((size_t)N * tiles * D * 4 + 15) & ~(size_t)15);
+    return (size_t)N * tiles * D * K * sizeof(int4) + align16((size_t)N * tiles * D * sizeof(unsigned)) +
+           align16((size_t)N * K * 16 * sizeof(float)) + align16((size_t)N * D * sizeof(float));
 }
+
+// the backward pass also wants the sampling positions themselves: 8 B per (view, tile pixel, plane, neighbour)
+namespace mvsdet {
+size_t sweep_table_bytes(int N, int K, int D, int H, int W) {
+    if (N <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
+    return (size_t)N * tiles * D * K * kTilePix * sizeof(float2);
+}
+}  // namespace mvsdet
 
 static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,
                        void* var, void* scratch, size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
-                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0, bool half_out = false) {
+                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0, bool half_out = false,
+                       void* table = nullptr) {
     if (n_src < 0) n_src = N;
     MVS_REQUIRE(ref_first >= 0 && N <= n_src && ref_first <= n_src - N,
                 "%s: reference views [%d, %d) outside the %d packed views", name, ref_first, ref_first + N, n_src);
@@ -250,7 +279,7 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     MVS_REQUIRE(K == 0 || !(phases & 2) || nbr, "%s: NULL neighbour ids", name);
     MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "%s: bad shape N=%d C=%d D=%d H=%d W=%d", name, N, C, D, H, W);
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "%s: K=%d outside [0,%d]", name, K, MVSDET_MAX_NEIGHBORS);
-    MVS_REQUIRE(D <= 65535 && H < 65535 && W < 65535, "%s: D, H or W > 65534", name);
+    MVS_REQUIRE(D <= MVSDET_MAX_DEPTH && H < 65535 && W < 65535, "%s: D > %d, or H or W > 65534", name, MVSDET_MAX_DEPTH);
     MVS_REQUIRE((size_t)8 * D * H * W * sizeof(float) < ((size_t)1 << 32), "%s: 8 channel rows of the cost volume (8*D*H*W floats) exceed 4 GiB", name);
     MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "%s: one slab image exceeds 2^31 elements", name);
     if (scratch_bytes < mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)) {
@@ -260,8 +289,8 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "%s: scratch must be 16-byte aligned", name);
     const int tw = pick_tile_width(W);
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
-    return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, table, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, table, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
@@ -293,6 +322,15 @@ extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* dept
     return sweep_entry("plane_sweep_table", nullptr, nullptr, proj, depth, nullptr, scratch, scratch_bytes, N, K, 1, D, H, W,
                        stream, 1);
 }
+
+namespace mvsdet {
+// planesweep_bwd.hip: sweep geometry into `scratch` plus the sampling table into `table`
+int sweep_build_geometry_and_table(const float* proj, const float* depth, void* scratch, size_t scratch_bytes, void* table,
+                                   int N, int K, int D, int H, int W, mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_table", nullptr, nullptr, proj, depth, nullptr, scratch, scratch_bytes, N, K, 1, D, H, W,
+                       stream, 1, -1, 0, false, table);
+}
+}  // namespace mvsdet
 
 extern "C" int mvsdet_plane_sweep_variance_tabled_f32(const float* packed, const int64_t* nbr, const void* table,
                                                       size_t table_bytes, float* var, int N, int K, int C, int D, int H,

@@ -253,15 +253,17 @@ using namespace mvsdet;
 
 // defined in planesweep.hip
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W);
-extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,
-                                            int N, int K, int D, int H, int W, mvsdet_stream_t stream);
 namespace mvsdet {
-int sweep_tile_width(int W);  // planesweep.hip: the tile shape the sampling table was built for
+size_t sweep_table_bytes(int N, int K, int D, int H, int W);
+int sweep_tile_width(int W);  // the tile shape the sweep geometry is built for
+int sweep_build_geometry_and_table(const float* proj, const float* depth, void* scratch, size_t scratch_bytes, void* table,
+                                   int N, int K, int D, int H, int W, mvsdet_stream_t stream);
 }
 
 extern "C" size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, int D, int H, int W) {
     const size_t pb = (mvsdet_packed_bytes(N, C, H, W) + 255) / 256 * 256;
-    return 2 * pb + mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W);
+    const size_t sb = (mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W) + 255) / 256 * 256;
+    return 2 * pb + sb + sweep_table_bytes(N, K, D, H, W);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, const float* proj,
@@ -276,14 +278,16 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     MVS_REQUIRE(D <= 65535 && H < 65535 && W < 65535, "plane_sweep_variance_bwd: D, H or W > 65534");
     MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "plane_sweep_variance_bwd: one slab image exceeds 2^31 elements");
     const size_t pb = (mvsdet_packed_bytes(N, C, H, W) + 255) / 256 * 256;
-    const size_t sb = mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W);
-    if (workspace_bytes < 2 * pb + sb) {
-        set_error("plane_sweep_variance_bwd: workspace %zu B < %zu B", workspace_bytes, 2 * pb + sb);
+    const size_t sb = (mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W) + 255) / 256 * 256;
+    const size_t tb = sweep_table_bytes(N, K, D, H, W);
+    if (workspace_bytes < 2 * pb + sb + tb) {
+        set_error("plane_sweep_variance_bwd: workspace %zu B < %zu B", workspace_bytes, 2 * pb + sb + tb);
         return MVSDET_ERR_WORKSPACE;
     }
     float* packed = (float*)workspace;
     float* gpacked = (float*)((char*)workspace + pb);
     void* scratch = (char*)workspace + 2 * pb;
+    void* table_mem = (char*)workspace + 2 * pb + sb;
     const int64_t fs[4] = {(int64_t)C * H * W, (int64_t)H * W, W, 1};
     if (int rc = mvsdet_pack_features_f32(feat, fs, packed, N, C, H, W, stream_)) return rc;
     if (hipMemsetAsync(gpacked, 0, pb, stream) != hipSuccess) {
@@ -291,7 +295,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
         return MVSDET_ERR_HIP;
     }
     if (K > 0)
-        if (int rc = mvsdet_plane_sweep_table_f32(proj, depth, scratch, sb, N, K, D, H, W, stream_)) return rc;
+        if (int rc = sweep_build_geometry_and_table(proj, depth, scratch, sb, table_mem, N, K, D, H, W, stream_)) return rc;
     const int tw = sweep_tile_width(W);
     const int th = kTilePix / tw;
     const int S = num_slabs(C);
@@ -299,8 +303,8 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     const int tiles_x = (W + tw - 1) / tw, tiles = tiles_x * ((H + th - 1) / th);
     const long long nblocks = (long long)N * tiles * S;
     MVS_REQUIRE(nblocks <= INT32_MAX, "plane_sweep_variance_bwd: grid too large");
-    const float2* table = reinterpret_cast<const float2*>(scratch);
-    const int4* boxes = reinterpret_cast<const int4*>(table + (size_t)N * tiles * D * K * kTilePix);
+    const float2* table = reinterpret_cast<const float2*>(table_mem);
+    const int4* boxes = sweep_geometry(scratch, N, K, D, tiles).boxes;
     dim3 grid((unsigned)nblocks);
 #define MVS_BWD_CASE(KV)                                                                                               \
     case KV:                                                                                                           \

@@ -29,6 +29,8 @@
 // Arithmetic (device rounding, oracle mode 1): warped = fma chain over the 4 taps; S = f + w1 + ..;
 // Q = fma(w,w,Q); var = fma(-m, m, Q*r) with m = S*r, r = 1/(K+1).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "pack.h"
 
@@ -99,23 +101,35 @@ constexpr int kBoxSkip = INT32_MIN;       // boxes[].w of an empty footprint who
 constexpr int kBoxEmpty = INT32_MIN + 1;  // empty footprint with a non-finite position: taps run and give NaN
 constexpr float kNoSample = -2.0f;  // entry of a tile pixel outside the image: no tap inside, all weights +0
 
-__device__ __forceinline__ float2 sample_position(const float* __restrict__ P, float x, float y, float d, int H, int W) {
-    const float rx = fmaf(P[1], y, P[0] * x) + P[2];
-    const float ry = fmaf(P[5], y, P[4] * x) + P[6];
-    const float rz = fmaf(P[9], y, P[8] * x) + P[10];
-    const float X = rx * d + P[3];
-    const float Y = ry * d + P[7];
-    const float Z = rz * d + P[11];
+// module.py:116-143 in two steps, shared by the geometry kernel (footprint boxes, table for the backward pass) and the
+// slab kernel (positions recomputed per plane), so both get the same bits: the plane-independent ray of a pixel,
+// rot @ [x, y, 1], and the un-normalised sample position on the plane of depth d.
+struct SampleRay { float rx, ry, rz; };
+__device__ __forceinline__ SampleRay sample_ray(const float* __restrict__ P, float x, float y) {
+    SampleRay r;
+    r.rx = fmaf(P[1], y, P[0] * x) + P[2];
+    r.ry = fmaf(P[5], y, P[4] * x) + P[6];
+    r.rz = fmaf(P[9], y, P[8] * x) + P[10];
+    return r;
+}
+__device__ __forceinline__ float2 sample_at(const SampleRay& r, float t0, float t1, float t2, float d, int H, int W) {
+    const float X = r.rx * d + t0;
+    const float Y = r.ry * d + t1;
+    const float Z = r.rz * d + t2;
     const float px = X / Z;
     const float py = Y / Z;
     const float gx = px / ((float)(W - 1) * 0.5f) - 1.0f;
     const float gy = py / ((float)(H - 1) * 0.5f) - 1.0f;
     return make_float2(fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f), fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f));
 }
+__device__ __forceinline__ float2 sample_position(const float* __restrict__ P, float x, float y, float d, int H, int W) {
+    return sample_at(sample_ray(P, x, y), P[3], P[7], P[11], d, H, W);
+}
 
 // ---------------------------------------------------------------------------------------------
-// (1) sampling table: block = (view, tile); thread = (neighbour, pixel); loops over all planes.
-//     table [((n*tiles + tile)*D + d)*K + j][128] float2;  boxes [((n*tiles + tile)*D + d)*K + j] int4.
+// (1) sweep geometry: block = (view, tile); thread = (neighbour, pixel); loops over all planes.
+//     boxes [((n*tiles + tile)*D + d)*K + j] int4, flags [(n*tiles + tile)*D + d]; copies of proj / depth for the slab
+//     kernel; table [((n*tiles + tile)*D + d)*K + j][128] float2 only where the backward pass asks for it (table != NULL).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool box_nonempty(const int4& b) { return b.y >= b.x && b.w >= b.z; }
 __device__ __forceinline__ int box_area(const int4& b) { return (b.y - b.x + 1) * (b.w - b.z + 1); }
@@ -124,11 +138,15 @@ template <int K, int TW>
 __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const float* __restrict__ proj,
                                                                        const float* __restrict__ depth,
                                                                        float2* __restrict__ table, int4* __restrict__ boxes,
-                                                                       unsigned* __restrict__ flags, int D, int H, int W,
+                                                                       unsigned* __restrict__ flags, float* __restrict__ proj_copy,
+                                                                       float* __restrict__ depth_copy, int D, int H, int W,
                                                                        int tiles_x, int tiles, int box_cap) {
     constexpr int TH = kTilePix / TW;
     constexpr int ITER = (K * kTilePix + kThreads - 1) / kThreads;
     __shared__ int s_red[2][K][2][5];  // [plane parity][neighbour][wave of the neighbour][xlo,xhi,ylo,yhi,all finite]
+    extern __shared__ int4 s_geo[];    // [K][D] the tile's boxes of all planes, then [D] flags words
+    int4* s_pb = s_geo;
+    unsigned* s_fl = reinterpret_cast<unsigned*>(s_geo + (size_t)K * D);
     const int bt = blockIdx.x;  // n*tiles + tile
     const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
@@ -136,7 +154,21 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     const int p = tid % kTilePix;
     const int x = tx0 + (p % TW), y = ty0 + (p / TW);
     const bool inside = (x < W) && (y < H);
-    for (int d = tid; d < D; d += kThreads) flags[(size_t)bt * D + d] = 0u;  // nibbles are OR-ed in below
+    for (int d = tid; d < D; d += kThreads) s_fl[d] = 0u;  // nibbles are OR-ed in below
+    if (tile == 0) {  // the slab kernel reads the camera data from the scratch buffer (the tabled entry point has no other)
+        for (int i = tid; i < K * 16; i += kThreads) proj_copy[(size_t)n * K * 16 + i] = proj[(size_t)n * K * 16 + i];
+        for (int d = tid; d < D; d += kThreads) depth_copy[(size_t)n * D + d] = depth[(size_t)n * D + d];
+    }
+    // the thread's pixel rays (plane-independent) and translation columns, one per neighbour it handles
+    SampleRay ray[ITER];
+    float t0[ITER], t1[ITER], t2[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int j = min((it * kThreads + tid) / kTilePix, K - 1);
+        const float* P = proj + ((size_t)n * K + j) * 16;
+        ray[it] = sample_ray(P, (float)x, (float)y);
+        t0[it] = P[3]; t1[it] = P[7]; t2[it] = P[11];
+    }
     for (int d = 0; d < D; ++d) {
         const int par = d & 1;
         const float dval = depth[(size_t)n * D + d];
@@ -150,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                 float2 e = make_float2(kNoSample, kNoSample);  // pixel outside the image: no taps, no footprint
                 int fin = 1;
                 if (inside) {
-                    e = sample_position(proj + ((size_t)n * K + j) * 16, (float)x, (float)y, dval, H, W);
+                    e = sample_at(ray[it], t0[it], t1[it], t2[it], dval, H, W);
                     fin = (isfinite(e.x) && isfinite(e.y)) ? 1 : 0;
                     const SampleTaps t = decode_sample(e.x, e.y, H, W);
                     if ((t.x0in || t.x1in) && (t.y0in || t.y1in)) {  // bounding box of the taps that are inside
@@ -160,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                         yhi = t.y1in ? t.y0 + 1 : t.y0;
                     }
                 }
-                table[(base + j) * kTilePix + p] = e;
+                if (table) table[(base + j) * kTilePix + p] = e;
                 xlo = wave_reduce<true>(xlo);
                 xhi = wave_reduce<false>(xhi);
                 ylo = wave_reduce<true>(ylo);
@@ -180,24 +212,25 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
             // no tap of the whole tile is inside the source image: the warped values are exactly 0 and the sweep
             // skips this neighbour (kBoxSkip) -- unless a position is NaN / Inf, whose taps must still produce NaN
             if (bx.y < bx.x || bx.w < bx.z) bx = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, min(a[4], b[4]) ? kBoxSkip : kBoxEmpty);
-            boxes[base + tid] = bx;
+            s_pb[(size_t)tid * D + d] = bx;
         }
     }
     // Runs: consecutive live planes of one neighbour whose union box holds at most box_cap texels all get that union
     // box (greedy; out-of-view planes in between do not break a run -- the resident box stays valid across them -- a
-    // footprint larger than the cap does).  Thread j reads back what it wrote itself above, then publishes per plane
-    // its nibble of the flags word: kFlagLive (taps run), kFlagStaged (from the LDS box), kFlagRefill (the box differs
-    // from the one the previous staged plane of this neighbour left resident).
-    __syncthreads();  // the zeroed flags words
+    // footprint larger than the cap does).  Thread j walks its neighbour's boxes in LDS, then publishes per plane its
+    // nibble of the flags word: kFlagLive (taps run), kFlagStaged (from the LDS box), kFlagRefill (the box differs from
+    // the one the previous staged plane of this neighbour left resident).  (Cutting the runs of all neighbours together,
+    // so that their refills share one stall, was tried: fewer stalls, more box traffic, no net gain.)
+    __syncthreads();  // the zeroed flags words, the last plane's boxes
     if (tid < K) {
-        int4* bj = boxes + (size_t)bt * D * K + tid;
+        int4* bj = s_pb + (size_t)tid * D;
         int run_first = -1;
         int4 u = make_int4(0, 0, 0, 0);
         for (int d = 0; d <= D && box_cap > 0; ++d) {
             bool close = (d == D);
             int4 b = make_int4(0, -1, 0, -1);
             if (d < D) {
-                b = bj[(size_t)d * K];
+                b = bj[d];
                 if (!box_nonempty(b)) continue;
                 if (box_area(b) > box_cap) {
                     close = true;
@@ -209,8 +242,8 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
             }
             if (close && run_first >= 0) {
                 for (int e = run_first; e < d; ++e) {
-                    const int4 o = bj[(size_t)e * K];
-                    if (box_nonempty(o) && box_area(o) <= box_cap) bj[(size_t)e * K] = u;
+                    const int4 o = bj[e];
+                    if (box_nonempty(o) && box_area(o) <= box_cap) bj[e] = u;
                 }
                 run_first = -1;
             }
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
         }
         int4 res = make_int4(0, -1, 0, -1);  // what the sweep holds resident in this neighbour's slot
         for (int d = 0; d < D; ++d) {
-            const int4 b = bj[(size_t)d * K];
+            const int4 b = bj[d];
             unsigned f = 0;
             if (box_nonempty(b)) {
                 f = kFlagLive;
@@ -230,34 +263,32 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
             } else if (b.w != kBoxSkip) {
                 f = kFlagLive;  // empty footprint with a non-finite position: the taps run (from global memory) and give NaN
             }
-            if (f) atomicOr(flags + (size_t)bt * D + d, f << (4 * tid));
+            if (f) atomicOr(s_fl + d, f << (4 * tid));
         }
     }
+    __syncthreads();
+    for (int i = tid; i < D * K; i += kThreads) boxes[(size_t)bt * D * K + i] = s_pb[(size_t)(i % K) * D + i / K];
+    for (int d = tid; d < D; d += kThreads) flags[(size_t)bt * D + d] = s_fl[d];
 }
 
-// ---------------------------------------------------------------------------------------------
-// (2) the slab kernel
-// ---------------------------------------------------------------------------------------------
-// quad broadcast: every lane reads the value of lane (lane & ~3) + S of its quad
+// DPP helpers.  A wave's lanes are (pixel slot ps = lane >> 3, channel group g = lane & 7): an 8-lane group = two quads.
+// quad_bcast<S>:   every lane reads quad-lane S of its own quad.
+// from_quad<Q>:    every lane of the 8-lane group reads the value its quad Q (0 = lanes 0-3, 1 = lanes 4-7) holds at the
+//                  reader's quad-lane: the other quad's lanes take it over a row shift by 4 (bank-masked), the quad's own
+//                  lanes keep theirs.
 template <int S>
 __device__ __forceinline__ int quad_bcast(int v) {
     return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xf, 0xf, true);
 }
-template <int S>
-__device__ __forceinline__ float quad_bcast(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), S * 0x55, 0xf, 0xf, true));
+template <int Q>
+__device__ __forceinline__ int from_quad(int v) {
+    return Q == 0 ? __builtin_amdgcn_update_dpp(v, v, 0x114 /* row_shr:4 */, 0xf, 0xA, false)
+                  : __builtin_amdgcn_update_dpp(v, v, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));  // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 operands
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
-
-// what one lane holds of a decoded table entry: 4 tap offsets (float4 units inside the LDS slots, or inside the slab
-// image for a gathered footprint) and the 4 bilinear weights
-struct DecodedTaps {
-    int o0, o1, o2, o3;
-    float w0, w1, w2, w3;
-};
 
 // LDS bank swizzle of a staged box: box texel t (row-major) is kept in texel slot t ^ bit2(t).  The 8 pixel slots of a
 // wave-instruction read texels about 4 apart (each lane owns 4 consecutive pixels); unswizzled they would all start in
@@ -265,49 +296,27 @@ struct DecodedTaps {
 // An involution; the largest slot index of an n-texel box is n (hence kBoxPad).
 __device__ __forceinline__ int box_slot(int t) { return t ^ ((t >> 2) & 1); }
 
+__host__ __device__ constexpr size_t sweep_lds_bytes(int K, int box_cap) { return (size_t)K * (box_cap + kBoxPad) * 128; }
+
 // OutT = float, or __half: the variance is computed in fp32 exactly as before and rounded to nearest-even at the
 // store (BASELINE configs[4], fp16 storage), which halves the dominant write stream.
-constexpr int kRingPlanes = 4;  // own planes of table entries a wave keeps in its private LDS ring (K x 256 B each)
-__host__ __device__ constexpr size_t sweep_lds_bytes(int K, int G, int box_cap) {
-    return (size_t)K * (box_cap + kBoxPad) * 128 + (size_t)(4 * G) * kRingPlanes * K * 256;
-}
-
-// s_waitcnt vmcnt(n) with a run-time n <= 15 (the instruction takes an immediate): expcnt / lgkmcnt not waited for
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-#define MVS_W(N) case N: __builtin_amdgcn_s_waitcnt(0x0F70 | N); break;
-        MVS_W(1) MVS_W(2) MVS_W(3) MVS_W(4) MVS_W(5) MVS_W(6) MVS_W(7) MVS_W(8) MVS_W(9) MVS_W(10) MVS_W(11) MVS_W(12)
-        MVS_W(13) MVS_W(14) MVS_W(15)
-#undef MVS_W
-        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;  // vmcnt(0)
-    }
-}
-
 template <int K, int TW, int G, bool NT, typename OutT = float>
 __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
-    const float2* __restrict__ table, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
-    OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
+    const float* __restrict__ proj, const float* __restrict__ depth, const int4* __restrict__ boxes,
+    const unsigned* __restrict__ flags, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
     int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts, int dbg) {
     constexpr int KK = K > 0 ? K : 1;
+    constexpr int NP = (K + 1) / 2;             // decode passes: a lane decodes ONE (pixel-step, neighbour) pair per pass
+    constexpr int NPP = NP > 0 ? NP : 1;
     constexpr int TH = kTilePix / TW;
-    constexpr int R = kRingPlanes;
-    extern __shared__ float4 s_box[];  // K slots of (box_cap + kBoxPad) texels (8 float4 each), then the waves' entry rings
+    extern __shared__ float4 s_box[];  // K slots of (box_cap + kBoxPad) texels (8 float4 each)
 
     const int HW = H * W;
     const int id = blockIdx.x;
     int slab = id % S;
     int bt = id / S;  // n*tiles + tile
-    if (xcd_parts < 0) {
-        // tile-major: blocks b and b + 8 share an XCD (round-robin dispatch), so XCD x takes the (view, tile) pairs
-        // 8*q + x and runs their S slabs back to back: the slabs of a tile read the SAME sampling-table rows, which now
-        // come out of that XCD's L2 for all but the first of them (with slab = id % S they sat on 8 different XCDs and
-        // the table crossed the fabric 8 times: 2.9 of 14 ms at the 64-plane shape).  Speed only, never correctness.
-        const int xcd = id & 7, k = id >> 3;
-        slab = k % S;
-        bt = (k / S) * 8 + xcd;
-        if (bt >= n_bt) return;  // padding blocks of the rounded-up grid (whole block, before any barrier)
-    } else if (xcd_parts > 1) {
+    if (xcd_parts > 1) {
         // fewer than 8 slabs (C < 256): the 8/S XCDs that share a slab each take one contiguous range of
         // (view, tile) pairs, so an XCD's L2 sees a compact set of source rows instead of every 8th tile's
         const int xcd = id & 7, k = id >> 3;
@@ -337,8 +346,6 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
     }
     const float rcp = 1.0f / (float)(K + 1);
     const int slot_f4 = (box_cap + kBoxPad) * 8;  // float4 per LDS slot
-    // this wave's ring of table entries: [R own planes][K][32 pixels] float2
-    float2* s_ring = reinterpret_cast<float2*>(s_box + (size_t)KK * slot_f4) + (size_t)wave * R * KK * 32;
 
     // the lane's 4 consecutive pixels: tile-local p0 .. p0+3 (4 | TW, so they share a row)
     const int p0 = 32 * sub + 4 * ps;
@@ -356,6 +363,35 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
     const unsigned st_off = ((unsigned)g * (unsigned)D * (unsigned)HW + (unsigned)(py * W + px0)) * (unsigned)sizeof(OutT);
     const int st_n = (py < H) ? max(0, min(4, W - px0)) : 0;               // how many of the 4 pixels are inside the image
     const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);  // 16-byte aligned in every channel row
+
+    // ---- the lane's decode duty.  The sampling position of (pixel, plane, neighbour) does not depend on the channel:
+    // in pass p lane (ps, g) computes it for pixel p0 + (g & 3) and neighbour 2p + (g >> 2) -- ONE position, one decode
+    // per lane, pass and plane -- and the 8 lanes of the pixel slot fetch the results with DPP (quad broadcast for the
+    // step, row shift by 4 for the neighbour's quad).  No sampling table: the positions are recomputed from the pixel's
+    // ray (plane-independent, kept in registers) with the very arithmetic of the geometry kernel (sample_at), 4 IEEE
+    // divisions per position; this costs ~15 % more VALU work than decoding table entries, and saves the table's
+    // 8 B per (pixel, plane, neighbour) -- read by every slab, 12 % of the sweep's traffic, and worse than its share
+    // in time because the reads interleave with the write stream (measured 2.3 of 13.6 ms).
+    const int sd = g & 3, qd = g >> 2;
+    const int dx = px0 + sd;                            // the pixel this lane decodes (same row as its own)
+    const bool d_inside = (dx < W) && (py < H);
+    SampleRay ray[NPP];
+    float tr0[NPP], tr1[NPP], tr2[NPP];                 // translation column of the lane's neighbour
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int jd = min(2 * p + qd, K - 1);
+        const float* P = proj + ((size_t)n * K + jd) * 16;
+        ray[p] = sample_ray(P, (float)dx, (float)py);
+        tr0[p] = P[3]; tr1[p] = P[7]; tr2[p] = P[11];
+    }
+    // the box resident in the slot of the lane's neighbour (per pass), and block-uniform copies per neighbour
+    int lx0[NPP], lx1[NPP], ly0[NPP], ly1[NPP];
+    int rx0[KK], ry0[KK], rx1[KK], ry1[KK];
+    bool have[KK];
+#pragma unroll
+    for (int p = 0; p < NPP; ++p) { lx0[p] = 0; lx1[p] = 0; ly0[p] = 0; ly1[p] = 0; }
+#pragma unroll
+    for (int j = 0; j < KK; ++j) { rx0[j] = 0; ry0[j] = 0; rx1[j] = -1; ry1[j] = -1; have[j] = false; }
 
     // LDS-DMA of one footprint box into its slot: each wave-instruction fills 8 texel slots = 1 KiB without touching
     // VGPRs (LDS address = wave-uniform base + 16*lane, global address per lane: the texel that belongs in the lane's
@@ -376,56 +412,9 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
     };
 
     const unsigned* fl_bt = flags + (size_t)bt * D;
+    const float* depth_n = depth + (size_t)n * D;
     unsigned fl_next = (K > 0 && d_begin < d_end) ? fl_bt[d_begin] : 0u;
-    // the box resident in slot j: origin, last column / row (block-uniform scalars)
-    int rx0[KK], ry0[KK], rx1[KK], ry1[KK];
-    bool have[KK];
-#pragma unroll
-    for (int j = 0; j < KK; ++j) { rx0[j] = 0; ry0[j] = 0; rx1[j] = -1; ry1[j] = -1; have[j] = false; }
-
-    // ---- table entries.  gfx950 has ONE in-order counter (vmcnt) for loads, stores and LDS-DMA, and under a 3+ TB/s
-    // write stream a store takes thousands of cycles to be acknowledged: a wave that waits for a table entry with the
-    // compiler's conservative vmcnt also waits for the stores of its previous plane (measured: 3.7 of 15.5 ms).  So the
-    // entries travel by LDS-DMA into a wave-private ring, kRingPlanes - 1 own planes ahead, and the wave waits for them
-    // with an EXACT vmcnt(n): n = the vector-memory instructions it has issued since that DMA (one DMA per own plane +
-    // the stores of the planes in between, counted below), which are all younger and may stay in flight.
-    // One DMA instruction per own plane: lane l < 16*K fetches 16 B = the entries of pixels 2*(l&15), +1 of neighbour l>>4.
-    const int n_own = (d_end - d_begin - grp + G - 1) / G;  // own planes: d = d_begin + grp + m*G
-    const char* tab_wave = reinterpret_cast<const char*>(table + (size_t)bt * D * K * kTilePix + 32 * sub) +
-                           (size_t)(lane >> 4) * (kTilePix * sizeof(float2)) + 16 * (lane & 15);
-    // The DMA is issued from inline assembly on purpose: hipcc's wait-count pass puts an s_waitcnt vmcnt(0) in front of
-    // every LDS read that may alias a pending LDS-DMA it knows of -- exactly the wait (for all stores in flight) this
-    // scheme exists to avoid.  M0 = LDS byte address of the ring slot (one wait state between the write of M0 and its use).
-    auto request = [&](int m) {  // own plane m -> ring slot m % R
-        const char* src = tab_wave + (size_t)(d_begin + grp + ((dbg & 64) ? 0 : m) * G) * K * (kTilePix * sizeof(float2));
-        const unsigned dst = __builtin_amdgcn_readfirstlane(
-            (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(s_ring + (size_t)(m % R) * KK * 32));
-        if (lane < 16 * K)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory");
-    };
-    // stores this wave issues per computed plane, counted only where the count is exact (whole float4 stores: lanes are
-    // all-in or all-out, a channel row is skipped by the whole wave or by none); otherwise 0 = "assume none in flight"
-    int n_st = 0;
-    {
-        const bool exact = ((W & 3) == 0) && ((HW & 3) == 0);
-        const bool any_lane = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__ballot(st_n == 4))) != 0;
-        if (exact && any_lane && !(dbg & 1))
-            for (int i = 0; i < 4; ++i) n_st += (slab * kSlab + 8 * i < C) ? 1 : 0;
-    }
-    int issued = 0;                  // vector-memory instructions issued so far that are certainly counted in vmcnt
-    int mark0 = 0, mark1 = 0, mark2 = 0;  // `issued` right after the DMA of own plane m, m+1, m+2
-    if (K > 0) {
-        asm volatile("" ::: "memory");
-        if (0 < n_own) { request(0); ++issued; } mark0 = issued;
-        if (1 < n_own) { request(1); ++issued; } mark1 = issued;
-        if (2 < n_own) { request(2); ++issued; } mark2 = issued;
-        asm volatile("" ::: "memory");
-    }
-    const int pdec = 4 * ps + (g & 3);  // the wave-local pixel whose entry this lane decodes
-    int m_own = 0;
-    float2 en[KK];
-#pragma unroll
-    for (int j = 0; j < KK; ++j) en[j] = make_float2(kNoSample, kNoSample);
+    float dv_next = (K > 0 && d_begin < d_end) ? depth_n[d_begin] : 0.0f;
 
     // results of the last computed plane, and the stores that send them out: straight from registers, 16 bytes per lane =
     // 8 channel rows x 128 contiguous bytes per wave-instruction
@@ -467,15 +456,14 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
                 }
             }
         }
-        asm volatile("" ::: "memory");
-        issued += n_st;
     };
 
     for (int d = d_begin; d < d_end; ++d) {
-        // ---- this plane's flags (one scalar word, requested a plane ahead); every wave follows every plane so that all
+        // ---- this plane's flags and depth (scalars, requested a plane ahead); every wave follows every plane so that all
         //      of them take the same refill decisions, whichever planes they compute
         const unsigned fl = __builtin_amdgcn_readfirstlane(fl_next);
-        if (K > 0 && d + 1 < d_end) fl_next = fl_bt[d + 1];
+        const float dval = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dv_next)));
+        if (K > 0 && d + 1 < d_end) { fl_next = fl_bt[d + 1]; dv_next = depth_n[d + 1]; }
         bool refill = false;
 #pragma unroll
         for (int j = 0; j < K; ++j)
@@ -492,27 +480,20 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
                     ry0[j] = __builtin_amdgcn_readfirstlane(b.z);
                     ry1[j] = __builtin_amdgcn_readfirstlane(b.w);
                     have[j] = true;
+                    if (min(2 * (j / 2) + qd, K - 1) == j) { lx0[j / 2] = rx0[j]; lx1[j / 2] = rx1[j]; ly0[j / 2] = ry0[j]; ly1[j / 2] = ry1[j]; }
                     if (!(dbg & 4)) load_box(j, rx0[j], ry0[j], rx1[j] - rx0[j] + 1, ry1[j] - ry0[j] + 1);
                 }
             }
             // The LDS-DMA pieces of this wave count on vmcnt, and for a workgroup barrier hipcc only waits for lgkmcnt:
             // without the explicit wait a wave can pass the barrier while its own pieces are still in flight and the
-            // other waves read stale box texels.  (Everything this wave has in flight is older than its pieces.)
+            // other waves read stale box texels.  (vmcnt is the one in-order counter of loads AND stores: the wait also
+            // drains this wave's stores -- the reason the compute loop below contains no other load.)
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
         }
         if (d_pending >= 0) { flush(d_pending); d_pending = -1; }
         if (G > 1 && ((d - d_begin) & (G - 1)) != grp) continue;  // the other wave group's plane
 
-        if (K > 0 && !(dbg & 2)) {
-            // this plane's entries: everything issued since their DMA may stay in flight
-            asm volatile("" ::: "memory");
-            if (!(dbg & 16)) wait_vmcnt(min(issued - mark0, 15));
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < K; ++j) en[j] = s_ring[((size_t)(m_own % R) * K + j) * 32 + pdec];
-            asm volatile("" ::: "memory");
-        }
         f2 S_[4][2], Q_[4][2];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -521,12 +502,14 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
             if (G > 1) asm volatile("" : "+v"(S_[s][0]), "+v"(S_[s][1]));
             Q_[s][0] = S_[s][0] * S_[s][0]; Q_[s][1] = S_[s][1] * S_[s][1];
         }
-#define MVS_TAP_STEP(SS, LOADER)                                                                                      \
+#define MVS_TAP_STEP(SS, QQ, LOADER)                                                                                  \
         {                                                                                                             \
-            const int o0 = quad_bcast<SS>(dt.o0), o1 = quad_bcast<SS>(dt.o1);                                         \
-            const int o2 = quad_bcast<SS>(dt.o2), o3 = quad_bcast<SS>(dt.o3);                                         \
-            const f2 w0 = splat(quad_bcast<SS>(dt.w0)), w1 = splat(quad_bcast<SS>(dt.w1));                            \
-            const f2 w2 = splat(quad_bcast<SS>(dt.w2)), w3 = splat(quad_bcast<SS>(dt.w3));                            \
+            const int o0 = from_quad<QQ>(quad_bcast<SS>(do0)), o1 = from_quad<QQ>(quad_bcast<SS>(do1));               \
+            const int o2 = from_quad<QQ>(quad_bcast<SS>(do2)), o3 = from_quad<QQ>(quad_bcast<SS>(do3));               \
+            const f2 w0 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.x)))));                 \
+            const f2 w1 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.y)))));                 \
+            const f2 w2 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.z)))));                 \
+            const f2 w3 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.w)))));                 \
             const float4 t0 = LOADER(o0), t1 = LOADER(o1), t2 = LOADER(o2), t3 = LOADER(o3);                          \
             f2 va = (f2){t0.x, t0.y} * w0, vb = (f2){t0.z, t0.w} * w0;                                                \
             va = pk_fma((f2){t1.x, t1.y}, w1, va); vb = pk_fma((f2){t1.z, t1.w}, w1, vb);                             \
@@ -534,49 +517,59 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
             va = pk_fma((f2){t3.x, t3.y}, w3, va); vb = pk_fma((f2){t3.z, t3.w}, w3, vb);                             \
             S_[SS][0] = S_[SS][0] + va; S_[SS][1] = S_[SS][1] + vb;                                                   \
             Q_[SS][0] = pk_fma(va, va, Q_[SS][0]); Q_[SS][1] = pk_fma(vb, vb, Q_[SS][1]);                             \
-            if (G > 1) __builtin_amdgcn_sched_barrier(0); /* 128-VGPR budget: keep the steps' live ranges apart */  \
         }
 #define MVS_LDS_TAP(O) s_box[(O) + g]
 #define MVS_GLB_TAP(O) nb_img[j][(O) + g]
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const unsigned fj = fl >> (4 * j);
-            if (!(fj & kFlagLive)) continue;  // nothing of this neighbour is visible: its warped features are all zero
-            // ---- decode this plane's table entry of the lane's pixel-step (tap origin, weights, tap offsets)
-            const SampleTaps tp = decode_sample(en[j].x, en[j].y, H, W);
-            const float4 w = tap_weights(tp);
-            DecodedTaps dt;
-            dt.w0 = w.x; dt.w1 = w.y; dt.w2 = w.z; dt.w3 = w.w;
-            if (fj & kFlagStaged) {  // taps from the resident box
-                const int pitch = rx1[j] - rx0[j] + 1;
-                const int xa = clampi(tp.x0, rx0[j], rx1[j]) - rx0[j], xb = clampi(tp.x0 + 1, rx0[j], rx1[j]) - rx0[j];
-                const int ya = (clampi(tp.y0, ry0[j], ry1[j]) - ry0[j]) * pitch, yb = (clampi(tp.y0 + 1, ry0[j], ry1[j]) - ry0[j]) * pitch;
-                dt.o0 = box_slot(ya + xa) * 8 + j * slot_f4; dt.o1 = box_slot(ya + xb) * 8 + j * slot_f4;
-                dt.o2 = box_slot(yb + xa) * 8 + j * slot_f4; dt.o3 = box_slot(yb + xb) * 8 + j * slot_f4;
-                MVS_TAP_STEP(0, MVS_LDS_TAP) MVS_TAP_STEP(1, MVS_LDS_TAP) MVS_TAP_STEP(2, MVS_LDS_TAP) MVS_TAP_STEP(3, MVS_LDS_TAP)
-            } else {                 // footprint too large (or empty with non-finite positions): taps from the slab image
-                const int xa = clampi(tp.x0, 0, W - 1), xb = clampi(tp.x0 + 1, 0, W - 1);
-                const int ya = clampi(tp.y0, 0, H - 1) * W, yb = clampi(tp.y0 + 1, 0, H - 1) * W;
-                dt.o0 = (ya + xa) * 8; dt.o1 = (ya + xb) * 8; dt.o2 = (yb + xa) * 8; dt.o3 = (yb + xb) * 8;
-                MVS_TAP_STEP(0, MVS_GLB_TAP) MVS_TAP_STEP(1, MVS_GLB_TAP) MVS_TAP_STEP(2, MVS_GLB_TAP) MVS_TAP_STEP(3, MVS_GLB_TAP)
-            }
+#define MVS_TAPS_OF(QQ)                                                                                               \
+        {                                                                                                             \
+            if constexpr (2 * p + QQ < K) {                                                                           \
+                constexpr int j = 2 * p + QQ;                                                                         \
+                const unsigned fj = fl >> (4 * j);                                                                    \
+                if (fj & kFlagLive) {                                                                                 \
+                    if (fj & kFlagStaged) {                                                                           \
+                        MVS_TAP_STEP(0, QQ, MVS_LDS_TAP) MVS_TAP_STEP(1, QQ, MVS_LDS_TAP)                             \
+                        MVS_TAP_STEP(2, QQ, MVS_LDS_TAP) MVS_TAP_STEP(3, QQ, MVS_LDS_TAP)                             \
+                    } else {                                                                                          \
+                        MVS_TAP_STEP(0, QQ, MVS_GLB_TAP) MVS_TAP_STEP(1, QQ, MVS_GLB_TAP)                             \
+                        MVS_TAP_STEP(2, QQ, MVS_GLB_TAP) MVS_TAP_STEP(3, QQ, MVS_GLB_TAP)                             \
+                    }                                                                                                 \
+                }                                                                                                     \
+            }                                                                                                         \
         }
+        // one pass = the neighbours 2p and 2p+1: every lane decodes its (pixel-step, neighbour) pair, then the taps of both
+        auto pass = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            const unsigned fp = fl >> (8 * p);
+            if (!(fp & (kFlagLive | (kFlagLive << 4)))) return;  // nothing of these neighbours is visible: warped values all zero
+            const unsigned fq = qd ? ((2 * p + 1 < K) ? (fp >> 4) : fp) : fp;   // the nibble of the lane's neighbour
+            const bool l_staged = (fq & kFlagStaged) != 0;
+            float2 e = make_float2(kNoSample, kNoSample);  // pixel outside the image: no tap inside, all weights +0
+            if (d_inside) e = sample_at(ray[p], tr0[p], tr1[p], tr2[p], dval, H, W);
+            const SampleTaps tp = decode_sample(e.x, e.y, H, W);
+            const float4 dw = tap_weights(tp);
+            // tap offsets: inside the resident box of the lane's neighbour (slot index with the bank swizzle), or inside
+            // its slab image for a gathered footprint (too large for the box, or empty with non-finite positions)
+            const int lox = l_staged ? lx0[p] : 0, hix = l_staged ? lx1[p] : W - 1;
+            const int loy = l_staged ? ly0[p] : 0, hiy = l_staged ? ly1[p] : H - 1;
+            const int pitch = hix - lox + 1;
+            const int xa = clampi(tp.x0, lox, hix) - lox, xb = clampi(tp.x0 + 1, lox, hix) - lox;
+            const int ya = (clampi(tp.y0, loy, hiy) - loy) * pitch, yb = (clampi(tp.y0 + 1, loy, hiy) - loy) * pitch;
+            const int sbase = min(2 * p + qd, K - 1) * slot_f4;
+            const int do0 = l_staged ? box_slot(ya + xa) * 8 + sbase : (ya + xa) * 8;
+            const int do1 = l_staged ? box_slot(ya + xb) * 8 + sbase : (ya + xb) * 8;
+            const int do2 = l_staged ? box_slot(yb + xa) * 8 + sbase : (yb + xa) * 8;
+            const int do3 = l_staged ? box_slot(yb + xb) * 8 + sbase : (yb + xb) * 8;
+            MVS_TAPS_OF(0)
+            MVS_TAPS_OF(1)
+        };
+        if constexpr (NP > 0) pass(std::integral_constant<int, 0>{});
+        if constexpr (NP > 1) pass(std::integral_constant<int, 1>{});
+#undef MVS_TAPS_OF
 #undef MVS_TAP_STEP
 #undef MVS_LDS_TAP
 #undef MVS_GLB_TAP
-        if (K > 0 && !(dbg & 2)) {
-            // request the entries of own plane m + 3 (into the ring slot read one own plane ago).  Placed here, a whole
-            // tap phase after this wave's last stores: a vector-memory instruction issued right behind a burst of stores
-            // waits at issue until the store path has taken them.
-            asm volatile("" ::: "memory");
-            mark0 = mark1; mark1 = mark2;
-            if (m_own + 3 < n_own && !(dbg & 32)) { request(m_own + 3); ++issued; }
-            mark2 = issued;
-            asm volatile("" ::: "memory");
-        }
-        ++m_own;
         // ---- variance (channel 8*i + g, the lane's 4 consecutive pixels): kept in registers, stored at the top of the
-        //      next iteration (after a possible box refill, whose vmcnt(0) then only meets stores a whole plane old)
+        //      next iteration (after a possible box refill)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll

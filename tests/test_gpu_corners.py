@@ -83,7 +83,7 @@ def test_backward_stage1_over_box_capacity(gpu, oracle):
     tw = 32 if (W % 32 == 0 or W % 16 != 0) else 16
     tiles = ((W + tw - 1) // tw) * ((H + 128 // tw - 1) // (128 // tw))
     nent = N * tiles * D * K
-    b = table[nent * 256: nent * 256 + nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)
+    b = table[:nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)  # boxes lead the scratch buffer
     area = np.maximum(b[:, 1] - b[:, 0] + 1, 0) * np.maximum(b[:, 3] - b[:, 2] + 1, 0)
     assert (area > 256).any() and ((area > 0) & (area <= 256)).any(), "fixture must mix boxed and over-capacity footprints"
     _check_bwd(gpu, oracle, feat, nbr, torch.from_numpy(proj), torch.from_numpy(depth))

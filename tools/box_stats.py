@@ -27,7 +27,7 @@ for name in sys.argv[1:] or ["scannet_40v_64d_120x160"]:
     tiles = ((W + tw - 1) // tw) * ((H + th - 1) // th)
     table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
     nent = N * tiles * D * K
-    boxes = table[nent * 128 * 2: nent * 128 * 2 + nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)
+    boxes = table[:nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)
     nc, nr = boxes[:, 1] - boxes[:, 0] + 1, boxes[:, 3] - boxes[:, 2] + 1
     empty = (nc <= 0) | (nr <= 0)
     area = np.where(empty, 0, nc * nr)
