@@ -48,7 +48,7 @@ WORKLOADS = {
     "tiny_3v_8d_48x64": dict(N=3, C=32, D=8, H=48, W=64, near_far=(0.2, 5.0), per_view_K=False),
 }
 N_VOXELS, VOXEL_SIZE = [40, 40, 16], [0.16, 0.16, 0.2]
-SWEEP_KERNEL_NAME = "plane_sweep_variance_kernel<2,TW,NT>"
+SWEEP_KERNEL_NAME = "plane_sweep_variance_kernel<2,TW,G,NT,float>"
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -92,12 +92,26 @@ def run_gpu(args, w, rank, world, device):
         vol, valid = hp.lift_packed(packed, geo, est_depth, est_dens, w["C"], w["H"], w["W"])
         return keep, vol, valid
 
+    # every step sees a NEW img_meta object (same contents): the camera algebra is really redone per scene -- on the
+    # geometry worker thread, announced one scene ahead so that it overlaps the previous scene's kernels
+    metas = {}
+
+    def meta_of(i):
+        for k in (i, i + 1):
+            if k not in metas:
+                metas[k] = dict(scenes[k % len(scenes)].meta)
+        for k in [k for k in metas if k < i]:
+            del metas[k]
+        return metas[i]
+
     def step(i, timed):
         if w.get("chunk"):
             return step_chunked(i, timed)
         s = scenes[i % len(scenes)]
         feat = s.features
-        geo = hp.prepare_scene(s.meta, device)
+        meta = meta_of(i)
+        hp.prefetch_scene(metas[i + 1], device)
+        geo = hp.prepare_scene(meta, device)
         packed = ops.pack_features(feat)
         if timed:  # HIP events on torch's current stream (where the ops launch): stage 1 = table + slab kernel
             e0, em, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -124,7 +138,7 @@ def run_gpu(args, w, rank, world, device):
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     out = None
-    for i in range(args.steps):
+    for i in range(args.warmup, args.warmup + args.steps):
         out = None  # release the previous cost volume before the next one is allocated (126 GB at the stress shape)
         out = step(i, True)
     torch.cuda.synchronize(device)
@@ -147,12 +161,13 @@ def run_gpu(args, w, rank, world, device):
 def stage_breakdown(w, hp, scene, device, reps=3):
     """Per-stage HIP-event timings of one scene (reported as extras; not the headline)."""
     from mvsdet_amd import ops
-    names = ["host_prep+h2d", "pack", "plane_sweep_table+variance", "depth_prob_topk", "backproject_mean"]
+    names = ["host_prep+h2d (serial; overlapped in the timed loop)", "pack", "plane_sweep_geometry+variance", "depth_prob_topk",
+             "backproject_mean"]
     acc = {n: [] for n in names}
     for _ in range(reps):
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        geo = hp.prepare_scene(scene.meta, device)
+        geo = hp.prepare_scene(dict(scene.meta), device)   # a new object: not served from the identity cache
         torch.cuda.synchronize(device)
         acc[names[0]].append((time.perf_counter() - t0) * 1e3)
         es = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -286,8 +301,15 @@ def footprint_stats(w, hp, scene, device):
     nc, nr = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
     empty = (nc <= 0) | (nr <= 0)
     area = np.where(empty, 0, nc * nr)
-    return {"out_of_view": round(float(empty.mean()), 4), "staged_in_lds": round(float((~empty & (area <= 256)).mean()), 4),
-            "gathered": round(float((~empty & (area > 256)).mean()), 4)}
+    from mvsdet_amd import _lib
+    cap = min(_lib.get_option("sweep_boxcap"), (80 * 1024 // 128) // K - 8)   # planesweep.hip: effective_box_cap
+    live = ~empty
+    fl = table[nent * 4: nent * 4 + N * tiles * D].view(torch.int32).cpu().numpy().astype(np.int64)   # flags follow the boxes
+    staged_n = sum(int(((fl >> (4 * j + 1)) & 1).sum()) for j in range(K))
+    refill_n = sum(int(((fl >> (4 * j + 2)) & 1).sum()) for j in range(K))
+    return {"out_of_view": round(float(empty.mean()), 4), "staged_in_lds": round(float((live & (area <= cap)).mean()), 4),
+            "gathered": round(float((live & (area > cap)).mean()), 4), "box_texels": int(cap),
+            "box_refills_per_staged": round(refill_n / max(1, staged_n), 4)}
 
 
 def hbm_copy_ceiling(device, gib=2.0, reps=5):

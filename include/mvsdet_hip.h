@@ -141,8 +141,7 @@ int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const
 /* backward of the above w.r.t. feat (the sampling grid carries no gradient, module.py:115).
  *   g (N,C,D,H,W) = dL/dvar;  gfeat (N,C,H,W) is OVERWRITTEN with dL/dfeat.
  *   workspace_bytes >= mvsdet_plane_sweep_bwd_workspace_bytes(N,K,C,D,H,W)
- *   (packed features + packed gradient + sweep geometry + the sampling positions, 8 B per view, pixel, plane and
- *   neighbour, which the backward pass reads instead of recomputing). */
+ *   (packed features + packed gradient + sweep geometry). */
 size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, int D, int H, int W);
 int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, const float* proj,
                                         const float* depth, const float* g, float* gfeat, void* workspace,

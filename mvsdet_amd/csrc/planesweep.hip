@@ -174,12 +174,11 @@ int launch_slab(dim3 grid, hipStream_t stream, size_t lds, const float* packed, 
 
 template <int TW>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, void* var_any,
-                 void* scratch, void* table, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
+                 void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
                  int ref_first, bool half_out) {
     float* var = static_cast<float*>(var_any);
     __half* var16 = static_cast<__half*>(var_any);  // half_out: same kernel, variance rounded to fp16 at the store
-    // phases: bit 0 = build the sweep geometry (coords kernel; + the sampling table when `table` is given), bit 1 = run
-    // the slab kernel.  N reference views starting at view ref_first of the n_src packed source views (a view shard;
+    // phases: bit 0 = build the sweep geometry (coords kernel), bit 1 = run the slab kernel.  N reference views starting at view ref_first of the n_src packed source views (a view shard;
     // N == n_src and ref_first == 0 for a whole scene); nbr / proj / depth / var / scratch are indexed by the LOCAL view
     constexpr int TH = kTilePix / TW;
     const int S = num_slabs(C);
@@ -221,8 +220,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         if (phases & 1)                                                                                               \
             hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads),                            \
                                (size_t)D * (KV * sizeof(int4) + sizeof(unsigned)), stream, proj, depth,               \
-                               static_cast<float2*>(table), geo.boxes, geo.flags, geo.proj, geo.depth, D, H, W,       \
-                               tiles_x, tiles, box_cap);                                                              \
+                               geo.boxes, geo.flags, geo.proj, geo.depth, D, H, W, tiles_x, tiles, box_cap);           \
         if (phases & 2) rc = (G == 1) ? MVS_SLAB(KV, 1) : MVS_SLAB(KV, 2);                                            \
         break;
     switch (K) {
@@ -257,19 +255,9 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
            align16((size_t)N * K * 16 * sizeof(float)) + align16((size_t)N * D * sizeof(float));
 }
 
-// the backward pass also wants the sampling positions themselves: 8 B per (view, tile pixel, plane, neighbour)
-namespace mvsdet {
-size_t sweep_table_bytes(int N, int K, int D, int H, int W) {
-    if (N <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
-    return (size_t)N * tiles * D * K * kTilePix * sizeof(float2);
-}
-}  // namespace mvsdet
-
 static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,
                        void* var, void* scratch, size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
-                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0, bool half_out = false,
-                       void* table = nullptr) {
+                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0, bool half_out = false) {
     if (n_src < 0) n_src = N;
     MVS_REQUIRE(ref_first >= 0 && N <= n_src && ref_first <= n_src - N,
                 "%s: reference views [%d, %d) outside the %d packed views", name, ref_first, ref_first + N, n_src);
@@ -289,8 +277,8 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "%s: scratch must be 16-byte aligned", name);
     const int tw = pick_tile_width(W);
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, table, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
-    return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, table, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
@@ -322,15 +310,6 @@ extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* dept
     return sweep_entry("plane_sweep_table", nullptr, nullptr, proj, depth, nullptr, scratch, scratch_bytes, N, K, 1, D, H, W,
                        stream, 1);
 }
-
-namespace mvsdet {
-// planesweep_bwd.hip: sweep geometry into `scratch` plus the sampling table into `table`
-int sweep_build_geometry_and_table(const float* proj, const float* depth, void* scratch, size_t scratch_bytes, void* table,
-                                   int N, int K, int D, int H, int W, mvsdet_stream_t stream) {
-    return sweep_entry("plane_sweep_table", nullptr, nullptr, proj, depth, nullptr, scratch, scratch_bytes, N, K, 1, D, H, W,
-                       stream, 1, -1, 0, false, table);
-}
-}  // namespace mvsdet
 
 extern "C" int mvsdet_plane_sweep_variance_tabled_f32(const float* packed, const int64_t* nbr, const void* table,
                                                       size_t table_bytes, float* var, int N, int K, int C, int D, int H,

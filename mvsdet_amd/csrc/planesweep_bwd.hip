@@ -5,18 +5,18 @@
 //   dvar/dv = 2 v r - 2 S r^2   (r = 1/(K+1)) for each contributing value v in {f, w_1..w_K}
 //   w_j = sum_t weight_t * tap_t  ->  dL/dtap_t += weight_t * dL/dw_j   (bilinear scatter)
 //
-// Same decomposition as the forward slab kernel (sweep_kernel.h): block = (reference view, 128-pixel tile,
-// 32-channel slab), lanes = (pixel slot, channel group), the channel-independent sampling table and the tap
-// bounding boxes come from plane_sweep_coords_kernel.  Per plane:
-//   1. the incoming gradient tile is read as whole 128-byte rows of (N,C,D,H,W) and transposed through LDS;
-//   2. the warped values are recomputed (taps gathered from the slab images, which sit in the XCD's L2);
-//   3. per neighbour the tap gradients are accumulated with LDS atomics into a gradient image of the footprint
-//      box and then flushed to the packed gradient map with fp32 global atomics shaped as 256 contiguous bytes
-//      per wave-instruction -- about 3x fewer and far better shaped atomics than one per tap
-//      (MI355X_MICROARCH "Global float atomics": full rate only for contiguous 256-byte instructions);
-//      a footprint that does not fit the LDS box falls back to per-tap global atomics;
-//   4. the reference view's own term is kept in registers across the planes and added once per block.
-// Bound: the chip-wide float-atomic rate.  The packed gradient map is unpacked to (N,C,H,W) afterwards.
+// Same decomposition, lane map and sweep geometry as the forward slab kernel (sweep_kernel.h): block = (reference
+// view, 128-pixel tile, 32-channel slab); lane (ps, g) owns 4 consecutive pixels x channels 8*i + g, so dL/dvar is
+// read as 16 bytes per lane (8 channel rows x 128 contiguous bytes per wave-instruction, no LDS transpose); the
+// sampling positions are recomputed per plane from the pixel rays (one position per lane and pass, DPP broadcasts).
+// Where the forward keeps a neighbour's footprint box of SOURCE texels resident in LDS for a run of planes, the
+// backward keeps a GRADIENT image of the same box there: tap gradients are accumulated with LDS atomics over the
+// whole run and flushed to the packed gradient map only when the run's box changes -- 256 contiguous bytes of fp32
+// global atomics per wave-instruction (MI355X_MICROARCH "Global float atomics": full rate only in that shape).
+// Round 1 flushed a box per plane and neighbour: 1.9 G lane-atomics at the reference-true shape, 14.2 ms; a run is
+// ~9-35 planes long, so the flushes shrink by that factor.  The warped values are recomputed with taps gathered from
+// the slab images (L2).  A footprint larger than the box falls back to one global atomic per tap.
+// The packed gradient map is unpacked to (N,C,H,W) afterwards.
 #include "common.h"
 
 #include <algorithm>
@@ -26,18 +26,24 @@
 
 namespace mvsdet {
 
+// LDS bank swizzle of the gradient images: float 4*g + i of the texel at float index `base` (a multiple of 32) is kept at
+// 4*g + (i ^ ((base >> 7) & 3)).  One LDS atomic of a wave touches a fixed i of 8 texels x 8 channel groups; unswizzled
+// that is 8 banks out of 32 (8-way conflicts); the texels of neighbouring pixel slots lie ~4 slots apart, so XOR-ing i
+// with bits 2-3 of the slot index spreads them over all 32 banks (2-way: 64 lanes on 32 banks).
+__device__ __forceinline__ int grad_swizzle(int base) { return (base >> 7) & 3; }
+
 template <int K, int TW>
-__global__ __launch_bounds__(kThreads, 3) void plane_sweep_variance_bwd_kernel(
-    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float2* __restrict__ table,
-    const int4* __restrict__ boxes, const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S,
-    int D, int H, int W, int tiles_x, int tiles) {
+__global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
+    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
+    const float* __restrict__ depth, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
+    const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S, int D, int H, int W, int tiles_x,
+    int tiles, int box_cap, int dbg) {
     constexpr int KK = K > 0 ? K : 1;
+    constexpr int NP = (K + 1) / 2;
+    constexpr int NPP = NP > 0 ? NP : 1;
     constexpr int TH = kTilePix / TW;
-    constexpr int ITER = (KK * kTilePix + kThreads - 1) / kThreads;
-    __shared__ float4 s_g4[kBoxCap * 8];      // gradient image of one neighbour's footprint box; first the dL/dvar tile
-    __shared__ int2 s_xy[KK][kTilePix];       // tap origin per (neighbour, pixel)
-    __shared__ float4 s_w[KK][kTilePix];      // tap weights
-    float* s_g = reinterpret_cast<float*>(s_g4);
+    extern __shared__ float4 s_grad4[];  // K slots of (box_cap + kBoxPad) texels x 32 floats: gradient images of the resident boxes
+    float* s_grad = reinterpret_cast<float*>(s_grad4);
 
     const int HW = H * W;
     const int id = blockIdx.x;
@@ -61,189 +67,250 @@ __global__ __launch_bounds__(kThreads, 3) void plane_sweep_variance_bwd_kernel(
     }
     const float r = 1.0f / (float)(K + 1);
     const float two_r = 2.0f * r, two_r2 = 2.0f * r * r;
+    const int slot_fl = (box_cap + kBoxPad) * kSlab;  // floats per LDS slot
 
-    // the lane's 4 pixels (one per step), their reference features and the running reference-term gradient
-    float4 f[4];
-    int ppix[4];
+    // the lane's 4 consecutive pixels, their reference features and the running reference-term gradient
+    const int p0 = 32 * wave + 4 * ps;
+    const int px0 = tx0 + p0 % TW, py = ty0 + p0 / TW;
+    float f[4][4], gref[4][4];
     bool pok[4];
-    float gref[4][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int p = (wave * 4 + s) * 8 + ps;
-        const int x = tx0 + (p % TW), y = ty0 + (p / TW);
-        pok[s] = (x < W) && (y < H);
-        ppix[s] = min(y, H - 1) * W + min(x, W - 1);
-        f[s] = *reinterpret_cast<const float4*>(ref_img + (size_t)ppix[s] * kSlab + 4 * g);
+        pok[s] = (px0 + s < W) && (py < H);
+        const int pix = min(py, H - 1) * W + min(px0 + s, W - 1);
+        const float4 v = *reinterpret_cast<const float4*>(ref_img + (size_t)pix * kSlab + 4 * g);
+        f[s][0] = v.x; f[s][1] = v.y; f[s][2] = v.z; f[s][3] = v.w;
         gref[s][0] = gref[s][1] = gref[s][2] = gref[s][3] = 0.0f;
     }
-    // row loader of the dL/dvar tile: float4 slot sq of the 128-pixel tile, channel rows 8*wave + 2*k + sh
-    const int sq = lane & 31, sh = lane >> 5;
-    const int st_x = tx0 + (sq % (TW / 4)) * 4, st_y = ty0 + sq / (TW / 4);
-    const int st_off = st_y * W + st_x;
-    const int st_n = (st_y < H) ? max(0, min(4, W - st_x)) : 0;
+    const int st_n = (py < H) ? max(0, min(4, W - px0)) : 0;
     const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);
+    const size_t g_lane = (size_t)g * D * HW + (size_t)py * W + px0;  // channel g, the lane's pixels (elements)
 
+    // decode duty of the lane (sweep_kernel.h): pixel p0 + (g & 3), neighbour 2*pass + (g >> 2)
+    const int sd = g & 3, qd = g >> 2;
+    const int dx = px0 + sd;
+    const bool d_inside = (dx < W) && (py < H);
+    SampleRay ray[NPP];
+    float tr0[NPP], tr1[NPP], tr2[NPP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int jd = min(2 * p + qd, K - 1);
+        const float* P = proj + ((size_t)n * K + jd) * 16;
+        ray[p] = sample_ray(P, (float)dx, (float)py);
+        tr0[p] = P[3]; tr1[p] = P[7]; tr2[p] = P[11];
+    }
+    int lx0[NPP], lx1[NPP], ly0[NPP], ly1[NPP];   // resident box of the lane's neighbour
+    int rx0[KK], ry0[KK], rx1[KK], ry1[KK];       // resident box per neighbour (block-uniform)
+    bool have[KK];
+#pragma unroll
+    for (int p = 0; p < NPP; ++p) { lx0[p] = 0; lx1[p] = 0; ly0[p] = 0; ly1[p] = 0; }
+#pragma unroll
+    for (int j = 0; j < KK; ++j) { rx0[j] = 0; ry0[j] = 0; rx1[j] = -1; ry1[j] = -1; have[j] = false; }
+
+    // the gradient image of neighbour j's resident box -> packed gradient map, then zero again.  Two box texels per
+    // wave-instruction (256 contiguous bytes when they are neighbours in a row).
+    auto flush_box = [&](int j) {
+        const int nc = rx1[j] - rx0[j] + 1, ntex = nc * (ry1[j] - ry0[j] + 1);
+        const float inv_nc = 1.0f / (float)nc;
+        for (int t0 = wave * 2; t0 < ntex; t0 += 8) {
+            const int t = t0 + (lane >> 5), q = lane & 31;
+            if (t < ntex) {
+                const int row = (int)(((float)t + 0.5f) * inv_nc), col = t - row * nc;
+                const int base = j * slot_fl + box_slot(t) * kSlab;
+                float* cell = s_grad + base + (q ^ grad_swizzle(base));
+                const float v = *cell;
+                if (v != 0.0f && !(dbg & 4)) atomicAdd(nb_grad[j] + ((size_t)(ry0[j] + row) * W + (rx0[j] + col)) * kSlab + q, v);
+                *cell = 0.0f;
+            }
+        }
+    };
+
+    for (int e = tid; e < K * slot_fl / 4; e += kThreads) s_grad4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const unsigned* fl_bt = flags + (size_t)bt * D;
+    const float* depth_n = depth + (size_t)n * D;
     for (int d = 0; d < D; ++d) {
-        const size_t tbase = ((size_t)bt * D + d) * K;
-        // ---- 1. dL/dvar tile -> LDS [channel row][pixel]; table entries -> tap origin + weights
-        {
-            float* t = s_g + (wave * 8 + sh) * kTileStride + 4 * sq;
+        const unsigned fl = K > 0 ? fl_bt[d] : 0u;
+        const float dval = K > 0 ? depth_n[d] : 0.0f;
+        bool refill = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = slab * kSlab + wave * 8 + 2 * k + sh;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < C) {
-                    const float* src = gvar + (((size_t)n * C + c) * D + d) * HW + st_off;
-                    if (st_vec) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        if (st_n > 0) v.x = src[0];
-                        if (st_n > 1) v.y = src[1];
-                        if (st_n > 2) v.z = src[2];
-                        if (st_n > 3) v.w = src[3];
-                    }
+        for (int j = 0; j < K; ++j)
+            if ((fl >> (4 * j)) & kFlagStaged)
+                if (((fl >> (4 * j)) & kFlagRefill) || !have[j]) refill = true;
+        if (refill) {
+            __syncthreads();  // every wave has added its taps of the planes that used the old boxes
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (((fl >> (4 * j)) & kFlagStaged) && (((fl >> (4 * j)) & kFlagRefill) || !have[j])) {
+                    if (have[j]) flush_box(j);
+                    const int4 b = boxes[((size_t)bt * D + d) * K + j];
+                    rx0[j] = __builtin_amdgcn_readfirstlane(b.x);
+                    rx1[j] = __builtin_amdgcn_readfirstlane(b.y);
+                    ry0[j] = __builtin_amdgcn_readfirstlane(b.z);
+                    ry1[j] = __builtin_amdgcn_readfirstlane(b.w);
+                    have[j] = true;
+                    if (min(2 * (j / 2) + qd, K - 1) == j) { lx0[j / 2] = rx0[j]; lx1[j / 2] = rx1[j]; ly0[j / 2] = ry0[j]; ly1[j / 2] = ry1[j]; }
                 }
-                *reinterpret_cast<float4*>(t + 2 * k * kTileStride) = v;
             }
+            __syncthreads();  // slots zeroed again before anyone adds into them
         }
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
-            if (j < K) {
-                const int p = tid % kTilePix;
-                const float2 e = table[(tbase + j) * kTilePix + p];
-                const SampleTaps tp = decode_sample(e.x, e.y, H, W);
-                s_w[j][p] = tap_weights(tp);
-                s_xy[j][p] = make_int2(tp.x0, tp.y0);
-            }
-        }
-        __syncthreads();
+        // ---- dL/dvar of the lane's pixels and channels
         float go[4][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float* t = s_g + g * kTileStride + (wave * 4 + s) * 8 + ps;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) go[s][i] = pok[s] ? t[8 * i * kTileStride] : 0.0f;
+        for (int i = 0; i < 4; ++i) {
+            const int c = slab * kSlab + 8 * i + g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C && st_n > 0) {
+                const float* src = gvar + (((size_t)n * C + slab * kSlab + 8 * i) * D + d) * HW + g_lane;
+                if (st_vec) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (st_n > 1) v.y = src[1];
+                    if (st_n > 2) v.z = src[2];
+                    if (st_n > 3) v.w = src[3];
+                }
+            }
+            go[0][i] = v.x; go[1][i] = v.y; go[2][i] = v.z; go[3][i] = v.w;
         }
-        // ---- 2. recompute the warped values (taps from the slab images) and S
-        bool skip[KK];  // neighbour entirely outside the source image (and all positions finite): w_j == 0, no gradient
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int4 bx = boxes[tbase + j];
-            skip[j] = (__builtin_amdgcn_readfirstlane(bx.y) < __builtin_amdgcn_readfirstlane(bx.x)) &&
-                      (__builtin_amdgcn_readfirstlane(bx.w) == kBoxSkip);
-        }
+        // ---- pass 1 over the neighbours: warped values (taps gathered from the slab images), S.  The lane keeps what it
+        //      decoded (tap offsets in the gradient slot / gradient image, weights) for pass 2, which fetches it again
+        //      by DPP: holding the broadcast copies of both neighbours would cost 64 VGPRs.
         float S_[4][4], wv[KK][4][4];
+        int dox[NPP][4];
+        float dwx[NPP][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { S_[s][0] = f[s].x; S_[s][1] = f[s].y; S_[s][2] = f[s].z; S_[s][3] = f[s].w; }
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            if (skip[j]) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) wv[j][s][0] = wv[j][s][1] = wv[j][s][2] = wv[j][s][3] = 0.0f;
-                continue;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int p = (wave * 4 + s) * 8 + ps;
-                const int2 xy = s_xy[j][p];
-                const float4 w = s_w[j][p];
-                const int xa = clampi(xy.x, 0, W - 1), xb = clampi(xy.x + 1, 0, W - 1);
-                const int ya = clampi(xy.y, 0, H - 1) * W, yb = clampi(xy.y + 1, 0, H - 1) * W;
-                const float4* b = nb_img[j] + g;
-                const float4 t0 = b[(ya + xa) * 8], t1 = b[(ya + xb) * 8], t2 = b[(yb + xa) * 8], t3 = b[(yb + xb) * 8];
-                const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};
-                const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = a0[i] * w.x;
-                    v = fmaf(a1[i], w.y, v);
-                    v = fmaf(a2[i], w.z, v);
-                    v = fmaf(a3[i], w.w, v);
-                    wv[j][s][i] = v;
-                    S_[s][i] += v;
-                }
-            }
+        for (int s = 0; s < 4; ++s) { S_[s][0] = f[s][0]; S_[s][1] = f[s][1]; S_[s][2] = f[s][2]; S_[s][3] = f[s][3]; }
+#define MVS_BWD_STEP(SS, QQ)                                                                                          \
+        {                                                                                                             \
+            const int i0 = from_quad<QQ>(quad_bcast<SS>(di0)), i1 = from_quad<QQ>(quad_bcast<SS>(di1));               \
+            const int i2 = from_quad<QQ>(quad_bcast<SS>(di2)), i3 = from_quad<QQ>(quad_bcast<SS>(di3));               \
+            const float w0 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.x))));                     \
+            const float w1 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.y))));                     \
+            const float w2 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.z))));                     \
+            const float w3 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.w))));                     \
+            const int gg = (dbg & 2) ? 0 : g;                                                                         \
+            const float4 t0 = nb_img[j][((dbg & 2) ? 0 : i0) + gg], t1 = nb_img[j][((dbg & 2) ? 0 : i1) + gg],        \
+                         t2 = nb_img[j][((dbg & 2) ? 0 : i2) + gg], t3 = nb_img[j][((dbg & 2) ? 0 : i3) + gg];        \
+            const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};                           \
+            const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+                float v = a0[i] * w0;                                                                                 \
+                v = fmaf(a1[i], w1, v);                                                                               \
+                v = fmaf(a2[i], w2, v);                                                                               \
+                v = fmaf(a3[i], w3, v);                                                                               \
+                wv[j][SS][i] = v;                                                                                     \
+                S_[SS][i] += v;                                                                                       \
+            }                                                                                                         \
         }
-        // ---- 4. reference term, kept in registers across the planes
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float fv[4] = {f[s].x, f[s].y, f[s].z, f[s].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gref[s][i] = fmaf(go[s][i], two_r * fv[i] - two_r2 * S_[s][i], gref[s][i]);
+#define MVS_BWD_OF(QQ)                                                                                                \
+        if constexpr (2 * p + QQ < K) {                                                                               \
+            constexpr int j = 2 * p + QQ;                                                                             \
+            if ((fl >> (4 * j)) & kFlagLive) {                                                                        \
+                MVS_BWD_STEP(0, QQ) MVS_BWD_STEP(1, QQ) MVS_BWD_STEP(2, QQ) MVS_BWD_STEP(3, QQ)                       \
+            } else {                                                                                                  \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                         \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) wv[j][s][i] = 0.0f;                                 \
+            }                                                                                                         \
         }
-        // ---- 3. tap gradients of every neighbour
+        auto pass = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            const unsigned fp = fl >> (8 * p);
+            const unsigned fq = qd ? ((2 * p + 1 < K) ? (fp >> 4) : fp) : fp;
+            const bool l_staged = (fq & kFlagStaged) != 0;
+            float2 e = make_float2(kNoSample, kNoSample);
+            if (d_inside) e = sample_at(ray[p], tr0[p], tr1[p], tr2[p], dval, H, W);
+            const SampleTaps tp = decode_sample(e.x, e.y, H, W);
+            const float4 dw = tap_weights(tp);
+            // taps clamped into the resident box (staged) or the image: an invalid tap carries weight 0, so reading a
+            // clamped texel and adding 0 to it is harmless; a valid one lies inside the box by construction
+            const int lox = l_staged ? lx0[p] : 0, hix = l_staged ? lx1[p] : W - 1;
+            const int loy = l_staged ? ly0[p] : 0, hiy = l_staged ? ly1[p] : H - 1;
+            const int xa = clampi(tp.x0, lox, hix), xb = clampi(tp.x0 + 1, lox, hix);
+            const int ya = clampi(tp.y0, loy, hiy), yb = clampi(tp.y0 + 1, loy, hiy);
+            const int di0 = (ya * W + xa) * 8, di1 = (ya * W + xb) * 8, di2 = (yb * W + xa) * 8, di3 = (yb * W + xb) * 8;
+            const int pitch = hix - lox + 1;
+            const int sbase = min(2 * p + qd, K - 1) * slot_fl;
+            const int ta = (ya - loy) * pitch - lox, tb = (yb - loy) * pitch - lox;
+            dox[p][0] = l_staged ? box_slot(ta + xa) * kSlab + sbase : di0 * 4;
+            dox[p][1] = l_staged ? box_slot(ta + xb) * kSlab + sbase : di1 * 4;
+            dox[p][2] = l_staged ? box_slot(tb + xa) * kSlab + sbase : di2 * 4;
+            dox[p][3] = l_staged ? box_slot(tb + xb) * kSlab + sbase : di3 * 4;
+            dwx[p][0] = dw.x; dwx[p][1] = dw.y; dwx[p][2] = dw.z; dwx[p][3] = dw.w;
+            MVS_BWD_OF(0)
+            MVS_BWD_OF(1)
+        };
+        if constexpr (NP > 0) pass(std::integral_constant<int, 0>{});
+        if constexpr (NP > 1) pass(std::integral_constant<int, 1>{});
+#undef MVS_BWD_OF
+#undef MVS_BWD_STEP
+        // ---- reference term, kept in registers across the planes
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int4 bx = boxes[tbase + j];
-            const int bx0 = __builtin_amdgcn_readfirstlane(bx.x), bx1 = __builtin_amdgcn_readfirstlane(bx.y);
-            const int by0 = __builtin_amdgcn_readfirstlane(bx.z), by1 = __builtin_amdgcn_readfirstlane(bx.w);
-            const int nc = bx1 - bx0 + 1, nr = by1 - by0 + 1;
-            const bool nonempty = (bx1 >= bx0) && (by1 >= by0);
-            const bool boxed = nonempty && (nc * nr <= kBoxCap);
-            __syncthreads();  // tile (first neighbour) / previous flush fully read
-            if (boxed) {
-                const int nfl = nc * nr * kSlab;
-                for (int e = tid; e < nfl / 4; e += kThreads) s_g4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-                __syncthreads();
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int p = (wave * 4 + s) * 8 + ps;
-                    const int2 xy = s_xy[j][p];
-                    const float4 w = s_w[j][p];
-                    const float wt[4] = {w.x, w.y, w.z, w.w};
-                    // invalid taps carry weight 0: adding 0 to a clamped texel of the box is harmless
-                    const int xa = clampi(xy.x, bx0, bx1) - bx0, xb = clampi(xy.x + 1, bx0, bx1) - bx0;
-                    const int ya = (clampi(xy.y, by0, by1) - by0) * nc, yb = (clampi(xy.y + 1, by0, by1) - by0) * nc;
-                    const int to[4] = {(ya + xa) * kSlab, (ya + xb) * kSlab, (yb + xa) * kSlab, (yb + xb) * kSlab};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float gw = go[s][i] * (two_r * wv[j][s][i] - two_r2 * S_[s][i]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (wt[t] != 0.0f) atomicAdd(s_g + to[t] + 4 * g + i, gw * wt[t]);
-                    }
-                }
-                __syncthreads();
-                // flush: rows of the box are contiguous nc*32 floats in the packed gradient image
-                const int row_fl = nc * kSlab;
-                for (int row = wave; row < nr; row += 4) {
-                    float* dst = nb_grad[j] + ((size_t)(by0 + row) * W + bx0) * kSlab;
-                    const float* src = s_g + row * row_fl;
-                    for (int q = lane; q < row_fl; q += 64) {
-                        const float v = src[q];
-                        if (v != 0.0f) atomicAdd(dst + q, v);
-                    }
-                }
-            } else if (nonempty) {  // footprint larger than the LDS box: one global atomic per tap
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int p = (wave * 4 + s) * 8 + ps;
-                    const int2 xy = s_xy[j][p];
-                    const float4 w = s_w[j][p];
-                    const float wt[4] = {w.x, w.y, w.z, w.w};
-                    const int xa = clampi(xy.x, 0, W - 1), xb = clampi(xy.x + 1, 0, W - 1);
-                    const int ya = clampi(xy.y, 0, H - 1) * W, yb = clampi(xy.y + 1, 0, H - 1) * W;
-                    const int to[4] = {(ya + xa) * kSlab, (ya + xb) * kSlab, (yb + xa) * kSlab, (yb + xb) * kSlab};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float gw = go[s][i] * (two_r * wv[j][s][i] - two_r2 * S_[s][i]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (wt[t] != 0.0f) atomicAdd(nb_grad[j] + to[t] + 4 * g + i, gw * wt[t]);
-                    }
-                }
-            }
+            for (int i = 0; i < 4; ++i)
+                if (pok[s]) gref[s][i] = fmaf(go[s][i], two_r * f[s][i] - two_r2 * S_[s][i], gref[s][i]);
+        // ---- pass 2: tap gradients of every live neighbour
+#define MVS_GRAD_STEP(SS, QQ, ADD)                                                                                    \
+        if (pok[SS]) {                                                                                                \
+            int to[4];                                                                                                \
+            float tw[4];                                                                                              \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
+                to[t] = from_quad<QQ>(quad_bcast<SS>(dox[p][t]));                                                     \
+                tw[t] = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dwx[p][t]))));                     \
+            }                                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+                const float gw = go[SS][i] * (two_r * wv[j][SS][i] - two_r2 * S_[SS][i]);                             \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
+                    if (tw[t] != 0.0f) ADD(to[t], i, gw * tw[t]);                                                     \
+            }                                                                                                         \
         }
-        __syncthreads();  // last flush / tables fully read before the next plane overwrites them
+        // LDS: ds_add_f32 on the swizzled gradient image (an explicit LDS pointer: a select between an LDS and a global
+        // address would make hipcc emit flat atomics, ~10x slower); larger than the box: one global atomic per tap
+#define MVS_ADD_LDS(O, I, V) \
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(s_grad + (O) + 4 * g + ((I) ^ grad_swizzle(O))), (V), 0, 0, false)
+#define MVS_ADD_GLB(O, I, V) atomicAdd(nb_grad[j] + (O) + 4 * g + (I), (V))
+#define MVS_GRAD_OF(QQ)                                                                                               \
+        if constexpr (2 * p + QQ < K) {                                                                               \
+            constexpr int j = 2 * p + QQ;                                                                             \
+            const unsigned fj = fl >> (4 * j);                                                                        \
+            if (fj & kFlagLive) {                                                                                     \
+                if (fj & kFlagStaged) {                                                                               \
+                    MVS_GRAD_STEP(0, QQ, MVS_ADD_LDS) MVS_GRAD_STEP(1, QQ, MVS_ADD_LDS)                               \
+                    MVS_GRAD_STEP(2, QQ, MVS_ADD_LDS) MVS_GRAD_STEP(3, QQ, MVS_ADD_LDS)                               \
+                } else {                                                                                              \
+                    MVS_GRAD_STEP(0, QQ, MVS_ADD_GLB) MVS_GRAD_STEP(1, QQ, MVS_ADD_GLB)                               \
+                    MVS_GRAD_STEP(2, QQ, MVS_ADD_GLB) MVS_GRAD_STEP(3, QQ, MVS_ADD_GLB)                               \
+                }                                                                                                     \
+            }                                                                                                         \
+        }
+        auto grads = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            MVS_GRAD_OF(0)
+            MVS_GRAD_OF(1)
+        };
+        if (!(dbg & 1)) {
+            if constexpr (NP > 0) grads(std::integral_constant<int, 0>{});
+            if constexpr (NP > 1) grads(std::integral_constant<int, 1>{});
+        }
+#undef MVS_GRAD_OF
+#undef MVS_GRAD_STEP
+#undef MVS_ADD_LDS
+#undef MVS_ADD_GLB
     }
-    // ---- reference term: once per block
+    // ---- the boxes still resident, then the reference term: once per block
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (have[j]) flush_box(j);
     float* gr = gpacked + ((size_t)n * S + slab) * slab_stride;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         if (pok[s]) {
+            const int pix = py * W + px0 + s;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(gr + (size_t)ppix[s] * kSlab + 4 * g + i, gref[s][i]);
+            for (int i = 0; i < 4; ++i) atomicAdd(gr + (size_t)pix * kSlab + 4 * g + i, gref[s][i]);
         }
 }
 
@@ -253,17 +320,16 @@ using namespace mvsdet;
 
 // defined in planesweep.hip
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W);
+extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,
+                                            int N, int K, int D, int H, int W, mvsdet_stream_t stream);
 namespace mvsdet {
-size_t sweep_table_bytes(int N, int K, int D, int H, int W);
 int sweep_tile_width(int W);  // the tile shape the sweep geometry is built for
-int sweep_build_geometry_and_table(const float* proj, const float* depth, void* scratch, size_t scratch_bytes, void* table,
-                                   int N, int K, int D, int H, int W, mvsdet_stream_t stream);
+int sweep_box_cap(int K);
 }
 
 extern "C" size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, int D, int H, int W) {
     const size_t pb = (mvsdet_packed_bytes(N, C, H, W) + 255) / 256 * 256;
-    const size_t sb = (mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W) + 255) / 256 * 256;
-    return 2 * pb + sb + sweep_table_bytes(N, K, D, H, W);
+    return 2 * pb + mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, const float* proj,
@@ -275,19 +341,17 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     MVS_REQUIRE(K == 0 || (nbr && proj), "plane_sweep_variance_bwd: NULL neighbour arrays with K=%d", K);
     MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "plane_sweep_variance_bwd: bad shape");
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "plane_sweep_variance_bwd: K=%d outside [0,%d]", K, MVSDET_MAX_NEIGHBORS);
-    MVS_REQUIRE(D <= 65535 && H < 65535 && W < 65535, "plane_sweep_variance_bwd: D, H or W > 65534");
+    MVS_REQUIRE(D <= MVSDET_MAX_DEPTH && H < 65535 && W < 65535, "plane_sweep_variance_bwd: D > %d, or H or W > 65534", MVSDET_MAX_DEPTH);
     MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "plane_sweep_variance_bwd: one slab image exceeds 2^31 elements");
     const size_t pb = (mvsdet_packed_bytes(N, C, H, W) + 255) / 256 * 256;
-    const size_t sb = (mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W) + 255) / 256 * 256;
-    const size_t tb = sweep_table_bytes(N, K, D, H, W);
-    if (workspace_bytes < 2 * pb + sb + tb) {
-        set_error("plane_sweep_variance_bwd: workspace %zu B < %zu B", workspace_bytes, 2 * pb + sb + tb);
+    const size_t sb = mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W);
+    if (workspace_bytes < 2 * pb + sb) {
+        set_error("plane_sweep_variance_bwd: workspace %zu B < %zu B", workspace_bytes, 2 * pb + sb);
         return MVSDET_ERR_WORKSPACE;
     }
     float* packed = (float*)workspace;
     float* gpacked = (float*)((char*)workspace + pb);
     void* scratch = (char*)workspace + 2 * pb;
-    void* table_mem = (char*)workspace + 2 * pb + sb;
     const int64_t fs[4] = {(int64_t)C * H * W, (int64_t)H * W, W, 1};
     if (int rc = mvsdet_pack_features_f32(feat, fs, packed, N, C, H, W, stream_)) return rc;
     if (hipMemsetAsync(gpacked, 0, pb, stream) != hipSuccess) {
@@ -295,7 +359,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
         return MVSDET_ERR_HIP;
     }
     if (K > 0)
-        if (int rc = sweep_build_geometry_and_table(proj, depth, scratch, sb, table_mem, N, K, D, H, W, stream_)) return rc;
+        if (int rc = mvsdet_plane_sweep_table_f32(proj, depth, scratch, sb, N, K, D, H, W, stream_)) return rc;
     const int tw = sweep_tile_width(W);
     const int th = kTilePix / tw;
     const int S = num_slabs(C);
@@ -303,17 +367,25 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     const int tiles_x = (W + tw - 1) / tw, tiles = tiles_x * ((H + th - 1) / th);
     const long long nblocks = (long long)N * tiles * S;
     MVS_REQUIRE(nblocks <= INT32_MAX, "plane_sweep_variance_bwd: grid too large");
-    const float2* table = reinterpret_cast<const float2*>(table_mem);
-    const int4* boxes = sweep_geometry(scratch, N, K, D, tiles).boxes;
+    const SweepGeometry geo = sweep_geometry(scratch, N, K, D, tiles);
+    const int box_cap = sweep_box_cap(K);
+    const size_t lds = sweep_lds_bytes(K, box_cap);
     dim3 grid((unsigned)nblocks);
-#define MVS_BWD_CASE(KV)                                                                                               \
-    case KV:                                                                                                           \
-        if (tw == 16)                                                                                                  \
-            hipLaunchKernelGGL((plane_sweep_variance_bwd_kernel<KV, 16>), grid, dim3(kThreads), 0, stream, packed, nbr, \
-                               table, boxes, g, gpacked, N, C, S, D, H, W, tiles_x, tiles);                            \
-        else                                                                                                           \
-            hipLaunchKernelGGL((plane_sweep_variance_bwd_kernel<KV, 32>), grid, dim3(kThreads), 0, stream, packed, nbr, \
-                               table, boxes, g, gpacked, N, C, S, D, H, W, tiles_x, tiles);                            \
+#define MVS_BWD_LAUNCH(KV, TWV)                                                                                        \
+    {                                                                                                                  \
+        auto* k = plane_sweep_variance_bwd_kernel<KV, TWV>;                                                            \
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   80 * 1024) != hipSuccess) {                                         \
+            set_error("plane_sweep_variance_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");             \
+            return MVSDET_ERR_HIP;                                                                                     \
+        }                                                                                                              \
+        hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
+                           gpacked, N, C, S, D, H, W, tiles_x, tiles, box_cap, options().sweep_debug);                                        \
+    }
+#define MVS_BWD_CASE(KV)                     \
+    case KV:                                 \
+        if (tw == 16) MVS_BWD_LAUNCH(KV, 16) \
+        else MVS_BWD_LAUNCH(KV, 32)          \
         break;
     switch (K) {
         MVS_BWD_CASE(0)
@@ -323,6 +395,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
         MVS_BWD_CASE(4)
     }
 #undef MVS_BWD_CASE
+#undef MVS_BWD_LAUNCH
     MVS_LAUNCH_CHECK("plane_sweep_variance_bwd");
     dim3 ugrid((HW + 63) / 64, S, N);
     hipLaunchKernelGGL(unpack_features_kernel, ugrid, dim3(kThreads), 0, stream, gpacked, gfeat, C, S, H, W);

@@ -129,7 +129,7 @@ __device__ __forceinline__ float2 sample_position(const float* __restrict__ P, f
 // ---------------------------------------------------------------------------------------------
 // (1) sweep geometry: block = (view, tile); thread = (neighbour, pixel); loops over all planes.
 //     boxes [((n*tiles + tile)*D + d)*K + j] int4, flags [(n*tiles + tile)*D + d]; copies of proj / depth for the slab
-//     kernel; table [((n*tiles + tile)*D + d)*K + j][128] float2 only where the backward pass asks for it (table != NULL).
+//     kernels (forward and backward recompute the sample positions from them).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool box_nonempty(const int4& b) { return b.y >= b.x && b.w >= b.z; }
 __device__ __forceinline__ int box_area(const int4& b) { return (b.y - b.x + 1) * (b.w - b.z + 1); }
@@ -137,7 +137,7 @@ __device__ __forceinline__ int box_area(const int4& b) { return (b.y - b.x + 1) 
 template <int K, int TW>
 __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const float* __restrict__ proj,
                                                                        const float* __restrict__ depth,
-                                                                       float2* __restrict__ table, int4* __restrict__ boxes,
+                                                                       int4* __restrict__ boxes,
                                                                        unsigned* __restrict__ flags, float* __restrict__ proj_copy,
                                                                        float* __restrict__ depth_copy, int D, int H, int W,
                                                                        int tiles_x, int tiles, int box_cap) {
@@ -172,7 +172,6 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     for (int d = 0; d < D; ++d) {
         const int par = d & 1;
         const float dval = depth[(size_t)n * D + d];
-        const size_t base = ((size_t)bt * D + d) * K;
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             // 128 pixels = 2 whole waves per neighbour: j is wave-uniform
@@ -192,7 +191,6 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                         yhi = t.y1in ? t.y0 + 1 : t.y0;
                     }
                 }
-                if (table) table[(base + j) * kTilePix + p] = e;
                 xlo = wave_reduce<true>(xlo);
                 xhi = wave_reduce<false>(xhi);
                 ylo = wave_reduce<true>(ylo);

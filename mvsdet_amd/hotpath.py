@@ -33,6 +33,102 @@ class SceneGeometry:
     width: int
 
 
+class _GeometryWorker:
+    """One daemon thread per MVSDetHotPath: evaluates `_host_geometry` (ATen-CPU, one intra-op thread -- set ONCE, in this
+    thread), packs the results into a pinned staging buffer and uploads them with a single asynchronous copy on its own
+    stream.  Entries are kept by `img_meta` identity (the dict itself is referenced, so its id cannot be recycled)."""
+
+    _ALIGN = 16
+
+    def __init__(self, owner, max_entries: int = 32):
+        import queue
+        import threading
+        self.owner = owner
+        self.max_entries = max_entries
+        self.entries: dict = {}        # id(img_meta) -> [img_meta, device, threading.Event, SceneGeometry | Exception, cuda Event]
+        self.lock = threading.Lock()
+        self.todo: "queue.Queue" = queue.Queue()
+        self.thread = None
+        self.streams: dict = {}
+
+    def _start(self):
+        import threading
+        if self.thread is None or not self.thread.is_alive():
+            self.thread = threading.Thread(target=self._run, name="mvsdet-geometry", daemon=True)
+            self.thread.start()
+
+    def submit(self, img_meta: dict, device):
+        import threading
+        key = (id(img_meta), str(device))
+        with self.lock:
+            ent = self.entries.get(key)
+            if ent is not None and ent[0] is img_meta:
+                return ent
+            if len(self.entries) >= self.max_entries:   # drop the oldest finished entries
+                for k in [k for k, e in self.entries.items() if e[2].is_set()][: self.max_entries // 2]:
+                    del self.entries[k]
+            ent = [img_meta, device, threading.Event(), None, None]
+            self.entries[key] = ent
+        self._start()
+        self.todo.put(ent)
+        return ent
+
+    def get(self, img_meta: dict, device) -> "SceneGeometry":
+        ent = self.submit(img_meta, device)
+        ent[2].wait()
+        if isinstance(ent[3], BaseException):
+            with self.lock:
+                self.entries.pop((id(img_meta), str(device)), None)
+            raise ent[3]
+        if ent[4] is not None:   # the caller's stream waits for the upload; the host does not
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ent[4])
+            ent[3].neighbor_ids.record_stream(cur)   # all four views share the one uploaded buffer
+        return ent[3]
+
+    def _run(self):
+        torch.set_num_threads(1)   # once, in this thread: N 4x4 matrices do not want an OpenMP team
+        while True:
+            ent = self.todo.get()
+            try:
+                ent[3], ent[4] = self._build(ent[0], ent[1])
+            except BaseException as exc:  # noqa: BLE001 -- handed to the waiting caller
+                ent[3] = exc
+            ent[2].set()
+
+    def _build(self, img_meta: dict, device):
+        hp = self.owner
+        nbr, proj_rel, depth_values, projection, origin, height, width = hp._host_geometry(img_meta)
+        parts = [nbr.contiguous(), proj_rel.contiguous(), depth_values.contiguous(), projection.contiguous()]
+        if device.type != "cuda":
+            points = hp._voxel_points(origin, device)
+            return SceneGeometry(parts[0], parts[1], parts[2], parts[3], points, height, width), None
+        offs, total = [], 0
+        for t in parts:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + self._ALIGN - 1) // self._ALIGN * self._ALIGN
+        stage = torch.empty(max(total, self._ALIGN), dtype=torch.uint8, pin_memory=True)
+        for t, o in zip(parts, offs):
+            nb = t.numel() * t.element_size()
+            if nb:
+                stage[o:o + nb].copy_(t.reshape(-1).view(torch.uint8))
+        stream = self.streams.get(str(device))
+        if stream is None:
+            stream = self.streams[str(device)] = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            dev = stage.to(device, non_blocking=True)        # ONE host-to-device copy per scene
+            points = hp._voxel_points(origin, device)
+            done = torch.cuda.Event()
+            done.record(stream)
+        views = []
+        for t, o in zip(parts, offs):
+            nb = t.numel() * t.element_size()
+            views.append(dev[o:o + nb].view(t.dtype).view(t.shape))
+        geo = SceneGeometry(views[0], views[1], views[2], views[3], points, height, width)
+        geo._staging = stage   # keeps the pinned buffer alive until the geometry is dropped
+        return geo, done
+
+
 class MVSDetHotPath:
     """Holds the hyper-parameters MVSDet.__init__ keeps for this path (mvsdet.py:165-230)."""
 
@@ -51,6 +147,8 @@ class MVSDetHotPath:
                                       dtype=np.float32)
         assert len(self.depth_values) == self.num_depth
         self.cost_regularization = cost_regularization
+        self._points_cache: dict = {}
+        self._geometry = _GeometryWorker(self)
 
     # ---- reference-named methods (mvsdet.py:249, 266, 298) -------------------------------------------
     def collect_proj(self, w2c, intr, neighbor_ids):
@@ -70,22 +168,21 @@ class MVSDetHotPath:
     # ---- host-side camera algebra -----------------------------------------------------------------------
     def prepare_scene(self, img_meta: dict, device) -> SceneGeometry:
         """mvsdet.py:407-450 for one scene, evaluated with ATen-CPU exactly as the reference does, then uploaded.
-        The tensors are tiny (N 4x4 matrices): run the ATen calls single-threaded -- on a 256-core host the OpenMP
-        fork/join of the default thread pool costs ~10 ms per scene, 10x the GPU time of the reference-true shape."""
-        nthreads = torch.get_num_threads()
-        if nthreads > 1:
-            torch.set_num_threads(1)
-        try:
-            return self._prepare_scene(img_meta, device)
-        finally:
-            if nthreads > 1:
-                torch.set_num_threads(nthreads)
+        The algebra runs on this object's geometry worker thread (single-threaded ATen: on a 256-core host the OpenMP
+        fork/join of the default pool costs ~10 ms per scene for N 4x4 matrices), is packed into ONE pinned staging
+        buffer and reaches the device as ONE asynchronous copy on a side stream; the caller's stream waits for it with
+        an event, never the host.  Results are kept by `img_meta` identity, so a scene seen again (or announced with
+        `prefetch_scene` while the previous scene was running) costs a dictionary lookup."""
+        return self._geometry.get(img_meta, torch.device(device))
 
-    def _prepare_scene(self, img_meta: dict, device) -> SceneGeometry:
+    def prefetch_scene(self, img_meta: dict, device) -> None:
+        """Start the camera algebra and the upload of a coming scene on the worker thread; returns at once."""
+        self._geometry.submit(img_meta, torch.device(device))
+
+    def _host_geometry(self, img_meta: dict):
+        """The reference's ATen-CPU operator sequence (mvsdet.py:407-450) -> host tensors."""
         stride = self.stride
         projection = F_.compute_projection(img_meta, stride)
-        points = F_.get_points(n_voxels=torch.tensor(self.n_voxels), voxel_size=torch.tensor(self.voxel_size),
-                               origin=torch.tensor(img_meta["lidar2img"]["origin"]))
         height = img_meta["img_shape"][0] // stride
         width = img_meta["img_shape"][1] // stride
         w2c = torch.tensor(np.array(img_meta["lidar2img"]["extrinsic"]))
@@ -100,6 +197,7 @@ class MVSDetHotPath:
         k = min(2, n - 1)  # mvsdet.py:432
         c2w = w2c.inverse()
         nbr = F_.get_nearest_pose_ids(c2w, c2w, k, maskself=True)
+        ops.validate_neighbors(nbr, n)  # the reference's index gather raises on an id outside [0, N)
         ref_proj, nei_projs = F_.collect_proj(w2c, K_feat, nbr)
         inv_ref = torch.inverse(ref_proj)
         if k > 0:
@@ -107,9 +205,20 @@ class MVSDetHotPath:
         else:
             proj_rel = torch.zeros((n, 0, 4, 4))
         depth_values = torch.tensor(self.depth_values).unsqueeze(0).repeat(n, 1)
-        to = dict(device=device, non_blocking=True)
-        return SceneGeometry(nbr.to(**to), proj_rel.to(**to), depth_values.to(**to), projection.to(**to),
-                             points.to(**to), int(height), int(width))
+        origin = torch.tensor(img_meta["lidar2img"]["origin"])
+        return nbr, proj_rel, depth_values, projection, origin, int(height), int(width)
+
+    def _voxel_points(self, origin: Tensor, device) -> Tensor:
+        """get_points (mvsdet.py:1316) depends on the grid and the scene origin only: kept on the device per origin."""
+        key = (tuple(float(v) for v in origin.tolist()), str(device))
+        pts = self._points_cache.get(key)
+        if pts is None:
+            pts = F_.get_points(n_voxels=torch.tensor(self.n_voxels), voxel_size=torch.tensor(self.voxel_size),
+                                origin=origin).to(device)
+            if len(self._points_cache) > 64:
+                self._points_cache.clear()
+            self._points_cache[key] = pts
+        return pts
 
     # ---- the hot path -------------------------------------------------------------------------------------
     def cost_volume(self, feature: Tensor, geo: SceneGeometry, packed: Optional[Tensor] = None) -> Tensor:

@@ -78,6 +78,18 @@ def _(src, proj, depth):
 
 
 # ------------------------------------------------------------------------------------------- a3+a4
+def validate_neighbors(nbr: Tensor, n_src: int) -> None:
+    """Host check of neighbour view ids (include/mvsdet_hip.h: mvsdet_validate_neighbors): the reference's index gather
+    (mvsdet.py:440) raises on an id outside [0, N); the kernels only clamp.  `nbr` must be a CPU tensor."""
+    if nbr.device.type != "cpu":
+        raise ValueError("validate_neighbors: the ids are checked on their host copy")
+    t = nbr.to(torch.int64).contiguous()
+    m, k = (t.shape[0], t.shape[1]) if t.dim() == 2 else (t.numel(), 1)
+    import ctypes
+    p = ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_int64)) if t.numel() else None
+    _lib.check(_lib.load().mvsdet_validate_neighbors(p, int(m), int(k), int(n_src)), "validate_neighbors")
+
+
 def _check_sweep(feat, nbr, proj, depth):
     _req(feat, "feat", dim=4)
     _req(nbr, "nbr", dtype=torch.int64, dim=2)

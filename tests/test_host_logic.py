@@ -95,3 +95,38 @@ def test_synthetic_scene_is_reproducible_and_overlapping():
     assert torch.equal(f1, f2)
     pv = synthetic.make_img_meta(5, (60, 80), seed=3, per_view_intrinsics=True)
     assert isinstance(pv["lidar2img"]["intrinsic"], list) and len(pv["lidar2img"]["intrinsic"]) == 5
+
+
+def test_neighbor_ids_are_validated_on_the_host():
+    """mvsdet.py:434-440 feeds the ids to an index gather, which raises on an id outside [0, N): the C ABI's host check
+    (mvsdet_validate_neighbors) does the same before anything is uploaded."""
+    import torch
+    from mvsdet_amd import ops
+    ops.validate_neighbors(torch.tensor([[1, 2], [0, 2], [0, 1]]), 3)
+    for bad in ([[1, 3]], [[-1, 0]]):
+        with pytest.raises(ValueError, match="outside"):
+            ops.validate_neighbors(torch.tensor(bad), 3)
+
+
+def test_scene_geometry_worker_cpu():
+    """prepare_scene: camera algebra on the worker thread, results by img_meta identity; prefetch returns at once;
+    a new dict with the same contents is recomputed (and equal); errors surface in the caller."""
+    import torch
+    from mvsdet_amd import synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    hp = MVSDetHotPath([40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], 12)
+    meta = synthetic.make_img_meta(6, (60, 80), seed=3)
+    other = synthetic.make_img_meta(4, (60, 80), seed=4, per_view_intrinsics=True)
+    hp.prefetch_scene(other, "cpu")
+    g1 = hp.prepare_scene(meta, "cpu")
+    assert hp.prepare_scene(meta, "cpu") is g1
+    g2 = hp.prepare_scene(dict(meta), "cpu")
+    assert g2 is not g1 and torch.equal(g2.proj_rel, g1.proj_rel) and torch.equal(g2.neighbor_ids, g1.neighbor_ids)
+    g3 = hp.prepare_scene(other, "cpu")
+    assert g3.neighbor_ids.shape == (4, 2) and g3.points.shape == (3, 40, 40, 16)
+    n0 = torch.get_num_threads()
+    assert torch.get_num_threads() == n0          # the caller's thread settings are never touched
+    broken = dict(meta)
+    broken["lidar2img"] = dict(meta["lidar2img"], extrinsic=[])
+    with pytest.raises(Exception):
+        hp.prepare_scene(broken, "cpu")
