@@ -302,7 +302,8 @@ def footprint_stats(w, hp, scene, device):
     empty = (nc <= 0) | (nr <= 0)
     area = np.where(empty, 0, nc * nr)
     from mvsdet_amd import _lib
-    cap = min(_lib.get_option("sweep_boxcap"), (80 * 1024 // 128) // K - 8)   # planesweep.hip: effective_box_cap
+    budget = 52 * 1024 if (tw == 16 and K <= 2) else 80 * 1024
+    cap = min(_lib.get_option("sweep_boxcap"), (budget // 128) // K - 8)   # planesweep.hip: effective_box_cap
     live = ~empty
     fl = table[nent * 4: nent * 4 + N * tiles * D].view(torch.int32).cpu().numpy().astype(np.int64)   # flags follow the boxes
     staged_n = sum(int(((fl >> (4 * j + 1)) & 1).sum()) for j in range(K))

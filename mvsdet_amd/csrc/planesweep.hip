@@ -117,11 +117,14 @@ int num_tiles(int H, int W, int tw) {
     return ((W + tw - 1) / tw) * ((H + th - 1) / th);
 }
 
-// texels of one LDS footprint box: K resident boxes of 128-byte texels, two blocks per CU (80 KiB each)
-int effective_box_cap(int K) {
+// texels of one LDS footprint box.  K resident boxes of 128-byte texels share the block's LDS: 80 KiB = two blocks per CU
+// for the 32x4 tiles (their footprints need ~300 texels to form long runs); the 16x8 tiles of maps whose width is no
+// multiple of 32 have smaller footprints and run three blocks per CU on 52 KiB (+5 % at the reference-true shape).
+int effective_box_cap(int K, int tw) {
     if (K <= 0) return 0;
     int cap = options().sweep_boxcap;
-    const int fit = (80 * 1024 / 128) / K - kBoxPad;
+    const int budget = (tw == 16 && K <= 2) ? 52 * 1024 : 80 * 1024;
+    const int fit = (budget / 128) / K - kBoxPad;
     cap = cap < 0 ? 0 : (cap > fit ? fit : cap);
     return cap > 512 ? 512 : cap;
 }
@@ -190,7 +193,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         return MVSDET_ERR_INVALID_ARG;
     }
     const int G = options().sweep_groups == 2 ? 2 : 1;
-    const int box_cap = effective_box_cap(K);
+    const int box_cap = effective_box_cap(K, TW);
     // every block sweeps all its planes (reference features stay in registers, a resident footprint box serves a run
     // of planes) unless the grid would be too small to fill 256 CUs x 2 blocks
     int dsplit = 1;
@@ -219,7 +222,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     case KV:                                                                                                          \
         if (phases & 1)                                                                                               \
             hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads),                            \
-                               (size_t)D * (KV * sizeof(int4) + sizeof(unsigned)), stream, proj, depth,               \
+                               (size_t)D * (KV * sizeof(int4) + sizeof(unsigned) + sizeof(float)), stream, proj, depth,               \
                                geo.boxes, geo.flags, geo.proj, geo.depth, D, H, W, tiles_x, tiles, box_cap);           \
         if (phases & 2) rc = (G == 1) ? MVS_SLAB(KV, 1) : MVS_SLAB(KV, 2);                                            \
         break;
@@ -242,7 +245,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
 
 namespace mvsdet {
 int sweep_tile_width(int W) { return pick_tile_width(W); }  // shared with planesweep_bwd.hip
-int sweep_box_cap(int K) { return effective_box_cap(K); }
+int sweep_box_cap(int K, int tw) { return effective_box_cap(K, tw); }
 int sweep_num_tiles(int H, int W) { return num_tiles(H, W, pick_tile_width(W)); }
 }
 

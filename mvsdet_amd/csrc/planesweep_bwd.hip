@@ -324,7 +324,7 @@ extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* dept
                                             int N, int K, int D, int H, int W, mvsdet_stream_t stream);
 namespace mvsdet {
 int sweep_tile_width(int W);  // the tile shape the sweep geometry is built for
-int sweep_box_cap(int K);
+int sweep_box_cap(int K, int tw);
 }
 
 extern "C" size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, int D, int H, int W) {
@@ -368,7 +368,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     const long long nblocks = (long long)N * tiles * S;
     MVS_REQUIRE(nblocks <= INT32_MAX, "plane_sweep_variance_bwd: grid too large");
     const SweepGeometry geo = sweep_geometry(scratch, N, K, D, tiles);
-    const int box_cap = sweep_box_cap(K);
+    const int box_cap = sweep_box_cap(K, tw);
     const size_t lds = sweep_lds_bytes(K, box_cap);
     dim3 grid((unsigned)nblocks);
 #define MVS_BWD_LAUNCH(KV, TWV)                                                                                        \

@@ -41,23 +41,24 @@ constexpr int kBoxCap = 256;        // default texels (128 B each) of one LDS fo
 constexpr int kBoxCapMax = 320;     // 2 neighbours x 320 texels x 2 blocks = the CU's 160 KiB
 constexpr int kTileStride = 132;    // floats per channel row of the backward kernel's gradient tile
 
-// Wave-wide integer min / max: butterfly inside each row of 16 lanes with DPP (4 VALU), then the four row
-// results are combined on the scalar unit.  The result is wave-uniform (an SGPR).
+// Wave-wide integer min / max, all on DPP: butterfly inside each row of 16 lanes (every lane of a row ends up with the
+// row's result), then row_bcast:15 folds row 0 into row 1 and row 2 into row 3, row_bcast:31 folds rows 0-1 into row 3;
+// lane 63 holds the wave's result (6 VALU + 1 readlane).  The result is wave-uniform (an SGPR).
 template <bool kMin>
 __device__ __forceinline__ int wave_reduce(int v) {
-#define MVS_DPP_STEP(ctrl)                                                         \
-    {                                                                              \
-        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);    \
-        v = kMin ? min(v, o) : max(v, o);                                          \
+#define MVS_DPP_STEP(ctrl, rmask)                                                    \
+    {                                                                                \
+        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false);    \
+        v = kMin ? min(v, o) : max(v, o);                                            \
     }
-    MVS_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
-    MVS_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
-    MVS_DPP_STEP(0x141)  // row_half_mirror
-    MVS_DPP_STEP(0x140)  // row_mirror
+    MVS_DPP_STEP(0xB1, 0xf)   // quad_perm [1,0,3,2]
+    MVS_DPP_STEP(0x4E, 0xf)   // quad_perm [2,3,0,1]
+    MVS_DPP_STEP(0x141, 0xf)  // row_half_mirror
+    MVS_DPP_STEP(0x140, 0xf)  // row_mirror
+    MVS_DPP_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
+    MVS_DPP_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
 #undef MVS_DPP_STEP
-    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return kMin ? min(min(a, b), min(c, d)) : max(max(a, b), max(c, d));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Table entry = the un-normalised sample position (ix, iy) of module.py:116-143 (8 bytes); everything bilinear
@@ -144,9 +145,10 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     constexpr int TH = kTilePix / TW;
     constexpr int ITER = (K * kTilePix + kThreads - 1) / kThreads;
     __shared__ int s_red[2][K][2][5];  // [plane parity][neighbour][wave of the neighbour][xlo,xhi,ylo,yhi,all finite]
-    extern __shared__ int4 s_geo[];    // [K][D] the tile's boxes of all planes, then [D] flags words
+    extern __shared__ int4 s_geo[];    // [K][D] the tile's boxes of all planes, then [D] flags words, then [D] plane depths
     int4* s_pb = s_geo;
     unsigned* s_fl = reinterpret_cast<unsigned*>(s_geo + (size_t)K * D);
+    float* s_dv = reinterpret_cast<float*>(s_fl + D);
     const int bt = blockIdx.x;  // n*tiles + tile
     const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
@@ -154,7 +156,11 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     const int p = tid % kTilePix;
     const int x = tx0 + (p % TW), y = ty0 + (p / TW);
     const bool inside = (x < W) && (y < H);
-    for (int d = tid; d < D; d += kThreads) s_fl[d] = 0u;  // nibbles are OR-ed in below
+    for (int d = tid; d < D; d += kThreads) {
+        s_fl[d] = 0u;  // nibbles are OR-ed in below
+        s_dv[d] = depth[(size_t)n * D + d];   // one global round trip for all planes instead of one per plane
+    }
+    __syncthreads();
     if (tile == 0) {  // the slab kernel reads the camera data from the scratch buffer (the tabled entry point has no other)
         for (int i = tid; i < K * 16; i += kThreads) proj_copy[(size_t)n * K * 16 + i] = proj[(size_t)n * K * 16 + i];
         for (int d = tid; d < D; d += kThreads) depth_copy[(size_t)n * D + d] = depth[(size_t)n * D + d];
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     }
     for (int d = 0; d < D; ++d) {
         const int par = d & 1;
-        const float dval = depth[(size_t)n * D + d];
+        const float dval = s_dv[d];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             // 128 pixels = 2 whole waves per neighbour: j is wave-uniform
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                 xhi = wave_reduce<false>(xhi);
                 ylo = wave_reduce<true>(ylo);
                 yhi = wave_reduce<false>(yhi);
-                fin = wave_reduce<true>(fin);
+                fin = __builtin_amdgcn_readfirstlane((int)(__ballot(fin == 0) == 0ull));  // all of the wave's positions finite
                 if (lane == 0) {
                     int* r = s_red[par][j][(tid >> 6) & 1];
                     r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi; r[4] = fin;
