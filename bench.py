@@ -252,10 +252,12 @@ def full_chain_rate(device, steps=10):
     shipped config runs: what a scene costs end to end on the GPU (the network is ~30x the hot path around it)."""
     from mvsdet_amd.costreg import CostRegNet3DGS
     from mvsdet_amd.hotpath import MVSDetHotPath
+    from mvsdet_amd.neck import IndoorImVoxelNeck
     wr = WORKLOADS["scannet_ref_40v_12d_60x80"]
     torch.manual_seed(0)
     net = CostRegNet3DGS(wr["C"]).to(device).eval()
-    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(wr["near_far"]), wr["D"], topk=3, cost_regularization=net)
+    neck = IndoorImVoxelNeck(wr["C"], 128, [1, 1, 1]).to(device).eval()   # configs/mvsdet_res50_2x_low_res.py: neck_3d
+    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(wr["near_far"]), wr["D"], topk=3, cost_regularization=net, neck_3d=neck)
     scene = SceneInputs(wr, seed=0, device=device)
     with torch.no_grad():
         for _ in range(2):
@@ -280,7 +282,21 @@ def full_chain_rate(device, steps=10):
     roof = {"bound": "mfma", "achieved": round(tfl / net_ms * 1e3, 1), "peak": 157.3, "unit": "TFLOP/s",
             "frac": round(tfl / net_ms * 1e3 / 157.3, 4), "kernel": "cost network forward (8 layers, fp32 MFMA)",
             "kernel_ms": round(net_ms, 3)}
-    return {"workload": "scannet_ref_40v_12d_60x80", "scenes_per_sec": round(steps / el, 3), "cost_network_roofline": roof,
+    with torch.no_grad():
+        vol = out["volume"].unsqueeze(0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            neck(vol)
+        e1.record()
+        torch.cuda.synchronize(device)
+    neck_ms = e0.elapsed_time(e1) / 3
+    ntfl = IndoorImVoxelNeck.flops(1, N_VOXELS, wr["C"], 128) / 1e12
+    neck_roof = {"bound": "mfma", "achieved": round(ntfl / neck_ms * 1e3, 1), "peak": 157.3, "unit": "TFLOP/s",
+                 "frac": round(ntfl / neck_ms * 1e3 / 157.3, 4), "kernel": "IndoorImVoxelNeck forward (fp32 MFMA convolutions + GEMMs)",
+                 "kernel_ms": round(neck_ms, 3)}
+    return {"workload": "scannet_ref_40v_12d_60x80", "chain": "a1..a10 + CostRegNet_3DGS + IndoorImVoxelNeck, eval",
+            "scenes_per_sec": round(steps / el, 3), "cost_network_roofline": roof, "neck_roofline": neck_roof,
             "ms_per_scene": round(el / steps * 1e3, 3), "cost_network_tflop": round(CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12, 3),
             "non_empty_voxels": int((out["valid"] > 0).sum().item())}
 

@@ -187,6 +187,12 @@ int mvsdet_depth_prob_topk_bwd_f32(const float* prob, const float* off, const in
  *   relu != 0 clamps at 0.  Forward only. */
 int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift, float* out,
                               int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* The same convolution with a residual added between the affine and the ReLU: out = act(v*scale[o] + shift[o] + residual)
+ * -- the tail of the 3-D neck's ResModule, mmdet3d/models/necks/imvoxel_neck.py:219-230 (x = conv1(conv0(x)); x = x +
+ * identity; x = relu(x)).  residual: shape of out, or NULL. */
+int mvsdet_conv3d_k3_res_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                  const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                  mvsdet_stream_t stream);
 /* The stride-2 layers (mvsnet.py:78,81: conv1 64->128, conv3 128->256): same arguments, x (N,Cin,D,H,W) ->
  * out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1). */
 int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,

@@ -31,7 +31,7 @@ constexpr int kC0WStage = (kC0WPair / 4 + kThreads - 1) / kThreads;  // 4 float4
 // TD = tile planes (2 or 4): the 256 output voxels of a block are TD x (256 / (TD * TWC)) x TWC.
 template <int TWC, int ST, int TD>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
-    const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ scale,
+    const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ residual, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int Cin, int Cout, int Di, int Hi, int Wi, int D, int H,
     int W, int tiles_w, int tiles_h, int relu) {
     constexpr int kC0W = TWC, kC0H = 256 / (TD * TWC);
@@ -163,8 +163,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
                 const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 float v = acc[ob][rb][r];
                 if (scale) v = fmaf(v, scale[o], shift[o]);
+                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+                if (residual) v = v + residual[idx];   // ResModule: x = act(bn(conv(h)) + identity), imvoxel_neck.py:227-229
                 if (relu) v = fmaxf(v, 0.0f);
-                out[((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w] = v;
+                out[idx] = v;
             }
     }
 }
@@ -175,7 +177,7 @@ using namespace mvsdet;
 
 static int launch_conv_mfma(const char* name, const float* x, const float* weight_perm, const float* scale,
                             const float* shift, float* out, int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
-                            int relu, mvsdet_stream_t stream) {
+                            int relu, mvsdet_stream_t stream, const float* residual = nullptr) {
     MVS_REQUIRE(x && weight_perm && out, "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && Di > 0 && Hi > 0 && Wi > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, Di, Hi,
@@ -203,7 +205,7 @@ static int launch_conv_mfma(const char* name, const float* x, const float* weigh
     const float4* w4 = reinterpret_cast<const float4*>(weight_perm);
     hipStream_t st = (hipStream_t)stream;
 #define MVS_CONV_CASE(TW_, ST_, TD_)                                                                                          \
-    hipLaunchKernelGGL((conv3d_k3_mfma_kernel<TW_, ST_, TD_>), grid, dim3(kThreads), 0, st, x, w4, scale, shift, out, Cin, \
+    hipLaunchKernelGGL((conv3d_k3_mfma_kernel<TW_, ST_, TD_>), grid, dim3(kThreads), 0, st, x, w4, residual, scale, shift, out, Cin, \
                        Cout, Di, Hi, Wi, D, H, W, tiles_w, tiles_h, relu)
     if (stride == 1) {
         if (td == 4) MVS_CONV_CASE(16, 1, 4);
@@ -221,6 +223,12 @@ extern "C" int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_per
                                          float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
                                          mvsdet_stream_t stream) {
     return launch_conv_mfma("conv3d_k3_mfma", x, weight_perm, scale, shift, out, N, Cin, Cout, D, H, W, 1, relu, stream);
+}
+
+extern "C" int mvsdet_conv3d_k3_res_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                             const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W,
+                                             int relu, mvsdet_stream_t stream) {
+    return launch_conv_mfma("conv3d_k3_res_mfma", x, weight_perm, scale, shift, out, N, Cin, Cout, D, H, W, 1, relu, stream, residual);
 }
 
 extern "C" int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale,

@@ -134,7 +134,8 @@ class MVSDetHotPath:
 
     def __init__(self, n_voxels: Sequence[int], voxel_size: Sequence[float], near_far_range: Sequence[float],
                  num_monocular_samples: int, topk: int = 3,
-                 cost_regularization: Optional[Callable[[Tensor], Tensor]] = None, stride: int = 4):
+                 cost_regularization: Optional[Callable[[Tensor], Tensor]] = None, stride: int = 4,
+                 neck_3d: Optional[Callable[[Tensor], list]] = None):
         self.n_voxels = [int(v) for v in n_voxels]
         self.voxel_size = [float(v) for v in voxel_size]      # python floats -> torch.tensor(...) is fp32, as in the reference
         self.near_far_range = [float(v) for v in near_far_range]
@@ -147,6 +148,7 @@ class MVSDetHotPath:
                                       dtype=np.float32)
         assert len(self.depth_values) == self.num_depth
         self.cost_regularization = cost_regularization
+        self.neck_3d = neck_3d   # mvsdet.py:681-698: x = self.neck_3d(torch.stack(volumes)); SURVEY 8 f-3 (mvsdet_amd.neck)
         self._points_cache: dict = {}
         self._geometry = _GeometryWorker(self)
 
@@ -295,6 +297,9 @@ class MVSDetHotPath:
         prob, off, est_depth, est_dens, est_idx, avg_depth = self.depth_distribution(cost_logits)
         volume_mean, valid = self.lift(feature, packed, geo, est_depth, est_dens)
         h, w = geo.height, geo.width
-        return dict(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
-                    est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
-                    depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo)
+        out = dict(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
+                   est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
+                   depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo)
+        if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU)
+            out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
+        return out

@@ -1,0 +1,167 @@
+"""The 3-D neck that consumes the hot path's voxel volume: `IndoorImVoxelNeck` of
+mmdet3d/models/necks/imvoxel_neck.py:70-231 -- a three-level 3-D FPN of residual blocks over the (C,40,40,16) volume,
+~0.49 TFLOP per scene with the shipped configuration (in_channels=256, out_channels=128, n_blocks=[1,1,1]).
+
+The module is plain PyTorch with the reference's parameter names (mmcv's ConvModule registers its layers as `conv`
+and `bn`, so `down_layer_1.0.conv0.conv.weight`, `down_layer_1.0.downsample.bn.running_mean`, `up_block_2.0.weight`,
+`out_block_0.1.bias` ... load from a reference checkpoint's `neck_3d.*` entries with `load_state_dict`).  In eval mode
+without autograd, on a ROCm device, every 3x3x3 convolution runs on the fp32-MFMA kernels of csrc/costreg_conv0.hip
+with eval-mode BatchNorm, ReLU and the residual addition folded into the epilogue (exact fp32 FMA sums, like ATen's in
+another order); the 1x1x1 stride-2 shortcut and the kernel-2 stride-2 transposed convolutions are one dense GEMM each
+(rocBLAS through torch.matmul: a kernel-2 stride-2 transposed convolution is 8 independent single-tap classes).
+Training, CPU tensors and other shapes take the framework's layers.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+
+class _ConvModule(nn.Module):
+    """mmcv.cnn.ConvModule(conv_cfg=Conv3d, norm_cfg=BN3d, act_cfg=ReLU|None) as used by imvoxel_neck.py:196-217:
+    Conv3d without bias -> BatchNorm3d [-> ReLU], sub-modules named `conv` and `bn` as mmcv names them."""
+
+    def __init__(self, cin: int, cout: int, kernel: int, stride: int = 1, padding: int = 0, act: bool = True):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm3d(cout)
+        self.with_act = act
+
+    def forward(self, x):
+        x = self.bn(self.conv(x))
+        return F.relu(x, inplace=True) if self.with_act else x
+
+
+def _bn_affine(bn: nn.BatchNorm3d):
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+    return scale, (bn.bias - bn.running_mean * scale).detach()
+
+
+def _hip_ok(x: Tensor, module: nn.Module) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not module.training
+
+
+def _conv_k3(x: Tensor, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool, residual: Tensor | None = None) -> Tensor:
+    """Conv3d(k=3, p=1, stride 1|2) + BN(eval) [+ residual] [+ ReLU] in one MFMA kernel."""
+    from . import ops
+    scale, shift = _bn_affine(bn)
+    return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(conv.weight), scale, shift, relu, conv.stride[0], residual)
+
+
+class ResModule(nn.Module):
+    """imvoxel_neck.py:183-231."""
+
+    def __init__(self, cin: int, cout: int, stride: int = 1):
+        super().__init__()
+        self.conv0 = _ConvModule(cin, cout, 3, stride, 1, act=True)
+        self.conv1 = _ConvModule(cout, cout, 3, 1, 1, act=False)
+        if stride != 1:
+            self.downsample = _ConvModule(cin, cout, 1, stride, 0, act=False)
+        self.stride = stride
+
+    def forward(self, x):
+        if _hip_ok(x, self) and self.conv0.conv.out_channels % 64 == 0:
+            identity = x
+            if self.stride != 1:   # 1x1x1 stride-2 convolution + BN: one GEMM on the sub-sampled volume
+                ds = self.downsample
+                xs = x[:, :, ::self.stride, ::self.stride, ::self.stride]
+                n, c, d, h, w = xs.shape
+                scale, shift = _bn_affine(ds.bn)
+                wmat = ds.conv.weight.detach().reshape(ds.conv.out_channels, c) * scale[:, None]
+                identity = torch.baddbmm(shift.view(1, -1, 1), wmat.unsqueeze(0).expand(n, -1, -1), xs.reshape(n, c, -1))
+                identity = identity.view(n, -1, d, h, w)
+            h0 = _conv_k3(x, self.conv0.conv, self.conv0.bn, True)
+            return _conv_k3(h0, self.conv1.conv, self.conv1.bn, True, identity)   # relu(bn(conv1) + identity)
+        identity = x
+        x = self.conv1(self.conv0(x))
+        if self.stride != 1:
+            identity = self.downsample(identity)
+        return F.relu(x + identity, inplace=True)
+
+
+class _UpBlock(nn.Sequential):
+    """imvoxel_neck.py:166-180: ConvTranspose3d(k=2, s=2) BN ReLU Conv3d(k=3) BN ReLU, Sequential indices as the reference's."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__(nn.ConvTranspose3d(cin, cout, 2, 2, bias=False), nn.BatchNorm3d(cout), nn.ReLU(inplace=True),
+                         nn.Conv3d(cout, cout, 3, 1, 1, bias=False), nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if _hip_ok(x, self) and self[3].out_channels % 64 == 0:
+            deconv, bn = self[0], self[1]
+            n, cin, d, h, w = x.shape
+            cout = deconv.out_channels
+            scale, shift = _bn_affine(bn)
+            # out[:, o, 2i+p, 2j+q, 2k+r] = sum_c x[:, c, i, j, k] * W[c, o, p, q, r]: one (8*Cout x Cin) GEMM
+            wmat = (deconv.weight.detach() * scale.view(1, -1, 1, 1, 1)).permute(2, 3, 4, 1, 0).reshape(8 * cout, cin)
+            y = torch.matmul(wmat.unsqueeze(0), x.reshape(n, cin, -1)).view(n, 2, 2, 2, cout, d, h, w)
+            y = y.permute(0, 4, 5, 1, 6, 2, 7, 3).reshape(n, cout, 2 * d, 2 * h, 2 * w)
+            y = F.relu_(y + shift.view(1, -1, 1, 1, 1))
+            return _conv_k3(y, self[3], self[4], True)
+        return super().forward(x)
+
+
+class _OutBlock(nn.Sequential):
+    """imvoxel_neck.py:152-163: Conv3d(k=3) BN ReLU."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__(nn.Conv3d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if _hip_ok(x, self) and self[0].out_channels % 64 == 0:
+            return _conv_k3(x, self[0], self[1], True)
+        return super().forward(x)
+
+
+class IndoorImVoxelNeck(nn.Module):
+    """imvoxel_neck.py:70-131: x (N, C_in, Nx, Ny, Nz) -> list of n_scales tensors (N, C_out, Nx/2^i, Ny/2^i, Nz/2^i)."""
+
+    def __init__(self, in_channels: int, out_channels: int, n_blocks: Sequence[int]):
+        super().__init__()
+        self.n_scales = len(n_blocks)
+        n_channels = in_channels
+        for i, nb in enumerate(n_blocks):
+            stride = 1 if i == 0 else 2
+            blocks = []
+            for b in range(nb):   # imvoxel_neck.py:133-149
+                if b == 0 and stride != 1:
+                    blocks.append(ResModule(n_channels, n_channels * 2, stride))
+                    n_channels = n_channels * 2
+                else:
+                    blocks.append(ResModule(n_channels, n_channels))
+            setattr(self, f"down_layer_{i}", nn.Sequential(*blocks))
+            if i > 0:
+                setattr(self, f"up_block_{i}", _UpBlock(n_channels, n_channels // 2))
+            setattr(self, f"out_block_{i}", _OutBlock(n_channels, out_channels))
+
+    def forward(self, x: Tensor) -> List[Tensor]:
+        down_outs = []
+        for i in range(self.n_scales):
+            x = getattr(self, f"down_layer_{i}")(x)
+            down_outs.append(x)
+        outs = []
+        for i in range(self.n_scales - 1, -1, -1):
+            if i < self.n_scales - 1:
+                x = getattr(self, f"up_block_{i + 1}")(x)
+                x = down_outs[i] + x
+            outs.append(getattr(self, f"out_block_{i}")(x))
+        return outs[::-1]
+
+    @staticmethod
+    def flops(n: int, grid: Sequence[int], in_channels: int = 256, out_channels: int = 128, n_scales: int = 3) -> float:
+        """2 x multiply-adds of one forward pass with n_blocks = [1]*n_scales (for the MFMA roofline)."""
+        total, c = 0.0, in_channels
+        v = [n * (grid[0] >> i) * (grid[1] >> i) * (grid[2] >> i) for i in range(n_scales)]
+        for i in range(n_scales):
+            if i == 0:
+                total += 2 * 54 * c * c * v[0]
+            else:
+                total += 54 * c * 2 * c * v[i] + 54 * (2 * c) ** 2 * v[i] + 2 * c * 2 * c * v[i]
+                c *= 2
+            total += 54 * c * out_channels * v[i]
+            if i > 0:
+                total += 2 * c * (c // 2) * v[i - 1] + 54 * (c // 2) ** 2 * v[i - 1]
+        return total

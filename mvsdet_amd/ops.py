@@ -656,7 +656,7 @@ def permute_conv_weight(weight: Tensor) -> Tensor:
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_mfma", mutates_args=(), device_types="cuda")
 def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
-                   stride: int = 1) -> Tensor:
+                   stride: int = 1, residual: Optional[Tensor] = None) -> Tensor:
     """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1 or 2, padding 1, no bias) [+ per-channel affine + ReLU] of
     mvs_models/mvsnet.py:76-82 on the fp32 matrix cores: x (N,Cin,D,H,W), weight_perm = permute_conv_weight(weight)
     -> (N,Cout,D',H',W').  Forward only."""
@@ -679,6 +679,16 @@ def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shif
     x, weight_perm = x.contiguous(), weight_perm.contiguous()
     od, oh, ow = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.empty((N, Cout, od, oh, ow), dtype=torch.float32, device=x.device)
+    if residual is not None:   # added between the affine and the ReLU (imvoxel_neck.py:227-229); stride 1 only
+        _req(residual, "residual", dim=5)
+        if stride != 1 or tuple(residual.shape) != tuple(out.shape):
+            raise ValueError(f"conv3d_k3_mfma: residual {tuple(residual.shape)} needs stride 1 and the output shape {tuple(out.shape)}")
+        residual = residual.contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mvsdet_conv3d_k3_res_mfma_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale),
+                                                                 _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(out), N, Cin,
+                                                                 Cout, D, H, W, int(relu), _stream(x)), "conv3d_k3_res_mfma")
+        return out
     fn = _lib.load().mvsdet_conv3d_k3_mfma_f32 if stride == 1 else _lib.load().mvsdet_conv3d_k3_s2_mfma_f32
     with torch.cuda.device(x.device):
         _lib.check(fn(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
@@ -688,7 +698,7 @@ def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shif
 
 
 @conv3d_k3_mfma.register_fake
-def _(x, weight_perm, scale, shift, relu, stride=1):
+def _(x, weight_perm, scale, shift, relu, stride=1, residual=None):
     return x.new_empty((x.shape[0], weight_perm.shape[4]) + tuple((s - 1) // stride + 1 for s in x.shape[2:]))
 
 

@@ -1,0 +1,101 @@
+"""the 3-D neck that consumes the hot path's volume (mmdet3d/models/necks/imvoxel_neck.py:70-231).
+CPU: structure, parameter names (what a reference checkpoint's `neck_3d.*` entries are called) and the GEMM forms of
+the 1x1x1 shortcut and the kernel-2 transposed convolution against ATen's layers.  GPU: the MFMA route against the
+framework's layers (ATen-CPU) on the same weights."""
+import numpy as np
+import pytest
+import torch
+
+
+def _randomise(m, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for name, p in m.named_parameters():
+        with torch.no_grad():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 / max(1, p[0].numel()) ** 0.5 if p.dim() > 1 else 0.3) + (1.0 if name.endswith("bn.weight") or name.endswith(".1.weight") or name.endswith(".4.weight") else 0.0))
+    for name, b in m.named_buffers():
+        if name.endswith("running_mean"):
+            b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+        elif name.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    return m.eval()
+
+
+def test_structure_and_parameter_names():
+    from mvsdet_amd.neck import IndoorImVoxelNeck
+    m = IndoorImVoxelNeck(256, 128, [1, 1, 1])   # configs/mvsdet_res50_2x_low_res.py: neck_3d
+    keys = set(m.state_dict())
+    for k in ("down_layer_0.0.conv0.conv.weight", "down_layer_0.0.conv1.bn.running_var", "down_layer_1.0.downsample.conv.weight",
+              "down_layer_2.0.downsample.bn.bias", "up_block_1.0.weight", "up_block_2.3.weight", "up_block_2.4.running_mean",
+              "out_block_0.0.weight", "out_block_2.1.bias"):
+        assert k in keys, k
+    assert not any(k.startswith("up_block_0") for k in keys)
+    sd = m.state_dict()
+    assert sd["down_layer_1.0.conv0.conv.weight"].shape == (512, 256, 3, 3, 3)
+    assert sd["down_layer_2.0.downsample.conv.weight"].shape == (1024, 512, 1, 1, 1)
+    assert sd["up_block_2.0.weight"].shape == (1024, 512, 2, 2, 2) and sd["out_block_2.0.weight"].shape == (128, 1024, 3, 3, 3)
+    n_params = sum(p.numel() for p in m.parameters())
+    assert 70e6 < n_params < 85e6          # "~77 M params by my count"
+    outs = IndoorImVoxelNeck(8, 4, [1, 2, 1]).eval()(torch.randn(2, 8, 8, 8, 4))
+    assert [tuple(o.shape) for o in outs] == [(2, 4, 8, 8, 4), (2, 4, 4, 4, 2), (2, 4, 2, 2, 1)]
+    assert abs(IndoorImVoxelNeck.flops(1, [40, 40, 16]) / 1e9 - 490) < 5
+
+
+def test_gemm_forms_match_aten_layers():
+    """The fast route's two GEMM rewrites, evaluated on the CPU: 1x1x1 stride-2 conv + BN, ConvTranspose3d(k=2,s=2) + BN + ReLU."""
+    from mvsdet_amd import neck as NK
+    g = torch.Generator().manual_seed(3)
+    ds = _randomise(NK._ConvModule(6, 10, 1, 2, 0, act=False), 1)
+    x = torch.randn(2, 6, 8, 6, 4, generator=g)
+    xs = x[:, :, ::2, ::2, ::2]
+    scale, shift = NK._bn_affine(ds.bn)
+    wmat = ds.conv.weight.detach().reshape(10, 6) * scale[:, None]
+    got = torch.baddbmm(shift.view(1, -1, 1), wmat.unsqueeze(0).expand(2, -1, -1), xs.reshape(2, 6, -1)).view(2, 10, 4, 3, 2)
+    with torch.no_grad():
+        np.testing.assert_allclose(got.numpy(), ds(x).numpy(), rtol=1e-5, atol=1e-5)
+    up = _randomise(NK._UpBlock(6, 4), 2)
+    x = torch.randn(2, 6, 3, 4, 2, generator=g)
+    deconv, bn = up[0], up[1]
+    scale, shift = NK._bn_affine(bn)
+    wmat = (deconv.weight.detach() * scale.view(1, -1, 1, 1, 1)).permute(2, 3, 4, 1, 0).reshape(8 * 4, 6)
+    y = torch.matmul(wmat.unsqueeze(0), x.reshape(2, 6, -1)).view(2, 2, 2, 2, 4, 3, 4, 2)
+    y = torch.relu(y.permute(0, 4, 5, 1, 6, 2, 7, 3).reshape(2, 4, 6, 8, 4) + shift.view(1, -1, 1, 1, 1))
+    with torch.no_grad():
+        ref = torch.relu(bn(deconv(x)))
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,grid,n", [(64, 64, (24, 24, 8), 1), (128, 64, (12, 20, 8), 2)])
+def test_neck_mfma_route_vs_aten(gpu, cin, cout, grid, n):
+    from mvsdet_amd.neck import IndoorImVoxelNeck
+    m = _randomise(IndoorImVoxelNeck(cin, cout, [1, 1, 1]), 5)
+    x = torch.randn((n, cin) + grid, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        ref = m(x)                     # the framework's layers, ATen-CPU
+        got = m.to(gpu)(x.to(gpu))     # MFMA kernels + GEMMs
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        scale = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=1e-4 * max(scale, 1.0))
+    # under autograd the module takes the framework's layers (training is not on this route): gradients flow
+    m.train()
+    xg = x.to(gpu).requires_grad_(True)
+    sum(o.square().mean() for o in m(xg)).backward()
+    assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_neck_shipped_configuration(gpu):
+    """in_channels=256, out_channels=128, n_blocks=[1,1,1] on the (256,40,40,16) volume: the first residual block against
+    ATen-CPU (90 GFLOP of the 490), all outputs finite and of the reference's shapes."""
+    from mvsdet_amd.neck import IndoorImVoxelNeck
+    m = _randomise(IndoorImVoxelNeck(256, 128, [1, 1, 1]), 7)
+    x = torch.randn((1, 256, 40, 40, 16), generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        ref0 = m.down_layer_0(x)
+        mg = m.to(gpu)
+        got0 = mg.down_layer_0(x.to(gpu))
+        outs = mg(x.to(gpu))
+    np.testing.assert_allclose(got0.cpu().numpy(), ref0.numpy(), rtol=0, atol=1e-4 * max(1.0, float(ref0.abs().max())))
+    assert [tuple(o.shape) for o in outs] == [(1, 128, 40, 40, 16), (1, 128, 20, 20, 8), (1, 128, 10, 10, 4)]
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
