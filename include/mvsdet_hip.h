@@ -167,6 +167,13 @@ int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* off_logit, fl
 int mvsdet_sample_depth_prob_f32(const float* prob, const float* off, float* est_depth, float* est_dens,
                                  int32_t* est_idx, float* avg_depth, int N, int D, int H, int W, int topk,
                                  float near, float interval, mvsdet_stream_t stream);
+/* NVS-branch input -- mvsdet.py:1158-1216 compute_depth_scale / compute_depth_scale_MultiIntrin and :494:
+ *   intr (N,5) = {fx, fy, cx, cy, skew} of the feature-level intrinsics of every view (K[:2] / ratio, mvsdet.py:1180-1181);
+ *   depth_scale (N,h,w) = z component of the normalised camera ray through pixel (x, y) (lift :1300 + normalize :1295);
+ *   est_ray_depth (N,J,h,w) = est_depth[:, :, :h, :w] / (depth_scale + 1e-8), est_depth (N,J,H,W) padded maps (both NULL to
+ *   get the scale alone). */
+int mvsdet_ray_depth_f32(const float* intr, const float* est_depth, float* depth_scale, float* est_ray_depth, int N, int J,
+                         int H, int W, int h, int w, mvsdet_stream_t stream);
 /* backward: any of g_prob (N,D,H,W), g_depth, g_dens (N,topk,H,W), g_avg (N,H,W) may be NULL. */
 int mvsdet_depth_prob_topk_bwd_f32(const float* prob, const float* off, const int32_t* est_idx,
                                    const float* g_prob, const float* g_depth, const float* g_dens,

@@ -179,6 +179,46 @@ extern "C" int mvsdet_sample_depth_prob_f32(const float* prob, const float* off,
     return MVSDET_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// NVS-branch input: mvsdet.py:1158-1216 compute_depth_scale[_MultiIntrin] + :494.
+//   ray = lift(x, y, 1) with the feature-level intrinsics (mvsdet.py:1300-1313), depth_scale = z of the normalised ray
+//   = 1 / |ray| (get_camera_params with the identity pose, :1272-1297), est_ray_depth = est_depth / (depth_scale + 1e-8).
+// One thread per pixel of the un-padded (h, w) feature map; the candidates come from the padded (H, W) maps.
+// ---------------------------------------------------------------------------------------------
+namespace mvsdet {
+__global__ __launch_bounds__(kThreads) void ray_depth_kernel(const float* __restrict__ intr, const float* __restrict__ est_depth,
+                                                             float* __restrict__ scale, float* __restrict__ ray_depth, int J,
+                                                             int H, int W, int h, int w) {
+    const int pix = blockIdx.x * kThreads + threadIdx.x;
+    const int n = blockIdx.y;
+    if (pix >= h * w) return;
+    const int y = pix / w, x = pix - y * w;
+    const float fx = intr[n * 5 + 0], fy = intr[n * 5 + 1], cx = intr[n * 5 + 2], cy = intr[n * 5 + 3], sk = intr[n * 5 + 4];
+    // mvsdet.py:1308-1309, same operator order (z = 1)
+    const float xl = ((float)x - cx + cy * sk / fy - sk * (float)y / fy) / fx * 1.0f;
+    const float yl = ((float)y - cy) / fy * 1.0f;
+    const float nrm = fmaxf(sqrtf(xl * xl + yl * yl + 1.0f), 1e-12f);   // F.normalize(dim=2): v / max(|v|, eps)
+    const float sc = 1.0f / nrm;
+    scale[(size_t)n * h * w + pix] = sc;
+    if (ray_depth)
+        for (int j = 0; j < J; ++j)
+            ray_depth[((size_t)n * J + j) * h * w + pix] = est_depth[((size_t)n * J + j) * H * W + (size_t)y * W + x] / (sc + 1e-8f);
+}
+}  // namespace mvsdet
+
+extern "C" int mvsdet_ray_depth_f32(const float* intr, const float* est_depth, float* depth_scale, float* est_ray_depth, int N,
+                                    int J, int H, int W, int h, int w, mvsdet_stream_t stream) {
+    MVS_REQUIRE(intr && depth_scale, "ray_depth: NULL pointer");
+    MVS_REQUIRE((est_depth == nullptr) == (est_ray_depth == nullptr), "ray_depth: est_depth and est_ray_depth come together");
+    MVS_REQUIRE(N > 0 && N <= 65535 && J >= 0 && h > 0 && w > 0 && h <= H && w <= W, "ray_depth: bad shape N=%d J=%d H=%d W=%d h=%d w=%d",
+                N, J, H, W, h, w);
+    dim3 grid((h * w + kThreads - 1) / kThreads, N);
+    hipLaunchKernelGGL(ray_depth_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, intr, est_depth, depth_scale, est_ray_depth,
+                       J, H, W, h, w);
+    MVS_LAUNCH_CHECK("ray_depth");
+    return MVSDET_OK;
+}
+
 extern "C" int mvsdet_depth_prob_topk_bwd_f32(const float* prob, const float* off, const int32_t* est_idx,
                                               const float* g_prob, const float* g_depth, const float* g_dens,
                                               const float* g_avg, float* g_cost, float* g_offlogit, int N, int D, int H,

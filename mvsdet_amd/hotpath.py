@@ -181,6 +181,21 @@ class MVSDetHotPath:
         """Start the camera algebra and the upload of a coming scene on the worker thread; returns at once."""
         self._geometry.submit(img_meta, torch.device(device))
 
+    def ray_depth(self, img_meta: dict, est_depth: Tensor):
+        """NVS-branch input (mvsdet.py:487-494): `cur_depth_scale` (N, h*w, 1) of compute_depth_scale[_MultiIntrin]
+        (:1158-1216) and `est_ray_depth` (N, h*w, 1, J) = est_depth / (scale + 1e-8) from the padded (N,J,Hf,Wf) candidates."""
+        stride = self.stride
+        h, w = img_meta["img_shape"][0] // stride, img_meta["img_shape"][1] // stride
+        K = torch.tensor(np.array(img_meta["lidar2img"]["intrinsic"])).clone()
+        ratio = img_meta["ori_shape"][0] / (img_meta["img_shape"][0] / stride)
+        if K.dim() == 2:
+            K[:2] /= ratio
+            K = K.unsqueeze(0).repeat(est_depth.shape[0], 1, 1)      # one intrinsic matrix for all views (ScanNet)
+        else:
+            K[:, :2] /= ratio                                         # per-view intrinsics (ARKitScenes)
+        intr = torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 0, 1]], dim=1).float()
+        return ops.ray_depth(intr.to(est_depth.device), est_depth, int(h), int(w))
+
     def _host_geometry(self, img_meta: dict):
         """The reference's ATen-CPU operator sequence (mvsdet.py:407-450) -> host tensors."""
         stride = self.stride

@@ -78,6 +78,28 @@ def _(src, proj, depth):
 
 
 # ------------------------------------------------------------------------------------------- a3+a4
+def ray_depth(intr: Tensor, est_depth: Optional[Tensor], h: int, w: int):
+    """mvsdet.py:1158-1216 + :494: intr (N,5) {fx,fy,cx,cy,skew} at feature level -> depth_scale (N,h*w,1) and, when
+    est_depth (N,J,H,W) is given, est_ray_depth (N,h*w,1,J) in the layout extract_feat hands to the Gaussian adapter."""
+    _req(intr, "intr", dim=2)
+    N = intr.shape[0]
+    intr = intr.contiguous()
+    scale = torch.empty((N, h * w, 1), dtype=torch.float32, device=intr.device)
+    ray = None
+    J, H, W = 0, h, w
+    if est_depth is not None:
+        _req(est_depth, "est_depth", dim=4)
+        if est_depth.shape[0] != N:
+            raise ValueError("ray_depth: est_depth and intr disagree on the number of views")
+        est_depth = est_depth.contiguous()
+        J, H, W = est_depth.shape[1:]
+        ray = torch.empty((N, J, h * w), dtype=torch.float32, device=intr.device)
+    with torch.cuda.device(intr.device):
+        _lib.check(_lib.load().mvsdet_ray_depth_f32(_lib.ptr(intr), _lib.ptr(est_depth), _lib.ptr(scale), _lib.ptr(ray), N, J, H, W,
+                                                    h, w, _stream(intr)), "ray_depth")
+    return scale, (None if ray is None else ray.transpose(2, 1).unsqueeze(2))
+
+
 def validate_neighbors(nbr: Tensor, n_src: int) -> None:
     """Host check of neighbour view ids (include/mvsdet_hip.h: mvsdet_validate_neighbors): the reference's index gather
     (mvsdet.py:440) raises on an id outside [0, N); the kernels only clamp.  `nbr` must be a CPU tensor."""

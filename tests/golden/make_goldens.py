@@ -364,9 +364,53 @@ def g7_end_to_end():
          est_dens=est_dens, depth_coding=depth_coding, volume_mean=mean, valid_count=cnt, inline_restated=1)
 
 
+def g8_cost_regularisation():
+    """mvs_models/mvsnet.py:73-113 CostRegNet_3DGS, eval mode, on LCG weights and an LCG input (tests/golden/lcg.py):
+    only the reference's output is stored.  Shipped width (in_channels 256, base 64) on a (1,256,8,12,16) volume."""
+    from lcg import lcg_fill_state, lcg_uniform
+    mvsnet = sys.modules["refpkg.mvs_models.mvsnet"]
+    torch.manual_seed(0)
+    net = mvsnet.CostRegNet_3DGS().eval()   # the reference class has no arguments: 256 -> 64 -> ... -> 2
+    with torch.no_grad():
+        lcg_fill_state(net, 8)
+        x = torch.from_numpy(lcg_uniform(256 * 8 * 12 * 16, 88)).reshape(1, 256, 8, 12, 16).abs()   # a variance is >= 0
+        y = net(x)
+    save("g8_cost_regularisation", logits=y, in_shape=np.array(x.shape), weight_seed=8, input_seed=88,
+         keys=np.array(sorted(net.state_dict())))
+    print("g8 logits", tuple(y.shape), float(y.abs().max()))
+
+
+def g9_depth_scale():
+    """mvsdet.py:1158-1216 compute_depth_scale / compute_depth_scale_MultiIntrin (+ get_camera_params :1272, lift :1300)
+    and the est_ray_depth statement of extract_feat (:494).  The helpers call `.cuda()` on their tensors; this
+    container has no GPU, so `torch.Tensor.cuda` is a no-op for the duration of the calls (the reference source is
+    untouched and runs on ATen-CPU).  est_ray_depth is the inline statement of :494 (inline_restated=1)."""
+    out = {}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, per_view in (("scannet", False), ("arkit", True)):
+            N, hw = 6, (60, 80)
+            meta = synthetic.make_img_meta(N, hw, seed=91, per_view_intrinsics=per_view)
+            height, width = meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+            fn = MVSDet.compute_depth_scale_MultiIntrin if per_view else MVSDet.compute_depth_scale
+            scale = fn(SimpleNamespace(), height, width, torch.device("cpu"), meta, 4, N)[0]      # (N, h*w, 1)
+            g = torch.Generator().manual_seed(92)
+            est_depth = torch.rand((N, 3, hw[0], hw[1]), generator=g) * 4.8 + 0.2
+            ed = est_depth[:, :, :height, :width].reshape(N, 3, -1).transpose(2, 1).unsqueeze(2)   # mvsdet.py:484
+            ray = ed / (scale.unsqueeze(-1).repeat(1, 1, 1, ed.shape[-1]) + 1e-8)                   # mvsdet.py:494
+            out.update({f"{tag}_extrinsic": np.array(meta["lidar2img"]["extrinsic"]),
+                        f"{tag}_intrinsic": np.array(meta["lidar2img"]["intrinsic"]), f"{tag}_scale": scale,
+                        f"{tag}_est_depth": est_depth, f"{tag}_est_ray_depth": ray})
+            print("g9", tag, tuple(scale.shape), float(scale.min()), float(scale.max()))
+    finally:
+        torch.Tensor.cuda = real_cuda
+    save("g9_depth_scale", img_shape=np.array(meta["img_shape"]), ori_shape=np.array(meta["ori_shape"]), inline_restated=1, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_homo_warping, g2=g2_variance, g3=g3_knn, g4=g4_depth_prob, g5=g5_backproject,
-               g6=g6_backward, g7=g7_end_to_end)
+               g6=g6_backward, g7=g7_end_to_end, g8=g8_cost_regularisation, g9=g9_depth_scale)
     for w in which:
         fns[w]()

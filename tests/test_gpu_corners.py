@@ -344,3 +344,41 @@ def test_end_to_end_1e4_on_decided_voxels(gpu, oracle, record_property):
     err = np.abs(vol - ref)[:, decided]
     assert (g["valid_count"].reshape(-1)[decided] > 0).sum() > 1000
     assert err.max() <= TOL, f"max |dvolume| on decided voxels {err.max():.3e}"
+
+
+# --------------------------------------------------------------------------------------------- f-1 pinned on the GPU box
+def test_g8_cost_regularisation_network_mfma(gpu):
+    """G8 on the device: the eval route of mvsdet_amd.costreg (every layer on the fp32-MFMA / streaming HIP kernels) against
+    the output of the REFERENCE CostRegNet_3DGS (mvs_models/mvsnet.py:73-113) for the same LCG weights and input -- the
+    fixture stores only that output; 1e-4 (north_star tolerance)."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from lcg import lcg_fill_state, lcg_uniform
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    g = load_golden("g8_cost_regularisation")
+    net = CostRegNet3DGS(256, 64).eval()
+    with torch.no_grad():
+        lcg_fill_state(net, int(g["weight_seed"]))
+        shape = tuple(int(v) for v in g["in_shape"])
+        x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), int(g["input_seed"]))).reshape(shape).abs()
+        y = net.to(gpu)(x.to(gpu))
+    np.testing.assert_allclose(y.cpu().numpy(), g["logits"], rtol=0, atol=TOL)
+
+
+# --------------------------------------------------------------------------------------------- f-4: NVS-branch depth scale
+@pytest.mark.parametrize("tag", ["scannet", "arkit"])
+def test_ray_depth_vs_reference(gpu, tag):
+    """G9: `cur_depth_scale` of MVSDet.compute_depth_scale / compute_depth_scale_MultiIntrin (mvsdet.py:1158-1216) and
+    `est_ray_depth` (mvsdet.py:494) as the reference produced them, against mvsdet_ray_depth_f32: 1e-6 / 1e-5."""
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    g = load_golden("g9_depth_scale")
+    intr = g[f"{tag}_intrinsic"]
+    meta = {"lidar2img": {"extrinsic": list(g[f"{tag}_extrinsic"]), "intrinsic": (list(intr) if intr.ndim == 3 else intr),
+                          "origin": np.zeros(3, np.float32)},
+            "img_shape": tuple(int(v) for v in g["img_shape"]), "ori_shape": tuple(int(v) for v in g["ori_shape"])}
+    hp = MVSDetHotPath([40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], 12)
+    scale, ray = hp.ray_depth(meta, dev(g[f"{tag}_est_depth"], gpu))
+    assert scale.shape == g[f"{tag}_scale"].shape and ray.shape == g[f"{tag}_est_ray_depth"].shape
+    np.testing.assert_allclose(scale.cpu().numpy(), g[f"{tag}_scale"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ray.cpu().numpy(), g[f"{tag}_est_ray_depth"], rtol=1e-6, atol=1e-5)

@@ -177,3 +177,23 @@ def test_torch_restatement(tag):
     g1 = load_golden("g1_homo_warping")
     w = T.homo_warp(torch.tensor(g1["src_fea"]), torch.tensor(g1["proj_rel"]), torch.tensor(g1["depth_values"])).numpy()
     np.testing.assert_allclose(w, g1["warped"], rtol=0, atol=1e-6)
+
+
+def test_g8_cost_regularisation_network_cpu():
+    """G8: mvsdet_amd.costreg.CostRegNet3DGS (framework layers, CPU) against the output the reference's CostRegNet_3DGS
+    (mvs_models/mvsnet.py:73-113) produced for the same LCG weights and input: same state-dict keys, <= 1e-4."""
+    import sys
+    import torch
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from lcg import lcg_fill_state, lcg_uniform
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    g = load_golden("g8_cost_regularisation")
+    net = CostRegNet3DGS(256, 64).eval()
+    assert sorted(net.state_dict()) == list(g["keys"])
+    with torch.no_grad():
+        lcg_fill_state(net, int(g["weight_seed"]))
+        shape = tuple(int(v) for v in g["in_shape"])
+        x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), int(g["input_seed"]))).reshape(shape).abs()
+        y = net(x)
+    np.testing.assert_allclose(y.numpy(), g["logits"], rtol=0, atol=1e-4)
