@@ -25,6 +25,7 @@ from . import ops
 # Set by integration.patch_reference: homo_warping then returns a deferred volume (lazywarp.LazyVolume) instead of
 # launching the warp kernel.  Off for direct callers of this module.
 LAZY_WARP = False
+LAZY_ANY_DEVICE = False   # tests only: defer on CPU tensors too (the fused launches are stubbed there)
 
 
 def relative_projection(src_proj: Tensor, ref_proj: Tensor) -> Tensor:
@@ -105,7 +106,7 @@ def homo_warping(src_fea: Tensor, src_proj: Tensor, ref_proj: Tensor, depth_valu
         raise NotImplementedError("per-pixel depth_values (B,D,H,W) (module.py:130-133) is unused by MVSDet")
     proj = relative_projection(src_proj, ref_proj).to(src_fea.device)
     depth_values = depth_values.to(src_fea.device)
-    if LAZY_WARP and src_fea.is_cuda and src_fea.dtype == torch.float32:
+    if LAZY_WARP and (src_fea.is_cuda or LAZY_ANY_DEVICE) and src_fea.dtype == torch.float32:
         # inside the patched reference: defer, so that its variance loop collapses into the fused kernel (lazywarp.py)
         from . import lazywarp
         return lazywarp.lazy_homo_warp(src_fea, proj, depth_values)
@@ -125,7 +126,7 @@ def backproject_Weigh(features: Tensor, points: Tensor, projection: Tensor, dept
     # (N, h*w, 1, J) is a view of (N,J,h,w): hand the kernel that view, no copy (mvsdet.py:1393-1395)
     est_depth = depth.reshape(n, h, w, j).permute(0, 3, 1, 2)
     est_dens = prob.reshape(n, h, w, j).permute(0, 3, 1, 2)
-    if LAZY_WARP and features.is_cuda and features.dtype == torch.float32:
+    if LAZY_WARP and (features.is_cuda or LAZY_ANY_DEVICE) and features.dtype == torch.float32:
         # inside the patched reference: `volume.sum(dim=0)` / `valid.sum(dim=0)` (mvsdet.py:509-511) then cost one launch
         # of the fused lifting kernel instead of a (N,C,X,Y,Z) volume and a reduction over it (lazywarp.py)
         from . import lazywarp

@@ -46,6 +46,11 @@ class LazyVolume(Tensor):
     def materialize(self) -> Tensor:
         from . import ops
         stats["materialized"] += 1
+        if stats["materialized"] == 1:   # once per process: the fused route was expected, the eager kernels ran instead
+            import warnings
+            warnings.warn("mvsdet_amd.lazywarp: an operation outside the recognised variance / view-sum pattern touched a "
+                          f"deferred volume (kind '{self.kind}'); it is evaluated with the eager kernels (correct, slower). "
+                          "lazywarp.stats counts both routes.", RuntimeWarning, stacklevel=3)
         k, p = self.kind, self.payload
         if k == "warp":
             return ops.homo_warp(p["src"], p["proj"], p["depth"])

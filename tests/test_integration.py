@@ -79,3 +79,84 @@ def test_cost_regularisation_network_matches_the_reference_module(reference):
     assert 2.5e12 < CostRegNet3DGS.flops(40, 12, 60, 80) < 3.2e12
     with pytest.raises(ValueError):
         ours(torch.rand(1, 256, 6, 12, 16))
+
+
+def test_lazy_route_is_pinned_to_the_reference_source_text(reference, oracle, monkeypatch):
+    """The statements of MVSDet.extract_feat that the deferred-evaluation route must recognise, taken from the REFERENCE
+    FILE ITSELF (mvsdet.py:416-467: neighbour selection .. variance; :511-515: the sum over the views) and executed
+    against the patched module with the fused launches replaced by the CPU oracle: the variance loop (both its training
+    and its eval form) collapses into ONE fused plane-sweep call and the view sum into one fused lifting call, nothing is
+    materialised, and the results equal those of the same statements on the unpatched reference."""
+    import textwrap
+    from types import SimpleNamespace
+    import numpy as np
+    import torch
+    from mvsdet_amd import functional as F_, integration, lazywarp, ops, synthetic
+    ref, _ = reference
+    src = open(ref.__file__).read().splitlines()
+    block = textwrap.dedent("\n".join(src[415:467]))          # lines 416..467
+    assert block.lstrip().startswith("height = img_meta['img_shape'][0] // stride") and "volume_variance = volume_sq_sum.div_(k+1)" in block
+    tail = textwrap.dedent("\n".join(src[510:515]))           # lines 511..515
+    assert tail.lstrip().startswith("volume_sum = volume.sum(dim=0)") and "volume_mean[:, valid[0] == 0] = .0" in tail
+
+    N, C, D, hw = 4, 6, 8, (60, 80)
+    meta = synthetic.make_img_meta(N, hw, seed=21)
+    feature = synthetic.make_features(N, C, hw, seed=21)
+    depth_values = np.arange(0.2, 5.0, 4.8 / D, dtype=np.float32)
+
+    def run(training):
+        me = SimpleNamespace(gs_cfg=SimpleNamespace(num_monocular_samples=D), depth_values=depth_values, training=training)
+        me.collect_proj = lambda *a: ref.MVSDet.collect_proj(me, *a)
+        ns = dict(ref.__dict__)
+        ns.update(self=me, x=feature, feature=feature.clone(), img_meta=meta, stride=4, num_src=N)
+        exec(compile(block, "mvsdet.py:416-467", "exec"), ns)
+        return ns
+
+    plain = {t: run(t)["volume_variance"] for t in (True, False)}          # the unpatched reference, ATen-CPU
+
+    calls = {"sweep": 0, "lift": 0}
+
+    def sweep_stub(feat, ids, proj, depth):
+        calls["sweep"] += 1
+        return torch.from_numpy(oracle.plane_sweep_variance(feat, ids, proj, depth, mode=0))
+
+    def lift_stub(packed, points, projection, est_depth, est_dens, n, first, c, h, w, vz):
+        calls["lift"] += 1
+        o = oracle.backproject_weigh(packed.numpy(), points.reshape(3, -1).numpy(), projection.numpy(), est_depth.numpy(),
+                                     est_dens.numpy(), vz)
+        return torch.from_numpy(o["volume"].sum(0)), torch.from_numpy(o["valid"].sum(0).astype(np.int32))
+
+    monkeypatch.setattr(ops, "plane_sweep_variance", sweep_stub)
+    monkeypatch.setattr(ops, "backproject_weigh_sum_shard", lift_stub)
+    monkeypatch.setattr(ops, "pack_features", lambda f: f)
+    monkeypatch.setattr(F_, "LAZY_ANY_DEVICE", True)
+    orig = integration.patch_reference(ref)
+    try:
+        before = dict(lazywarp.stats)
+        for t in (True, False):
+            ns = run(t)
+            assert not isinstance(ns["volume_variance"], lazywarp.LazyVolume)
+            np.testing.assert_allclose(ns["volume_variance"].numpy(), plain[t].numpy(), rtol=0, atol=1e-4)
+        assert lazywarp.stats["fused"] == before["fused"] + 2 and lazywarp.stats["materialized"] == before["materialized"]
+        assert calls["sweep"] == 2
+        # the lifting statements (mvsdet.py:499-515) on the deferred (volume, valid) of the patched backproject_Weigh
+        height, width = ns["height"], ns["width"]
+        r = oracle.depth_prob_topk(synthetic.make_cost_logits(N, D, hw, seed=21, sharp=2.0)[:, 0].numpy(),
+                                   synthetic.make_cost_logits(N, D, hw, seed=21, sharp=2.0)[:, 1].numpy(), 0.2, 4.8 / D, 3)
+        ed = torch.from_numpy(r["est_depth"][:, :, :height, :width]).reshape(N, 3, -1).transpose(2, 1).unsqueeze(2)
+        en = torch.from_numpy(r["est_dens"][:, :, :height, :width]).reshape(N, 3, -1).transpose(2, 1).unsqueeze(2)
+        projection = ref.MVSDet._compute_projection(meta, 4, None)
+        points = ref.get_points(n_voxels=torch.tensor([40, 40, 16]), voxel_size=torch.tensor([0.16, 0.16, 0.2]),
+                                origin=torch.tensor(meta["lidar2img"]["origin"]))
+        volume, valid, _, _ = ref.backproject_Weigh(feature[:, :, :height, :width], points, projection, ed, [0.16, 0.16, 0.2], en)
+        assert isinstance(volume, lazywarp.LazyVolume)
+        ns2 = dict(volume=volume, valid=valid)
+        exec(compile(tail, "mvsdet.py:511-515", "exec"), ns2)
+        assert calls["lift"] == 1 and lazywarp.stats["materialized"] == before["materialized"]
+    finally:
+        integration.unpatch_reference(ref, orig)
+    vol_ref, val_ref, _, _ = ref.backproject_Weigh(feature[:, :, :height, :width], points, projection, ed, [0.16, 0.16, 0.2], en)
+    mean_ref = vol_ref.sum(dim=0) / (val_ref.sum(dim=0) + 1e-8)
+    mean_ref[:, val_ref.sum(dim=0)[0] == 0] = .0
+    np.testing.assert_allclose(ns2["volume_mean"].numpy(), mean_ref.numpy(), rtol=0, atol=1e-6)
+    assert int((ns2["valid"] > 0).sum()) > 100
