@@ -109,8 +109,8 @@ def test_neighbor_ids_are_validated_on_the_host():
 
 
 def test_scene_geometry_worker_cpu():
-    """prepare_scene: camera algebra on the worker thread, results by img_meta identity; prefetch returns at once;
-    a new dict with the same contents is recomputed (and equal); errors surface in the caller."""
+    """prepare_scene: camera algebra on the worker thread, results kept by the content of the camera data; prefetch
+    returns at once; a moved origin changes the voxel points only; errors surface in the caller."""
     import torch
     from mvsdet_amd import synthetic
     from mvsdet_amd.hotpath import MVSDetHotPath
@@ -120,8 +120,12 @@ def test_scene_geometry_worker_cpu():
     hp.prefetch_scene(other, "cpu")
     g1 = hp.prepare_scene(meta, "cpu")
     assert hp.prepare_scene(meta, "cpu") is g1
-    g2 = hp.prepare_scene(dict(meta), "cpu")
+    assert hp.prepare_scene(dict(meta), "cpu") is g1          # same cameras in a new dict: served by content
+    moved = dict(meta)
+    moved["lidar2img"] = dict(meta["lidar2img"], origin=np.array([0.1, 0.0, 0.5], np.float32))   # RandomShiftOrigin
+    g2 = hp.prepare_scene(moved, "cpu")
     assert g2 is not g1 and torch.equal(g2.proj_rel, g1.proj_rel) and torch.equal(g2.neighbor_ids, g1.neighbor_ids)
+    assert not torch.equal(g2.points, g1.points)
     g3 = hp.prepare_scene(other, "cpu")
     assert g3.neighbor_ids.shape == (4, 2) and g3.points.shape == (3, 40, 40, 16)
     n0 = torch.get_num_threads()
