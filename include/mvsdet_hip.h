@@ -42,13 +42,13 @@ int mvsdet_version(void);
 /* HOST, thread-local message of the last failing call on this thread ("" if none). */
 const char* mvsdet_last_error(void);
 /* Tuning options (schedule only: results are bit-identical under every setting).  Read ONCE from the environment
- * (MVSDET_SWEEP_TW, MVSDET_SWEEP_BOXCAP, MVSDET_SWEEP_XCD, MVSDET_SWEEP_GROUPS) when the library first needs them,
+ * (MVSDET_SWEEP_TW, MVSDET_SWEEP_BOXCAP, MVSDET_SWEEP_XCD) when the library first needs them,
  * afterwards changed only through mvsdet_set_option -- the launch path never calls getenv.  HOST, process-global:
  * set them before launching from several threads.
  *   "sweep_tw"      0 (by the map width) | 16 | 32   pixel-tile shape of the sweep (16x8 / 32x4)
- *   "sweep_boxcap"  texels of one LDS footprint box (default 256; 0 = gather every tap from global memory)
+ *   "sweep_boxcap"  texels of one LDS footprint box (default: what fits, 312 / 200 by the tile shape; 0 = gather every tap
+ *                   from global memory)
  *   "sweep_xcd"     0 | 1   XCD-aware block map for fewer than 8 channel slabs
- *   "sweep_groups"  1 | 2   wave groups per block (2 = eight waves, even / odd planes share the resident boxes)
  * "sweep_tw" decides the layout of the sampling table: consume a table (mvsdet_plane_sweep_variance_tabled_f32, the
  * backward pass) under the "sweep_tw" it was built with; the other options may change between the two calls. */
 int mvsdet_set_option(const char* name /*HOST*/, int value);

@@ -21,8 +21,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 Options& options() {
-    static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1),
-                        env_int("MVSDET_SWEEP_GROUPS", 1), 0};
+    static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1)};
     return o;
 }
 
@@ -32,8 +31,6 @@ static int* option_slot(const char* name) {
     if (!strcmp(name, "sweep_tw")) return &o.sweep_tw;
     if (!strcmp(name, "sweep_boxcap")) return &o.sweep_boxcap;
     if (!strcmp(name, "sweep_xcd")) return &o.sweep_xcd;
-    if (!strcmp(name, "sweep_groups")) return &o.sweep_groups;
-    if (!strcmp(name, "sweep_debug")) return &o.sweep_debug;
     return nullptr;
 }
 

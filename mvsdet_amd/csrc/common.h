@@ -12,14 +12,12 @@ namespace mvsdet {
 
 void set_error(const char* fmt, ...);
 
-// Tuning options of the library: initialised ONCE from the environment (MVSDET_SWEEP_TW, _BOXCAP, _XCD, _GROUPS) the
+// Tuning options of the library: initialised ONCE from the environment (MVSDET_SWEEP_TW, _BOXCAP, _XCD) the
 // first time they are needed, afterwards changed only through mvsdet_set_option() -- no getenv on the launch path.
 struct Options {
     int sweep_tw;      // 0 = by the map width, 16 / 32 force the tile shape (16x8 / 32x4)
     int sweep_boxcap;  // texels of one LDS footprint box (0 forces the global-gather path)
     int sweep_xcd;     // XCD-aware block map for fewer than 8 slabs
-    int sweep_groups;  // 1 = four waves per block, 2 = eight (two plane-parity groups share the boxes)
-    int sweep_debug;   // timing experiments only (wrong results): 1 no stores, 2 no table loads, 4 no box DMA, 8 no refills
 };
 Options& options();
 

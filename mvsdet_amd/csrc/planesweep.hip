@@ -164,14 +164,14 @@ SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles) {
 }  // namespace mvsdet
 
 namespace {
-template <int KV, int TW, int G, typename OutT>
+template <int KV, int TW, bool FAST, typename OutT>
 int launch_slab(dim3 grid, hipStream_t stream, size_t lds, const float* packed, const float* ref_packed, const int64_t* nbr,
                 const SweepGeometry& geo, OutT* var, int n_src, int C, int S, int D, int H, int W, int tiles_x,
                 int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
-    auto* k = plane_sweep_variance_kernel<KV, TW, G, true, OutT>;
+    auto* k = plane_sweep_variance_kernel<KV, TW, FAST, OutT>;
     if (int rc = allow_dynamic_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(kThreads * G), lds, stream, packed, ref_packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags,
-                       var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts, options().sweep_debug);
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, ref_packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags,
+                       var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts);
     return MVSDET_OK;
 }
 
@@ -192,12 +192,12 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         set_error("plane_sweep_variance: grid too large");
         return MVSDET_ERR_INVALID_ARG;
     }
-    const int G = options().sweep_groups == 2 ? 2 : 1;
+    const bool fast = (C % kSlab == 0) && (W % 4 == 0);   // whole float4 stores of whole slabs (see the kernel)
     const int box_cap = effective_box_cap(K, TW);
     // every block sweeps all its planes (reference features stay in registers, a resident footprint box serves a run
     // of planes) unless the grid would be too small to fill 256 CUs x 2 blocks
     int dsplit = 1;
-    while (nblocks * dsplit < 1024 && D / (dsplit * 2) >= 2 * G) dsplit *= 2;
+    while (nblocks * dsplit < 1024 && D / (dsplit * 2) >= 2) dsplit *= 2;
     const int d_per_block = (D + dsplit - 1) / dsplit;
     const SweepGeometry geo = sweep_geometry(scratch, N, K, D, tiles);
     dim3 cgrid((unsigned)(N * tiles));
@@ -213,10 +213,10 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     const float* ref_packed = packed ? packed + (size_t)ref_first * S * H * W * kSlab : nullptr;
     const size_t lds = sweep_lds_bytes(K, box_cap);
     int rc = MVSDET_OK;
-#define MVS_SLAB(KV, GV)                                                                                               \
-    (half_out ? launch_slab<KV, TW, GV, __half>(grid, stream, lds, packed, ref_packed, nbr, geo, var16, n_src, C, S,   \
+#define MVS_SLAB(KV, FV)                                                                                               \
+    (half_out ? launch_slab<KV, TW, FV, __half>(grid, stream, lds, packed, ref_packed, nbr, geo, var16, n_src, C, S,   \
                                                 D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts)       \
-              : launch_slab<KV, TW, GV, float>(grid, stream, lds, packed, ref_packed, nbr, geo, var, n_src, C, S, D,   \
+              : launch_slab<KV, TW, FV, float>(grid, stream, lds, packed, ref_packed, nbr, geo, var, n_src, C, S, D,   \
                                                H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts))
 #define MVS_SWEEP_CASE(KV)                                                                                            \
     case KV:                                                                                                          \
@@ -224,11 +224,11 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
             hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads),                            \
                                (size_t)D * (KV * sizeof(int4) + sizeof(unsigned) + sizeof(float)), stream, proj, depth,               \
                                geo.boxes, geo.flags, geo.proj, geo.depth, D, H, W, tiles_x, tiles, box_cap);           \
-        if (phases & 2) rc = (G == 1) ? MVS_SLAB(KV, 1) : MVS_SLAB(KV, 2);                                            \
+        if (phases & 2) rc = fast ? MVS_SLAB(KV, true) : MVS_SLAB(KV, false);                                         \
         break;
     switch (K) {
         case 0:
-            if (phases & 2) rc = MVS_SLAB(0, 1);
+            if (phases & 2) rc = fast ? MVS_SLAB(0, true) : MVS_SLAB(0, false);
             break;
         MVS_SWEEP_CASE(1)
         MVS_SWEEP_CASE(2)

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
     const float* __restrict__ depth, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
     const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int box_cap, int dbg) {
+    int tiles, int box_cap) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int NP = (K + 1) / 2;
     constexpr int NPP = NP > 0 ? NP : 1;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
                 const int base = j * slot_fl + box_slot(t) * kSlab;
                 float* cell = s_grad + base + (q ^ grad_swizzle(base));
                 const float v = *cell;
-                if (v != 0.0f && !(dbg & 4)) atomicAdd(nb_grad[j] + ((size_t)(ry0[j] + row) * W + (rx0[j] + col)) * kSlab + q, v);
+                if (v != 0.0f) atomicAdd(nb_grad[j] + ((size_t)(ry0[j] + row) * W + (rx0[j] + col)) * kSlab + q, v);
                 *cell = 0.0f;
             }
         }
@@ -190,9 +190,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             const float w1 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.y))));                     \
             const float w2 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.z))));                     \
             const float w3 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.w))));                     \
-            const int gg = (dbg & 2) ? 0 : g;                                                                         \
-            const float4 t0 = nb_img[j][((dbg & 2) ? 0 : i0) + gg], t1 = nb_img[j][((dbg & 2) ? 0 : i1) + gg],        \
-                         t2 = nb_img[j][((dbg & 2) ? 0 : i2) + gg], t3 = nb_img[j][((dbg & 2) ? 0 : i3) + gg];        \
+            const float4 t0 = nb_img[j][i0 + g], t1 = nb_img[j][i1 + g], t2 = nb_img[j][i2 + g], t3 = nb_img[j][i3 + g]; \
             const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};                           \
             const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};                           \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
@@ -290,10 +288,8 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             MVS_GRAD_OF(0)
             MVS_GRAD_OF(1)
         };
-        if (!(dbg & 1)) {
-            if constexpr (NP > 0) grads(std::integral_constant<int, 0>{});
-            if constexpr (NP > 1) grads(std::integral_constant<int, 1>{});
-        }
+        if constexpr (NP > 0) grads(std::integral_constant<int, 0>{});
+        if constexpr (NP > 1) grads(std::integral_constant<int, 1>{});
 #undef MVS_GRAD_OF
 #undef MVS_GRAD_STEP
 #undef MVS_ADD_LDS
@@ -380,7 +376,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
             return MVSDET_ERR_HIP;                                                                                     \
         }                                                                                                              \
         hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
-                           gpacked, N, C, S, D, H, W, tiles_x, tiles, box_cap, options().sweep_debug);                                        \
+                           gpacked, N, C, S, D, H, W, tiles_x, tiles, box_cap);                                        \
     }
 #define MVS_BWD_CASE(KV)                     \
     case KV:                                 \

@@ -8,7 +8,7 @@
 //     ~9 planes on the ScanNet-like geometry and ~35 on the ARKit-like one (tools/box_runs.py).
 //
 // (2) plane_sweep_variance_kernel -- the channel work, one 32-channel slab per block:
-//       block   = (reference view n, TWxTH pixel tile (128 pixels), slab s, depth chunk), 4*G waves
+//       block   = (reference view n, TWxTH pixel tile (128 pixels), slab s, depth chunk), 4 waves
 //       LDS     = ONE resident footprint box per neighbour (K slots of box_cap 128-byte texels).  A slot is
 //                 refilled (LDS-DMA, two block barriers) only when the run's union box changes: ~10 % of the live
 //                 (tile, plane, neighbour) triples.  All other planes run without any block-level synchronisation:
@@ -20,8 +20,8 @@
 //       decode  = lane (ps, g) decodes the table entry of pixel-step g&3 once per neighbour and plane (tap origin,
 //                 4 weights, 4 LDS offsets); the four steps read it from their quad-lane with DPP quad_perm
 //                 broadcasts -- no LDS tables, no barrier between decode and taps.
-//       G = 2   = eight waves share the boxes of one tile: waves 0-3 take the even planes of the block's depth
-//                 range and waves 4-7 the odd ones, which doubles the waves per CU for the same LDS.
+//       (eight waves per block -- two plane-parity groups sharing the boxes -- were measured and dropped: every wave
+//       then has to follow every plane's flags, and 127 VGPRs force f*f back into the loop; 13.4 vs 12.5 ms.)
 //
 // Design history: v1 gathered from global memory (fabric-bound, L2 hit 43 %), v3-v5 staged one box
 // per (plane, neighbour) with 5 barriers and 2 exposed DMA latencies per plane (wave wait 57 %, 3.4 TB/s).
@@ -304,12 +304,14 @@ __host__ __device__ constexpr size_t sweep_lds_bytes(int K, int box_cap) { retur
 
 // OutT = float, or __half: the variance is computed in fp32 exactly as before and rounded to nearest-even at the
 // store (BASELINE configs[4], fp16 storage), which halves the dominant write stream.
-template <int K, int TW, int G, bool NT, typename OutT = float>
-__global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kernel(
+// FAST: every channel row of the slab exists (C % 32 == 0) and every lane's 4 pixels are all inside or all outside the
+// image with 16-byte aligned rows (W % 4 == 0): the stores are four unconditional vector stores under one lane predicate.
+template <int K, int TW, bool FAST, typename OutT = float>
+__global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
     const float* __restrict__ proj, const float* __restrict__ depth, const int4* __restrict__ boxes,
     const unsigned* __restrict__ flags, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts, int dbg) {
+    int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int NP = (K + 1) / 2;             // decode passes: a lane decodes ONE (pixel-step, neighbour) pair per pass
     constexpr int NPP = NP > 0 ? NP : 1;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it scalar
-    const int sub = wave & 3, grp = wave >> 2;                  // pixel quarter of the tile, plane parity group
+    const int sub = wave;                                       // pixel quarter of the tile
     const int g = lane & 7, ps = lane >> 3;
     const size_t slab_stride = (size_t)HW * kSlab;       // floats per (view, slab) image
     // ref_packed = packed + first reference view of this launch (a view shard); N bounds the NEIGHBOUR ids
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
     auto load_box = [&](int j, int bx0, int by0, int nc, int nr) {
         const int ntex = nc * nr;
         const float inv_nc = 1.0f / (float)nc;
-        for (int q = wave; q * 8 <= ntex; q += 4 * G) {
+        for (int q = wave; q * 8 <= ntex; q += 4) {
             const int t = box_slot(q * 8 + ps);                 // the box texel kept in slot q*8 + ps
             const int row = (int)(((float)t + 0.5f) * inv_nc);  // t / nc for t < 2^11 (never within rounding of an integer)
             const int col = t - row * nc;
@@ -421,41 +423,62 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
     float dv_next = (K > 0 && d_begin < d_end) ? depth_n[d_begin] : 0.0f;
 
     // results of the last computed plane, and the stores that send them out: straight from registers, 16 bytes per lane =
-    // 8 channel rows x 128 contiguous bytes per wave-instruction
+    // 8 channel rows x 128 contiguous bytes per wave-instruction; non-temporal (written once, never re-read here: keeps the
+    // stream from evicting the source slabs)
     float vout[4][4];
     int d_pending = -1;
+    OutT* const var_slab = var + ((size_t)n * C + slab * kSlab) * D * HW;   // block-uniform: channel row 0 of the slab, plane 0
+    const size_t row8 = (size_t)8 * D * HW;                                 // 8 channel rows further
     auto flush = [&](int d) {
-        OutT* plane_base = var + (((size_t)n * C + slab * kSlab) * D + d) * HW;  // block-uniform
+        OutT* plane_base = var_slab + (size_t)d * HW;
+        if constexpr (FAST) {
+            if (st_n == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float* v = vout[i];
-            const int c = slab * kSlab + g + 8 * i;
-            if (c < C && !((dbg & 1) && v[0] != 12345.678f)) {
-                OutT* dst = reinterpret_cast<OutT*>(reinterpret_cast<char*>(plane_base + (size_t)(8 * i) * D * HW) + st_off);
-                // written once, never re-read here: non-temporal keeps the stream from evicting the source slabs
-                if constexpr (sizeof(OutT) == 4) {
-                    if (st_vec) {
+                for (int i = 0; i < 4; ++i) {
+                    const float* v = vout[i];
+                    OutT* dst = reinterpret_cast<OutT*>(reinterpret_cast<char*>(plane_base + i * row8) + st_off);
+                    if constexpr (sizeof(OutT) == 4) {
                         typedef float v4f __attribute__((ext_vector_type(4)));
                         const v4f vv = {v[0], v[1], v[2], v[3]};
-                        if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
-                        else *reinterpret_cast<v4f*>(dst) = vv;
+                        __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
                     } else {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (s < st_n) dst[s] = v[s];
-                    }
-                } else {
-                    const __half h[4] = {__float2half_rn(v[0]), __float2half_rn(v[1]), __float2half_rn(v[2]), __float2half_rn(v[3])};
-                    if (st_vec) {  // 4 pixels x 2 B: the fp32 alignment condition also gives 8-byte alignment
+                        const __half h[4] = {__float2half_rn(v[0]), __float2half_rn(v[1]), __float2half_rn(v[2]), __float2half_rn(v[3])};
                         typedef unsigned v2u __attribute__((ext_vector_type(2)));
                         const v2u vv = {(unsigned)__half_as_ushort(h[0]) | ((unsigned)__half_as_ushort(h[1]) << 16),
                                         (unsigned)__half_as_ushort(h[2]) | ((unsigned)__half_as_ushort(h[3]) << 16)};
-                        if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v2u*>(dst));
-                        else *reinterpret_cast<v2u*>(dst) = vv;
-                    } else {
+                        __builtin_nontemporal_store(vv, reinterpret_cast<v2u*>(dst));
+                    }
+                }
+            }
+        } else {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (s < st_n) dst[s] = h[s];
+            for (int i = 0; i < 4; ++i) {
+                const float* v = vout[i];
+                const int c = slab * kSlab + g + 8 * i;
+                if (c < C) {
+                    OutT* dst = reinterpret_cast<OutT*>(reinterpret_cast<char*>(plane_base + i * row8) + st_off);
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (st_vec) {
+                            typedef float v4f __attribute__((ext_vector_type(4)));
+                            const v4f vv = {v[0], v[1], v[2], v[3]};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                if (s < st_n) dst[s] = v[s];
+                        }
+                    } else {
+                        const __half h[4] = {__float2half_rn(v[0]), __float2half_rn(v[1]), __float2half_rn(v[2]), __float2half_rn(v[3])};
+                        if (st_vec) {  // 4 pixels x 2 B: the fp32 alignment condition also gives 8-byte alignment
+                            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                            const v2u vv = {(unsigned)__half_as_ushort(h[0]) | ((unsigned)__half_as_ushort(h[1]) << 16),
+                                            (unsigned)__half_as_ushort(h[2]) | ((unsigned)__half_as_ushort(h[3]) << 16)};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<v2u*>(dst));
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                if (s < st_n) dst[s] = h[s];
+                        }
                     }
                 }
             }
@@ -473,7 +496,7 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
         for (int j = 0; j < K; ++j)
             if ((fl >> (4 * j)) & kFlagStaged)
                 if (((fl >> (4 * j)) & kFlagRefill) || !have[j]) refill = true;
-        if (refill && !(dbg & 8)) {
+        if (refill) {
             __syncthreads();  // every wave is done with the planes that read the old boxes
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -485,7 +508,7 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
                     ry1[j] = __builtin_amdgcn_readfirstlane(b.w);
                     have[j] = true;
                     if (min(2 * (j / 2) + qd, K - 1) == j) { lx0[j / 2] = rx0[j]; lx1[j / 2] = rx1[j]; ly0[j / 2] = ry0[j]; ly1[j / 2] = ry1[j]; }
-                    if (!(dbg & 4)) load_box(j, rx0[j], ry0[j], rx1[j] - rx0[j] + 1, ry1[j] - ry0[j] + 1);
+                    load_box(j, rx0[j], ry0[j], rx1[j] - rx0[j] + 1, ry1[j] - ry0[j] + 1);
                 }
             }
             // The LDS-DMA pieces of this wave count on vmcnt, and for a workgroup barrier hipcc only waits for lgkmcnt:
@@ -495,16 +518,13 @@ __global__ __launch_bounds__(kThreads * G, 2 * G) void plane_sweep_variance_kern
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
         }
-        if (d_pending >= 0) { flush(d_pending); d_pending = -1; }
-        if (G > 1 && ((d - d_begin) & (G - 1)) != grp) continue;  // the other wave group's plane
+        if (d_pending >= 0) flush(d_pending);
 
         f2 S_[4][2], Q_[4][2];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             S_[s][0] = f[s][0]; S_[s][1] = f[s][1];
-            // eight waves per block live on 128 VGPRs: keep f*f inside the loop (hoisted, it costs 16 of them and spills)
-            if (G > 1) asm volatile("" : "+v"(S_[s][0]), "+v"(S_[s][1]));
-            Q_[s][0] = S_[s][0] * S_[s][0]; Q_[s][1] = S_[s][1] * S_[s][1];
+            Q_[s][0] = f[s][0] * f[s][0]; Q_[s][1] = f[s][1] * f[s][1];   // loop invariant: hoisted (16 VGPRs)
         }
 #define MVS_TAP_STEP(SS, QQ, LOADER)                                                                                  \
         {                                                                                                             \

@@ -17,16 +17,12 @@ hp = MVSDetHotPath(bench.N_VOXELS, bench.VOXEL_SIZE, list(w["near_far"]), w["D"]
 s = bench.SceneInputs(w, 0, dev)
 geo = hp.prepare_scene(s.meta, dev)
 g = torch.randn((w["N"], w["C"], w["D"], w["H"], w["W"]), device=dev)
-from mvsdet_amd import _lib  # noqa: E402
-for dbg in [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"])]:
-    _lib.set_option("sweep_debug", dbg)
-    ts = []
-    for _ in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ops.plane_sweep_variance_backward(s.features, geo.neighbor_ids, geo.proj_rel, geo.depth_values, g)
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    print(f"{name} backward, sweep_debug={dbg}: {min(ts):.3f} ms", flush=True)
-_lib.set_option("sweep_debug", 0)
+ts = []
+for _ in range(4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.plane_sweep_variance_backward(s.features, geo.neighbor_ids, geo.proj_rel, geo.depth_values, g)
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+print(f"{name} backward: {min(ts):.3f} ms", flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the sampling-table kernel and the slab kernel of the plane sweep under several option sets.
-Usage: python tools/sweep_variants.py [workload] ["sweep_groups=1,sweep_boxcap=256;sweep_groups=2;..."] [reps]"""
+Usage: python tools/sweep_variants.py [workload] ["sweep_boxcap=256;sweep_tw=16;..."] [reps]"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ from mvsdet_amd import _lib, ops  # noqa: E402
 from mvsdet_amd.hotpath import MVSDetHotPath  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "scannet_40v_64d_120x160"
-variants = sys.argv[2] if len(sys.argv) > 2 else "sweep_groups=1;sweep_groups=2"
+variants = sys.argv[2] if len(sys.argv) > 2 else ";"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 w = bench.WORKLOADS[name]
 dev = torch.device("cuda:0")
@@ -22,7 +22,7 @@ s = bench.SceneInputs(w, 0, dev)
 geo = hp.prepare_scene(s.meta, dev)
 packed = ops.pack_features(s.features)
 nbytes = bench.sweep_bytes_per_cv(w) * w["N"]
-defaults = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap", "sweep_groups", "sweep_xcd", "sweep_debug")}
+defaults = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap", "sweep_xcd")}
 ref = None
 for v in variants.split(";"):
     opts = dict(defaults)
