@@ -5,18 +5,22 @@
 //   dvar/dv = 2 v r - 2 S r^2   (r = 1/(K+1)) for each contributing value v in {f, w_1..w_K}
 //   w_j = sum_t weight_t * tap_t  ->  dL/dtap_t += weight_t * dL/dw_j   (bilinear scatter)
 //
-// Same decomposition, lane map and sweep geometry as the forward slab kernel (sweep_kernel.h): block = (reference
-// view, 128-pixel tile, 32-channel slab); lane (ps, g) owns 4 consecutive pixels x channels 8*i + g, so dL/dvar is
-// read as 16 bytes per lane (8 channel rows x 128 contiguous bytes per wave-instruction, no LDS transpose); the
-// sampling positions are recomputed per plane from the pixel rays (one position per lane and pass, DPP broadcasts).
-// Where the forward keeps a neighbour's footprint box of SOURCE texels resident in LDS for a run of planes, the
-// backward keeps a GRADIENT image of the same box there: tap gradients are accumulated with LDS atomics over the
-// whole run and flushed to the packed gradient map only when the run's box changes -- 256 contiguous bytes of fp32
-// global atomics per wave-instruction (MI355X_MICROARCH "Global float atomics": full rate only in that shape).
-// Round 1 flushed a box per plane and neighbour: 1.9 G lane-atomics at the reference-true shape, 14.2 ms; a run is
-// ~9-35 planes long, so the flushes shrink by that factor.  The warped values are recomputed with taps gathered from
-// the slab images (L2).  A footprint larger than the box falls back to one global atomic per tap.
-// The packed gradient map is unpacked to (N,C,H,W) afterwards.
+// Same tiles, decode duty and sweep geometry as the forward slab kernel (sweep_kernel.h): block = (reference view,
+// 128-pixel tile, 32-channel slab); the sampling positions are recomputed per plane from the pixel rays (one position
+// per lane and pass, DPP broadcasts).  Where the forward keeps a neighbour's footprint box of SOURCE texels resident
+// in LDS for a run of planes, the backward keeps a GRADIENT image of the same box there: tap gradients are
+// accumulated with LDS atomics over the whole run and flushed to the packed gradient map with global atomics only when
+// the run's box changes (a run is ~9-35 planes long).
+//
+// The gradient image is kept in DOUBLE.  tools/micro/lds_atomic.hip: on gfx950 ds_add_f32 retires 0.33 lane-op per
+// clock and CU whatever the address pattern (one lane every three clocks -- 2.8 G tap gradients = 11.6 of round 2's
+// 13.5 ms), ds_add_f64 4-8 and ds_add_u32 15.  So one kernel instance owns HALF a slab -- the packed floats
+// [16*HALF, 16*HALF + 16) of every texel, lane (ps, g) the two floats 2g, 2g+1 of its 4 consecutive pixels -- which
+// makes a texel of the image 16 doubles = the 128 bytes the fp32 image had, and the two instances (two launches)
+// together repeat the position decode and the tap gathers (8 bytes per lane, from L2) but not the arithmetic or the
+// atomics.  The sums are also more accurate than fp32 ones and lose nothing when a box collects thousands of taps.
+// A footprint larger than the box falls back to one global fp32 atomic per tap.  The packed gradient map is unpacked
+// to (N,C,H,W) afterwards.
 #include "common.h"
 
 #include <algorithm>
@@ -26,13 +30,15 @@
 
 namespace mvsdet {
 
-// LDS bank swizzle of the gradient images: float 4*g + i of the texel at float index `base` (a multiple of 32) is kept at
-// 4*g + (i ^ ((base >> 7) & 3)).  One LDS atomic of a wave touches a fixed i of 8 texels x 8 channel groups; unswizzled
-// that is 8 banks out of 32 (8-way conflicts); the texels of neighbouring pixel slots lie ~4 slots apart, so XOR-ing i
-// with bits 2-3 of the slot index spreads them over all 32 banks (2-way: 64 lanes on 32 banks).
-__device__ __forceinline__ int grad_swizzle(int base) { return (base >> 7) & 3; }
+// LDS bank swizzle of the gradient images: double 2*g + i of the texel at double index `base` (a multiple of 16) is kept
+// at 2*g + (i ^ ((base >> 6) & 1)).  One LDS atomic of a wave touches a fixed i of 8 texels x 8 lanes, 16 bytes apart:
+// half of the banks; the texels of neighbouring pixel slots lie ~4 slots apart, so flipping i with bit 2 of the slot
+// index spreads them over all of them.
+__device__ __forceinline__ int grad_swizzle(int base) { return (base >> 6) & 1; }
 
-template <int K, int TW>
+constexpr int kHalfSlab = kSlab / 2;  // packed floats of a texel one kernel instance owns
+
+template <int K, int TW, int HALF>
 __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
     const float* __restrict__ depth, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
@@ -42,8 +48,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     constexpr int NP = (K + 1) / 2;
     constexpr int NPP = NP > 0 ? NP : 1;
     constexpr int TH = kTilePix / TW;
-    extern __shared__ float4 s_grad4[];  // K slots of (box_cap + kBoxPad) texels x 32 floats: gradient images of the resident boxes
-    float* s_grad = reinterpret_cast<float*>(s_grad4);
+    extern __shared__ double s_grad[];  // K slots of (box_cap + kBoxPad) texels x 16 doubles: gradient images of the resident boxes
 
     const int HW = H * W;
     const int id = blockIdx.x;
@@ -55,36 +60,45 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane & 7, ps = lane >> 3;
     const size_t slab_stride = (size_t)HW * kSlab;
-    const float* ref_img = packed + ((size_t)n * S + slab) * slab_stride;
-    const float4* nb_img[KK];
+    // float2 views of the slab images, already at the lane's two floats: texel t is element 16 * t
+    const float2* ref_img = reinterpret_cast<const float2*>(packed + ((size_t)n * S + slab) * slab_stride) + 8 * HALF + g;
+    const float2* nb_img[KK];
     float* nb_grad[KK];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         int64_t v = nbr[(size_t)n * K + j];
         v = v < 0 ? 0 : (v >= N ? N - 1 : v);
-        nb_img[j] = reinterpret_cast<const float4*>(packed + ((size_t)v * S + slab) * slab_stride);
-        nb_grad[j] = gpacked + ((size_t)v * S + slab) * slab_stride;
+        nb_img[j] = reinterpret_cast<const float2*>(packed + ((size_t)v * S + slab) * slab_stride) + 8 * HALF + g;
+        nb_grad[j] = gpacked + ((size_t)v * S + slab) * slab_stride + kHalfSlab * HALF;
     }
     const float r = 1.0f / (float)(K + 1);
     const float two_r = 2.0f * r, two_r2 = 2.0f * r * r;
-    const int slot_fl = (box_cap + kBoxPad) * kSlab;  // floats per LDS slot
+    const int slot_el = (box_cap + kBoxPad) * kHalfSlab;  // doubles per LDS slot
 
     // the lane's 4 consecutive pixels, their reference features and the running reference-term gradient
     const int p0 = 32 * wave + 4 * ps;
     const int px0 = tx0 + p0 % TW, py = ty0 + p0 / TW;
-    float f[4][4], gref[4][4];
+    float f[4][2], gref[4][2];
     bool pok[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         pok[s] = (px0 + s < W) && (py < H);
         const int pix = min(py, H - 1) * W + min(px0 + s, W - 1);
-        const float4 v = *reinterpret_cast<const float4*>(ref_img + (size_t)pix * kSlab + 4 * g);
-        f[s][0] = v.x; f[s][1] = v.y; f[s][2] = v.z; f[s][3] = v.w;
-        gref[s][0] = gref[s][1] = gref[s][2] = gref[s][3] = 0.0f;
+        const float2 v = ref_img[(size_t)pix * kHalfSlab];
+        f[s][0] = v.x; f[s][1] = v.y;
+        gref[s][0] = gref[s][1] = 0.0f;
     }
     const int st_n = (py < H) ? max(0, min(4, W - px0)) : 0;
     const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);
-    const size_t g_lane = (size_t)g * D * HW + (size_t)py * W + px0;  // channel g, the lane's pixels (elements)
+    // packed float q = 16*HALF + 2g + i is channel 8*(q & 3) + (q >> 2) of the slab (pack.h)
+    size_t g_off[2];
+    bool g_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = slab * kSlab + 16 * (g & 1) + 8 * i + 4 * HALF + (g >> 1);
+        g_ok[i] = (c < C) && (st_n > 0);
+        g_off[i] = ((size_t)n * C + min(c, C - 1)) * D * HW + (size_t)py * W + px0;
+    }
 
     // decode duty of the lane (sweep_kernel.h): pixel p0 + (g & 3), neighbour 2*pass + (g >> 2)
     const int sd = g & 3, qd = g >> 2;
@@ -107,25 +121,25 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < KK; ++j) { rx0[j] = 0; ry0[j] = 0; rx1[j] = -1; ry1[j] = -1; have[j] = false; }
 
-    // the gradient image of neighbour j's resident box -> packed gradient map, then zero again.  Two box texels per
-    // wave-instruction (256 contiguous bytes when they are neighbours in a row).
+    // the gradient image of neighbour j's resident box -> packed gradient map, then zero again.  Four box texels per
+    // wave-instruction, 64 contiguous bytes each.
     auto flush_box = [&](int j) {
         const int nc = rx1[j] - rx0[j] + 1, ntex = nc * (ry1[j] - ry0[j] + 1);
         const float inv_nc = 1.0f / (float)nc;
-        for (int t0 = wave * 2; t0 < ntex; t0 += 8) {
-            const int t = t0 + (lane >> 5), q = lane & 31;
+        for (int t0 = wave * 4; t0 < ntex; t0 += 16) {
+            const int t = t0 + (lane >> 4), q = lane & 15;
             if (t < ntex) {
                 const int row = (int)(((float)t + 0.5f) * inv_nc), col = t - row * nc;
-                const int base = j * slot_fl + box_slot(t) * kSlab;
-                float* cell = s_grad + base + (q ^ grad_swizzle(base));
-                const float v = *cell;
+                const int base = j * slot_el + box_slot(t) * kHalfSlab;
+                double* cell = s_grad + base + (q ^ grad_swizzle(base));
+                const float v = (float)*cell;
                 if (v != 0.0f) atomicAdd(nb_grad[j] + ((size_t)(ry0[j] + row) * W + (rx0[j] + col)) * kSlab + q, v);
-                *cell = 0.0f;
+                *cell = 0.0;
             }
         }
     };
 
-    for (int e = tid; e < K * slot_fl / 4; e += kThreads) s_grad4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < K * slot_el / 2; e += kThreads) reinterpret_cast<double2*>(s_grad)[e] = make_double2(0.0, 0.0);
     __syncthreads();
 
     const unsigned* fl_bt = flags + (size_t)bt * D;
@@ -155,14 +169,13 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             }
             __syncthreads();  // slots zeroed again before anyone adds into them
         }
-        // ---- dL/dvar of the lane's pixels and channels
-        float go[4][4];
+        // ---- dL/dvar of the lane's pixels and channels: 8 channel rows x 128 contiguous bytes per wave-instruction
+        float go[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = slab * kSlab + 8 * i + g;
+        for (int i = 0; i < 2; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C && st_n > 0) {
-                const float* src = gvar + (((size_t)n * C + slab * kSlab + 8 * i) * D + d) * HW + g_lane;
+            if (g_ok[i]) {
+                const float* src = gvar + g_off[i] + (size_t)d * HW;
                 if (st_vec) {
                     v = *reinterpret_cast<const float4*>(src);
                 } else {
@@ -176,24 +189,20 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
         }
         // ---- pass 1 over the neighbours: warped values (taps gathered from the slab images), S.  The lane keeps what it
         //      decoded (tap offsets in the gradient slot / gradient image, weights) for pass 2, which fetches it again
-        //      by DPP: holding the broadcast copies of both neighbours would cost 64 VGPRs.
-        float S_[4][4], wv[KK][4][4];
+        //      by DPP instead of holding the broadcast copies of every neighbour.
+        float S_[4][2], wv[KK][4][2];
         int dox[NPP][4];
         float dwx[NPP][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { S_[s][0] = f[s][0]; S_[s][1] = f[s][1]; S_[s][2] = f[s][2]; S_[s][3] = f[s][3]; }
-#define MVS_BWD_STEP(SS, QQ)                                                                                          \
+        for (int s = 0; s < 4; ++s) { S_[s][0] = f[s][0]; S_[s][1] = f[s][1]; }
+#define MVS_BWD_STEP(SS)                                                                                              \
         {                                                                                                             \
-            const int i0 = from_quad<QQ>(quad_bcast<SS>(di0)), i1 = from_quad<QQ>(quad_bcast<SS>(di1));               \
-            const int i2 = from_quad<QQ>(quad_bcast<SS>(di2)), i3 = from_quad<QQ>(quad_bcast<SS>(di3));               \
-            const float w0 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.x))));                     \
-            const float w1 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.y))));                     \
-            const float w2 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.z))));                     \
-            const float w3 = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.w))));                     \
-            const float4 t0 = nb_img[j][i0 + g], t1 = nb_img[j][i1 + g], t2 = nb_img[j][i2 + g], t3 = nb_img[j][i3 + g]; \
-            const float a0[4] = {t0.x, t0.y, t0.z, t0.w}, a1[4] = {t1.x, t1.y, t1.z, t1.w};                           \
-            const float a2[4] = {t2.x, t2.y, t2.z, t2.w}, a3[4] = {t3.x, t3.y, t3.z, t3.w};                           \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+            const int i0 = quad_bcast<SS>(ri0), i1 = quad_bcast<SS>(ri1), i2 = quad_bcast<SS>(ri2), i3 = quad_bcast<SS>(ri3); \
+            const float w0 = __int_as_float(quad_bcast<SS>(rw0)), w1 = __int_as_float(quad_bcast<SS>(rw1));           \
+            const float w2 = __int_as_float(quad_bcast<SS>(rw2)), w3 = __int_as_float(quad_bcast<SS>(rw3));           \
+            const float2 t0 = nb_img[j][i0], t1 = nb_img[j][i1], t2 = nb_img[j][i2], t3 = nb_img[j][i3];              \
+            const float a0[2] = {t0.x, t0.y}, a1[2] = {t1.x, t1.y}, a2[2] = {t2.x, t2.y}, a3[2] = {t3.x, t3.y};       \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
                 float v = a0[i] * w0;                                                                                 \
                 v = fmaf(a1[i], w1, v);                                                                               \
                 v = fmaf(a2[i], w2, v);                                                                               \
@@ -206,10 +215,12 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
         if constexpr (2 * p + QQ < K) {                                                                               \
             constexpr int j = 2 * p + QQ;                                                                             \
             if ((fl >> (4 * j)) & kFlagLive) {                                                                        \
-                MVS_BWD_STEP(0, QQ) MVS_BWD_STEP(1, QQ) MVS_BWD_STEP(2, QQ) MVS_BWD_STEP(3, QQ)                       \
+                const int ri0 = from_quad<QQ>(di0), ri1 = from_quad<QQ>(di1), ri2 = from_quad<QQ>(di2), ri3 = from_quad<QQ>(di3); \
+                const int rw0 = from_quad<QQ>(__float_as_int(dw.x)), rw1 = from_quad<QQ>(__float_as_int(dw.y));       \
+                const int rw2 = from_quad<QQ>(__float_as_int(dw.z)), rw3 = from_quad<QQ>(__float_as_int(dw.w));       \
+                MVS_BWD_STEP(0) MVS_BWD_STEP(1) MVS_BWD_STEP(2) MVS_BWD_STEP(3)                                       \
             } else {                                                                                                  \
-                _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                         \
-                    _Pragma("unroll") for (int i = 0; i < 4; ++i) wv[j][s][i] = 0.0f;                                 \
+                _Pragma("unroll") for (int s = 0; s < 4; ++s) wv[j][s][0] = wv[j][s][1] = 0.0f;                       \
             }                                                                                                         \
         }
         auto pass = [&](auto pc) {
@@ -227,14 +238,17 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             const int loy = l_staged ? ly0[p] : 0, hiy = l_staged ? ly1[p] : H - 1;
             const int xa = clampi(tp.x0, lox, hix), xb = clampi(tp.x0 + 1, lox, hix);
             const int ya = clampi(tp.y0, loy, hiy), yb = clampi(tp.y0 + 1, loy, hiy);
-            const int di0 = (ya * W + xa) * 8, di1 = (ya * W + xb) * 8, di2 = (yb * W + xa) * 8, di3 = (yb * W + xb) * 8;
+            // float2 elements of the slab image
+            const int di0 = (ya * W + xa) * kHalfSlab, di1 = (ya * W + xb) * kHalfSlab;
+            const int di2 = (yb * W + xa) * kHalfSlab, di3 = (yb * W + xb) * kHalfSlab;
             const int pitch = hix - lox + 1;
-            const int sbase = min(2 * p + qd, K - 1) * slot_fl;
+            const int sbase = min(2 * p + qd, K - 1) * slot_el;
             const int ta = (ya - loy) * pitch - lox, tb = (yb - loy) * pitch - lox;
-            dox[p][0] = l_staged ? box_slot(ta + xa) * kSlab + sbase : di0 * 4;
-            dox[p][1] = l_staged ? box_slot(ta + xb) * kSlab + sbase : di1 * 4;
-            dox[p][2] = l_staged ? box_slot(tb + xa) * kSlab + sbase : di2 * 4;
-            dox[p][3] = l_staged ? box_slot(tb + xb) * kSlab + sbase : di3 * 4;
+            // doubles of the gradient slot (staged) or floats of the gradient map
+            dox[p][0] = l_staged ? box_slot(ta + xa) * kHalfSlab + sbase : di0 * 2;
+            dox[p][1] = l_staged ? box_slot(ta + xb) * kHalfSlab + sbase : di1 * 2;
+            dox[p][2] = l_staged ? box_slot(tb + xa) * kHalfSlab + sbase : di2 * 2;
+            dox[p][3] = l_staged ? box_slot(tb + xb) * kHalfSlab + sbase : di3 * 2;
             dwx[p][0] = dw.x; dwx[p][1] = dw.y; dwx[p][2] = dw.z; dwx[p][3] = dw.w;
             MVS_BWD_OF(0)
             MVS_BWD_OF(1)
@@ -247,39 +261,44 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
                 if (pok[s]) gref[s][i] = fmaf(go[s][i], two_r * f[s][i] - two_r2 * S_[s][i], gref[s][i]);
         // ---- pass 2: tap gradients of every live neighbour
-#define MVS_GRAD_STEP(SS, QQ, ADD)                                                                                    \
+#define MVS_GRAD_STEP(SS, ADD)                                                                                        \
         if (pok[SS]) {                                                                                                \
             int to[4];                                                                                                \
             float tw[4];                                                                                              \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
-                to[t] = from_quad<QQ>(quad_bcast<SS>(dox[p][t]));                                                     \
-                tw[t] = __int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dwx[p][t]))));                     \
+                to[t] = quad_bcast<SS>(ro[t]);                                                                        \
+                tw[t] = __int_as_float(quad_bcast<SS>(rw[t]));                                                        \
             }                                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
                 const float gw = go[SS][i] * (two_r * wv[j][SS][i] - two_r2 * S_[SS][i]);                             \
                 _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
                     if (tw[t] != 0.0f) ADD(to[t], i, gw * tw[t]);                                                     \
             }                                                                                                         \
         }
-        // LDS: ds_add_f32 on the swizzled gradient image (an explicit LDS pointer: a select between an LDS and a global
-        // address would make hipcc emit flat atomics, ~10x slower); larger than the box: one global atomic per tap
+        // LDS: ds_add_f64 on the swizzled gradient image (s_grad is used directly: a select between an LDS and a global
+        // address would make hipcc emit flat atomics); larger than the box: one global fp32 atomic per tap
 #define MVS_ADD_LDS(O, I, V) \
-    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)(s_grad + (O) + 4 * g + ((I) ^ grad_swizzle(O))), (V), 0, 0, false)
-#define MVS_ADD_GLB(O, I, V) atomicAdd(nb_grad[j] + (O) + 4 * g + (I), (V))
+    __hip_atomic_fetch_add(s_grad + (O) + 2 * g + ((I) ^ grad_swizzle(O)), (double)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define MVS_ADD_GLB(O, I, V) atomicAdd(nb_grad[j] + (O) + 2 * g + (I), (V))
 #define MVS_GRAD_OF(QQ)                                                                                               \
         if constexpr (2 * p + QQ < K) {                                                                               \
             constexpr int j = 2 * p + QQ;                                                                             \
             const unsigned fj = fl >> (4 * j);                                                                        \
             if (fj & kFlagLive) {                                                                                     \
+                int ro[4], rw[4];                                                                                     \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                       \
+                    ro[t] = from_quad<QQ>(dox[p][t]);                                                                 \
+                    rw[t] = from_quad<QQ>(__float_as_int(dwx[p][t]));                                                 \
+                }                                                                                                     \
                 if (fj & kFlagStaged) {                                                                               \
-                    MVS_GRAD_STEP(0, QQ, MVS_ADD_LDS) MVS_GRAD_STEP(1, QQ, MVS_ADD_LDS)                               \
-                    MVS_GRAD_STEP(2, QQ, MVS_ADD_LDS) MVS_GRAD_STEP(3, QQ, MVS_ADD_LDS)                               \
+                    MVS_GRAD_STEP(0, MVS_ADD_LDS) MVS_GRAD_STEP(1, MVS_ADD_LDS)                                       \
+                    MVS_GRAD_STEP(2, MVS_ADD_LDS) MVS_GRAD_STEP(3, MVS_ADD_LDS)                                       \
                 } else {                                                                                              \
-                    MVS_GRAD_STEP(0, QQ, MVS_ADD_GLB) MVS_GRAD_STEP(1, QQ, MVS_ADD_GLB)                               \
-                    MVS_GRAD_STEP(2, QQ, MVS_ADD_GLB) MVS_GRAD_STEP(3, QQ, MVS_ADD_GLB)                               \
+                    MVS_GRAD_STEP(0, MVS_ADD_GLB) MVS_GRAD_STEP(1, MVS_ADD_GLB)                                       \
+                    MVS_GRAD_STEP(2, MVS_ADD_GLB) MVS_GRAD_STEP(3, MVS_ADD_GLB)                                       \
                 }                                                                                                     \
             }                                                                                                         \
         }
@@ -300,13 +319,13 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < K; ++j)
         if (have[j]) flush_box(j);
-    float* gr = gpacked + ((size_t)n * S + slab) * slab_stride;
+    float* gr = gpacked + ((size_t)n * S + slab) * slab_stride + kHalfSlab * HALF;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         if (pok[s]) {
             const int pix = py * W + px0 + s;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(gr + (size_t)pix * kSlab + 4 * g + i, gref[s][i]);
+            for (int i = 0; i < 2; ++i) atomicAdd(gr + (size_t)pix * kSlab + 2 * g + i, gref[s][i]);
         }
 }
 
@@ -367,9 +386,11 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     const int box_cap = sweep_box_cap(K, tw);
     const size_t lds = sweep_lds_bytes(K, box_cap);
     dim3 grid((unsigned)nblocks);
-#define MVS_BWD_LAUNCH(KV, TWV)                                                                                        \
+    // two instances: the lower and the upper 16 packed floats of every texel = channels 8i + {0..3} and 8i + {4..7} of the
+    // slab (pack.h), so the upper one has nothing to do only when C <= 4
+#define MVS_BWD_LAUNCH1(KV, TWV, HV)                                                                                   \
     {                                                                                                                  \
-        auto* k = plane_sweep_variance_bwd_kernel<KV, TWV>;                                                            \
+        auto* k = plane_sweep_variance_bwd_kernel<KV, TWV, HV>;                                                        \
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                    80 * 1024) != hipSuccess) {                                         \
             set_error("plane_sweep_variance_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");             \
@@ -377,6 +398,11 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
         }                                                                                                              \
         hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
                            gpacked, N, C, S, D, H, W, tiles_x, tiles, box_cap);                                        \
+    }
+#define MVS_BWD_LAUNCH(KV, TWV)                        \
+    {                                                  \
+        MVS_BWD_LAUNCH1(KV, TWV, 0)                    \
+        if (C > 4) MVS_BWD_LAUNCH1(KV, TWV, 1)         \
     }
 #define MVS_BWD_CASE(KV)                     \
     case KV:                                 \
@@ -392,6 +418,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     }
 #undef MVS_BWD_CASE
 #undef MVS_BWD_LAUNCH
+#undef MVS_BWD_LAUNCH1
     MVS_LAUNCH_CHECK("plane_sweep_variance_bwd");
     dim3 ugrid((HW + 63) / 64, S, N);
     hipLaunchKernelGGL(unpack_features_kernel, ugrid, dim3(kThreads), 0, stream, gpacked, gfeat, C, S, H, W);

@@ -526,14 +526,11 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
             S_[s][0] = f[s][0]; S_[s][1] = f[s][1];
             Q_[s][0] = f[s][0] * f[s][0]; Q_[s][1] = f[s][1] * f[s][1];   // loop invariant: hoisted (16 VGPRs)
         }
-#define MVS_TAP_STEP(SS, QQ, LOADER)                                                                                  \
+#define MVS_TAP_STEP(SS, LOADER)                                                                                      \
         {                                                                                                             \
-            const int o0 = from_quad<QQ>(quad_bcast<SS>(do0)), o1 = from_quad<QQ>(quad_bcast<SS>(do1));               \
-            const int o2 = from_quad<QQ>(quad_bcast<SS>(do2)), o3 = from_quad<QQ>(quad_bcast<SS>(do3));               \
-            const f2 w0 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.x)))));                 \
-            const f2 w1 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.y)))));                 \
-            const f2 w2 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.z)))));                 \
-            const f2 w3 = splat(__int_as_float(from_quad<QQ>(quad_bcast<SS>(__float_as_int(dw.w)))));                 \
+            const int o0 = quad_bcast<SS>(ro0), o1 = quad_bcast<SS>(ro1), o2 = quad_bcast<SS>(ro2), o3 = quad_bcast<SS>(ro3); \
+            const f2 w0 = splat(__int_as_float(quad_bcast<SS>(rw0))), w1 = splat(__int_as_float(quad_bcast<SS>(rw1)));  \
+            const f2 w2 = splat(__int_as_float(quad_bcast<SS>(rw2))), w3 = splat(__int_as_float(quad_bcast<SS>(rw3)));  \
             const float4 t0 = LOADER(o0), t1 = LOADER(o1), t2 = LOADER(o2), t3 = LOADER(o3);                          \
             f2 va = (f2){t0.x, t0.y} * w0, vb = (f2){t0.z, t0.w} * w0;                                                \
             va = pk_fma((f2){t1.x, t1.y}, w1, va); vb = pk_fma((f2){t1.z, t1.w}, w1, vb);                             \
@@ -550,12 +547,17 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
                 constexpr int j = 2 * p + QQ;                                                                         \
                 const unsigned fj = fl >> (4 * j);                                                                    \
                 if (fj & kFlagLive) {                                                                                 \
+                    /* quad QQ of every 8-lane group decoded this neighbour: bring its 8 values to both quads once, */ \
+                    /* then each step is one quad broadcast per value                                               */ \
+                    const int ro0 = from_quad<QQ>(do0), ro1 = from_quad<QQ>(do1), ro2 = from_quad<QQ>(do2), ro3 = from_quad<QQ>(do3); \
+                    const int rw0 = from_quad<QQ>(__float_as_int(dw.x)), rw1 = from_quad<QQ>(__float_as_int(dw.y));   \
+                    const int rw2 = from_quad<QQ>(__float_as_int(dw.z)), rw3 = from_quad<QQ>(__float_as_int(dw.w));   \
                     if (fj & kFlagStaged) {                                                                           \
-                        MVS_TAP_STEP(0, QQ, MVS_LDS_TAP) MVS_TAP_STEP(1, QQ, MVS_LDS_TAP)                             \
-                        MVS_TAP_STEP(2, QQ, MVS_LDS_TAP) MVS_TAP_STEP(3, QQ, MVS_LDS_TAP)                             \
+                        MVS_TAP_STEP(0, MVS_LDS_TAP) MVS_TAP_STEP(1, MVS_LDS_TAP)                                     \
+                        MVS_TAP_STEP(2, MVS_LDS_TAP) MVS_TAP_STEP(3, MVS_LDS_TAP)                                     \
                     } else {                                                                                          \
-                        MVS_TAP_STEP(0, QQ, MVS_GLB_TAP) MVS_TAP_STEP(1, QQ, MVS_GLB_TAP)                             \
-                        MVS_TAP_STEP(2, QQ, MVS_GLB_TAP) MVS_TAP_STEP(3, QQ, MVS_GLB_TAP)                             \
+                        MVS_TAP_STEP(0, MVS_GLB_TAP) MVS_TAP_STEP(1, MVS_GLB_TAP)                                     \
+                        MVS_TAP_STEP(2, MVS_GLB_TAP) MVS_TAP_STEP(3, MVS_GLB_TAP)                                     \
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
