@@ -48,7 +48,7 @@ WORKLOADS = {
     "tiny_3v_8d_48x64": dict(N=3, C=32, D=8, H=48, W=64, near_far=(0.2, 5.0), per_view_K=False),
 }
 N_VOXELS, VOXEL_SIZE = [40, 40, 16], [0.16, 0.16, 0.2]
-SWEEP_KERNEL_NAME = "plane_sweep_variance_kernel<2,TW,G,NT,float>"
+SWEEP_KERNEL_NAME = "plane_sweep_variance_kernel<K,TW,FAST,OutT>"   # K neighbours, tile width, unconditional-store form, float or _Float16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 

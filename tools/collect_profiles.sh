@@ -10,6 +10,8 @@ export TMPDIR=/tmp
 cd $root
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-seconds 0 > $out/bench_under_rocprof.log 2>&1
 find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bwd -o kt -- python3 tools/profile_bwd.py > $out/kt_bwd.log 2>&1
+find $out/kt_bwd -name "*kernel_stats.csv" -exec cp {} $out/bwd_scannet_ref_40v_12d_60x80_kernel_stats.csv \;
 for wl in scannet_40v_64d_120x160 scannet_ref_40v_12d_60x80 arkit_50v_96d_60x80 stress_100v_128d_240x320_c32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$wl -o kt -- python3 tools/profile_sweep.py $wl 3 > $out/kt_$wl.log 2>&1
   find $out/kt_$wl -name "*kernel_stats.csv" -exec cp {} $out/${wl}_kernel_stats.csv \;
