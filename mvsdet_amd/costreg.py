@@ -2,8 +2,8 @@
 `CostRegNet_3DGS` of mvs_models/mvsnet.py:73-113 -- a three-level 3-D U-Net, (N,256,D,H,W) variance ->
 (N,2,D,H,W) {cost logits, offset logits}.
 
-The module is plain PyTorch; under autograd the stride-1 convolutions and the head use our forward / input-gradient /
-weight-gradient kernels (training step 108 ms instead of 859 ms on MIOpen), in eval mode without autograd every layer is
+The module is plain PyTorch; under autograd every convolution (stride 1, stride 2, transposed, head) uses our forward /
+input-gradient / weight-gradient kernels (training step 100 ms instead of 858 ms on MIOpen), in eval mode without autograd every layer is
 routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
 csrc/costreg_head.hip (27.9 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
 (`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,
@@ -43,6 +43,56 @@ class _ConvK3S1(torch.autograd.Function):
             gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(wflip), None, None, False)
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_k3_dw(x, gy)
+        return gx, gw
+
+
+class _ConvK3S2(torch.autograd.Function):
+    """Conv3d(kernel 3, stride 2, padding 1, no bias) of conv1 / conv3 (mvsnet.py:77,80) under autograd: forward on
+    `ops.conv3d_k3_mfma(stride=2)`; the input gradient is the transposed convolution of grad_out with the same weight
+    (`ops.convT3d_k3_s2_mfma`: the (Cout,Cin,3,3,3) tensor read as a ConvTranspose3d weight), the weight gradient
+    `ops.conv3d_k3_dw(stride=2)`.  D, H, W even (the network asks for multiples of 4)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import ops
+        ctx.save_for_backward(x, weight)
+        return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(weight), None, None, False, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.convT3d_k3_s2_mfma(gy, ops.permute_convT_weight(weight.detach()), None, None, None, False)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv3d_k3_dw(x, gy, 0, 2)
+        return gx, gw
+
+
+class _ConvT3S2(torch.autograd.Function):
+    """ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1, no bias) of conv9 / conv11 (mvsnet.py:92-100) under
+    autograd, the mirror image of `_ConvK3S2`: forward on `ops.convT3d_k3_s2_mfma`, input gradient = the stride-2
+    convolution of grad_out with the (Cin,Cout,3,3,3) weight read as a Conv3d weight, weight gradient = the stride-2
+    weight-gradient kernel with the two tensors exchanged."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import ops
+        ctx.save_for_backward(x, weight)
+        return ops.convT3d_k3_s2_mfma(x, ops.permute_convT_weight(weight), None, None, None, False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(weight.detach()), None, None, False, 2)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv3d_k3_dw(gy, x, 0, 2)
         return gx, gw
 
 
@@ -94,7 +144,7 @@ class CostRegNet3DGS(nn.Module):
         self.conv9 = _up(4 * base, 2 * base)
         self.conv11 = _up(2 * base, base)
         self.prob = nn.Conv3d(base, 2, 3, stride=1, padding=1)
-        # under autograd the stride-1 ConvBnReLU layers (conv0, conv2, conv4) use our forward / dX / dW kernels
+        # under autograd every convolution (stride 1, stride 2, transposed, head) uses our forward / dX / dW kernels
         self.hip_backward = True
 
     def forward(self, x):
@@ -121,9 +171,10 @@ class CostRegNet3DGS(nn.Module):
             shift = (bn.bias - bn.running_mean * scale).detach()
             return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-                and conv.stride == (1, 1, 1) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
+                and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
             # training: convolution forward / backward on our kernels, BatchNorm (batch statistics) and ReLU stay torch's
-            return torch.relu_(bn(_ConvK3S1.apply(x, conv.weight)))
+            fn = _ConvK3S1 if conv.stride == (1, 1, 1) else _ConvK3S2
+            return torch.relu_(bn(fn.apply(x, conv.weight)))
         return layer(x)
 
     def _up(self, seq, x, skip):
@@ -137,6 +188,9 @@ class CostRegNet3DGS(nn.Module):
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
             shift = (bn.bias - bn.running_mean * scale).detach()
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)
+        if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and deconv.out_channels % 64 == 0 and deconv.in_channels % 64 == 0):
+            return skip + torch.relu_(bn(_ConvT3S2.apply(x, deconv.weight)))
         return skip + seq(x)
 
     def _head(self, full):

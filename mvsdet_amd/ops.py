@@ -776,30 +776,35 @@ def _(x, weight_perm, scale, shift, residual, relu):
 
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_dw", mutates_args=(), device_types="cuda")
-def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0) -> Tensor:
-    """Weight gradient of Conv3d(kernel 3, stride 1, padding 1): x (N,Cin,D,H,W), grad_out (N,Cout,D,H,W) ->
+def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1) -> Tensor:
+    """Weight gradient of Conv3d(kernel 3, stride 1 or 2, padding 1): x (N,Cin,D,H,W), grad_out (N,Cout,D/s,H/s,W/s) ->
     (Cout,Cin,3,3,3), on the fp32 matrix cores; `nsplit` voxel splits are accumulated separately and summed
-    (0 = automatic: up to 128 splits, fewer when Cin*Cout is large so that the partial sums stay below 256 MB)."""
+    (0 = automatic: up to 128 splits, fewer when Cin*Cout is large so that the partial sums stay below 256 MB).
+    With stride 2 and the tensors exchanged (x = grad of the output, grad_out = the input) this is the weight gradient of
+    ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1) in its own (Cin,Cout,3,3,3) layout."""
     _req(x, "x", dim=5)
     _req(grad_out, "grad_out", dim=5)
+    if stride not in (1, 2):
+        raise ValueError(f"conv3d_k3_dw: stride {stride} not in (1, 2)")
     N, Cin, D, H, W = x.shape
     Cout = grad_out.shape[1]
-    if tuple(grad_out.shape) != (N, Cout, D, H, W):
-        raise ValueError(f"conv3d_k3_dw: grad_out {tuple(grad_out.shape)} does not match x {tuple(x.shape)}")
+    if any(v % stride for v in (D, H, W)) or tuple(grad_out.shape) != (N, Cout, D // stride, H // stride, W // stride):
+        raise ValueError(f"conv3d_k3_dw: grad_out {tuple(grad_out.shape)} does not match x {tuple(x.shape)} at stride {stride}")
     x, grad_out = x.contiguous(), grad_out.contiguous()
     lib = _lib.load()
     if nsplit <= 0:
         nsplit = max(8, min(128, (256 << 20) // (Cout * Cin * 108)))
     pbytes = lib.mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)
     partial = torch.empty((nsplit, Cout, Cin, 27), dtype=torch.float32, device=x.device)
+    fn = lib.mvsdet_conv3d_k3_dw_mfma_f32 if stride == 1 else lib.mvsdet_conv3d_k3_s2_dw_mfma_f32
     with torch.cuda.device(x.device):
-        _lib.check(lib.mvsdet_conv3d_k3_dw_mfma_f32(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), pbytes, nsplit, N, Cin,
-                                                    Cout, D, H, W, _stream(x)), "conv3d_k3_dw")
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), pbytes, nsplit, N, Cin, Cout, D, H, W, _stream(x)),
+                   "conv3d_k3_dw")
     return partial.sum(0).view(Cout, Cin, 3, 3, 3)
 
 
 @conv3d_k3_dw.register_fake
-def _(x, grad_out, nsplit=0):
+def _(x, grad_out, nsplit=0, stride=1):
     return x.new_empty((grad_out.shape[1], x.shape[1], 3, 3, 3))
 
 

@@ -995,9 +995,42 @@ def test_cost_network_weight_gradient_mfma(gpu, N, Cin, Cout, D, H, W, nsplit):
         torch.testing.assert_close(got_x, ref_x, rtol=0, atol=3e-6 * float(ref_x.abs().max()) * max(1.0, (27 * Cout) ** 0.5 / 8))
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,nsplit", [(2, 64, 128, 4, 8, 16, 4), (1, 40, 70, 2, 10, 36, 3), (2, 5, 3, 2, 2, 2, 2),
+                                                     (1, 64, 64, 6, 14, 34, 200)])
+def test_cost_network_stride2_gradients(gpu, N, Cin, Cout, D, H, W, nsplit):
+    """The stride-2 layers (conv1, conv3) and the transposed ones (conv9, conv11) under autograd: dW on the strided
+    weight-gradient kernel -- for the transposed layers with the two tensors exchanged -- and the input gradients through
+    each other's forward kernels, against ATen-CPU's conv3d_weight / conv3d_input / autograd of conv_transpose3d."""
+    from mvsdet_amd import ops
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(N * 100 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    gy = torch.randn(N, Cout, D // 2, H // 2, W // 2, generator=g)
+    wgt = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    nv = N * D * H * W / 8
+    # Conv3d stride 2
+    ref_w = torch.nn.grad.conv3d_weight(x, wgt.shape, gy, stride=2, padding=1)
+    got_w = ops.conv3d_k3_dw(x.to(gpu), gy.to(gpu), nsplit, 2).cpu()
+    assert got_w.shape == ref_w.shape
+    torch.testing.assert_close(got_w, ref_w, rtol=0, atol=3e-6 * float(ref_w.abs().max()) * max(1.0, nv ** 0.5 / 8))
+    if Cin % 64 == 0:
+        ref_x = torch.nn.grad.conv3d_input(x.shape, wgt, gy, stride=2, padding=1)
+        got_x = ops.convT3d_k3_s2_mfma(gy.to(gpu), ops.permute_convT_weight(wgt.to(gpu)), None, None, None, False).cpu()
+        torch.testing.assert_close(got_x, ref_x, rtol=0, atol=3e-6 * float(ref_x.abs().max()) * max(1.0, (27 * Cout) ** 0.5 / 8))
+    # ConvTranspose3d(k3, s2, p1, op1) with weight (Cout -> Cin): input `gy`-shaped, output `x`-shaped
+    xt = gy.clone().requires_grad_(True)
+    wt = wgt.clone().requires_grad_(True)          # (Cout, Cin, 3,3,3) = (in, out, ...) of the transposed layer
+    F.conv_transpose3d(xt, wt, stride=2, padding=1, output_padding=1).backward(x)
+    got_wt = ops.conv3d_k3_dw(x.to(gpu), gy.to(gpu), nsplit, 2).cpu()   # fine tensor first, coarse one second
+    torch.testing.assert_close(got_wt, wt.grad, rtol=0, atol=3e-6 * float(wt.grad.abs().max()) * max(1.0, nv ** 0.5 / 8))
+    if Cout % 64 == 0:
+        got_xt = ops.conv3d_k3_mfma(x.to(gpu), ops.permute_conv_weight(wgt.to(gpu)), None, None, False, 2).cpu()
+        torch.testing.assert_close(got_xt, xt.grad, rtol=0, atol=3e-6 * float(xt.grad.abs().max()) * max(1.0, (27 * Cin) ** 0.5 / 8))
+
+
 def test_cost_network_training_gradients_hip_vs_torch(gpu):
-    """CostRegNet3DGS under autograd: with `hip_backward` the stride-1 convolutions run forward, dX and dW on our kernels;
-    outputs and every parameter / input gradient agree with the all-torch route."""
+    """CostRegNet3DGS under autograd: with `hip_backward` every convolution (stride 1, stride 2, transposed, head) runs
+    forward, dX and dW on our kernels; outputs and every parameter / input gradient agree with the all-torch route."""
     from mvsdet_amd.costreg import CostRegNet3DGS
     torch.manual_seed(3)
     # BatchNorm on its running statistics: with batch statistics over the few quarter-resolution voxels of this small

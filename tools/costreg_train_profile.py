@@ -16,7 +16,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
-rows = sorted(prof.key_averages(), key=lambda r: -r.device_time_total)[:16]
+rows = sorted(prof.key_averages(), key=lambda r: -r.device_time_total)[:28]
 tot = sum(r.device_time_total for r in prof.key_averages())
 print(f"total device time {tot / 1e3:.1f} ms")
 for r in rows:
