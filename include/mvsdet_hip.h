@@ -204,6 +204,15 @@ int mvsdet_conv3d_k3_res_mfma_f32(const float* x, const float* weight_perm, cons
  * out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1). */
 int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
                                  float* out, int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* The general form of the three entry points above, for small volumes (the 3-D neck at one scene: 400 / 50 / 8 tiles of
+ * 256 voxels): with a workspace of mvsdet_conv3d_k3_mfma_workspace_bytes(...) bytes (0 = the grid fills the chip unsplit)
+ * the input-channel loop is split over several blocks per tile, which write raw partial sums; a second kernel adds them in
+ * ascending split order and applies affine, residual (stride 1 only, NULL = none) and ReLU.  workspace NULL or too small:
+ * unsplit.  stride 1 or 2. */
+size_t mvsdet_conv3d_k3_mfma_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int stride);
+int mvsdet_conv3d_k3_mfma_ws_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                 const float* residual, float* out, void* workspace, size_t workspace_bytes, int N, int Cin,
+                                 int Cout, int D, int H, int W, int stride, int relu, mvsdet_stream_t stream);
 /* The up-sampling layers (mvsnet.py:92-100,110-111: conv9 256->128, conv11 128->64): ConvTranspose3d(kernel 3, stride 2,
  * padding 1, output_padding 1, no bias) [+ affine + ReLU] [+ residual]: x (N,Cin,D,H,W) -> out (N,Cout,2D,2H,2W);
  * weight_perm: the (Cin,Cout,3,3,3) weight permuted to [c][kd][kh][kw][o]; residual (shape of out, or NULL) is added

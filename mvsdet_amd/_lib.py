@@ -49,6 +49,8 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_res_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_convT3d_k3_s2_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_s2_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_conv3d_k3_mfma_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i],
+    "mvsdet_conv3d_k3_mfma_ws_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_dw_partial_bytes": [_i, _i, _i],
     "mvsdet_conv3d_k3_dw_mfma_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_s2_dw_mfma_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -70,7 +72,8 @@ SIGNATURES = {
 _RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_packed_bytes": ctypes.c_size_t,
             "mvsdet_plane_sweep_scratch_bytes": ctypes.c_size_t, "mvsdet_plane_sweep_workspace_bytes": ctypes.c_size_t,
             "mvsdet_plane_sweep_bwd_workspace_bytes": ctypes.c_size_t,
-            "mvsdet_conv3d_k3_dw_partial_bytes": ctypes.c_size_t}
+            "mvsdet_conv3d_k3_dw_partial_bytes": ctypes.c_size_t,
+            "mvsdet_conv3d_k3_mfma_workspace_bytes": ctypes.c_size_t}
 
 
 def build(verbose: bool = False) -> str:

@@ -16,6 +16,8 @@
 // Measured 15.1 ms = 135 TFLOP/s (MIOpen: 33.6 ms).
 #include "common.h"
 
+#include <algorithm>
+
 namespace mvsdet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -33,7 +35,7 @@ template <int TWC, int ST, int TD>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
     const float* __restrict__ x, const float4* __restrict__ wperm, const float* __restrict__ residual, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ out, int Cin, int Cout, int Di, int Hi, int Wi, int D, int H,
-    int W, int tiles_w, int tiles_h, int relu) {
+    int W, int tiles_w, int tiles_h, int relu, int nsplit, float* __restrict__ partial, size_t partial_stride) {
     constexpr int kC0W = TWC, kC0H = 256 / (TD * TWC);
     // halo of the input tile: ST*(T-1) + 3 per dimension (stride 1, TD = 2: 4 x 6 x 34 or 4 x 10 x 18)
     constexpr int kC0HD = ST * (TD - 1) + 3, kC0HH = ST * (kC0H - 1) + 3, kC0HW = ST * (kC0W - 1) + 3;
@@ -47,13 +49,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
-    // blockIdx.z = (view, block of 64 output channels): Cout > 64 runs as Cout/64 independent slices of the weights
+    // blockIdx.z = (view, block of 64 output channels, split of the input channels): Cout > 64 runs as Cout/64
+    // independent slices of the weights; a small volume (the 3-D neck: 2-100 tiles) is also split over the channel pairs
+    // so that the grid fills the chip, each split writing raw partial sums that splitk_epilogue_kernel adds up
     const int nob = Cout / kC0Out;
-    const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * TD, n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
+    const int w0 = bw * kC0W, h0 = bh * kC0H, d0 = blockIdx.y * TD, n = zo / nob, ob64 = zo % nob;
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;        // output
     const size_t iplane = (size_t)Hi * Wi, ivol = (size_t)Di * iplane;  // input
     const float* xn = x + (size_t)n * Cin * ivol;
     const int npairs = (Cin + 1) / 2;
+    const int cp_begin = (int)((long long)npairs * split / nsplit), cp_end = (int)((long long)npairs * (split + 1) / nsplit);
 
     // this wave's two MFMA column groups g = 2*wave, 2*wave+1 of the tile's 8 (8/TD per plane, both in one plane):
     // plane dz0 = g / (8/TD), h-rows (g % (8/TD))*kRowsPerCol .. ; inside a group column c is voxel
@@ -119,12 +125,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
             if (e < kC0WPair / 4) s_w42[buf][e] = w_reg[k];
         }
     };
-    fetch(0);
+    fetch(cp_begin);
     stage(0);
     __syncthreads();
-    if (npairs > 1) fetch(1);
-    for (int cp = 0; cp < npairs; ++cp) {
-        const int buf = cp & 1;
+    if (cp_begin + 1 < cp_end) fetch(cp_begin + 1);
+    for (int cp = cp_begin; cp < cp_end; ++cp) {
+        const int buf = (cp - cp_begin) & 1;
         const float* bin = s_in2[buf] + kk * kC0Halo + (ST * dz0 * kC0HH + ST * (hy0 + chy)) * kC0HW + ST * cw;
         const float* ain = reinterpret_cast<const float*>(s_w42[buf]) + kk * 27 * kC0Out + col;
 #pragma unroll
@@ -142,11 +148,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                 }
-        if (cp + 1 < npairs) {
+        if (cp + 1 < cp_end) {
             // the other stage was last read in iteration cp - 1, which every wave left through the barrier below
             stage(buf ^ 1);
             __syncthreads();
-            if (cp + 2 < npairs) fetch(cp + 2);
+            if (cp + 2 < cp_end) fetch(cp + 2);
         }
     }
 
@@ -162,8 +168,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 float v = acc[ob][rb][r];
-                if (scale) v = fmaf(v, scale[o], shift[o]);
                 const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+                if (nsplit > 1) {
+                    partial[(size_t)split * partial_stride + idx] = v;
+                    continue;
+                }
+                if (scale) v = fmaf(v, scale[o], shift[o]);
                 if (residual) v = v + residual[idx];   // ResModule: x = act(bn(conv(h)) + identity), imvoxel_neck.py:227-229
                 if (relu) v = fmaxf(v, 0.0f);
                 out[idx] = v;
@@ -171,13 +181,74 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
     }
 }
 
+// out = [relu]([scale * ] sum over splits (ascending) of partial [+ shift] [+ residual]): the epilogue of the split form
+__global__ __launch_bounds__(kThreads) void splitk_epilogue_kernel(const float* __restrict__ partial, int nsplit, size_t total,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ residual, float* __restrict__ out,
+                                                                   int Cout, size_t vol, int relu) {
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    float v = partial[i];
+    for (int s = 1; s < nsplit; ++s) v += partial[(size_t)s * total + i];
+    const int o = (int)((i / vol) % Cout);
+    if (scale) v = fmaf(v, scale[o], shift[o]);
+    if (residual) v = v + residual[i];
+    if (relu) v = fmaxf(v, 0.0f);
+    out[i] = v;
+}
+
 }  // namespace mvsdet
 
 using namespace mvsdet;
 
+namespace {
+struct ConvPlan {
+    int D, H, W, twc, td, tiles_w, tiles_h, tiles_d, nsplit;
+};
+
+// tile shape (TWC along w, TD planes, 256/(TD*TWC) rows): the one that pads (D, H, W) least; the 4-plane tile only exists
+// for stride 1 and 16-wide column groups.  nsplit: splits of the channel pairs so that a small grid reaches ~2 blocks
+// per CU, each split at least 8 pairs long.
+ConvPlan conv_plan(int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride) {
+    ConvPlan p;
+    // output extent of kernel 3, padding 1: floor((in - 1) / stride) + 1
+    p.D = (Di - 1) / stride + 1; p.H = (Hi - 1) / stride + 1; p.W = (Wi - 1) / stride + 1;
+    auto padded = [&](int twc_, int td_) {
+        const int th_ = 256 / (td_ * twc_);
+        return (long long)((p.W + twc_ - 1) / twc_ * twc_) * ((p.H + th_ - 1) / th_ * th_) * ((p.D + td_ - 1) / td_ * td_);
+    };
+    // candidates in order of preference at equal padding: wide column groups first (fewer, longer LDS rows).  The 4-plane
+    // tiles only exist for stride 1 (a stride-2 halo of 4 planes does not fit), the 8- and 4-wide groups serve the small
+    // grids (the neck's 20x20x8 and 10x10x4, the cost network's 3x15x20 quarter resolution)
+    static const int cand1[][2] = {{32, 2}, {16, 2}, {16, 4}, {8, 4}, {4, 4}};
+    static const int cand2[][2] = {{32, 2}, {16, 2}, {8, 2}};
+    const int (*cand)[2] = stride == 1 ? cand1 : cand2;
+    const int ncand = stride == 1 ? 5 : 3;
+    p.twc = cand[0][0]; p.td = cand[0][1];
+    long long best = padded(p.twc, p.td);
+    for (int i = 1; i < ncand; ++i)
+        if (padded(cand[i][0], cand[i][1]) < best) { best = padded(cand[i][0], cand[i][1]); p.twc = cand[i][0]; p.td = cand[i][1]; }
+    const int th = 256 / (p.td * p.twc);
+    p.tiles_w = (p.W + p.twc - 1) / p.twc; p.tiles_h = (p.H + th - 1) / th; p.tiles_d = (p.D + p.td - 1) / p.td;
+    const long long blocks = (long long)p.tiles_w * p.tiles_h * p.tiles_d * N * (Cout / kC0Out);
+    const int npairs = (Cin + 1) / 2;
+    p.nsplit = 1;
+    if (blocks < 384) p.nsplit = (int)std::max(1LL, std::min<long long>((512 + blocks - 1) / blocks, npairs / 8));
+    return p;
+}
+}  // namespace
+
+// Bytes of workspace the convolution wants for its partial sums at this shape (0: the grid is large enough unsplit).
+extern "C" size_t mvsdet_conv3d_k3_mfma_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int stride) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Cout % kC0Out || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return 0;
+    const ConvPlan p = conv_plan(N, Cin, Cout, D, H, W, stride);
+    return p.nsplit > 1 ? (size_t)p.nsplit * N * Cout * p.D * p.H * p.W * sizeof(float) : 0;
+}
+
 static int launch_conv_mfma(const char* name, const float* x, const float* weight_perm, const float* scale,
                             const float* shift, float* out, int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride,
-                            int relu, mvsdet_stream_t stream, const float* residual = nullptr) {
+                            int relu, mvsdet_stream_t stream, const float* residual = nullptr, float* workspace = nullptr,
+                            size_t workspace_bytes = 0) {
     MVS_REQUIRE(x && weight_perm && out, "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && Di > 0 && Hi > 0 && Wi > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, Di, Hi,
@@ -186,37 +257,48 @@ static int launch_conv_mfma(const char* name, const float* x, const float* weigh
     MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "%s: weights must be 16-byte aligned", name);
     MVS_REQUIRE((size_t)Di * Hi * Wi < ((size_t)1 << 30), "%s: one channel volume exceeds 2^30 elements", name);
     MVS_REQUIRE(Cout > 0 && Cout % kC0Out == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
-    // output extent of kernel 3, padding 1: floor((in - 1) / stride) + 1
-    const int D = (Di - 1) / stride + 1, H = (Hi - 1) / stride + 1, W = (Wi - 1) / stride + 1;
-    // tile shapes (TWC along w, TD planes, 256/(TD*TWC) rows): the one that pads (D, H, W) least; the 4-plane tile only
-    // exists for stride 1 and 16-wide column groups
-    auto padded = [&](int twc_, int td_) {
-        const int th_ = 256 / (td_ * twc_);
-        return (long long)((W + twc_ - 1) / twc_ * twc_) * ((H + th_ - 1) / th_ * th_) * ((D + td_ - 1) / td_ * td_);
-    };
-    int twc = 32, td = 2;
-    long long best = padded(32, 2);
-    if (padded(16, 2) < best) { best = padded(16, 2); twc = 16; td = 2; }
-    if (stride == 1 && padded(16, 4) < best) { best = padded(16, 4); twc = 16; td = 4; }
-    const int th = 256 / (td * twc);
-    const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + td - 1) / td;
-    MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
-    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out)));
+    ConvPlan p = conv_plan(N, Cin, Cout, Di, Hi, Wi, stride);
+    const int D = p.D, H = p.H, W = p.W, twc = p.twc, td = p.td, tiles_w = p.tiles_w, tiles_h = p.tiles_h, tiles_d = p.tiles_d;
+    const size_t total = (size_t)N * Cout * D * H * W;
+    // without (enough) workspace the convolution runs unsplit
+    const int nsplit = (workspace && workspace_bytes >= (size_t)p.nsplit * total * sizeof(float)) ? p.nsplit : 1;
+    MVS_REQUIRE((long long)N * (Cout / kC0Out) * nsplit <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out) * nsplit));
     const float4* w4 = reinterpret_cast<const float4*>(weight_perm);
     hipStream_t st = (hipStream_t)stream;
 #define MVS_CONV_CASE(TW_, ST_, TD_)                                                                                          \
     hipLaunchKernelGGL((conv3d_k3_mfma_kernel<TW_, ST_, TD_>), grid, dim3(kThreads), 0, st, x, w4, residual, scale, shift, out, Cin, \
-                       Cout, Di, Hi, Wi, D, H, W, tiles_w, tiles_h, relu)
+                       Cout, Di, Hi, Wi, D, H, W, tiles_w, tiles_h, relu, nsplit, workspace, total)
     if (stride == 1) {
-        if (td == 4) MVS_CONV_CASE(16, 1, 4);
+        if (twc == 4) MVS_CONV_CASE(4, 1, 4);
+        else if (twc == 8) MVS_CONV_CASE(8, 1, 4);
+        else if (td == 4) MVS_CONV_CASE(16, 1, 4);
         else if (twc == 16) MVS_CONV_CASE(16, 1, 2);
         else MVS_CONV_CASE(32, 1, 2);
     } else {
-        if (twc == 16) MVS_CONV_CASE(16, 2, 2); else MVS_CONV_CASE(32, 2, 2);
+        if (twc == 8) MVS_CONV_CASE(8, 2, 2);
+        else if (twc == 16) MVS_CONV_CASE(16, 2, 2);
+        else MVS_CONV_CASE(32, 2, 2);
     }
 #undef MVS_CONV_CASE
     MVS_LAUNCH_CHECK(name);
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                           workspace, nsplit, total, scale, shift, residual, out, Cout, (size_t)D * H * W, relu);
+        MVS_LAUNCH_CHECK(name);
+    }
     return MVSDET_OK;
+}
+
+// The general form: stride 1 or 2, optional affine, residual (added between the affine and the ReLU; stride 1 only) and
+// workspace (mvsdet_conv3d_k3_mfma_workspace_bytes; NULL or too small: unsplit).
+extern "C" int mvsdet_conv3d_k3_mfma_ws_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
+                                            const float* residual, float* out, void* workspace, size_t workspace_bytes, int N,
+                                            int Cin, int Cout, int D, int H, int W, int stride, int relu,
+                                            mvsdet_stream_t stream) {
+    MVS_REQUIRE(residual == nullptr || stride == 1, "conv3d_k3_mfma_ws: a residual needs stride 1");
+    return launch_conv_mfma("conv3d_k3_mfma_ws", x, weight_perm, scale, shift, out, N, Cin, Cout, D, H, W, stride, relu, stream,
+                            residual, (float*)workspace, workspace_bytes);
 }
 
 extern "C" int mvsdet_conv3d_k3_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,

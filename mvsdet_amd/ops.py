@@ -706,16 +706,14 @@ def conv3d_k3_mfma(x: Tensor, weight_perm: Tensor, scale: Optional[Tensor], shif
         if stride != 1 or tuple(residual.shape) != tuple(out.shape):
             raise ValueError(f"conv3d_k3_mfma: residual {tuple(residual.shape)} needs stride 1 and the output shape {tuple(out.shape)}")
         residual = residual.contiguous()
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.load().mvsdet_conv3d_k3_res_mfma_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale),
-                                                                 _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(out), N, Cin,
-                                                                 Cout, D, H, W, int(relu), _stream(x)), "conv3d_k3_res_mfma")
-        return out
-    fn = _lib.load().mvsdet_conv3d_k3_mfma_f32 if stride == 1 else _lib.load().mvsdet_conv3d_k3_s2_mfma_f32
+    lib = _lib.load()
+    # a small volume (the neck at one scene) is split over the input channels: partial sums in a workspace
+    wbytes = lib.mvsdet_conv3d_k3_mfma_workspace_bytes(N, Cin, Cout, D, H, W, stride)
+    ws = torch.empty((wbytes // 4,), dtype=torch.float32, device=x.device) if wbytes else None
     with torch.cuda.device(x.device):
-        _lib.check(fn(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
-                                                         _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu), _stream(x)),
-                   "conv3d_k3_mfma")
+        _lib.check(lib.mvsdet_conv3d_k3_mfma_ws_f32(_lib.ptr(x), _lib.ptr(weight_perm), _lib.ptr(scale), _lib.ptr(shift),
+                                                    _lib.ptr(residual), _lib.ptr(out), _lib.ptr(ws), wbytes, N, Cin, Cout, D, H, W,
+                                                    stride, int(relu), _stream(x)), "conv3d_k3_mfma")
     return out
 
 

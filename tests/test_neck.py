@@ -99,3 +99,41 @@ def test_neck_shipped_configuration(gpu):
     np.testing.assert_allclose(got0.cpu().numpy(), ref0.numpy(), rtol=0, atol=1e-4 * max(1.0, float(ref0.abs().max())))
     assert [tuple(o.shape) for o in outs] == [(1, 128, 40, 40, 16), (1, 128, 20, 20, 8), (1, 128, 10, 10, 4)]
     assert all(bool(torch.isfinite(o).all()) for o in outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,grid,stride,res", [(1, 512, 128, (10, 10, 4), 1, False), (1, 96, 64, (20, 20, 8), 1, True),
+                                                      (1, 256, 128, (20, 20, 8), 2, False)])
+def test_conv_split_over_input_channels(gpu, N, Cin, Cout, grid, stride, res):
+    """Small volumes run the 3x3x3 convolution split over the input channels (partial sums + epilogue kernel): through the
+    C ABI the split form (workspace given) against the unsplit one (workspace NULL) and against ATen-CPU."""
+    from mvsdet_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Cin + stride)
+    x = torch.randn((N, Cin) + grid, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv3d(x, w, stride=stride, padding=1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    residual = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + residual
+    ref = torch.relu(ref)
+    xd, wd, sc, sh = x.to(gpu), ops.permute_conv_weight(w.to(gpu)), scale.to(gpu), shift.to(gpu)
+    rd = residual.to(gpu) if res else None
+    wbytes = lib.mvsdet_conv3d_k3_mfma_workspace_bytes(N, Cin, Cout, *grid, stride)
+    assert wbytes > 0, "this shape is meant to be split"
+    ws = torch.empty(wbytes // 4, device=gpu)
+    outs = []
+    for wsp, wsb in ((ws, wbytes), (None, 0)):
+        out = torch.full(ref.shape, float("nan"), device=gpu)
+        _lib.check(lib.mvsdet_conv3d_k3_mfma_ws_f32(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd), _lib.ptr(out),
+                                                    _lib.ptr(wsp), wsb, N, Cin, Cout, *grid, stride, 1, _lib.current_stream(gpu)), "conv")
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    tol = 1e-4 * max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(outs[1].numpy(), ref.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(outs[0].numpy(), outs[1].numpy(), rtol=0, atol=tol)
+    # the operator takes the split route by itself
+    got = ops.conv3d_k3_mfma(xd, wd, sc, sh, True, stride, rd).cpu()
+    assert torch.equal(got, outs[0])
