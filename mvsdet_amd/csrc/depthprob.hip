@@ -3,14 +3,15 @@
 // (sample_depth_prob), :298-317 (compute_avg_depth) of Pixie8888/MVSDet.
 //
 // Roofline: HBM.  Algorithmic bytes per scene: read 2*N*D*H*W*4, write N*(2D+2*topk+1)*H*W*4.
-// One thread per pixel, lanes along W so every plane access is a coalesced 256-byte run; the D logits
-// are re-read from L2 in the second/third pass instead of being kept in registers (D is a run-time
-// value up to 512).
+// One thread per pixel, lanes along W so every plane access is a coalesced 256-byte run.  DREG > 0 (D <= DREG, DREG =
+// 16 / 64): the D cost logits, then their exponentials, stay in registers -- every input is read once, one expf per
+// plane instead of two, and all loads of a pass are in flight together.  DREG = 0 (D up to 512): the logits are re-read
+// from L2 in the second / third pass.  Same operations in the same order either way.
 #include "common.h"
 
 namespace mvsdet {
 
-template <bool kFromLogits>
+template <bool kFromLogits, int DREG>
 __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
     const float* __restrict__ cost_reg, const float* __restrict__ off_logit, float* __restrict__ prob,
     float* __restrict__ off, float* __restrict__ est_depth, float* __restrict__ est_dens,
@@ -22,15 +23,35 @@ __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
     const float* c = cost_reg + base;
     const float* o = off_logit + base;
 
+    constexpr int kReg = DREG > 0 ? DREG : 1;
+    float e[kReg];   // logits, then exp(logit - max)
     float m = 0.0f, s = 1.0f;
     if (kFromLogits) {
-        m = c[0];
-        for (int d = 1; d < D; ++d) {
-            const float v = c[(size_t)d * HW];
-            m = v > m ? v : m;
+        if (DREG > 0) {
+#pragma unroll
+            for (int d = 0; d < DREG; ++d) e[d] = d < D ? c[(size_t)d * HW] : 0.0f;
+            m = e[0];
+#pragma unroll
+            for (int d = 1; d < DREG; ++d)
+                if (d < D) m = e[d] > m ? e[d] : m;
+            s = 0.0f;
+#pragma unroll
+            for (int d = 0; d < DREG; ++d)
+                if (d < D) {
+                    e[d] = expf(e[d] - m);
+                    s += e[d];
+                }
+        } else {
+            m = c[0];
+#pragma unroll 4
+            for (int d = 1; d < D; ++d) {
+                const float v = c[(size_t)d * HW];
+                m = v > m ? v : m;
+            }
+            s = 0.0f;
+#pragma unroll 4
+            for (int d = 0; d < D; ++d) s += expf(c[(size_t)d * HW] - m);
         }
-        s = 0.0f;
-        for (int d = 0; d < D; ++d) s += expf(c[(size_t)d * HW] - m);
     }
 
     // sorted (descending) candidate list in registers; strict '>' keeps the lower plane on ties
@@ -43,10 +64,10 @@ __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
         bi[k] = 0;
     }
     float avg = 0.0f;
-    for (int d = 0; d < D; ++d) {
+    auto plane = [&](int d, float ed) {
         float pd, od;
         if (kFromLogits) {
-            pd = expf(c[(size_t)d * HW] - m) / s;
+            pd = (DREG > 0 ? ed : expf(c[(size_t)d * HW] - m)) / s;
             od = 1.0f / (1.0f + expf(-o[(size_t)d * HW]));
             prob[base + (size_t)d * HW] = pd;
             off[base + (size_t)d * HW] = od;
@@ -71,6 +92,14 @@ __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
             co = gt ? to : co;
             cidx = gt ? ti : cidx;
         }
+    };
+    if (kFromLogits && DREG > 0) {
+#pragma unroll
+        for (int d = 0; d < DREG; ++d)
+            if (d < D) plane(d, e[d]);
+    } else {
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) plane(d, 0.0f);
     }
     avg_depth[(size_t)n * HW + pix] = avg;
 #pragma unroll
@@ -160,8 +189,13 @@ extern "C" int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* of
     if (int rc = check_stage2("depth_prob_topk", N, D, H, W, topk)) return rc;
     const int HW = H * W;
     dim3 grid((HW + kThreads - 1) / kThreads, N);
-    hipLaunchKernelGGL(depth_prob_topk_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, cost_reg, off_logit, prob,
-                       off, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval);
+#define MVS_DP_LAUNCH(DR)                                                                                                  \
+    hipLaunchKernelGGL((depth_prob_topk_kernel<true, DR>), grid, dim3(kThreads), 0, (hipStream_t)stream, cost_reg, off_logit, prob, \
+                       off, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval)
+    if (D <= 16) MVS_DP_LAUNCH(16);
+    else if (D <= 64) MVS_DP_LAUNCH(64);
+    else MVS_DP_LAUNCH(0);
+#undef MVS_DP_LAUNCH
     MVS_LAUNCH_CHECK("depth_prob_topk");
     return MVSDET_OK;
 }
@@ -173,7 +207,7 @@ extern "C" int mvsdet_sample_depth_prob_f32(const float* prob, const float* off,
     if (int rc = check_stage2("sample_depth_prob", N, D, H, W, topk)) return rc;
     const int HW = H * W;
     dim3 grid((HW + kThreads - 1) / kThreads, N);
-    hipLaunchKernelGGL(depth_prob_topk_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, prob, off,
+    hipLaunchKernelGGL((depth_prob_topk_kernel<false, 0>), grid, dim3(kThreads), 0, (hipStream_t)stream, prob, off,
                        (float*)nullptr, (float*)nullptr, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval);
     MVS_LAUNCH_CHECK("sample_depth_prob");
     return MVSDET_OK;
