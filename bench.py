@@ -311,17 +311,15 @@ def footprint_stats(w, hp, scene, device):
     N, K, D, H, W = w["N"], geo.neighbor_ids.shape[1], w["D"], w["H"], w["W"]
     if K == 0:
         return None
-    tw = 32 if (W % 32 == 0 or W % 16 != 0) else 16
-    tiles = ((W + tw - 1) // tw) * ((H + 128 // tw - 1) // (128 // tw))
+    from mvsdet_amd import _lib
+    tw, th, cap = _lib.sweep_tile_shape(K, D, H, W)
+    tiles = ((W + tw - 1) // tw) * ((H + th - 1) // th)
     table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
     nent = N * tiles * D * K
     b = table[:nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)  # boxes lead the scratch buffer
     nc, nr = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
     empty = (nc <= 0) | (nr <= 0)
     area = np.where(empty, 0, nc * nr)
-    from mvsdet_amd import _lib
-    budget = 52 * 1024 if (tw == 16 and K <= 2) else 80 * 1024
-    cap = min(_lib.get_option("sweep_boxcap"), (budget // 128) // K - 8)   # planesweep.hip: effective_box_cap
     live = ~empty
     fl = table[nent * 4: nent * 4 + N * tiles * D].view(torch.int32).cpu().numpy().astype(np.int64)   # flags follow the boxes
     staged_n = sum(int(((fl >> (4 * j + 1)) & 1).sum()) for j in range(K))

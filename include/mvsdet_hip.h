@@ -45,7 +45,7 @@ const char* mvsdet_last_error(void);
  * (MVSDET_SWEEP_TW, MVSDET_SWEEP_BOXCAP, MVSDET_SWEEP_XCD) when the library first needs them,
  * afterwards changed only through mvsdet_set_option -- the launch path never calls getenv.  HOST, process-global:
  * set them before launching from several threads.
- *   "sweep_tw"      0 (by the map width) | 16 | 32   pixel-tile shape of the sweep (16x8 / 32x4)
+ *   "sweep_tw"      0 (by the map shape) | 16 | 32   pixel-tile shape of the sweep (16x8 / 32x4)
  *   "sweep_boxcap"  texels of one LDS footprint box (default: what fits, 312 / 200 by the tile shape; 0 = gather every tap
  *                   from global memory)
  *   "sweep_xcd"     0 | 1   XCD-aware block map for fewer than 8 channel slabs
@@ -104,6 +104,10 @@ int mvsdet_homo_warp_f32(const float* src, const float* proj, const float* depth
  * The _f32 form packs `feat` (N,C,H,W dense) into `workspace` first
  * (workspace_bytes >= mvsdet_plane_sweep_workspace_bytes(N,K,C,D,H,W) = packed + scratch).
  * ------------------------------------------------------------------------------------------- */
+/* The pixel-tile shape (32x4 or 16x8) and the LDS box capacity in texels the sweep uses for this problem; the layout of
+ * the geometry at the head of the scratch buffer follows from them: boxes int4[N][tiles][D][K], then flags
+ * uint32[N][tiles][D], tiles = ceil(W / tile_w) * ceil(H / tile_h).  For tools and statistics (bench.py). */
+int mvsdet_plane_sweep_tile_shape(int K, int D, int H, int W, int* tile_w, int* tile_h, int* box_texels);
 size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W);
 size_t mvsdet_plane_sweep_workspace_bytes(int N, int K, int C, int D, int H, int W);
 int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_res_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_convT3d_k3_s2_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_s2_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_tile_shape": [_i, _i, _i, _i, _vp, _vp, _vp],
     "mvsdet_conv3d_k3_mfma_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i],
     "mvsdet_conv3d_k3_mfma_ws_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_dw_partial_bytes": [_i, _i, _i],
@@ -133,3 +134,10 @@ def ptr(t):
 def current_stream(device) -> ctypes.c_void_p:
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def sweep_tile_shape(K: int, D: int, H: int, W: int):
+    """(tile_w, tile_h, box_texels) the sweep uses for this problem (mvsdet_plane_sweep_tile_shape)."""
+    tw, th, cap = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(load().mvsdet_plane_sweep_tile_shape(K, D, H, W, ctypes.byref(tw), ctypes.byref(th), ctypes.byref(cap)), "sweep_tile_shape")
+    return tw.value, th.value, cap.value

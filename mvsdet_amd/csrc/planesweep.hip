@@ -106,10 +106,15 @@ extern "C" int mvsdet_homo_warp_f32(const float* src, const float* proj, const f
 }
 
 namespace {
-int pick_tile_width(int W) {
-    const int tw = options().sweep_tw;  // tuning knob (mvsdet_set_option "sweep_tw"); 0 = by the map width
+// 32x4 tiles write 128-byte runs per channel row, 16x8 tiles 64-byte ones (5.5 against 3.6 TB/s of pattern
+// ceiling).  A width that is a multiple of 16 but not of 32 (the 80-wide maps of the shipped configs) leaves a third column
+// of 32x4 tiles half empty: with many planes per block the wider runs win all the same (50 views x 96 planes, 60x80:
+// 6.6 against 7.1 ms), with the reference's 12 planes the smaller footprints and the fuller grid of the 16x8 tiles do.
+int pick_tile_width(int W, int D) {
+    const int tw = options().sweep_tw;  // tuning knob (mvsdet_set_option "sweep_tw"); 0 = by the map shape
     if (tw == 16 || tw == 32) return tw;
-    return (W % 32 == 0 || W % 16 != 0) ? 32 : 16;
+    if (W % 32 == 0 || W % 16 != 0) return 32;
+    return D >= 48 ? 32 : 16;
 }
 
 int num_tiles(int H, int W, int tw) {
@@ -244,9 +249,19 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
 }  // namespace
 
 namespace mvsdet {
-int sweep_tile_width(int W) { return pick_tile_width(W); }  // shared with planesweep_bwd.hip
+int sweep_tile_width(int W, int D) { return pick_tile_width(W, D); }  // shared with planesweep_bwd.hip
 int sweep_box_cap(int K, int tw) { return effective_box_cap(K, tw); }
-int sweep_num_tiles(int H, int W) { return num_tiles(H, W, pick_tile_width(W)); }
+}
+
+// The tile shape and LDS box capacity the sweep uses for this problem (the layout of the geometry in the scratch buffer
+// follows from them): for tools and statistics.
+extern "C" int mvsdet_plane_sweep_tile_shape(int K, int D, int H, int W, int* tile_w, int* tile_h, int* box_texels) {
+    MVS_REQUIRE(K >= 0 && D > 0 && H > 0 && W > 0, "plane_sweep_tile_shape: bad shape");
+    const int tw = pick_tile_width(W, D);
+    if (tile_w) *tile_w = tw;
+    if (tile_h) *tile_h = kTilePix / tw;
+    if (box_texels) *box_texels = effective_box_cap(K, tw);
+    return MVSDET_OK;
 }
 
 extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, int W) {
@@ -278,7 +293,7 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
         return MVSDET_ERR_WORKSPACE;
     }
     MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "%s: scratch must be 16-byte aligned", name);
-    const int tw = pick_tile_width(W);
+    const int tw = pick_tile_width(W, D);
     hipStream_t st = (hipStream_t)stream;
     if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
     return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);

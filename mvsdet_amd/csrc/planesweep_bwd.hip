@@ -338,7 +338,7 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
 extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,
                                             int N, int K, int D, int H, int W, mvsdet_stream_t stream);
 namespace mvsdet {
-int sweep_tile_width(int W);  // the tile shape the sweep geometry is built for
+int sweep_tile_width(int W, int D);  // the tile shape the sweep geometry is built for
 int sweep_box_cap(int K, int tw);
 }
 
@@ -375,7 +375,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     }
     if (K > 0)
         if (int rc = mvsdet_plane_sweep_table_f32(proj, depth, scratch, sb, N, K, D, H, W, stream_)) return rc;
-    const int tw = sweep_tile_width(W);
+    const int tw = sweep_tile_width(W, D);
     const int th = kTilePix / tw;
     const int S = num_slabs(C);
     const int HW = H * W;

@@ -106,3 +106,15 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("#", "//", "*", "/*")))
                 assert "import oracle" not in code and "from oracle" not in code and "libplanesweep_oracle" not in code, f
+
+
+def test_sweep_tile_shape_query():
+    """mvsdet_plane_sweep_tile_shape: 32x4 tiles unless the width is a multiple of 16 but not of 32 AND the block has few
+    planes; the box capacity is what K resident boxes leave of the block's LDS budget."""
+    from mvsdet_amd import _lib
+    assert _lib.sweep_tile_shape(2, 64, 120, 160) == (32, 4, 312)
+    assert _lib.sweep_tile_shape(2, 12, 60, 80) == (16, 8, 200)     # reference-true shape
+    assert _lib.sweep_tile_shape(2, 96, 60, 80) == (32, 4, 312)     # ARKit: 96 planes per block
+    assert _lib.sweep_tile_shape(2, 12, 33, 47)[:2] == (32, 4)
+    tw, th, cap = _lib.sweep_tile_shape(4, 64, 120, 160)
+    assert (tw, th) == (32, 4) and 4 * (cap + 8) * 128 <= 80 * 1024

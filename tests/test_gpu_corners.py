@@ -80,8 +80,9 @@ def test_backward_stage1_over_box_capacity(gpu, oracle):
     depth = np.tile(np.array([[0.5, 1.0, 2.0]], np.float32), (N, 1))
     from mvsdet_amd import ops
     table = ops.plane_sweep_table(torch.from_numpy(proj).to(gpu), torch.from_numpy(depth).to(gpu), H, W)
-    tw = 32 if (W % 32 == 0 or W % 16 != 0) else 16
-    tiles = ((W + tw - 1) // tw) * ((H + 128 // tw - 1) // (128 // tw))
+    from mvsdet_amd import _lib
+    tw, th, _ = _lib.sweep_tile_shape(K, D, H, W)
+    tiles = ((W + tw - 1) // tw) * ((H + th - 1) // th)
     nent = N * tiles * D * K
     b = table[:nent * 4].view(torch.int32).view(nent, 4).cpu().numpy().astype(np.int64)  # boxes lead the scratch buffer
     area = np.maximum(b[:, 1] - b[:, 0] + 1, 0) * np.maximum(b[:, 3] - b[:, 2] + 1, 0)

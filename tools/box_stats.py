@@ -21,9 +21,8 @@ for name in sys.argv[1:] or ["scannet_40v_64d_120x160"]:
     meta = synthetic.make_img_meta(w["N"], (w["H"], w["W"]), seed=0, per_view_intrinsics=w["per_view_K"])
     geo = hp.prepare_scene(meta, dev)
     N, K, D, H, W = w["N"], geo.neighbor_ids.shape[1], w["D"], w["H"], w["W"]
-    tw = 32 if (W % 32 == 0 or W % 16 != 0) else 16
-    tw = int(os.environ.get("MVSDET_SWEEP_TW", tw))
-    th = 128 // tw
+    from mvsdet_amd import _lib
+    tw, th, CAP = _lib.sweep_tile_shape(K, D, H, W)
     tiles = ((W + tw - 1) // tw) * ((H + th - 1) // th)
     table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
     nent = N * tiles * D * K
