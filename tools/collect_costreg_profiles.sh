@@ -9,6 +9,12 @@ cd $root
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o costreg -- python3 tools/costreg_layers_hip.py > $out/kt.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc -o pmc -- python3 tools/costreg_layers_hip.py > $out/pmc.log 2>&1
 find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+# the 3-D neck (eval) and one training step of the cost network (forward + backward on our kernels)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_neck -o neck -- python3 tools/neck_timing.py > $out/kt_neck.log 2>&1
+find $out/kt_neck -name "*kernel_stats.csv" -exec cp {} $out/neck_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_train -o train -- python3 tools/costreg_train_profile.py > $out/kt_train.log 2>&1
+find $out/kt_train -name "*kernel_stats.csv" -exec cp {} $out/costreg_train_kernel_stats.csv \;
+find $out -name "*_kernel_trace.csv" -delete
 python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt 2>&1
 find $out -name "*.csv" -size +2000k -delete
 tail -3 $out/pmc.log | cut -c1-200
