@@ -220,7 +220,8 @@ int mvsdet_conv3d_k3_mfma_ws_f32(const float* x, const float* weight_perm, const
 /* The up-sampling layers (mvsnet.py:92-100,110-111: conv9 256->128, conv11 128->64): ConvTranspose3d(kernel 3, stride 2,
  * padding 1, output_padding 1, no bias) [+ affine + ReLU] [+ residual]: x (N,Cin,D,H,W) -> out (N,Cout,2D,2H,2W);
  * weight_perm: the (Cin,Cout,3,3,3) weight permuted to [c][kd][kh][kw][o]; residual (shape of out, or NULL) is added
- * AFTER the affine + ReLU (x = skip + conv(x)).  Eight launches, one per output parity class. */
+ * AFTER the affine + ReLU (x = skip + conv(x)).  Four launches, one per output parity in (d, h); a lane writes the two w
+ * parities as one float2 (out and residual 8-byte aligned). */
 int mvsdet_convT3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
                                   const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
                                   mvsdet_stream_t stream);

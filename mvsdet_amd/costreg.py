@@ -179,7 +179,7 @@ class CostRegNet3DGS(nn.Module):
 
     def _up(self, seq, x, skip):
         """mvsnet.py:110-111: skip + Sequential(ConvTranspose3d, BatchNorm3d, ReLU)(x); one fp32-MFMA kernel per output
-        parity class (csrc/costreg_conv0.hip) without autograd in eval mode."""
+        parity in (d, h) (csrc/costreg_conv0.hip) without autograd in eval mode."""
         deconv, bn = seq[0], seq[1]
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not self.training
                 and deconv.out_channels % 64 == 0):

@@ -329,9 +329,13 @@ extern "C" int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_
 // ---------------------------------------------------------------------------------------------------------------
 namespace mvsdet {
 
-// A class with T = 1, 2, 4 or 8 taps stages P = 8 / T channel pairs at once (and only its own taps' weights), so every
-// stage carries the same 8 tap-pairs = 32 MFMAs per wave behind one barrier pair, whatever the class.
-template <int TWC, int PD, int PH, int PW>
+// One kernel instance per (PD, PH) output parity in d and h; BOTH w parities are computed by the same block -- output
+// 2i (tap kw = 1, input i) and output 2i + 1 (taps kw = 0, input i + 1, and kw = 2, input i) -- so that a lane writes
+// the two neighbouring outputs as one float2 (32 lanes x 8 B = 256 contiguous bytes; reads the skip tensor the same way)
+// instead of two launches writing every other float.  G = ND * NH tap groups over (d, h), each with the 3 kw taps; a
+// stage carries P = 8 / G channel pairs = 96 MFMAs per wave behind one barrier pair (48 for the single-group class; the
+// 8-launch form had 32: shorter than the latency of the next stage's global loads).
+template <int TWC, int PD, int PH>
 __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wperm, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ out, int Cin, int Cout,
@@ -340,12 +344,12 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
     constexpr int kHD = kC0D + 1, kHH = kTH + 1, kHW = kTW + 1;   // +1 on the high side: input i + 1 for tap 0
     constexpr int kHalo = kHD * kHH * kHW;                         // per channel
     constexpr int kRowsPerCol = 32 / TWC;
-    constexpr int ND = PD ? 2 : 1, NH = PH ? 2 : 1, NW = PW ? 2 : 1, T = ND * NH * NW;
-    constexpr int P = 8 / T;                                       // channel pairs per stage
+    constexpr int ND = PD ? 2 : 1, NH = PH ? 2 : 1, G = ND * NH, T = 3 * G;
+    constexpr int P = G == 1 ? 4 : 8 / G;                          // channel pairs per stage (8 would spill at G = 1)
     constexpr int kInFloats = P * 2 * kHalo;                       // staged input values
     constexpr int kInStage = (kInFloats + kThreads - 1) / kThreads;
-    constexpr int kWFloats = P * 2 * T * kC0Out;                   // staged weights: [pair][k][tap of the class][64] = 1024
-    constexpr int kWStage = (kWFloats + kThreads - 1) / kThreads;  // 4
+    constexpr int kWFloats = P * 2 * T * kC0Out;                   // staged weights: [pair][k][group][kw][64] = 3072 (1536)
+    constexpr int kWStage = (kWFloats + kThreads - 1) / kThreads;  // 12
     __shared__ float s_in[kInFloats];
     __shared__ float s_w[kWFloats];
 
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
     const int chy = col / TWC, cw = col % TWC;
 
     // staging plans.  Input element e -> (channel q of the stage's 2P, halo position); weight element e ->
-    // (pair p, channel k of the pair, class tap t, output channel o)
+    // (channel q = 2*pair + k, tap group, kw, output channel o)
     int in_off[kInStage];
 #pragma unroll
     for (int k = 0; k < kInStage; ++k) {
@@ -377,15 +381,6 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
         const int d = d0 + dz, h = h0 + hy, w = w0 + wx;
         const bool ok = e < kInFloats && d < Di && h < Hi && w < Wi;
         in_off[k] = ok ? (int)((size_t)d * iplane + (size_t)h * Wi + w) : -1;   // channel q = e / kHalo recomputed below
-    }
-    int w_off[kWStage];  // offset inside wperm relative to the stage's first channel: (q * 27 + tap27) * Cout + o
-#pragma unroll
-    for (int k = 0; k < kWStage; ++k) {
-        const int e = tid + k * kThreads;
-        const int o = e % kC0Out, t = (e / kC0Out) % T, q = e / (kC0Out * T);   // q = 2*p + k
-        const int tw = t % NW, th = (t / NW) % NH, td = t / (NW * NH);
-        const int kd = PD ? (td ? 2 : 0) : 1, kh = PH ? (th ? 2 : 0) : 1, kw = PW ? (tw ? 2 : 0) : 1;
-        w_off[k] = e < kWFloats ? (q * 27 + (kd * 3 + kh) * 3 + kw) * Cout + ob64 * kC0Out + o : -1;
     }
     float in_reg[kInStage], w_reg[kWStage];
     auto fetch = [&](int sidx) {
@@ -399,19 +394,27 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
         }
 #pragma unroll
         for (int k = 0; k < kWStage; ++k) {
-            const int q = (tid + k * kThreads) / (kC0Out * T);
+            // offset inside wperm relative to the stage's first channel: (q * 27 + tap27) * Cout + o; recomputed per stage
+            // (12 plan registers would not pay: the arithmetic is a handful of shifts)
+            const int e = tid + k * kThreads;
+            const int o = e % kC0Out, t = (e / kC0Out) % T, q = e / (kC0Out * T);
+            const int kw = t % 3, gi = t / 3, th = gi % NH, td = gi / NH;
+            const int kd = PD ? (td ? 2 : 0) : 1, kh = PH ? (th ? 2 : 0) : 1;
+            const int off = (q * 27 + (kd * 3 + kh) * 3 + kw) * Cout + ob64 * kC0Out + o;
             // wperm is zero padded to an even channel count by the caller; beyond that, zero here
-            w_reg[k] = (w_off[k] >= 0 && c0 + q < ((Cin + 1) & ~1)) ? wperm[(size_t)c0 * 27 * Cout + w_off[k]] : 0.0f;
+            w_reg[k] = (e < kWFloats && c0 + q < ((Cin + 1) & ~1)) ? wperm[(size_t)c0 * 27 * Cout + off] : 0.0f;
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2][2];   // [w parity][output-channel block][voxel row]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int pw = 0; pw < 2; ++pw)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pw][a][b][r] = 0.0f;
 
     fetch(0);
     for (int sidx = 0; sidx < nstages; ++sidx) {
@@ -433,23 +436,34 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
         for (int p = 0; p < P; ++p) {
             const float* bin = s_in + (2 * p + kk) * kHalo + (dz0 * kHH + hy0 + chy) * kHW + cw;
             const float* ain = s_w + (2 * p + kk) * T * kC0Out + col;
-            // parity 0: tap 1 at input offset 0; parity 1: tap 0 at offset +1 and tap 2 at offset 0
+            // per dimension: parity 0 sees tap 1 at input offset 0; parity 1 sees tap 0 at offset +1 and tap 2 at offset 0
 #pragma unroll
             for (int td = 0; td < ND; ++td)
 #pragma unroll
-                for (int th = 0; th < NH; ++th)
-#pragma unroll
-                    for (int tw = 0; tw < NW; ++tw) {
-                        const int od = PD ? (td ? 0 : 1) : 0, oh = PH ? (th ? 0 : 1) : 0, ow = PW ? (tw ? 0 : 1) : 0;
-                        const int t = (td * NH + th) * NW + tw;
-                        const float a0 = ain[t * kC0Out], a1 = ain[t * kC0Out + 32];
-                        const float b0 = bin[(od * kHH + oh) * kHW + ow];
-                        const float b1 = bin[(od * kHH + oh + kRowsPerCol) * kHW + ow];
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                    }
+                for (int th = 0; th < NH; ++th) {
+                    const int od = PD ? (td ? 0 : 1) : 0, oh = PH ? (th ? 0 : 1) : 0;
+                    const float* ag = ain + (td * NH + th) * 3 * kC0Out;
+                    const float a00 = ag[0], a01 = ag[32];                             // kw = 0
+                    const float a10 = ag[kC0Out], a11 = ag[kC0Out + 32];               // kw = 1
+                    const float a20 = ag[2 * kC0Out], a21 = ag[2 * kC0Out + 32];       // kw = 2
+                    const float* bg = bin + (od * kHH + oh) * kHW;
+                    const float b00 = bg[0], b01 = bg[1];                              // row 0: input i, i + 1
+                    const float b10 = bg[kRowsPerCol * kHW], b11 = bg[kRowsPerCol * kHW + 1];
+                    // even outputs: kw = 1 on input i
+                    acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b00, acc[0][0][0], 0, 0, 0);
+                    acc[0][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, b10, acc[0][0][1], 0, 0, 0);
+                    acc[0][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b00, acc[0][1][0], 0, 0, 0);
+                    acc[0][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b10, acc[0][1][1], 0, 0, 0);
+                    // odd outputs: kw = 0 on input i + 1, then kw = 2 on input i
+                    acc[1][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b01, acc[1][0][0], 0, 0, 0);
+                    acc[1][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b11, acc[1][0][1], 0, 0, 0);
+                    acc[1][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b01, acc[1][1][0], 0, 0, 0);
+                    acc[1][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, b11, acc[1][1][1], 0, 0, 0);
+                    acc[1][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a20, b00, acc[1][0][0], 0, 0, 0);
+                    acc[1][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a20, b10, acc[1][0][1], 0, 0, 0);
+                    acc[1][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a21, b00, acc[1][1][0], 0, 0, 0);
+                    acc[1][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a21, b10, acc[1][1][1], 0, 0, 0);
+                }
         }
     }
 
@@ -458,18 +472,29 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
     for (int rb = 0; rb < 2; ++rb) {
         const int di = d0 + dz0, hi = h0 + hy0 + rb * kRowsPerCol + chy;
         if (di >= Di || hi >= Hi || wi >= Wi) continue;
-        const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + (2 * wi + PW);
+        const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + 2 * wi;   // even: 8-byte aligned
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                float v = acc[ob][rb][r];
-                if (scale) v = fmaf(v, scale[o], shift[o]);
-                if (relu) v = fmaxf(v, 0.0f);
+                float2 v = make_float2(acc[0][ob][rb][r], acc[1][ob][rb][r]);
+                if (scale) {
+                    const float sc = scale[o], sh = shift[o];
+                    v.x = fmaf(v.x, sc, sh);
+                    v.y = fmaf(v.y, sc, sh);
+                }
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.0f);
+                    v.y = fmaxf(v.y, 0.0f);
+                }
                 const size_t idx = ((size_t)n * Cout + o) * ovol + pos;
-                if (residual) v = residual[idx] + v;
-                out[idx] = v;
+                if (residual) {
+                    const float2 rv = *reinterpret_cast<const float2*>(residual + idx);
+                    v.x = rv.x + v.x;
+                    v.y = rv.y + v.y;
+                }
+                *reinterpret_cast<float2*>(out + idx) = v;
             }
     }
 }
@@ -486,21 +511,26 @@ extern "C" int mvsdet_convT3d_k3_s2_mfma_f32(const float* x, const float* weight
     MVS_REQUIRE(((uintptr_t)weight_perm & 15u) == 0, "%s: weights must be 16-byte aligned", name);
     MVS_REQUIRE((size_t)D * H * W < ((size_t)1 << 27), "%s: one input channel volume exceeds 2^27 elements", name);
     MVS_REQUIRE(Cout > 0 && Cout % kC0Out == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
-    const long long pad32 = (long long)((W + 31) / 32 * 32) * ((H + 3) / 4 * 4);
-    const long long pad16 = (long long)((W + 15) / 16 * 16) * ((H + 7) / 8 * 8);
-    const int twc = pad16 < pad32 ? 16 : 32;
+    // tile = 2 planes x 4*(32/twc) rows x twc columns of the INPUT grid: the column-group width that pads (H, W) least
+    int twc = 32;
+    long long best = -1;
+    for (int cand : {32, 16, 8}) {
+        const int th_ = 4 * (32 / cand);
+        const long long padded = (long long)((W + cand - 1) / cand * cand) * ((H + th_ - 1) / th_ * th_);
+        if (best < 0 || padded < best) { best = padded; twc = cand; }
+    }
     const int th = 4 * (32 / twc);
     const int tiles_w = (W + twc - 1) / twc, tiles_h = (H + th - 1) / th, tiles_d = (D + kC0D - 1) / kC0D;
     MVS_REQUIRE((long long)N * (Cout / kC0Out) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / kC0Out)));
     hipStream_t st = (hipStream_t)stream;
-#define MVS_CT_CASE(TW_, PD_, PH_, PW_)                                                                                     \
-    hipLaunchKernelGGL((convT3d_k3_s2_mfma_kernel<TW_, PD_, PH_, PW_>), grid, dim3(kThreads), 0, st, x, weight_perm, scale, shift, \
+    MVS_REQUIRE(((uintptr_t)out & 7u) == 0 && (residual == nullptr || ((uintptr_t)residual & 7u) == 0),
+                "%s: out and residual must be 8-byte aligned", name);
+#define MVS_CT_CASE(TW_, PD_, PH_)                                                                                          \
+    hipLaunchKernelGGL((convT3d_k3_s2_mfma_kernel<TW_, PD_, PH_>), grid, dim3(kThreads), 0, st, x, weight_perm, scale, shift,  \
                        residual, out, Cin, Cout, D, H, W, tiles_w, tiles_h, relu)
-#define MVS_CT_ALL(TW_)                                                                                                     \
-    MVS_CT_CASE(TW_, 0, 0, 0); MVS_CT_CASE(TW_, 0, 0, 1); MVS_CT_CASE(TW_, 0, 1, 0); MVS_CT_CASE(TW_, 0, 1, 1);             \
-    MVS_CT_CASE(TW_, 1, 0, 0); MVS_CT_CASE(TW_, 1, 0, 1); MVS_CT_CASE(TW_, 1, 1, 0); MVS_CT_CASE(TW_, 1, 1, 1)
-    if (twc == 16) { MVS_CT_ALL(16); } else { MVS_CT_ALL(32); }
+#define MVS_CT_ALL(TW_) MVS_CT_CASE(TW_, 0, 0); MVS_CT_CASE(TW_, 0, 1); MVS_CT_CASE(TW_, 1, 0); MVS_CT_CASE(TW_, 1, 1)
+    if (twc == 8) { MVS_CT_ALL(8); } else if (twc == 16) { MVS_CT_ALL(16); } else { MVS_CT_ALL(32); }
 #undef MVS_CT_ALL
 #undef MVS_CT_CASE
     MVS_LAUNCH_CHECK(name);
