@@ -220,10 +220,10 @@ ConvPlan conv_plan(int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride)
     // candidates in order of preference at equal padding: wide column groups first (fewer, longer LDS rows).  The 4-plane
     // tiles only exist for stride 1 (a stride-2 halo of 4 planes does not fit), the 8- and 4-wide groups serve the small
     // grids (the neck's 20x20x8 and 10x10x4, the cost network's 3x15x20 quarter resolution)
-    static const int cand1[][2] = {{32, 2}, {16, 2}, {16, 4}, {8, 4}, {4, 4}};
+    static const int cand1[][2] = {{32, 2}, {16, 2}, {16, 4}, {8, 2}, {8, 4}, {4, 4}};
     static const int cand2[][2] = {{32, 2}, {16, 2}, {8, 2}};
     const int (*cand)[2] = stride == 1 ? cand1 : cand2;
-    const int ncand = stride == 1 ? 5 : 3;
+    const int ncand = stride == 1 ? 6 : 3;
     p.twc = cand[0][0]; p.td = cand[0][1];
     long long best = padded(p.twc, p.td);
     for (int i = 1; i < ncand; ++i)
@@ -271,6 +271,7 @@ static int launch_conv_mfma(const char* name, const float* x, const float* weigh
                        Cout, Di, Hi, Wi, D, H, W, tiles_w, tiles_h, relu, nsplit, workspace, total)
     if (stride == 1) {
         if (twc == 4) MVS_CONV_CASE(4, 1, 4);
+        else if (twc == 8 && td == 2) MVS_CONV_CASE(8, 1, 2);
         else if (twc == 8) MVS_CONV_CASE(8, 1, 4);
         else if (td == 4) MVS_CONV_CASE(16, 1, 4);
         else if (twc == 16) MVS_CONV_CASE(16, 1, 2);
