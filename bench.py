@@ -256,12 +256,15 @@ def full_chain_rate(device, steps=10):
     shipped config runs: what a scene costs end to end on the GPU (the network is ~30x the hot path around it)."""
     from mvsdet_amd.costreg import CostRegNet3DGS
     from mvsdet_amd.hotpath import MVSDetHotPath
+    from mvsdet_amd.head import NerfDetHeadConvs
     from mvsdet_amd.neck import IndoorImVoxelNeck
     wr = WORKLOADS["scannet_ref_40v_12d_60x80"]
     torch.manual_seed(0)
     net = CostRegNet3DGS(wr["C"]).to(device).eval()
     neck = IndoorImVoxelNeck(wr["C"], 128, [1, 1, 1]).to(device).eval()   # configs/mvsdet_res50_2x_low_res.py: neck_3d
-    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(wr["near_far"]), wr["D"], topk=3, cost_regularization=net, neck_3d=neck)
+    head = NerfDetHeadConvs(18, 3, 128, 6).to(device).eval()              # mvsdet_res50_2x_low_res_depth.py:40-43: bbox_head
+    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(wr["near_far"]), wr["D"], topk=3, cost_regularization=net, neck_3d=neck,
+                       bbox_head=head)
     scene = SceneInputs(wr, seed=0, device=device)
     with torch.no_grad():
         for _ in range(2):
@@ -299,7 +302,7 @@ def full_chain_rate(device, steps=10):
     neck_roof = {"bound": "mfma", "achieved": round(ntfl / neck_ms * 1e3, 1), "peak": 157.3, "unit": "TFLOP/s",
                  "frac": round(ntfl / neck_ms * 1e3 / 157.3, 4), "kernel": "IndoorImVoxelNeck forward (fp32 MFMA convolutions + GEMMs)",
                  "kernel_ms": round(neck_ms, 3)}
-    return {"workload": "scannet_ref_40v_12d_60x80", "chain": "a1..a10 + CostRegNet_3DGS + IndoorImVoxelNeck, eval",
+    return {"workload": "scannet_ref_40v_12d_60x80", "chain": "a1..a10 + CostRegNet_3DGS + IndoorImVoxelNeck + head convolutions, eval",
             "scenes_per_sec": round(steps / el, 3), "cost_network_roofline": roof, "neck_roofline": neck_roof,
             "ms_per_scene": round(el / steps * 1e3, 3), "cost_network_tflop": round(CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12, 3),
             "non_empty_voxels": int((out["valid"] > 0).sum().item())}

@@ -149,7 +149,8 @@ class MVSDetHotPath:
     def __init__(self, n_voxels: Sequence[int], voxel_size: Sequence[float], near_far_range: Sequence[float],
                  num_monocular_samples: int, topk: int = 3,
                  cost_regularization: Optional[Callable[[Tensor], Tensor]] = None, stride: int = 4,
-                 neck_3d: Optional[Callable[[Tensor], list]] = None):
+                 neck_3d: Optional[Callable[[Tensor], list]] = None,
+                 bbox_head: Optional[Callable[[list], tuple]] = None):
         self.n_voxels = [int(v) for v in n_voxels]
         self.voxel_size = [float(v) for v in voxel_size]      # python floats -> torch.tensor(...) is fp32, as in the reference
         self.near_far_range = [float(v) for v in near_far_range]
@@ -163,6 +164,7 @@ class MVSDetHotPath:
         assert len(self.depth_values) == self.num_depth
         self.cost_regularization = cost_regularization
         self.neck_3d = neck_3d   # mvsdet.py:681-698: x = self.neck_3d(torch.stack(volumes)); SURVEY 8 f-3 (mvsdet_amd.neck)
+        self.bbox_head = bbox_head   # nerfdet_head.py:116-118: the head's convolutions on the neck's levels (mvsdet_amd.head)
         self._points_cache: dict = {}
         self._geometry = _GeometryWorker(self)
 
@@ -331,4 +333,6 @@ class MVSDetHotPath:
                    depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo)
         if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU)
             out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
+            if self.bbox_head is not None:
+                out["head"] = self.bbox_head(out["neck"])   # (centerness, bbox, cls) lists over the levels
         return out
