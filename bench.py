@@ -380,7 +380,7 @@ def cpu_baseline(w, budget_s):
     while True:
         O.plane_sweep_variance(feat, geo.neighbor_ids, geo.proj_rel, geo.depth_values, mode=0)
         reps += 1
-        if time.perf_counter() - t0 > budget_s / 2 or reps >= 8:
+        if time.perf_counter() - t0 > budget_s / 2 or reps >= 64:
             break
     dt = time.perf_counter() - t0
     res["c_oracle"] = dict(value=ns * reps / dt, seconds=dt, threads=O.num_threads())
@@ -391,7 +391,7 @@ def cpu_baseline(w, budget_s):
     while True:
         T.plane_sweep_variance(feat, geo.neighbor_ids, geo.proj_rel, geo.depth_values, view_chunk=1)
         reps += 1
-        if time.perf_counter() - t0 > budget_s / 2 or reps >= 8:
+        if time.perf_counter() - t0 > budget_s / 2 or reps >= 64:
             break
     dt = time.perf_counter() - t0
     res["aten_ops"] = dict(value=ns * reps / dt, seconds=dt, threads=torch.get_num_threads())
