@@ -477,11 +477,11 @@ def committed_traffic(name):
         with open(os.path.join(ROOT, "profiles", "sweep_traffic.json")) as fh:
             prof = json.load(fh)
     except (OSError, ValueError):
-        return None
+        return None, None
     if prof.get("lib_version") != int(_lib.load().mvsdet_version()):
-        return None
+        return None, None
     ent = prof.get("workloads", {}).get(name)
-    return None if ent is None else {"bytes": ent["traffic_bytes"], "source": prof.get("source"), "measured_in_run": False}
+    return (None, None) if ent is None else (ent["traffic_bytes"], {"source": prof.get("source"), "measured_in_run": False})
 
 
 def main():
@@ -570,7 +570,8 @@ def main():
                    "parallelism": f"scene-sharded x{world}, no data-path collective"},
         "scenes_per_sec": round(args.steps * world / elapsed, 4),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": committed_traffic(name),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": committed_traffic(name)[0],
+                     "traffic_source": committed_traffic(name)[1],
                      "kernel": SWEEP_KERNEL_NAME,
                      "kernel_ms": round(sweep_ms, 4), "table_kernel_ms": round(table_ms, 4),
                      "stage1_frac_incl_table": round(stage1 / HBM_PEAK_GBPS, 4),

@@ -31,7 +31,7 @@ def test_single_gpu_line(gpu):
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["table_kernel_ms"] >= 0 and (r["traffic"] is None or r["traffic"]["measured_in_run"] is False)
+    assert r["table_kernel_ms"] >= 0 and (r["traffic"] is None or (r["traffic"] > 0 and r["traffic_source"]["measured_in_run"] is False))
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["config"]["workload"] == "tiny_3v_8d_48x64" and "model" not in d["config"]
