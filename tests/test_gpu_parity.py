@@ -62,6 +62,9 @@ def test_plane_sweep_variance_golden(gpu, oracle, tag):
     (50, 2, 32, 96, 12, 16),  # BASELINE config 4 plane / view counts (ARKit-like: 50 views, 96 planes)
     (4, 2, 64, 128, 10, 12),  # BASELINE config 5 plane count
     (3, 2, 32, 5, 33, 47),    # odd map: ragged tiles in x and y, unaligned rows (scalar store path)
+    (3, 2, 64, 6, 21, 80),    # width 32 m + 16 with few planes: 16x8 tiles
+    (2, 3, 40, 4, 9, 48),     # the same with a partial slab and k = 3
+    (2, 2, 32, 3, 12, 16),    # width 16: one column of 16x8 tiles
 ])
 def test_plane_sweep_variance_shapes(gpu, oracle, N, K, C, D, H, W):
     from mvsdet_amd import functional as F_, ops, synthetic
