@@ -5,7 +5,7 @@
 The module is plain PyTorch; under autograd every convolution (stride 1, stride 2, transposed, head) uses our forward /
 input-gradient / weight-gradient kernels (training step 100 ms instead of 858 ms on MIOpen), in eval mode without autograd every layer is
 routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
-csrc/costreg_head.hip (27.9 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
+csrc/costreg_head.hip (25 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
 (`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,
 `prob.weight/bias`), so a reference checkpoint's `cost_regularization.*` entries load with `load_state_dict`
 (tests/test_integration.py compares the outputs with the reference module itself).  D, H, W must be divisible by 4
