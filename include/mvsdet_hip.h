@@ -208,7 +208,8 @@ int mvsdet_conv3d_k3_res_mfma_f32(const float* x, const float* weight_perm, cons
  * out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1). */
 int mvsdet_conv3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, const float* scale, const float* shift,
                                  float* out, int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
-/* The general form of the three entry points above, for small volumes (the 3-D neck at one scene: 400 / 50 / 8 tiles of
+/* The general form of the three entry points above, for small volumes (mmdet3d/models/necks/imvoxel_neck.py:183-231, the
+ * 3-D neck's residual blocks at one scene, and nerfdet_head.py:96-101, the head's convolutions: 400 / 50 / 8 tiles of
  * 256 voxels): with a workspace of mvsdet_conv3d_k3_mfma_workspace_bytes(...) bytes (0 = the grid fills the chip unsplit)
  * the input-channel loop is split over several blocks per tile, which write raw partial sums; a second kernel adds them in
  * ascending split order and applies affine, residual (stride 1 only, NULL = none) and ReLU.  workspace NULL or too small:
