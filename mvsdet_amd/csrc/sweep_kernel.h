@@ -41,24 +41,31 @@ constexpr int kBoxCap = 256;        // default texels (128 B each) of one LDS fo
 constexpr int kBoxCapMax = 320;     // 2 neighbours x 320 texels x 2 blocks = the CU's 160 KiB
 constexpr int kTileStride = 132;    // floats per channel row of the backward kernel's gradient tile
 
-// Wave-wide integer min / max, all on DPP: butterfly inside each row of 16 lanes (every lane of a row ends up with the
-// row's result), then row_bcast:15 folds row 0 into row 1 and row 2 into row 3, row_bcast:31 folds rows 0-1 into row 3;
-// lane 63 holds the wave's result (6 VALU + 1 readlane).  The result is wave-uniform (an SGPR).
-template <bool kMin>
-__device__ __forceinline__ int wave_reduce(int v) {
-#define MVS_DPP_STEP(ctrl, rmask)                                                    \
-    {                                                                                \
-        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false);    \
-        v = kMin ? min(v, o) : max(v, o);                                            \
-    }
-    MVS_DPP_STEP(0xB1, 0xf)   // quad_perm [1,0,3,2]
-    MVS_DPP_STEP(0x4E, 0xf)   // quad_perm [2,3,0,1]
-    MVS_DPP_STEP(0x141, 0xf)  // row_half_mirror
-    MVS_DPP_STEP(0x140, 0xf)  // row_mirror
-    MVS_DPP_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
-    MVS_DPP_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
+// Wave-wide integer min / max of a footprint (xlo, xhi, ylo, yhi), all on DPP: butterfly inside each row of 16 lanes (every
+// lane of a row ends up with the row's result), then row_bcast:15 folds row 0 into row 1 and row 2 into row 3, row_bcast:31
+// folds rows 0-1 into row 3; lane 63 holds the wave's result, read into SGPRs.  The DPP operand sits on the min / max
+// itself (v_min_i32_dpp; hipcc emits a v_mov_b32_dpp + the operation + an s_nop for the DPP read-after-write hazard), and
+// the four independent reductions are interleaved step by step, which keeps dependent instructions three apart: 24 VALU
+// instructions instead of 48 + 24 s_nop -- a sixth of the geometry kernel's plane loop.
+__device__ __forceinline__ void wave_reduce_box(int& xlo, int& xhi, int& ylo, int& yhi) {
+#define MVS_DPP_STEP(MOD)                                                                     \
+    asm volatile("v_min_i32_dpp %0, %0, %0 " MOD "\n\t"                                       \
+                 "v_max_i32_dpp %1, %1, %1 " MOD "\n\t"                                       \
+                 "v_min_i32_dpp %2, %2, %2 " MOD "\n\t"                                       \
+                 "v_max_i32_dpp %3, %3, %3 " MOD                                              \
+                 : "+v"(xlo), "+v"(xhi), "+v"(ylo), "+v"(yhi));
+    asm volatile("s_nop 1" ::: "memory");   // the values may have been written by the instruction just before
+    MVS_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+    MVS_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+    MVS_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+    MVS_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+    MVS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")   // -> rows 1 and 3
+    MVS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")   // -> rows 2 and 3
 #undef MVS_DPP_STEP
-    return __builtin_amdgcn_readlane(v, 63);
+    xlo = __builtin_amdgcn_readlane(xlo, 63);
+    xhi = __builtin_amdgcn_readlane(xhi, 63);
+    ylo = __builtin_amdgcn_readlane(ylo, 63);
+    yhi = __builtin_amdgcn_readlane(yhi, 63);
 }
 
 // Table entry = the un-normalised sample position (ix, iy) of module.py:116-143 (8 bytes); everything bilinear
@@ -197,10 +204,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                         yhi = t.y1in ? t.y0 + 1 : t.y0;
                     }
                 }
-                xlo = wave_reduce<true>(xlo);
-                xhi = wave_reduce<false>(xhi);
-                ylo = wave_reduce<true>(ylo);
-                yhi = wave_reduce<false>(yhi);
+                wave_reduce_box(xlo, xhi, ylo, yhi);
                 fin = __builtin_amdgcn_readfirstlane((int)(__ballot(fin == 0) == 0ull));  // all of the wave's positions finite
                 if (lane == 0) {
                     int* r = s_red[par][j][(tid >> 6) & 1];
