@@ -11,7 +11,9 @@
 
 namespace mvsdet {
 
-template <bool kFromLogits, int DREG>
+// KT = length of the candidate list kept per pixel (3 for the reference's topk = 3, MVSDET_MAX_TOPK otherwise): the
+// insertion is 7 VALU instructions per entry and plane, and the kernel is VALU-bound (r02_stage_kernels_pmc.txt).
+template <bool kFromLogits, int DREG, int KT>
 __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
     const float* __restrict__ cost_reg, const float* __restrict__ off_logit, float* __restrict__ prob,
     float* __restrict__ off, float* __restrict__ est_depth, float* __restrict__ est_dens,
@@ -55,10 +57,10 @@ __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
     }
 
     // sorted (descending) candidate list in registers; strict '>' keeps the lower plane on ties
-    float bv[MVSDET_MAX_TOPK], bo[MVSDET_MAX_TOPK];
-    int bi[MVSDET_MAX_TOPK];
+    float bv[KT], bo[KT];
+    int bi[KT];
 #pragma unroll
-    for (int k = 0; k < MVSDET_MAX_TOPK; ++k) {
+    for (int k = 0; k < KT; ++k) {
         bv[k] = -1.0f;
         bo[k] = 0.0f;
         bi[k] = 0;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
         float cv = pd, co = od;
         int cidx = d;
 #pragma unroll
-        for (int k = 0; k < MVSDET_MAX_TOPK; ++k) {
+        for (int k = 0; k < KT; ++k) {
             const bool gt = cv > bv[k];
             const float tv = bv[k], to = bo[k];
             const int ti = bi[k];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
     }
     avg_depth[(size_t)n * HW + pix] = avg;
 #pragma unroll
-    for (int k = 0; k < MVSDET_MAX_TOPK; ++k) {
+    for (int k = 0; k < KT; ++k) {
         if (k < topk) {
             const size_t oi = ((size_t)n * topk + k) * HW + pix;
             est_depth[oi] = ((float)bi[k] * interval + near) + bo[k] * interval;
@@ -189,12 +191,15 @@ extern "C" int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* of
     if (int rc = check_stage2("depth_prob_topk", N, D, H, W, topk)) return rc;
     const int HW = H * W;
     dim3 grid((HW + kThreads - 1) / kThreads, N);
-#define MVS_DP_LAUNCH(DR)                                                                                                  \
-    hipLaunchKernelGGL((depth_prob_topk_kernel<true, DR>), grid, dim3(kThreads), 0, (hipStream_t)stream, cost_reg, off_logit, prob, \
-                       off, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval)
-    if (D <= 16) MVS_DP_LAUNCH(16);
-    else if (D <= 64) MVS_DP_LAUNCH(64);
-    else MVS_DP_LAUNCH(0);
+#define MVS_DP_LAUNCH(DR, KTV)                                                                                             \
+    hipLaunchKernelGGL((depth_prob_topk_kernel<true, DR, KTV>), grid, dim3(kThreads), 0, (hipStream_t)stream, cost_reg, off_logit, \
+                       prob, off, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval)
+#define MVS_DP_BY_D(KTV)                  \
+    if (D <= 16) MVS_DP_LAUNCH(16, KTV);  \
+    else if (D <= 64) MVS_DP_LAUNCH(64, KTV); \
+    else MVS_DP_LAUNCH(0, KTV);
+    if (topk <= 3) { MVS_DP_BY_D(3) } else { MVS_DP_BY_D(MVSDET_MAX_TOPK) }
+#undef MVS_DP_BY_D
 #undef MVS_DP_LAUNCH
     MVS_LAUNCH_CHECK("depth_prob_topk");
     return MVSDET_OK;
@@ -207,7 +212,11 @@ extern "C" int mvsdet_sample_depth_prob_f32(const float* prob, const float* off,
     if (int rc = check_stage2("sample_depth_prob", N, D, H, W, topk)) return rc;
     const int HW = H * W;
     dim3 grid((HW + kThreads - 1) / kThreads, N);
-    hipLaunchKernelGGL((depth_prob_topk_kernel<false, 0>), grid, dim3(kThreads), 0, (hipStream_t)stream, prob, off,
+    if (topk <= 3)
+        hipLaunchKernelGGL((depth_prob_topk_kernel<false, 0, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, prob, off,
+                           (float*)nullptr, (float*)nullptr, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval);
+    else
+    hipLaunchKernelGGL((depth_prob_topk_kernel<false, 0, MVSDET_MAX_TOPK>), grid, dim3(kThreads), 0, (hipStream_t)stream, prob, off,
                        (float*)nullptr, (float*)nullptr, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval);
     MVS_LAUNCH_CHECK("sample_depth_prob");
     return MVSDET_OK;

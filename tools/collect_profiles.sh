@@ -28,3 +28,12 @@ done
 find $out -name "*.csv" -size +2000k -delete   # keep the merge small
 find $out -name "*_kernel_trace.csv" -delete
 ls $out
+# every kernel of the hot path (pack, geometry, sweep, depth distribution, lifting) under the counters: the bench command itself
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $out/pmc_bench_$i -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-extras --cpu-seconds 0 > $out/pmc_bench_$i.log 2>&1
+done
+echo "## bench.py --steps 2 (scannet_40v_64d_120x160): all hot-path kernels" > $out/pmc_stage_summary.txt
+for j in 1 2 3; do python3 tools/pmc_summary.py $out/pmc_bench_$j | grep "mvsdet::" >> $out/pmc_stage_summary.txt; done
+find $out -name "*.csv" -size +2000k -delete
