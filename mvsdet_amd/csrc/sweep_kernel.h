@@ -1,30 +1,30 @@
 // a3+a4 fused: plane-sweep variance (included by planesweep.hip and planesweep_bwd.hip).  Two kernels:
 //
-// (1) plane_sweep_coords_kernel -- everything that depends on (view, neighbour, plane, pixel) but NOT on the
-//     channel: the sampling position of mvs_models/module.py:116-143 as an 8-byte table entry (the un-normalised
-//     sample position ix, iy) plus, per (tile, neighbour, plane), a footprint box.  Consecutive planes whose tap
-//     bounding boxes have a UNION of at most `box_cap` texels form a run and all carry that union box: beyond
-//     ~1.2 m the footprints of neighbouring planes move by less than a texel per plane, so a 256-texel box serves
-//     ~9 planes on the ScanNet-like geometry and ~35 on the ARKit-like one (tools/box_runs.py).
+// (1) plane_sweep_coords_kernel -- the sweep GEOMETRY, everything that depends on (view, tile, neighbour, plane) but not
+//     on the channel: per (tile, neighbour, plane) the bounding box of the bilinear taps of the tile's 128 pixels
+//     (sampling positions of mvs_models/module.py:116-143), then RUNS: consecutive planes whose boxes have a UNION of at
+//     most `box_cap` texels all carry that union box.  Beyond ~1.2 m the footprints of neighbouring planes move by less
+//     than a texel per plane, so a 312-texel box serves ~13 planes on the ScanNet-like geometry and ~50 on the ARKit-like
+//     one (tools/box_runs.py).  Output: boxes + one flags word per (tile, plane) (live / staged / refill per neighbour).
+//     There is no per-pixel table: the slab kernels recompute the positions with the same code (sample_at).
 //
 // (2) plane_sweep_variance_kernel -- the channel work, one 32-channel slab per block:
 //       block   = (reference view n, TWxTH pixel tile (128 pixels), slab s, depth chunk), 4 waves
-//       LDS     = ONE resident footprint box per neighbour (K slots of box_cap 128-byte texels).  A slot is
-//                 refilled (LDS-DMA, two block barriers) only when the run's union box changes: ~10 % of the live
-//                 (tile, plane, neighbour) triples.  All other planes run without any block-level synchronisation:
-//                 table entry -> decode -> taps from LDS -> variance -> stores, wave-private from end to end.
+//       LDS     = ONE resident footprint box per neighbour (K slots of box_cap 128-byte texels).  A slot is refilled
+//                 (LDS-DMA, two block barriers) only when the run's union box changes: ~8 % of the live (tile, plane,
+//                 neighbour) triples.  All other planes run without any block-level synchronisation: position -> decode
+//                 -> taps from LDS -> variance -> stores, wave-private from end to end.
 //       lanes   = (pixel slot ps = lane>>3, channel group g = lane&7); the lane owns the 4 CONSECUTIVE pixels
 //                 4*ps .. 4*ps+3 of its wave's 32 (one per step) x 4 channels (8*i+g), so a variance value is stored
 //                 straight from registers as 16 bytes per lane = 8 channel rows x 128 contiguous bytes per
 //                 wave-instruction -- no LDS transpose.
-//       decode  = lane (ps, g) decodes the table entry of pixel-step g&3 once per neighbour and plane (tap origin,
-//                 4 weights, 4 LDS offsets); the four steps read it from their quad-lane with DPP quad_perm
-//                 broadcasts -- no LDS tables, no barrier between decode and taps.
-//       (eight waves per block -- two plane-parity groups sharing the boxes -- were measured and dropped: every wave
-//       then has to follow every plane's flags, and 127 VGPRs force f*f back into the loop; 13.4 vs 12.5 ms.)
+//       decode  = in pass p lane (ps, g) computes the sampling position of pixel-step g&3 for neighbour 2p + (g>>2) --
+//                 one position (4 IEEE divisions), one bilinear decode per lane and plane; the 8 lanes of the pixel slot
+//                 fetch the tap offsets and weights with DPP (a bank-masked row shift for the neighbour's quad, once per
+//                 pass, then one quad_perm broadcast per value and step) -- no LDS tables, no barrier.
+//       FAST    = C % 32 == 0 and W % 4 == 0: four unconditional 16-byte stores under one lane predicate.
 //
-// Design history: v1 gathered from global memory (fabric-bound, L2 hit 43 %), v3-v5 staged one box
-// per (plane, neighbour) with 5 barriers and 2 exposed DMA latencies per plane (wave wait 57 %, 3.4 TB/s).
+// Design history and what bounds the kernel: DESIGN.md 4.1.
 //
 // Arithmetic (device rounding, oracle mode 1): warped = fma chain over the 4 taps; S = f + w1 + ..;
 // Q = fma(w,w,Q); var = fma(-m, m, Q*r) with m = S*r, r = 1/(K+1).
@@ -68,7 +68,7 @@ __device__ __forceinline__ void wave_reduce_box(int& xlo, int& xhi, int& ylo, in
     yhi = __builtin_amdgcn_readlane(yhi, 63);
 }
 
-// Table entry = the un-normalised sample position (ix, iy) of module.py:116-143 (8 bytes); everything bilinear
+// The un-normalised sample position (ix, iy) of module.py:116-143: everything bilinear
 // sampling derives from it -- tap origin, fractional weights, which taps are inside -- is decode_sample(), shared
 // by the coords kernel (footprint boxes), the slab kernel and the backward kernel, so all three agree bit for bit.
 struct SampleTaps {
