@@ -19,6 +19,8 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .neck import _bn_affine
+
 
 class _ConvK3S1(torch.autograd.Function):
     """Conv3d(kernel 3, stride 1, padding 1, no bias) with all three passes on the fp32 matrix cores: forward and input
@@ -167,8 +169,7 @@ class CostRegNet3DGS(nn.Module):
                 and conv.out_channels % 64 == 0 and conv.stride in ((1, 1, 1), (2, 2, 2))):
             from . import ops
             wperm = ops.permute_conv_weight(conv.weight)   # a few MB at most, negligible next to the convolution
-            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
-            shift = (bn.bias - bn.running_mean * scale).detach()
+            scale, shift = _bn_affine(bn)
             return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
@@ -185,8 +186,7 @@ class CostRegNet3DGS(nn.Module):
                 and deconv.out_channels % 64 == 0):
             from . import ops
             wperm = ops.permute_convT_weight(deconv.weight)
-            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
-            shift = (bn.bias - bn.running_mean * scale).detach()
+            scale, shift = _bn_affine(bn)
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and deconv.out_channels % 64 == 0 and deconv.in_channels % 64 == 0):

@@ -36,8 +36,16 @@ class _ConvModule(nn.Module):
 
 
 def _bn_affine(bn: nn.BatchNorm3d):
-    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
-    return scale, (bn.bias - bn.running_mean * scale).detach()
+    """Eval-mode BatchNorm as a per-channel affine; kept on the module until one of its four tensors changes (five tiny
+    kernels per layer otherwise: a twentieth of the neck's time at one scene)."""
+    key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    cached = getattr(bn, "_mvs_affine", None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            cached = (key, scale, bn.bias - bn.running_mean * scale)
+        bn._mvs_affine = cached
+    return cached[1], cached[2]
 
 
 def _hip_ok(x: Tensor, module: nn.Module) -> bool:
