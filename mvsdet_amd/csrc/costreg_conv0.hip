@@ -234,7 +234,7 @@ ConvPlan conv_plan(int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride)
     const int npairs = (Cin + 1) / 2;
     p.nsplit = 1;
     if (blocks < 384) p.nsplit = (int)std::max(1LL, std::min<long long>((512 + blocks - 1) / blocks, npairs / 8));
-    else if (blocks < 768) p.nsplit = (int)std::max(1LL, std::min<long long>((2048 + blocks - 1) / blocks, npairs / 8));   // 1-2 blocks per CU: even out the CUs
+    else if (blocks < 2048) p.nsplit = (int)std::max(1LL, std::min<long long>((2048 + blocks - 1) / blocks, npairs / 8));   // under 4 rounds of 2 blocks per CU: even out the CUs
     return p;
 }
 }  // namespace
