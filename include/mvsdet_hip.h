@@ -241,6 +241,22 @@ int mvsdet_conv3d_k3_dw_mfma_f32(const float* x, const float* grad_out, float* p
  * as a transposed-convolution weight, dX of a transposed layer = mvsdet_conv3d_k3_s2_mfma_f32 likewise. */
 int mvsdet_conv3d_k3_s2_dw_mfma_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
                                     int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
+/* Training-mode BatchNorm3d [+ ReLU] of the network's ConvBnReLU3D / Sequential(ConvTranspose3d, BatchNorm3d, ReLU) blocks
+ * (mvs_models/module.py:26-37, mvsnet.py:92-100): batch statistics over (N, D, H, W) per channel (biased variance),
+ * running statistics updated in place with `momentum` (unbiased variance, as torch.nn.BatchNorm3d; NULL = not tracked),
+ * out = [relu](gamma * (x - mean) * invstd + beta) (gamma / beta NULL = 1 / 0); save_mean / save_invstd (C floats) are what
+ * the backward needs.  x and out are (N, C, vol) contiguous, vol = D*H*W.  workspace: mvsdet_bn3d_workspace_bytes(C).
+ * Backward: grad_x, grad_gamma, grad_beta (the last two may be NULL) from x, grad_out and the saved statistics; the ReLU
+ * mask is recomputed from x with the forward's arithmetic. */
+size_t mvsdet_bn3d_workspace_bytes(int C);
+int mvsdet_bn3d_relu_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float* out, float* save_mean, float* save_invstd, void* workspace,
+                                   size_t workspace_bytes, int N, int C, long long vol, float momentum, float eps, int relu,
+                                   mvsdet_stream_t stream);
+int mvsdet_bn3d_relu_bwd_f32(const float* x, const float* grad_out, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_invstd, float* grad_x, float* grad_gamma,
+                             float* grad_beta, void* workspace, size_t workspace_bytes, int N, int C, long long vol, int relu,
+                             mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                                int D, int H, int W, mvsdet_stream_t stream);
 

@@ -51,6 +51,9 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_s2_mfma_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_tile_shape": [_i, _i, _i, _i, _vp, _vp, _vp],
     "mvsdet_conv3d_k3_mfma_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i],
+    "mvsdet_bn3d_workspace_bytes": [_i],
+    "mvsdet_bn3d_relu_train_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, ctypes.c_longlong, _f, _f, _i, _vp],
+    "mvsdet_bn3d_relu_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, ctypes.c_longlong, _i, _vp],
     "mvsdet_conv3d_k3_mfma_ws_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_dw_partial_bytes": [_i, _i, _i],
     "mvsdet_conv3d_k3_dw_mfma_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -74,7 +77,7 @@ _RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_packed_bytes": ctypes.
             "mvsdet_plane_sweep_scratch_bytes": ctypes.c_size_t, "mvsdet_plane_sweep_workspace_bytes": ctypes.c_size_t,
             "mvsdet_plane_sweep_bwd_workspace_bytes": ctypes.c_size_t,
             "mvsdet_conv3d_k3_dw_partial_bytes": ctypes.c_size_t,
-            "mvsdet_conv3d_k3_mfma_workspace_bytes": ctypes.c_size_t}
+            "mvsdet_conv3d_k3_mfma_workspace_bytes": ctypes.c_size_t, "mvsdet_bn3d_workspace_bytes": ctypes.c_size_t}
 
 
 def build(verbose: bool = False) -> str:

@@ -3,7 +3,8 @@
 (N,2,D,H,W) {cost logits, offset logits}.
 
 The module is plain PyTorch; under autograd every convolution (stride 1, stride 2, transposed, head) uses our forward /
-input-gradient / weight-gradient kernels (training step 100 ms instead of 858 ms on MIOpen), in eval mode without autograd every layer is
+input-gradient / weight-gradient kernels and BatchNorm + ReLU the streaming kernels of csrc/costreg_bn.hip (training step
+89 ms instead of 858 ms on MIOpen), in eval mode without autograd every layer is
 routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
 csrc/costreg_head.hip (25 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
 (`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,
@@ -98,6 +99,27 @@ class _ConvT3S2(torch.autograd.Function):
         return gx, gw
 
 
+def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor) -> torch.Tensor:
+    """relu(bn(x)) with batch statistics (module.py:26-37; mvsnet.py:92-100) on the streaming kernels of
+    csrc/costreg_bn.hip -- two passes over x forward, ReLU in the second, the mask recomputed going backward -- and the
+    running statistics updated the way torch.nn.BatchNorm3d does (momentum, unbiased variance, num_batches_tracked)."""
+    from . import ops
+    out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            m = x.numel() // x.shape[1]
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            var = (1.0 / (invstd * invstd) - bn.eps).clamp_min_(0.0) * (m / max(m - 1, 1))
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var, alpha=mom)
+    return out
+
+
+def _bn_hip_ok(bn: nn.BatchNorm3d, x: torch.Tensor) -> bool:
+    return bn.training and x.is_cuda and x.dtype == torch.float32 and bn.affine
+
+
 class _HeadConv(torch.autograd.Function):
     """The head Conv3d(64 -> 2, k=3, p=1, bias) with forward and both gradients on the streaming kernels of
     csrc/costreg_head.hip (MIOpen: 363 ms for one forward + backward at the reference-true shape; here about 2 ms)."""
@@ -173,9 +195,10 @@ class CostRegNet3DGS(nn.Module):
             return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
-            # training: convolution forward / backward on our kernels, BatchNorm (batch statistics) and ReLU stay torch's
+            # autograd: convolution forward / backward on our kernels; BatchNorm + ReLU too when it uses batch statistics
             fn = _ConvK3S1 if conv.stride == (1, 1, 1) else _ConvK3S2
-            return torch.relu_(bn(fn.apply(x, conv.weight)))
+            y = fn.apply(x, conv.weight)
+            return _bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y))
         return layer(x)
 
     def _up(self, seq, x, skip):
@@ -190,7 +213,8 @@ class CostRegNet3DGS(nn.Module):
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and deconv.out_channels % 64 == 0 and deconv.in_channels % 64 == 0):
-            return skip + torch.relu_(bn(_ConvT3S2.apply(x, deconv.weight)))
+            y = _ConvT3S2.apply(x, deconv.weight)
+            return skip + (_bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y)))
         return skip + seq(x)
 
     def _head(self, full):

@@ -830,3 +830,84 @@ def conv3d_k3_cout2_backward(x: Tensor, weight: Tensor, grad_out: Tensor, nsplit
 @conv3d_k3_cout2_backward.register_fake
 def _(x, weight, grad_out, nsplit=32):
     return torch.empty_like(x), torch.empty_like(weight)
+
+
+@torch.library.custom_op(f"{_NS}::bn3d_relu_train", mutates_args=(), device_types="cuda")
+def bn3d_relu_train(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float,
+                    relu: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """Training-mode BatchNorm3d [+ ReLU] (mvs_models/module.py:26-37) on the batch statistics of x (N,C,D,H,W) fp32 ->
+    (out, batch mean, 1/sqrt(biased batch variance + eps)).  The running statistics are the caller's to update (a custom
+    operator with an autograd formula must not mutate its inputs): mvsdet_amd.costreg does it from the returned vectors."""
+    _req(x, "x", dim=5)
+    N, C = x.shape[:2]
+    vol = x[0, 0].numel()
+    for t, name in ((weight, "weight"), (bias, "bias")):
+        if t is not None:
+            _req(t, name, dim=1)
+            if t.numel() != C:
+                raise ValueError(f"bn3d_relu_train: {name} must have {C} elements")
+    x = x.contiguous()
+    weight = None if weight is None else weight.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    out = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    lib = _lib.load()
+    wb = lib.mvsdet_bn3d_workspace_bytes(C)
+    ws = torch.empty(wb // 8, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mvsdet_bn3d_relu_train_fwd_f32(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), None, None, _lib.ptr(out),
+                                                      _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(ws), wb, N, C, vol, 0.0,
+                                                      float(eps), int(relu), _stream(x)), "bn3d_relu_train")
+    return out, mean, invstd
+
+
+@bn3d_relu_train.register_fake
+def _(x, weight, bias, eps, relu):
+    return torch.empty_like(x), x.new_empty(x.shape[1]), x.new_empty(x.shape[1])
+
+
+@torch.library.custom_op(f"{_NS}::bn3d_relu_backward", mutates_args=(), device_types="cuda")
+def bn3d_relu_backward(x: Tensor, grad_out: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], save_mean: Tensor,
+                       save_invstd: Tensor, relu: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """Backward of bn3d_relu_train -> (grad_x, grad_weight, grad_bias)."""
+    _req(x, "x", dim=5)
+    _req(grad_out, "grad_out", dim=5)
+    if grad_out.shape != x.shape:
+        raise ValueError("bn3d_relu_backward: grad_out does not match x")
+    N, C = x.shape[:2]
+    vol = x[0, 0].numel()
+    x, grad_out = x.contiguous(), grad_out.contiguous()
+    weight = None if weight is None else weight.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    gx = torch.empty_like(x)
+    gw = torch.empty(C, dtype=torch.float32, device=x.device)
+    gb = torch.empty_like(gw)
+    lib = _lib.load()
+    wb = lib.mvsdet_bn3d_workspace_bytes(C)
+    ws = torch.empty(wb // 8, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.mvsdet_bn3d_relu_bwd_f32(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(save_mean),
+                                                _lib.ptr(save_invstd), _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), wb, N, C,
+                                                vol, int(relu), _stream(x)), "bn3d_relu_backward")
+    return gx, gw, gb
+
+
+@bn3d_relu_backward.register_fake
+def _(x, grad_out, weight, bias, save_mean, save_invstd, relu):
+    return torch.empty_like(x), x.new_empty(x.shape[1]), x.new_empty(x.shape[1])
+
+
+def _bn_setup(ctx, inputs, output):
+    x, weight, bias, _, relu = inputs
+    ctx.save_for_backward(x, weight, bias, output[1], output[2])
+    ctx.relu = relu
+
+
+def _bn_bwd(ctx, g_out, g_mean, g_invstd):
+    x, weight, bias, mean, invstd = ctx.saved_tensors
+    gx, gw, gb = bn3d_relu_backward(x, g_out.contiguous(), weight, bias, mean, invstd, ctx.relu)
+    return gx, (gw if weight is not None else None), (gb if bias is not None else None), None, None
+
+
+bn3d_relu_train.register_autograd(_bn_bwd, setup_context=_bn_setup)

@@ -1074,3 +1074,51 @@ def test_cost_network_head_backward(gpu, N, Cin, D, H, W):
     gx, gw = ops.conv3d_k3_cout2_backward(x.to(gpu), wgt.to(gpu), gy.to(gpu), 5)
     torch.testing.assert_close(gx.cpu(), ref_x, rtol=0, atol=1e-5 * float(ref_x.abs().max()))
     torch.testing.assert_close(gw.cpu(), ref_w, rtol=0, atol=3e-6 * float(ref_w.abs().max()) * max(1.0, (N * D * H * W) ** 0.5 / 8))
+
+
+@pytest.mark.parametrize("N,C,D,H,W,relu", [(2, 8, 4, 6, 12, True), (3, 5, 3, 5, 7, True), (1, 64, 2, 4, 8, False), (2, 3, 1, 1, 1, True)])
+def test_batchnorm_relu_training_kernels(gpu, N, C, D, H, W, relu):
+    """Training-mode BatchNorm3d [+ ReLU] (csrc/costreg_bn.hip) against ATen-CPU: output, batch statistics, and the gradients
+    with respect to x, gamma and beta."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(C * 10 + N)
+    x = (torch.randn(N, C, D, H, W, generator=g) * 2 + 0.5)
+    wgt, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    gy = torch.randn(N, C, D, H, W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wgt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.batch_norm(xr, None, None, wr, br, True, 0.1, 1e-5)
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(gy)
+    xg, wg, bg = x.to(gpu).requires_grad_(True), wgt.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+    out, mean, invstd = ops.bn3d_relu_train(xg, wg, bg, 1e-5, relu)
+    out.backward(gy.to(gpu))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(mean.detach().cpu().numpy(), x.mean(dim=(0, 2, 3, 4)).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(invstd.detach().cpu().numpy(), (1.0 / torch.sqrt(x.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5)).numpy(), rtol=1e-5)
+    for got, want in ((xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(want.abs().max())))
+
+
+def test_cost_network_training_mode_batchnorm(gpu):
+    """CostRegNet3DGS in train() mode: BatchNorm on batch statistics through our kernels (hip_backward) against the
+    framework's layers -- outputs, running statistics and num_batches_tracked; gradients flow to every parameter."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    torch.manual_seed(4)
+    nets = [CostRegNet3DGS(64, base=64).to(gpu).train() for _ in range(2)]
+    nets[1].load_state_dict(nets[0].state_dict())
+    nets[1].hip_backward = False
+    x = torch.rand(2, 64, 8, 16, 32, device=gpu)
+    outs = []
+    for net in nets:
+        out = net(x)
+        out.square().mean().backward()
+        outs.append(out.detach())
+    torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=2e-4 * float(outs[1].abs().max()))
+    sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
+    for k in sd0:
+        if "running_" in k:
+            torch.testing.assert_close(sd0[k], sd1[k], rtol=1e-4, atol=1e-6, msg=k)
+        if "num_batches_tracked" in k:
+            assert int(sd0[k]) == int(sd1[k]) == 1, k
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in nets[0].parameters())
