@@ -4,7 +4,7 @@
 
 The module is plain PyTorch; under autograd every convolution (stride 1, stride 2, transposed, head) uses our forward /
 input-gradient / weight-gradient kernels and BatchNorm + ReLU the streaming kernels of csrc/costreg_bn.hip (training step
-89 ms instead of 858 ms on MIOpen), in eval mode without autograd every layer is
+83 ms instead of 858 ms on MIOpen), in eval mode without autograd every layer is
 routed to the fp32-MFMA / streaming HIP kernels of csrc/costreg_conv0.hip and
 csrc/costreg_head.hip (25 ms per scene instead of 59.3 ms at the reference-true shape, same fp32 sums).  Parameter names and shapes equal the reference's
 (`conv0.conv.weight`, `conv0.bn.*`, ..., `conv9.0.weight`, `conv9.1.*`, `conv11.0.weight`, `conv11.1.*`,

@@ -88,9 +88,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const fl
     // the NEW planes of X and the dY tile of output plane d, fetched into registers while the MFMAs of plane d-1 run
     // (the ring holds all three planes a tile reads, so they cannot land in LDS before that tile is done)
     constexpr int kNewPlanes = STRIDE;                                  // per tile: plane d+1, or planes 2d and 2d+1
-    constexpr int kXIter = (32 * kPlane + kThreads - 1) / kThreads;     // 14 / 20 values per thread and plane
+    // X: four lanes per halo row (row = channel * HH + hy), each taking the columns l, l + 4, ...: one division per row pass
+    // instead of two per element (the flat element order cost ~30 VALU instructions per value -- as much time as the MFMAs
+    // of a stride-2 tile), at 16 rows x 16 bytes per wave-instruction.
+    constexpr int kRows = 32 * T::HH, kRowPass = kThreads / 4;          // 192 / 288 rows, 64 per pass
+    constexpr int kPasses = (kRows + kRowPass - 1) / kRowPass;          // 3 / 5
+    constexpr int kColIter = (kDwHW + 3) / 4;                           // 5
     constexpr int kYIter = 32 * kDwVox / kThreads;                      // 8 / 4
-    float px[kNewPlanes][kXIter], py[kYIter];
+    float px[kNewPlanes][kPasses][kColIter], py[kYIter];
     auto new_plane = [&](int d, int pl) { return STRIDE == 1 ? d + 1 : 2 * d + pl; };
     // 32-bit element offsets from a block-uniform base (the host checks that 32 channels of one view fit)
     auto fetch = [&](int n, int h0, int w0, int d) {
@@ -100,20 +105,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const fl
         asm volatile("" : "+v"(tid));
         const float* xb = x + ((size_t)n * Cin + c0) * vol;
         const float* yb = gy + ((size_t)n * Cout + o0) * ovol + (size_t)d * oplane;
+        const int l4 = tid & 3;
 #pragma unroll
-        for (int pl = 0; pl < kNewPlanes; ++pl) {
-            const int dd = new_plane(d, pl);
-            const float* xp = xb + (size_t)dd * plane;
+        for (int p = 0; p < kPasses; ++p) {
+            const int row = p * kRowPass + (tid >> 2);
+            const int c = row / T::HH, hy = row - c * T::HH;
+            const int hh = STRIDE * h0 + hy - 1;
+            const bool row_ok = row < kRows && c0 + c < Cin && hh >= 0 && hh < H;
+            const int rbase = c * (int)vol + hh * W + STRIDE * w0 - 1;
 #pragma unroll
-            for (int it = 0; it < kXIter; ++it) {
-                const int e = tid + it * kThreads;
-                const int c = e / kPlane, r = e - c * kPlane;
-                const int hy = r / kDwHW, wx = r - hy * kDwHW;
-                const int hh = STRIDE * h0 + hy - 1, ww = STRIDE * w0 + wx - 1;
-                float v = 0.0f;
-                if (e < 32 * kPlane && c0 + c < Cin && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W)
-                    v = xp[(unsigned)(c * (int)vol + hh * W + ww)];
-                px[pl][it] = v;
+            for (int pl = 0; pl < kNewPlanes; ++pl) {
+                const int dd = new_plane(d, pl);
+                const float* xp = xb + (size_t)dd * plane;
+#pragma unroll
+                for (int k = 0; k < kColIter; ++k) {
+                    const int wx = l4 + 4 * k, ww = STRIDE * w0 + wx - 1;
+                    float v = 0.0f;
+                    if (row_ok && dd < D && wx < kDwHW && ww >= 0 && ww < W) v = xp[(unsigned)(rbase + wx)];
+                    px[pl][p][k] = v;
+                }
             }
         }
 #pragma unroll
@@ -130,14 +140,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_dw_mfma_kernel(const fl
     auto commit = [&](int d) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        const int l4 = tid & 3;
 #pragma unroll
-        for (int pl = 0; pl < kNewPlanes; ++pl) {
-            const int slot = new_plane(d, pl) % 3;
+        for (int p = 0; p < kPasses; ++p) {
+            const int row = p * kRowPass + (tid >> 2);
+            const int c = row / T::HH, hy = row - c * T::HH;
+            const int lbase = c * kDwXStride + hy * kDwHW;
 #pragma unroll
-            for (int it = 0; it < kXIter; ++it) {
-                const int e = tid + it * kThreads;
-                const int c = e / kPlane, r = e - c * kPlane;
-                if (e < 32 * kPlane) s_x[c * kDwXStride + slot * kPlane + r] = px[pl][it];
+            for (int pl = 0; pl < kNewPlanes; ++pl) {
+                const int slot = new_plane(d, pl) % 3;
+#pragma unroll
+                for (int k = 0; k < kColIter; ++k) {
+                    const int wx = l4 + 4 * k;
+                    if (row < kRows && wx < kDwHW) s_x[lbase + slot * kPlane + wx] = px[pl][p][k];
+                }
             }
         }
 #pragma unroll
