@@ -112,17 +112,18 @@ def run_gpu(args, w, rank, world, device):
         meta = meta_of(i)
         hp.prefetch_scene(metas[i + 1], device)
         geo = hp.prepare_scene(meta, device)
+        # the product's own sequence (MVSDetHotPath.forward_scene): geometry kernel on a side stream beside the packing.
+        # HIP events on the streams the kernels launch on: table = (t0, t1) on the side stream, slab kernel = (em, e1)
+        tab = hp.sweep_geometry_async(geo, w["H"], w["W"], events=timed)
         packed = ops.pack_features(feat)
-        if timed:  # HIP events on torch's current stream (where the ops launch): stage 1 = table + slab kernel
-            e0, em, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record()
-        table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, w["H"], w["W"])
         if timed:
+            em, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+            torch.cuda.current_stream(device).wait_event(tab[1])
             em.record()
-        var = ops.plane_sweep_variance_tabled(packed, geo.neighbor_ids, table, w["C"], w["D"], w["H"], w["W"])
+        var = hp.cost_volume_tabled(packed, geo, tab[:2], w["C"], w["H"], w["W"])
         if timed:
             e1.record()
-            ev.append((e0, em, e1))
+            ev.append((tab[2], tab[3], em, e1))
         prob, off, est_depth, est_dens, est_idx, avg = hp.depth_distribution(s.cost_logits)
         vol, valid = hp.lift(feat, packed, geo, est_depth, est_dens)
         return var, vol, valid
@@ -147,8 +148,8 @@ def run_gpu(args, w, rank, world, device):
     checksum = float(out[1].abs().sum().item()) + float(out[0][0, 0, 0].abs().sum().item())
     del out
     # (table ms, slab-kernel ms) per launch; the chunked workload's shard entry point enqueues both behind one pair
-    if ev and len(ev[0]) == 3:
-        sweep_ms = (float(np.mean([a.elapsed_time(m) for a, m, b in ev])), float(np.mean([m.elapsed_time(b) for a, m, b in ev])))
+    if ev and len(ev[0]) == 4:
+        sweep_ms = (float(np.mean([a.elapsed_time(b) for a, b, _, _ in ev])), float(np.mean([m.elapsed_time(e) for _, _, m, e in ev])))
     elif ev:
         sweep_ms = (0.0, float(np.mean([a.elapsed_time(b) for a, b in ev])))
     else:

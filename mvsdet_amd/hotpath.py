@@ -166,6 +166,7 @@ class MVSDetHotPath:
         self.neck_3d = neck_3d   # mvsdet.py:681-698: x = self.neck_3d(torch.stack(volumes)); SURVEY 8 f-3 (mvsdet_amd.neck)
         self.bbox_head = bbox_head   # nerfdet_head.py:116-118: the head's convolutions on the neck's levels (mvsdet_amd.head)
         self._points_cache: dict = {}
+        self._geo_streams: dict = {}
         self._geometry = _GeometryWorker(self)
 
     # ---- reference-named methods (mvsdet.py:249, 266, 298) -------------------------------------------
@@ -254,6 +255,35 @@ class MVSDetHotPath:
         return pts
 
     # ---- the hot path -------------------------------------------------------------------------------------
+    def sweep_geometry_async(self, geo: SceneGeometry, H: int, W: int, events: bool = False):
+        """The sweep geometry (footprint boxes and runs: plane_sweep_coords_kernel, VALU-bound) enqueued on a side stream,
+        so that it runs beside the feature packing (memory-bound) instead of in front of the sweep.  Returns
+        (table, event[, start, end timing events]); `cost_volume_tabled` waits for the event on the current stream."""
+        dev = geo.proj_rel.device
+        cur = torch.cuda.current_stream(dev)
+        side = self._geo_streams.get(str(dev))
+        if side is None:
+            side = self._geo_streams[str(dev)] = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)   # proj_rel / depth_values may have been produced on the current stream
+        with torch.cuda.stream(side):
+            t0 = t1 = None
+            if events:   # bench.py: timing events on the stream the kernel launches on
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(side)
+            table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
+            if events:
+                t1.record(side)
+            done = torch.cuda.Event()
+            done.record(side)
+        table.record_stream(cur)   # allocated under the side stream, consumed on the current one
+        return (table, done, t0, t1) if events else (table, done)
+
+    def cost_volume_tabled(self, packed: Tensor, geo: SceneGeometry, table_and_event, C: int, H: int, W: int) -> Tensor:
+        """a3+a4 from the packed maps and a geometry built by `sweep_geometry_async` (forward only)."""
+        table, done = table_and_event
+        torch.cuda.current_stream(packed.device).wait_event(done)
+        return ops.plane_sweep_variance_tabled(packed, geo.neighbor_ids, table, C, self.num_depth, H, W)
+
     def cost_volume(self, feature: Tensor, geo: SceneGeometry, packed: Optional[Tensor] = None) -> Tensor:
         """a3+a4, mvsdet.py:439-467 -> variance (N,C,D,Hf,Wf)."""
         if packed is not None and not (feature.requires_grad and torch.is_grad_enabled()):
@@ -319,8 +349,14 @@ class MVSDetHotPath:
         network's output when `self.cost_regularization` is None (benchmarks / parity tests)."""
         if geo is None:
             geo = self.prepare_scene(img_meta, feature.device)
-        packed = ops.pack_features(feature.detach())
-        variance = self.cost_volume(feature, geo, packed)
+        if feature.is_cuda and not (feature.requires_grad and torch.is_grad_enabled()) and geo.neighbor_ids.shape[1] > 0:
+            n, c, h_, w_ = feature.shape
+            tab = self.sweep_geometry_async(geo, h_, w_)     # side stream: beside the packing
+            packed = ops.pack_features(feature.detach())
+            variance = self.cost_volume_tabled(packed, geo, tab, c, h_, w_)
+        else:
+            packed = ops.pack_features(feature.detach())
+            variance = self.cost_volume(feature, geo, packed)
         if self.cost_regularization is not None:
             cost_logits = self.cost_regularization(variance)
         elif cost_logits is None:
