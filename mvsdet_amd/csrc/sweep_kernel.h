@@ -37,9 +37,6 @@
 namespace mvsdet {
 
 constexpr int kTilePix = 128;       // pixels per tile
-constexpr int kBoxCap = 256;        // default texels (128 B each) of one LDS footprint box: 32 KiB per neighbour
-constexpr int kBoxCapMax = 320;     // 2 neighbours x 320 texels x 2 blocks = the CU's 160 KiB
-constexpr int kTileStride = 132;    // floats per channel row of the backward kernel's gradient tile
 
 // Wave-wide integer min / max of a footprint (xlo, xhi, ylo, yhi), all on DPP: butterfly inside each row of 16 lanes (every
 // lane of a row ends up with the row's result), then row_bcast:15 folds row 0 into row 1 and row 2 into row 3, row_bcast:31
@@ -129,9 +126,6 @@ __device__ __forceinline__ float2 sample_at(const SampleRay& r, float t0, float 
     const float gx = px / ((float)(W - 1) * 0.5f) - 1.0f;
     const float gy = py / ((float)(H - 1) * 0.5f) - 1.0f;
     return make_float2(fmaf(gx + 1.0f, (float)W * 0.5f, -0.5f), fmaf(gy + 1.0f, (float)H * 0.5f, -0.5f));
-}
-__device__ __forceinline__ float2 sample_position(const float* __restrict__ P, float x, float y, float d, int H, int W) {
-    return sample_at(sample_ray(P, x, y), P[3], P[7], P[11], d, H, W);
 }
 
 // ---------------------------------------------------------------------------------------------
