@@ -206,7 +206,7 @@ struct ConvPlan {
     int D, H, W, twc, td, tiles_w, tiles_h, tiles_d, nsplit;
 };
 
-// tile shape (TWC along w, TD planes, 256/(TD*TWC) rows): the one that pads (D, H, W) least; the 4-plane tile only exists
+// tile shape (TWC along w, TD planes, 256/(TD*TWC) rows): the one that pads (D, H, W) least (conv_plan); the 4-plane tile with 16-wide groups only exists
 // for stride 1 and 16-wide column groups.  nsplit: splits of the channel pairs so that a small grid reaches ~2 blocks
 // per CU, each split at least 8 pairs long.
 ConvPlan conv_plan(int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride) {
@@ -217,13 +217,13 @@ ConvPlan conv_plan(int N, int Cin, int Cout, int Di, int Hi, int Wi, int stride)
         const int th_ = 256 / (td_ * twc_);
         return (long long)((p.W + twc_ - 1) / twc_ * twc_) * ((p.H + th_ - 1) / th_ * th_) * ((p.D + td_ - 1) / td_ * td_);
     };
-    // candidates in order of preference at equal padding: wide column groups first (fewer, longer LDS rows).  The 4-plane
-    // tiles only exist for stride 1 (a stride-2 halo of 4 planes does not fit), the 8- and 4-wide groups serve the small
+    // candidates in order of preference at equal padding: wide column groups first (fewer, longer LDS rows).  The 8- and
+    // 4-wide groups (and, at stride 2, their 4-plane forms: a 9 x 17 x 17 halo is no larger than 5 x 33 x 17) serve the small
     // grids (the neck's 20x20x8 and 10x10x4, the cost network's 3x15x20 quarter resolution)
     static const int cand1[][2] = {{32, 2}, {16, 2}, {16, 4}, {8, 2}, {8, 4}, {4, 4}};
-    static const int cand2[][2] = {{32, 2}, {16, 2}, {8, 2}};
+    static const int cand2[][2] = {{32, 2}, {16, 2}, {8, 2}, {8, 4}, {4, 4}};
     const int (*cand)[2] = stride == 1 ? cand1 : cand2;
-    const int ncand = stride == 1 ? 6 : 3;
+    const int ncand = stride == 1 ? 6 : 5;
     p.twc = cand[0][0]; p.td = cand[0][1];
     long long best = padded(p.twc, p.td);
     for (int i = 1; i < ncand; ++i)
@@ -278,7 +278,9 @@ static int launch_conv_mfma(const char* name, const float* x, const float* weigh
         else if (twc == 16) MVS_CONV_CASE(16, 1, 2);
         else MVS_CONV_CASE(32, 1, 2);
     } else {
-        if (twc == 8) MVS_CONV_CASE(8, 2, 2);
+        if (twc == 4) MVS_CONV_CASE(4, 2, 4);
+        else if (twc == 8 && td == 4) MVS_CONV_CASE(8, 2, 4);
+        else if (twc == 8) MVS_CONV_CASE(8, 2, 2);
         else if (twc == 16) MVS_CONV_CASE(16, 2, 2);
         else MVS_CONV_CASE(32, 2, 2);
     }
