@@ -1,9 +1,10 @@
 """The convolutions of the detection head that consume the neck's outputs ("neck + head"):
-`NerfDetHead._init_layers / _forward_single / forward` of projects/NeRF-Det/nerfdet/nerfdet_head.py:94-118 (the 7-DoF
-`ImVoxelHead_ARKit` has the same three layers with n_reg_outs = 7).  Per neck level:
+`NerfDetHead._init_layers / _forward_single / forward` of projects/NeRF-Det/nerfdet/nerfdet_head.py:90-118, and the 7-DoF
+`ImVoxelHead_ARKit` (:663-700: the same three layers with n_reg_outs = 7; `arkit_head=True`).  Per neck level:
 
     centerness = conv_center(x)               Conv3d(C -> 1,         k=3, p=1, no bias)
-    bbox       = exp(scale_l(conv_reg(x)))    Conv3d(C -> n_reg_outs, k=3, p=1, no bias), one learnable scalar per level
+    bbox       = exp(scale_l(conv_reg(x)))    Conv3d(C -> n_reg_outs, k=3, p=1, no bias), one learnable scalar per level;
+                                              ImVoxelHead_ARKit: exp(scale_l(.)) on the 6 distances, the angle channel raw
     cls        = conv_cls(x)                  Conv3d(C -> n_classes,  k=3, p=1, bias)
 
 Target assignment, the losses and NMS (nerfdet_head.py:120 ff.) are detection logic outside the path and stay the
@@ -37,9 +38,11 @@ class Scale(nn.Module):
 class NerfDetHeadConvs(nn.Module):
     """The learnable layers of NerfDetHead and their forward pass (nerfdet_head.py:94-118)."""
 
-    def __init__(self, n_classes: int = 18, n_levels: int = 3, n_channels: int = 128, n_reg_outs: int = 6):
+    def __init__(self, n_classes: int = 18, n_levels: int = 3, n_channels: int = 128, n_reg_outs: int = 6,
+                 arkit_head: bool = False):
         super().__init__()
         self.n_classes, self.n_levels, self.n_reg_outs = n_classes, n_levels, n_reg_outs
+        self.arkit_head = bool(arkit_head)   # ImVoxelHead_ARKit._forward_single (nerfdet_head.py:677-692)
         self.conv_center = nn.Conv3d(n_channels, 1, 3, padding=1, bias=False)
         self.conv_reg = nn.Conv3d(n_channels, n_reg_outs, 3, padding=1, bias=False)
         self.conv_cls = nn.Conv3d(n_channels, n_classes, 3, padding=1)
@@ -70,9 +73,15 @@ class NerfDetHeadConvs(nn.Module):
             y = ops.conv3d_k3_mfma(x, self._fused_weight(), None, None, False)
             r, c = self.n_reg_outs, self.n_classes
             center = y[:, :1].contiguous()
-            reg = torch.exp(y[:, 1:1 + r] * scale.scale.detach())
             cls = y[:, 1 + r:1 + r + c] + self.conv_cls.bias.detach().view(1, -1, 1, 1, 1)
+            if self.arkit_head:
+                reg = torch.cat((torch.exp(y[:, 1:7] * scale.scale.detach()), y[:, 7:1 + r]), dim=1)
+            else:
+                reg = torch.exp(y[:, 1:1 + r] * scale.scale.detach())
             return center, reg, cls
+        if self.arkit_head:
+            reg_final = self.conv_reg(x)
+            return self.conv_center(x), torch.cat((torch.exp(scale(reg_final[:, :6])), reg_final[:, 6:]), dim=1), self.conv_cls(x)
         return self.conv_center(x), torch.exp(scale(self.conv_reg(x))), self.conv_cls(x)
 
     def forward(self, x: Sequence[Tensor]) -> Tuple[List[Tensor], List[Tensor], List[Tensor]]:

@@ -38,10 +38,10 @@ def test_head_structure_and_reference_forward():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_classes,n_reg,ch,grid", [(18, 6, 128, (40, 40, 16)), (10, 7, 64, (12, 20, 8))])
-def test_head_fused_mfma_route_vs_aten(gpu, n_classes, n_reg, ch, grid):
+@pytest.mark.parametrize("n_classes,n_reg,ch,grid,arkit", [(18, 6, 128, (40, 40, 16), False), (17, 7, 64, (12, 20, 8), True)])
+def test_head_fused_mfma_route_vs_aten(gpu, n_classes, n_reg, ch, grid, arkit):
     from mvsdet_amd.head import NerfDetHeadConvs
-    m = _randomise(NerfDetHeadConvs(n_classes, 3, ch, n_reg), 2)
+    m = _randomise(NerfDetHeadConvs(n_classes, 3, ch, n_reg, arkit_head=arkit), 2)
     with torch.no_grad():
         for i, s in enumerate(m.scales):
             s.scale.fill_(0.5 + 0.25 * i)

@@ -160,3 +160,66 @@ def test_lazy_route_is_pinned_to_the_reference_source_text(reference, oracle, mo
     mean_ref[:, val_ref.sum(dim=0)[0] == 0] = .0
     np.testing.assert_allclose(ns2["volume_mean"].numpy(), mean_ref.numpy(), rtol=0, atol=1e-6)
     assert int((ns2["valid"] > 0).sum()) > 100
+
+
+@pytest.mark.parametrize("cls_name,cfg,arkit", [("NerfDetHead", (128, 6, 18, 3), False), ("ImVoxelHead_ARKit", (128, 7, 17, 3), True)])
+def test_head_convolutions_are_pinned_to_the_reference_source_text(cls_name, cfg, arkit):
+    """`_init_layers`, `_forward_single` and `forward` of NerfDetHead (nerfdet_head.py:90-118) and of the 7-DoF
+    ImVoxelHead_ARKit (:663-700), taken from the REFERENCE FILE ITSELF and executed as methods of a bare nn.Module -- with
+    mmcv's `Scale` (a learnable scalar factor) and mmdet's `multi_apply` (map + transpose of the result tuples) spelled out,
+    neither package being installed here: the same parameter names and shapes as mvsdet_amd.head.NerfDetHeadConvs, and
+    after load_state_dict the same outputs."""
+    import os
+    import textwrap
+    import torch
+    from torch import nn, Tensor
+    from mvsdet_amd.head import NerfDetHeadConvs
+    path = "/root/reference/projects/NeRF-Det/nerfdet/nerfdet_head.py"
+    if not os.path.isfile(path):
+        pytest.skip("reference tree not mounted")
+    src = open(path).read().splitlines()
+    cls_line = next(i for i, l in enumerate(src) if l.startswith(f"class {cls_name}("))
+    first = next(i for i in range(cls_line, len(src)) if src[i].startswith("    def _init_layers"))
+    last = next(i for i in range(first, len(src)) if src[i].startswith("    def loss("))
+    block = textwrap.dedent("\n".join(src[first:last]))
+    assert "self.conv_center = nn.Conv3d(n_channels, 1, 3, padding=1, bias=False)" in block
+    assert "multi_apply(self._forward_single, x, self.scales)" in block
+    assert ("reg_final[:, 6:]" in block) == arkit
+
+    class Scale(nn.Module):                      # mmcv.cnn.Scale
+        def __init__(self, scale=1.0):
+            super().__init__()
+            self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+        def forward(self, x):
+            return x * self.scale
+
+    def multi_apply(func, *args):                # mmdet.models.utils.multi_apply without its kwargs
+        return tuple(map(list, zip(*map(func, *args))))
+
+    ns = dict(nn=nn, torch=torch, Tensor=Tensor, Scale=Scale, multi_apply=multi_apply, normal_init=lambda *a, **k: None,
+              bias_init_with_prob=lambda p: 0.0)
+    exec(block, ns)
+    n_channels, n_reg_outs, n_classes, n_levels = cfg   # configs: mvsdet_res50_2x_low_res_depth.py:40-43, mvsdet_arkit_base.py:41-44
+
+    class RefHead(nn.Module):
+        _init_layers, _forward_single, forward = ns["_init_layers"], ns["_forward_single"], ns["forward"]
+
+        def __init__(self):
+            super().__init__()
+            self._init_layers(n_channels, n_reg_outs, n_classes, n_levels)
+
+    torch.manual_seed(0)
+    ref, ours = RefHead().eval(), NerfDetHeadConvs(n_classes, n_levels, n_channels, n_reg_outs, arkit_head=arkit).eval()
+    assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn_like(p) * 0.05)
+    ours.load_state_dict(ref.state_dict())
+    xs = [torch.randn(1, n_channels, 8 >> i, 8 >> i, 4 >> i) for i in range(n_levels)]
+    with torch.no_grad():
+        a, b = ref(xs), ours(xs)
+    assert len(a) == len(b) == 3
+    for la, lb in zip(a, b):
+        for ta, tb in zip(la, lb):
+            assert torch.equal(ta, tb)
