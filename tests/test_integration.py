@@ -223,3 +223,57 @@ def test_head_convolutions_are_pinned_to_the_reference_source_text(cls_name, cfg
     for la, lb in zip(a, b):
         for ta, tb in zip(la, lb):
             assert torch.equal(ta, tb)
+
+
+def test_neck_is_pinned_to_the_reference_source_text():
+    """`IndoorImVoxelNeck` and `ResModule`, taken from the REFERENCE FILE ITSELF (mmdet3d/models/necks/imvoxel_neck.py:68-231)
+    and executed with mmcv's `ConvModule` spelled out (Conv3d without bias -> BatchNorm3d -> optional ReLU, sub-modules `conv`,
+    `bn`, `activate`), `BaseModule` = nn.Module and a no-op registry, none of those packages being installed here: the same
+    parameter / buffer names and shapes as mvsdet_amd.neck.IndoorImVoxelNeck, and after load_state_dict the same outputs in
+    eval and in train mode."""
+    import os
+    import textwrap
+    import torch
+    from torch import nn
+    from mvsdet_amd.neck import IndoorImVoxelNeck
+    path = "/root/reference/mmdet3d/models/necks/imvoxel_neck.py"
+    if not os.path.isfile(path):
+        pytest.skip("reference tree not mounted")
+    src = open(path).read().splitlines()
+    first = next(i for i, l in enumerate(src) if l.startswith("class IndoorImVoxelNeck("))
+    block = textwrap.dedent("\n".join(src[first:]))
+    assert "class ResModule(nn.Module):" in block and "x = down_outs[i] + x" in block and "x = x + identity" in block
+
+    class ConvModule(nn.Module):                 # mmcv.cnn.ConvModule for conv_cfg Conv3d, norm_cfg BN3d, act_cfg ReLU | None
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None, norm_cfg=None, act_cfg=None):
+            super().__init__()
+            assert conv_cfg == dict(type='Conv3d') and norm_cfg == dict(type='BN3d')
+            self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False)
+            self.bn = nn.BatchNorm3d(out_channels)
+            self.with_activation = act_cfg is not None
+            if self.with_activation:
+                self.activate = nn.ReLU(inplace=act_cfg.get('inplace', True))
+
+        def forward(self, x):
+            x = self.bn(self.conv(x))
+            return self.activate(x) if self.with_activation else x
+
+    ns = dict(nn=nn, ConvModule=ConvModule, BaseModule=nn.Module)
+    exec(block, ns)
+    torch.manual_seed(1)
+    ref = ns["IndoorImVoxelNeck"](8, 4, [1, 1, 1])
+    ours = IndoorImVoxelNeck(8, 4, [1, 1, 1])
+    assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    with torch.no_grad():
+        for k, v in ref.state_dict().items():
+            if v.dtype.is_floating_point:
+                v.copy_(torch.rand_like(v) + 0.5 if "running_var" in k else torch.randn_like(v) * 0.2)
+    ours.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 8, 8, 8, 4)
+    for training in (False, True):
+        ref.train(training); ours.train(training)
+        with torch.no_grad():
+            a, b = ref(x.clone()), ours(x.clone())
+        assert [tuple(t.shape) for t in a] == [(2, 4, 8, 8, 4), (2, 4, 4, 4, 2), (2, 4, 2, 2, 1)]
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
