@@ -144,8 +144,6 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                                                                        float* __restrict__ depth_copy, int D, int H, int W,
                                                                        int tiles_x, int tiles, int box_cap) {
     constexpr int TH = kTilePix / TW;
-    constexpr int ITER = (K * kTilePix + kThreads - 1) / kThreads;
-    __shared__ int s_red[2][K][2][5];  // [plane parity][neighbour][wave of the neighbour][xlo,xhi,ylo,yhi,all finite]
     extern __shared__ int4 s_geo[];    // [K][D] the tile's boxes of all planes, then [D] flags words, then [D] plane depths
     int4* s_pb = s_geo;
     unsigned* s_fl = reinterpret_cast<unsigned*>(s_geo + (size_t)K * D);
@@ -154,9 +152,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int p = tid % kTilePix;
-    const int x = tx0 + (p % TW), y = ty0 + (p / TW);
-    const bool inside = (x < W) && (y < H);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int d = tid; d < D; d += kThreads) {
         s_fl[d] = 0u;  // nibbles are OR-ed in below
         s_dv[d] = depth[(size_t)n * D + d];   // one global round trip for all planes instead of one per plane
@@ -166,55 +162,50 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
         for (int i = tid; i < K * 16; i += kThreads) proj_copy[(size_t)n * K * 16 + i] = proj[(size_t)n * K * 16 + i];
         for (int d = tid; d < D; d += kThreads) depth_copy[(size_t)n * D + d] = depth[(size_t)n * D + d];
     }
-    // the thread's pixel rays (plane-independent) and translation columns, one per neighbour it handles
-    SampleRay ray[ITER];
-    float t0[ITER], t1[ITER], t2[ITER];
+    // A (plane, neighbour) footprint is the work of ONE wave: its lanes take the tile's pixels lane and lane + 64 (two
+    // independent positions in flight per lane), one wave reduction gives the box, lane 0 files it -- no block barrier
+    // and no cross-wave merge per plane.  Wave w takes the planes w, w + 4, ... of every neighbour.
+    bool inside[2];
+    SampleRay ray[K > 0 ? K : 1][2];   // the pixel rays (plane-independent)
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int j = min((it * kThreads + tid) / kTilePix, K - 1);
-        const float* P = proj + ((size_t)n * K + j) * 16;
-        ray[it] = sample_ray(P, (float)x, (float)y);
-        t0[it] = P[3]; t1[it] = P[7]; t2[it] = P[11];
+    for (int h = 0; h < 2; ++h) {
+        const int p = lane + 64 * h;
+        const int x = tx0 + (p % TW), y = ty0 + (p / TW);
+        inside[h] = (x < W) && (y < H);
+#pragma unroll
+        for (int j = 0; j < K; ++j) ray[j][h] = sample_ray(proj + ((size_t)n * K + j) * 16, (float)x, (float)y);
     }
-    for (int d = 0; d < D; ++d) {
-        const int par = d & 1;
-        const float dval = s_dv[d];
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            // 128 pixels = 2 whole waves per neighbour: j is wave-uniform
-            const int j = __builtin_amdgcn_readfirstlane((it * kThreads + tid) / kTilePix);
-            if (j < K) {
-                int xlo = INT32_MAX, xhi = INT32_MIN, ylo = INT32_MAX, yhi = INT32_MIN;
-                float2 e = make_float2(kNoSample, kNoSample);  // pixel outside the image: no taps, no footprint
-                int fin = 1;
-                if (inside) {
-                    e = sample_at(ray[it], t0[it], t1[it], t2[it], dval, H, W);
-                    fin = (isfinite(e.x) && isfinite(e.y)) ? 1 : 0;
+    for (int j = 0; j < K; ++j) {
+        const float* P = proj + ((size_t)n * K + j) * 16;
+        const float t0 = P[3], t1 = P[7], t2 = P[11];
+        for (int d = wave; d < D; d += kThreads / 64) {
+            const float dval = s_dv[d];
+            int xlo = INT32_MAX, xhi = INT32_MIN, ylo = INT32_MAX, yhi = INT32_MIN;
+            int fin = 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (inside[h]) {   // a pixel outside the image has no taps and no footprint
+                    const float2 e = sample_at(ray[j][h], t0, t1, t2, dval, H, W);
+                    fin &= (isfinite(e.x) && isfinite(e.y)) ? 1 : 0;
                     const SampleTaps t = decode_sample(e.x, e.y, H, W);
                     if ((t.x0in || t.x1in) && (t.y0in || t.y1in)) {  // bounding box of the taps that are inside
-                        xlo = t.x0in ? t.x0 : t.x0 + 1;
-                        xhi = t.x1in ? t.x0 + 1 : t.x0;
-                        ylo = t.y0in ? t.y0 : t.y0 + 1;
-                        yhi = t.y1in ? t.y0 + 1 : t.y0;
+                        xlo = min(xlo, t.x0in ? t.x0 : t.x0 + 1);
+                        xhi = max(xhi, t.x1in ? t.x0 + 1 : t.x0);
+                        ylo = min(ylo, t.y0in ? t.y0 : t.y0 + 1);
+                        yhi = max(yhi, t.y1in ? t.y0 + 1 : t.y0);
                     }
                 }
-                wave_reduce_box(xlo, xhi, ylo, yhi);
-                fin = __builtin_amdgcn_readfirstlane((int)(__ballot(fin == 0) == 0ull));  // all of the wave's positions finite
-                if (lane == 0) {
-                    int* r = s_red[par][j][(tid >> 6) & 1];
-                    r[0] = xlo; r[1] = xhi; r[2] = ylo; r[3] = yhi; r[4] = fin;
-                }
             }
-        }
-        __syncthreads();  // one barrier per plane: s_red is double-buffered by plane parity
-        if (tid < K) {
-            const int* a = s_red[par][tid][0];
-            const int* b = s_red[par][tid][1];
-            int4 bx = make_int4(min(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), max(a[3], b[3]));
-            // no tap of the whole tile is inside the source image: the warped values are exactly 0 and the sweep
-            // skips this neighbour (kBoxSkip) -- unless a position is NaN / Inf, whose taps must still produce NaN
-            if (bx.y < bx.x || bx.w < bx.z) bx = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, min(a[4], b[4]) ? kBoxSkip : kBoxEmpty);
-            s_pb[(size_t)tid * D + d] = bx;
+            wave_reduce_box(xlo, xhi, ylo, yhi);
+            const bool all_finite = __ballot(fin == 0) == 0ull;
+            if (lane == 0) {
+                int4 bx = make_int4(xlo, xhi, ylo, yhi);
+                // no tap of the whole tile is inside the source image: the warped values are exactly 0 and the sweep
+                // skips this neighbour (kBoxSkip) -- unless a position is NaN / Inf, whose taps must still produce NaN
+                if (bx.y < bx.x || bx.w < bx.z) bx = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, all_finite ? kBoxSkip : kBoxEmpty);
+                s_pb[(size_t)j * D + d] = bx;
+            }
         }
     }
     // Runs: consecutive live planes of one neighbour whose union box holds at most box_cap texels all get that union
