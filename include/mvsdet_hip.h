@@ -166,6 +166,13 @@ int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* off_logit, fl
                                float* est_depth, float* est_dens, int32_t* est_idx, float* avg_depth,
                                int N, int D, int H, int W, int topk, float near, float interval,
                                mvsdet_stream_t stream);
+/* The same with the two inputs as channel slices of the network's (N, 2, D, H, W) output (mvsdet.py:469 torch.unbind):
+ * view n of either input starts view_stride floats after view n-1, its (D, H, W) block is dense.  Saves the two copies
+ * that making the slices contiguous costs. */
+int mvsdet_depth_prob_topk_strided_f32(const float* cost_reg, const float* off_logit, long long view_stride, float* prob,
+                                       float* off, float* est_depth, float* est_dens, int32_t* est_idx, float* avg_depth,
+                                       int N, int D, int H, int W, int topk, float near, float interval,
+                                       mvsdet_stream_t stream);
 /* a6+a7 only, for callers that already hold prob = softmax(cost_reg) and off = sigmoid(off_logit)
  * (signature-level parity with MVSDet.sample_depth_prob / compute_avg_depth, mvsdet.py:266,298). */
 int mvsdet_sample_depth_prob_f32(const float* prob, const float* off, float* est_depth, float* est_dens,

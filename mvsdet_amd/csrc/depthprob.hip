@@ -17,13 +17,16 @@ template <bool kFromLogits, int DREG, int KT>
 __global__ __launch_bounds__(kThreads) void depth_prob_topk_kernel(
     const float* __restrict__ cost_reg, const float* __restrict__ off_logit, float* __restrict__ prob,
     float* __restrict__ off, float* __restrict__ est_depth, float* __restrict__ est_dens,
-    int32_t* __restrict__ est_idx, float* __restrict__ avg_depth, int D, int HW, int topk, float near, float interval) {
+    int32_t* __restrict__ est_idx, float* __restrict__ avg_depth, int D, int HW, int topk, float near, float interval,
+    size_t in_view_stride) {
     const int pix = blockIdx.x * kThreads + threadIdx.x;
     const int n = blockIdx.y;
     if (pix >= HW) return;
     const size_t base = (size_t)n * D * HW + pix;
-    const float* c = cost_reg + base;
-    const float* o = off_logit + base;
+    // the two inputs may be the channel slices of one (N, 2, D, H, W) tensor (the network's output, mvsdet.py:469): a view
+    // is in_view_stride floats after the previous one, its (D, H, W) block dense
+    const float* c = cost_reg + (size_t)n * in_view_stride + pix;
+    const float* o = off_logit + (size_t)n * in_view_stride + pix;
 
     constexpr int kReg = DREG > 0 ? DREG : 1;
     float e[kReg];   // logits, then exp(logit - max)
@@ -183,17 +186,18 @@ static int check_stage2(const char* name, int N, int D, int H, int W, int topk) 
     return MVSDET_OK;
 }
 
-extern "C" int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* off_logit, float* prob, float* off,
-                                          float* est_depth, float* est_dens, int32_t* est_idx, float* avg_depth, int N,
-                                          int D, int H, int W, int topk, float near, float interval,
-                                          mvsdet_stream_t stream) {
+extern "C" int mvsdet_depth_prob_topk_strided_f32(const float* cost_reg, const float* off_logit, long long view_stride,
+                                                  float* prob, float* off, float* est_depth, float* est_dens,
+                                                  int32_t* est_idx, float* avg_depth, int N, int D, int H, int W, int topk,
+                                                  float near, float interval, mvsdet_stream_t stream) {
     MVS_REQUIRE(cost_reg && off_logit && prob && off && est_depth && est_dens && avg_depth, "depth_prob_topk: NULL pointer");
     if (int rc = check_stage2("depth_prob_topk", N, D, H, W, topk)) return rc;
+    MVS_REQUIRE(view_stride >= (long long)D * H * W, "depth_prob_topk: view stride %lld < D*H*W", view_stride);
     const int HW = H * W;
     dim3 grid((HW + kThreads - 1) / kThreads, N);
 #define MVS_DP_LAUNCH(DR, KTV)                                                                                             \
     hipLaunchKernelGGL((depth_prob_topk_kernel<true, DR, KTV>), grid, dim3(kThreads), 0, (hipStream_t)stream, cost_reg, off_logit, \
-                       prob, off, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval)
+                       prob, off, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval, (size_t)view_stride)
 #define MVS_DP_BY_D(KTV)                  \
     if (D <= 16) MVS_DP_LAUNCH(16, KTV);  \
     else if (D <= 64) MVS_DP_LAUNCH(64, KTV); \
@@ -205,6 +209,14 @@ extern "C" int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* of
     return MVSDET_OK;
 }
 
+extern "C" int mvsdet_depth_prob_topk_f32(const float* cost_reg, const float* off_logit, float* prob, float* off,
+                                          float* est_depth, float* est_dens, int32_t* est_idx, float* avg_depth, int N,
+                                          int D, int H, int W, int topk, float near, float interval,
+                                          mvsdet_stream_t stream) {
+    return mvsdet_depth_prob_topk_strided_f32(cost_reg, off_logit, (long long)D * H * W, prob, off, est_depth, est_dens, est_idx,
+                                              avg_depth, N, D, H, W, topk, near, interval, stream);
+}
+
 extern "C" int mvsdet_sample_depth_prob_f32(const float* prob, const float* off, float* est_depth, float* est_dens,
                                             int32_t* est_idx, float* avg_depth, int N, int D, int H, int W, int topk,
                                             float near, float interval, mvsdet_stream_t stream) {
@@ -214,10 +226,12 @@ extern "C" int mvsdet_sample_depth_prob_f32(const float* prob, const float* off,
     dim3 grid((HW + kThreads - 1) / kThreads, N);
     if (topk <= 3)
         hipLaunchKernelGGL((depth_prob_topk_kernel<false, 0, 3>), grid, dim3(kThreads), 0, (hipStream_t)stream, prob, off,
-                           (float*)nullptr, (float*)nullptr, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval);
+                           (float*)nullptr, (float*)nullptr, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval,
+                           (size_t)D * HW);
     else
     hipLaunchKernelGGL((depth_prob_topk_kernel<false, 0, MVSDET_MAX_TOPK>), grid, dim3(kThreads), 0, (hipStream_t)stream, prob, off,
-                       (float*)nullptr, (float*)nullptr, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval);
+                       (float*)nullptr, (float*)nullptr, est_depth, est_dens, est_idx, avg_depth, D, HW, topk, near, interval,
+                       (size_t)D * HW);
     MVS_LAUNCH_CHECK("sample_depth_prob");
     return MVSDET_OK;
 }

@@ -303,19 +303,24 @@ def depth_prob_topk(cost_reg: Tensor, off_logit: Tensor, near: float, interval: 
     if cost_reg.shape != off_logit.shape:
         raise ValueError("depth_prob_topk: cost_reg / off_logit shape mismatch")
     N, D, H, W = cost_reg.shape
-    cost_reg, off_logit = cost_reg.contiguous(), off_logit.contiguous()
+    # the slices of one (N, 2, D, H, W) tensor (the network's output) are read in place: dense (D, H, W) blocks, one stride
+    # between the views; anything else is made contiguous first
+    dense = (W * H * D, W * H, W, 1)
+    if not (cost_reg.stride()[1:] == dense[1:] == off_logit.stride()[1:] and cost_reg.stride(0) == off_logit.stride(0) >= dense[0]):
+        cost_reg, off_logit = cost_reg.contiguous(), off_logit.contiguous()
+    view_stride = cost_reg.stride(0) if N > 1 else dense[0]
     dev = cost_reg.device
-    prob = torch.empty_like(cost_reg)
-    off = torch.empty_like(cost_reg)
+    prob = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
+    off = torch.empty((N, D, H, W), dtype=torch.float32, device=dev)
     est_depth = torch.empty((N, topk, H, W), dtype=torch.float32, device=dev)
     est_dens = torch.empty((N, topk, H, W), dtype=torch.float32, device=dev)
     est_idx = torch.empty((N, topk, H, W), dtype=torch.int32, device=dev)
     avg = torch.empty((N, H, W), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().mvsdet_depth_prob_topk_f32(_lib.ptr(cost_reg), _lib.ptr(off_logit), _lib.ptr(prob),
-                                                          _lib.ptr(off), _lib.ptr(est_depth), _lib.ptr(est_dens),
-                                                          _lib.ptr(est_idx), _lib.ptr(avg), N, D, H, W, topk, near,
-                                                          interval, _stream(cost_reg)), "depth_prob_topk")
+        _lib.check(_lib.load().mvsdet_depth_prob_topk_strided_f32(_lib.ptr(cost_reg), _lib.ptr(off_logit), view_stride,
+                                                                  _lib.ptr(prob), _lib.ptr(off), _lib.ptr(est_depth),
+                                                                  _lib.ptr(est_dens), _lib.ptr(est_idx), _lib.ptr(avg), N, D, H,
+                                                                  W, topk, near, interval, _stream(cost_reg)), "depth_prob_topk")
     return prob, off, est_depth, est_dens, est_idx, avg
 
 

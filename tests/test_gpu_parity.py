@@ -1122,3 +1122,24 @@ def test_cost_network_training_mode_batchnorm(gpu):
         if "num_batches_tracked" in k:
             assert int(sd0[k]) == int(sd1[k]) == 1, k
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in nets[0].parameters())
+
+
+def test_depth_prob_topk_reads_the_network_output_in_place(gpu):
+    """The two logit maps as channel slices of one (N, 2, D, H, W) tensor (mvsdet.py:469) are read through a view stride:
+    the same bits as from contiguous copies, also for a batch-sliced and for a transposed (copied) input."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    both = torch.randn(5, 2, 12, 9, 14, generator=g).to(gpu)
+    ref = ops.depth_prob_topk(both[:, 0].contiguous(), both[:, 1].contiguous(), 0.2, 0.4, 3)
+    got = ops.depth_prob_topk(both[:, 0], both[:, 1], 0.2, 0.4, 3)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    got = ops.depth_prob_topk(both[1:4, 0], both[1:4, 1], 0.2, 0.4, 3)
+    ref = ops.depth_prob_topk(both[1:4, 0].contiguous(), both[1:4, 1].contiguous(), 0.2, 0.4, 3)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    tr = both.transpose(3, 4)   # inner block not dense: falls back to a copy
+    got = ops.depth_prob_topk(tr[:, 0], tr[:, 1], 0.2, 0.4, 3)
+    ref = ops.depth_prob_topk(tr[:, 0].contiguous(), tr[:, 1].contiguous(), 0.2, 0.4, 3)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
