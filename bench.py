@@ -69,19 +69,35 @@ class SceneInputs:
         self.cost_logits = synthetic.make_cost_logits(w["N"], w["D"], hw, seed=seed, device=device)
 
 
+def unseen_metas(w, rank, count):
+    """One img_meta per step, each with cameras no earlier step had (own seed): the reference samples the views of a
+    scene anew for every item (multiview_pipeline.py:141) and RandomShiftOrigin moves the origin, so a real pipeline
+    never presents the same camera bytes twice and the hot path's content cache never hits.  Built before the timed
+    region -- in the reference this is the data loader's work, not extract_feat's."""
+    from mvsdet_amd import synthetic
+    return [synthetic.make_img_meta(w["N"], (w["H"], w["W"]), seed=rank * 100003 + 1000 + i,
+                                    per_view_intrinsics=w["per_view_K"]) for i in range(count)]
+
+
 def run_gpu(args, w, rank, world, device):
     from mvsdet_amd import ops, parallel
     from mvsdet_amd.hotpath import MVSDetHotPath
 
     hp = MVSDetHotPath(w.get("voxels", N_VOXELS), VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3)
     scenes = [SceneInputs(w, seed=rank * 100 + i, device=device) for i in range(args.scene_pool)]
+    # feature maps and stand-in logits cycle through a small resident pool (they are the 2-D backbone's output, resident
+    # in HBM when extract_feat's hot block starts); the CAMERAS of every step are new, so the host geometry a1/a2/a8
+    # (neighbour selection, projections, voxel points) and its upload run for every timed step.  What may hide them is
+    # the one-step-ahead prefetch on the worker thread, as a data loader allows -- never the content cache.
+    metas = unseen_metas(w, rank, args.warmup + args.steps + 1)
     torch.cuda.synchronize(device)
     ev = []
 
     def step_chunked(i, timed):
         """Cost volume produced in chunks of reference views (fp16 storage); every launch is one chunk."""
         s = scenes[i % len(scenes)]
-        geo = hp.prepare_scene(s.meta, device)
+        hp.prefetch_scene(metas[i + 1], device)
+        geo = hp.prepare_scene(metas[i], device)
         packed = ops.pack_features(s.features)
         keep = None
         for first, var in hp.cost_volume_chunks(packed, geo, w["C"], w["H"], w["W"], w["chunk"], half_out=w.get("half", False),
@@ -92,26 +108,13 @@ def run_gpu(args, w, rank, world, device):
         vol, valid = hp.lift_packed(packed, geo, est_depth, est_dens, w["C"], w["H"], w["W"])
         return keep, vol, valid
 
-    # every step sees a NEW img_meta object; the scene pool is small, so after its first pass the camera algebra is served
-    # from the content cache (as in a training epoch); the uncached cost is reported in stage_ms
-    metas = {}
-
-    def meta_of(i):
-        for k in (i, i + 1):
-            if k not in metas:
-                metas[k] = dict(scenes[k % len(scenes)].meta)
-        for k in [k for k in metas if k < i]:
-            del metas[k]
-        return metas[i]
-
     def step(i, timed):
         if w.get("chunk"):
             return step_chunked(i, timed)
         s = scenes[i % len(scenes)]
         feat = s.features
-        meta = meta_of(i)
         hp.prefetch_scene(metas[i + 1], device)
-        geo = hp.prepare_scene(meta, device)
+        geo = hp.prepare_scene(metas[i], device)
         # the product's own sequence (MVSDetHotPath.forward_scene): geometry kernel on a side stream beside the packing.
         # HIP events on the streams the kernels launch on: table = (t0, t1) on the side stream, slab kernel = (em, e1)
         tab = hp.sweep_geometry_async(geo, w["H"], w["W"], events=timed)
@@ -137,6 +140,7 @@ def run_gpu(args, w, rank, world, device):
     del out
     barrier()
     torch.cuda.synchronize(device)
+    stats0 = dict(hp._geometry.stats)
     t0 = time.perf_counter()
     out = None
     for i in range(args.warmup, args.warmup + args.steps):
@@ -145,6 +149,7 @@ def run_gpu(args, w, rank, world, device):
     torch.cuda.synchronize(device)
     barrier()
     elapsed = time.perf_counter() - t0
+    hp.geometry_stats = {k: hp._geometry.stats[k] - stats0[k] for k in stats0}   # of the timed region
     checksum = float(out[1].abs().sum().item()) + float(out[0][0, 0, 0].abs().sum().item())
     del out
     # (table ms, slab-kernel ms) per launch; the chunked workload's shard entry point enqueues both behind one pair
@@ -162,7 +167,7 @@ def run_gpu(args, w, rank, world, device):
 def stage_breakdown(w, hp, scene, device, reps=3):
     """Per-stage HIP-event timings of one scene (reported as extras; not the headline)."""
     from mvsdet_amd import ops
-    names = ["host_prep+h2d (uncached, serial; cached or prefetched in the timed loop)", "pack", "plane_sweep_geometry+variance", "depth_prob_topk",
+    names = ["host_prep+h2d (serial here; prefetched one step ahead in the timed loop)", "pack", "plane_sweep_geometry+variance", "depth_prob_topk",
              "backproject_mean"]
     acc = {n: [] for n in names}
     for rep in range(reps):
@@ -223,12 +228,13 @@ def run_train(args, w, rank, world, device):
     opt = torch.optim.SGD(net.parameters(), lr=1e-4)
     hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3, cost_regularization=model)
     scenes = [SceneInputs(w, seed=rank * 100 + i, device=device) for i in range(args.scene_pool)]
-    geos = [hp.prepare_scene(s.meta, device) for s in scenes]
+    metas = unseen_metas(w, rank, args.warmup + args.steps + 1)   # new cameras every step; index 0..warmup-1 = warm-up
 
     def step(i):
         s = scenes[i % len(scenes)]
         feat = s.features.detach().requires_grad_(True)   # the 2-D backbone's output: receives dL/dfeat
-        out = hp.forward_scene(feat, s.meta, geo=geos[i % len(scenes)])
+        hp.prefetch_scene(metas[args.warmup + i + 1], device)
+        out = hp.forward_scene(feat, metas[args.warmup + i])
         loss = out["volume"].square().mean() + out["depth_coding"].mean() + out["est_densities"].mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -267,13 +273,16 @@ def full_chain_rate(device, steps=10):
     hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(wr["near_far"]), wr["D"], topk=3, cost_regularization=net, neck_3d=neck,
                        bbox_head=head)
     scene = SceneInputs(wr, seed=0, device=device)
+    metas = unseen_metas(wr, 7, steps + 3)   # new cameras every scene, announced one scene ahead (as in run_gpu)
     with torch.no_grad():
-        for _ in range(2):
-            out = hp.forward_scene(scene.features, scene.meta)
+        for i in range(2):
+            hp.prefetch_scene(metas[i + 1], device)
+            out = hp.forward_scene(scene.features, metas[i])
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            out = hp.forward_scene(scene.features, scene.meta)
+        for i in range(2, steps + 2):
+            hp.prefetch_scene(metas[i + 1], device)
+            out = hp.forward_scene(scene.features, metas[i])
         torch.cuda.synchronize(device)
     el = time.perf_counter() - t0
     # the network alone on the variance volume of the last scene: fp32 matrix-core roofline (157.3 TFLOP/s dense)
@@ -455,7 +464,7 @@ def side_workload(name, device, steps=3, warmup=1):
     w = WORKLOADS[name]
     a = argparse.Namespace(steps=steps, warmup=warmup, scene_pool=1)
     el, (tab_ms, slab_ms), _, hp, sc = run_gpu(a, w, 0, 1, device)
-    del sc, hp
+    del sc
     torch.cuda.empty_cache()
     nbytes = sweep_bytes_per_cv(w) * (w.get("chunk") or w["N"])
     out = {"sweep_kernel_ms": round(slab_ms, 4), "table_kernel_ms": round(tab_ms, 4),
@@ -463,7 +472,7 @@ def side_workload(name, device, steps=3, warmup=1):
            "frac": round(nbytes / (slab_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
            "stage1_frac": round(nbytes / ((slab_ms + tab_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
            "scenes_per_sec": round(steps / el, 3), "cost_volumes_per_sec": round(w["N"] * steps / el, 2),
-           "voxels": w.get("voxels", N_VOXELS), "dtype": "f32 (f16 storage)" if w.get("half") else "f32"}
+           "geometry_cache": hp.geometry_stats, "voxels": w.get("voxels", N_VOXELS), "dtype": "f32 (f16 storage)" if w.get("half") else "f32"}
     if w.get("chunk"):
         out["views_per_launch"] = w["chunk"]
         out["note"] = "one launch = table + slab kernel of one view chunk"
@@ -570,6 +579,9 @@ def main():
                    "feat_hw": [w["H"], w["W"]], "voxels": w.get("voxels", N_VOXELS), "scenes_per_step_per_gpu": 1,
                    "parallelism": f"scene-sharded x{world}, no data-path collective"},
         "scenes_per_sec": round(args.steps * world / elapsed, 4),
+        # host geometry (a1, a2, a8) of the timed steps: every step's cameras are new -> content_hits must be 0; the
+        # algebra ran `misses` times (on the worker thread, announced one step ahead = prefetch_joins)
+        "geometry_cache_hits": hp.geometry_stats["content_hits"], "geometry_cache": hp.geometry_stats,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": committed_traffic(name)[0],
                      "traffic_source": committed_traffic(name)[1],
@@ -602,6 +614,7 @@ def main():
                                             "table_kernel_ms": round(tm, 4),
                                             "sweep_GBps": round(br / (sm * 1e-3) / 1e9, 1),
                                             "frac": round(br / (sm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                            "geometry_cache": hp_r.geometry_stats,
                                             "stage_ms": stage_breakdown(wr, hp_r, sc_r[0], device)}
             del sc_r, hp_r
             torch.cuda.empty_cache()

@@ -49,8 +49,10 @@ const char* mvsdet_last_error(void);
  *   "sweep_boxcap"  texels of one LDS footprint box (default: what fits, 312 / 200 by the tile shape; 0 = gather every tap
  *                   from global memory)
  *   "sweep_xcd"     0 | 1   XCD-aware block map for fewer than 8 channel slabs
- * "sweep_tw" decides the layout of the sampling table: consume a table (mvsdet_plane_sweep_variance_tabled_f32, the
- * backward pass) under the "sweep_tw" it was built with; the other options may change between the two calls. */
+ * "sweep_tw" decides the layout of the sweep geometry: consume one (mvsdet_plane_sweep_variance_tabled_f32) under the
+ * "sweep_tw" it was built with (mvsdet_plane_sweep_table_f32).  "sweep_boxcap" is baked into the geometry (union boxes,
+ * staged / refill flags); the consuming call sizes its LDS slots for the largest capacity a geometry of that tile shape
+ * can carry, so "sweep_boxcap" and "sweep_xcd" may change between the two calls. */
 int mvsdet_set_option(const char* name /*HOST*/, int value);
 int mvsdet_get_option(const char* name /*HOST*/, int* value /*HOST*/);
 /* HOST check of neighbour view ids before they are uploaded (mvsdet.py:434 feeds them to an index gather, where an

@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .neck import _bn_affine
+from .neck import DerivedTensorsMixin, _bn_affine
 
 
 class _ConvK3S1(torch.autograd.Function):
@@ -157,9 +157,10 @@ def _up(cin: int, cout: int) -> nn.Sequential:
                          nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
 
 
-class CostRegNet3DGS(nn.Module):
+class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
     def __init__(self, in_channels: int = 256, base: int = 64):
         super().__init__()
+        self._init_derived_hooks()
         self.conv0 = _ConvBnReLU3d(in_channels, base)
         self.conv1 = _ConvBnReLU3d(base, 2 * base, stride=2)
         self.conv2 = _ConvBnReLU3d(2 * base, 2 * base)

@@ -54,14 +54,19 @@ template <bool VEC>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, double2* __restrict__ partial, int N, int C,
                                                            size_t vol) {
     const int c = blockIdx.x, split = blockIdx.y;
+    // sums of (x - pivot) and (x - pivot)^2 with the channel's first element as the pivot: E[x^2] - mean^2 on the raw
+    // values cancels catastrophically in fp32 strips when |mean| >> std (a channel behind a large bias: error
+    // ~1e-7 * mean^2 / var); shifted, the strips hold values of the size of the spread
+    const float pv = x[(size_t)c * vol];
     float s = 0.0f, q = 0.0f;
     for_channel_strip<VEC>(N, C, vol, c, split, gridDim.y, [&](size_t off) {
         if (VEC) {
-            const float4 v = *reinterpret_cast<const float4*>(x + off);
+            float4 v = *reinterpret_cast<const float4*>(x + off);
+            v.x -= pv; v.y -= pv; v.z -= pv; v.w -= pv;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         } else {
-            const float v = x[off];
+            const float v = x[off] - pv;
             s += v;
             q += v * v;
         }
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
 }
 
 // one thread per channel: statistics from the partial sums, running statistics, the affine of the apply pass
-__global__ void bn_finalize_kernel(const double2* __restrict__ partial, int nsplit, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const float* __restrict__ x, size_t vol, const double2* __restrict__ partial, int nsplit, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
                                    float* __restrict__ shift, int C, double M, float momentum, float eps) {
@@ -79,8 +84,9 @@ __global__ void bn_finalize_kernel(const double2* __restrict__ partial, int nspl
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int i = 0; i < nsplit; ++i) { s += partial[(size_t)c * nsplit + i].x; q += partial[(size_t)c * nsplit + i].y; }
-    const double mean = s / M;
-    double var = q / M - mean * mean;
+    const double dm = s / M;                      // mean of (x - pivot), pivot = the channel's first element (bn_stats_kernel)
+    const double mean = (double)x[(size_t)c * vol] + dm;
+    double var = q / M - dm * dm;
     var = var < 0.0 ? 0.0 : var;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     save_mean[c] = (float)mean;
@@ -233,7 +239,7 @@ extern "C" int mvsdet_bn3d_relu_train_fwd_f32(const float* x, const float* gamma
     dim3 rgrid((unsigned)C, kBnSplit);
     if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, rgrid, dim3(kThreads), 0, stream, x, w.partial, N, C, (size_t)vol);
     else hipLaunchKernelGGL(bn_stats_kernel<false>, rgrid, dim3(kThreads), 0, stream, x, w.partial, N, C, (size_t)vol);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, w.partial, kBnSplit, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, x, (size_t)vol, w.partial, kBnSplit, gamma, beta, running_mean,
                        running_var, save_mean, save_invstd, w.scale, w.shift, C, (double)N * (double)vol, momentum, eps);
     const size_t cnt = (size_t)vol / (vec ? 4 : 1);
     dim3 agrid((unsigned)std::min<size_t>((cnt + kThreads - 1) / kThreads, 64), (unsigned)C, (unsigned)N);

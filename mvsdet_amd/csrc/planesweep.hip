@@ -125,13 +125,18 @@ int num_tiles(int H, int W, int tw) {
 // texels of one LDS footprint box.  K resident boxes of 128-byte texels share the block's LDS: 80 KiB = two blocks per CU
 // for the 32x4 tiles (their footprints need ~300 texels to form long runs); the 16x8 tiles of maps whose width is no
 // multiple of 32 have smaller footprints and run three blocks per CU on 52 KiB (+5 % at the reference-true shape).
-int effective_box_cap(int K, int tw) {
+// the largest capacity a table of this (K, tile shape) can have been built with, whatever "sweep_boxcap" said then
+int max_box_cap(int K, int tw) {
     if (K <= 0) return 0;
-    int cap = options().sweep_boxcap;
     const int budget = (tw == 16 && K <= 2) ? 52 * 1024 : 80 * 1024;
     const int fit = (budget / 128) / K - kBoxPad;
-    cap = cap < 0 ? 0 : (cap > fit ? fit : cap);
-    return cap > 512 ? 512 : cap;
+    return fit > 512 ? 512 : fit;
+}
+
+int effective_box_cap(int K, int tw) {
+    if (K <= 0) return 0;
+    const int cap = options().sweep_boxcap, fit = max_box_cap(K, tw);
+    return cap < 0 ? 0 : (cap > fit ? fit : cap);
 }
 
 template <typename F>
@@ -198,7 +203,10 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         return MVSDET_ERR_INVALID_ARG;
     }
     const bool fast = (C % kSlab == 0) && (W % 4 == 0);   // whole float4 stores of whole slabs (see the kernel)
-    const int box_cap = effective_box_cap(K, TW);
+    // A call that only CONSUMES a geometry (phases == 2) cannot know the capacity it was built with -- the staged /
+    // refill flags and the union boxes carry it implicitly -- so its LDS slots are sized for the largest capacity any
+    // geometry of this (K, tile shape) can have: "sweep_boxcap" may change between the two calls without harm.
+    const int box_cap = (phases == 2) ? max_box_cap(K, TW) : effective_box_cap(K, TW);
     // every block sweeps all its planes (reference features stay in registers, a resident footprint box serves a run
     // of planes) unless the grid would be too small to fill 256 CUs x 2 blocks
     int dsplit = 1;
@@ -251,6 +259,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
 namespace mvsdet {
 int sweep_tile_width(int W, int D) { return pick_tile_width(W, D); }  // shared with planesweep_bwd.hip
 int sweep_box_cap(int K, int tw) { return effective_box_cap(K, tw); }
+int sweep_max_box_cap(int K, int tw) { return max_box_cap(K, tw); }
 }
 
 // The tile shape and LDS box capacity the sweep uses for this problem (the layout of the geometry in the scratch buffer

@@ -23,6 +23,8 @@ from typing import List, Sequence, Tuple
 import torch
 from torch import Tensor, nn
 
+from .neck import DerivedTensorsMixin
+
 
 class Scale(nn.Module):
     """mmcv.cnn.Scale: a learnable scalar factor (parameter name `scale`)."""
@@ -35,7 +37,7 @@ class Scale(nn.Module):
         return x * self.scale
 
 
-class NerfDetHeadConvs(nn.Module):
+class NerfDetHeadConvs(DerivedTensorsMixin, nn.Module):
     """The learnable layers of NerfDetHead and their forward pass (nerfdet_head.py:94-118)."""
 
     def __init__(self, n_classes: int = 18, n_levels: int = 3, n_channels: int = 128, n_reg_outs: int = 6,
@@ -47,7 +49,8 @@ class NerfDetHeadConvs(nn.Module):
         self.conv_reg = nn.Conv3d(n_channels, n_reg_outs, 3, padding=1, bias=False)
         self.conv_cls = nn.Conv3d(n_channels, n_classes, 3, padding=1)
         self.scales = nn.ModuleList([Scale(1.0) for _ in range(n_levels)])
-        self._fused = None   # (key, permuted fused weight)
+        self._fused = None   # (key, permuted fused weight); dropped on train()/eval() and load_state_dict
+        self._init_derived_hooks()
 
     def init_weights(self):
         """nerfdet_head.py:104-108: normal_init(std=0.01), classification bias for a prior probability of 0.01."""

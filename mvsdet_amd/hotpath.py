@@ -35,9 +35,13 @@ class SceneGeometry:
 
 class _GeometryWorker:
     """One daemon thread per MVSDetHotPath: evaluates `_host_geometry` (ATen-CPU, one intra-op thread -- set ONCE, in this
-    thread), packs the results into a pinned staging buffer and uploads them with a single asynchronous copy on its own
-    stream.  Entries are kept by the CONTENT of the camera data (a 16-byte digest of extrinsics, intrinsics, origin and
-    image shapes: ~15 us for 40 views), so a scene presented again -- the next epoch, a new dict -- costs a lookup."""
+    thread; note that torch.set_num_threads also sets MKL's process-wide thread count), packs the results into a pinned
+    staging buffer and uploads them with a single asynchronous copy on its own stream.  What hides the camera algebra in a
+    real pipeline is `prefetch_scene`: the data loader knows the next scene while the current one runs.  Entries are also
+    kept by the CONTENT of the camera data (a 16-byte digest of extrinsics, intrinsics, origin and image shapes), which
+    only pays when the very same cameras AND origin come again (loss + predict on one batch, repeated evaluation): the
+    reference's training pipeline re-samples the views and shifts the origin per item (multiview_pipeline.py:141,
+    RandomShiftOrigin), so there every scene is a miss.  `stats` counts the three cases."""
 
     _ALIGN = 16
 
@@ -51,6 +55,9 @@ class _GeometryWorker:
         self.todo: "queue.Queue" = queue.Queue()
         self.thread = None
         self.streams: dict = {}
+        # prefetch_joins: prepare_scene found the entry its own prefetch_scene made (same dict object);
+        # content_hits: an entry made for ANOTHER dict with the same camera bytes; misses: algebra + upload ran
+        self.stats = {"misses": 0, "prefetch_joins": 0, "content_hits": 0}
 
     def _start(self):
         import threading
@@ -60,8 +67,7 @@ class _GeometryWorker:
 
     @staticmethod
     def _content_key(img_meta: dict, device):
-        """The camera data the geometry depends on, as bytes: a training epoch presents the same scenes again (new dicts,
-        same cameras; RandomShiftOrigin only moves `origin`, which enters through the voxel points alone)."""
+        """The camera data the geometry depends on, as bytes (`origin` included: the voxel points hang on it)."""
         import hashlib
         l2i = img_meta["lidar2img"]
         h = hashlib.blake2b(digest_size=16)
@@ -71,24 +77,30 @@ class _GeometryWorker:
         h.update(repr((tuple(img_meta["img_shape"][:2]), tuple(img_meta["ori_shape"][:2]), isinstance(l2i["intrinsic"], list))).encode())
         return (h.digest(), str(device))
 
-    def submit(self, img_meta: dict, device):
+    def submit(self, img_meta: dict, device, count: bool = False):
         import threading
         key = self._content_key(img_meta, device)
         with self.lock:
             ent = self.entries.get(key)
             if ent is not None:
+                if count:
+                    self.stats["prefetch_joins" if ent[0] is img_meta else "content_hits"] += 1
+                self.entries[key] = self.entries.pop(key)   # most recently used last
                 return ent
-            if len(self.entries) >= self.max_entries:   # drop the oldest finished entries
-                for k in [k for k, e in self.entries.items() if e[2].is_set()][: self.max_entries // 2]:
-                    del self.entries[k]
+            while len(self.entries) >= self.max_entries:    # least recently used finished entry first
+                old = next((k for k, e in self.entries.items() if e[2].is_set()), None)
+                if old is None:
+                    break
+                del self.entries[old]
             ent = [img_meta, device, threading.Event(), None, None]
             self.entries[key] = ent
+            self.stats["misses"] += 1
         self._start()
         self.todo.put(ent)
         return ent
 
     def get(self, img_meta: dict, device) -> "SceneGeometry":
-        ent = self.submit(img_meta, device)
+        ent = self.submit(img_meta, device, count=True)
         ent[2].wait()
         if isinstance(ent[3], BaseException):
             with self.lock:
@@ -98,6 +110,7 @@ class _GeometryWorker:
             cur = torch.cuda.current_stream(device)
             cur.wait_event(ent[4])
             ent[3].neighbor_ids.record_stream(cur)   # all four views share the one uploaded buffer
+            ent[3].points.record_stream(cur)         # allocated under the worker's stream too (its own block)
         return ent[3]
 
     def _run(self):
@@ -249,9 +262,11 @@ class MVSDetHotPath:
         if pts is None:
             pts = F_.get_points(n_voxels=torch.tensor(self.n_voxels), voxel_size=torch.tensor(self.voxel_size),
                                 origin=origin).to(device)
-            if len(self._points_cache) > 64:
-                self._points_cache.clear()
-            self._points_cache[key] = pts
+            while len(self._points_cache) >= 64:          # least recently used first; a dropped tensor that is still being
+                self._points_cache.pop(next(iter(self._points_cache)))   # read is protected by record_stream (worker.get)
+        else:
+            self._points_cache.pop(key)
+        self._points_cache[key] = pts
         return pts
 
     # ---- the hot path -------------------------------------------------------------------------------------

@@ -35,9 +35,34 @@ class _ConvModule(nn.Module):
         return F.relu(x, inplace=True) if self.with_act else x
 
 
+_DERIVED = ("_mvs_affine", "_fused", "_mvs_wsplit")   # tensors computed from parameters and kept on a module
+
+
+def drop_derived_tensors(root: nn.Module) -> None:
+    """Forget every tensor this package derived from `root`'s parameters (BatchNorm affines, fused / permuted / split
+    weights).  The caches key on (data_ptr, _version), which an in-place update through `.data` does not bump (mmengine's
+    EMAHook swaps parameters that way) -- so they are also dropped on every train()/eval() switch and after
+    load_state_dict (`DerivedTensorsMixin`); call this by hand after any other out-of-band `.data` write."""
+    for m in root.modules():
+        for name in _DERIVED:
+            if m.__dict__.get(name) is not None:
+                m.__dict__[name] = None
+
+
+class DerivedTensorsMixin:
+    """nn.Module mixin of the modules that own derived-tensor caches: mode switches and state-dict loads drop them."""
+
+    def _init_derived_hooks(self):
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: drop_derived_tensors(module))
+
+    def train(self, mode: bool = True):
+        drop_derived_tensors(self)
+        return super().train(mode)
+
+
 def _bn_affine(bn: nn.BatchNorm3d):
     """Eval-mode BatchNorm as a per-channel affine; kept on the module until one of its four tensors changes (five tiny
-    kernels per layer otherwise: a twentieth of the neck's time at one scene)."""
+    kernels per layer otherwise: a twentieth of the neck's time at one scene) or `drop_derived_tensors` runs."""
     key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
     cached = getattr(bn, "_mvs_affine", None)
     if cached is None or cached[0] != key:
@@ -124,11 +149,12 @@ class _OutBlock(nn.Sequential):
         return super().forward(x)
 
 
-class IndoorImVoxelNeck(nn.Module):
+class IndoorImVoxelNeck(DerivedTensorsMixin, nn.Module):
     """imvoxel_neck.py:70-131: x (N, C_in, Nx, Ny, Nz) -> list of n_scales tensors (N, C_out, Nx/2^i, Ny/2^i, Nz/2^i)."""
 
     def __init__(self, in_channels: int, out_channels: int, n_blocks: Sequence[int]):
         super().__init__()
+        self._init_derived_hooks()
         self.n_scales = len(n_blocks)
         n_channels = in_channels
         for i, nb in enumerate(n_blocks):

@@ -485,6 +485,19 @@ def test_sweep_variants_are_bit_identical(gpu):
     finally:
         for k, v in saved.items():
             _lib.set_option(k, v)
+    # a geometry built under one "sweep_boxcap" and consumed under another (include/mvsdet_hip.h: the consuming call
+    # sizes its LDS slots for the largest capacity the tile shape allows; the geometry carries its own runs)
+    packed, nbr, proj, depth = args[:4]
+    D = depth.shape[1]
+    try:
+        for build, consume in ((saved["sweep_boxcap"], 0), (saved["sweep_boxcap"], 40), (40, saved["sweep_boxcap"]), (0, 200)):
+            _lib.set_option("sweep_boxcap", build)
+            table = ops.plane_sweep_table(proj, depth, H, W)
+            _lib.set_option("sweep_boxcap", consume)
+            assert torch.equal(ops.plane_sweep_variance_tabled(packed, nbr, table, C, D, H, W), ref), (build, consume)
+    finally:
+        for k, v in saved.items():
+            _lib.set_option(k, v)
     with pytest.raises(ValueError):
         _lib.set_option("no_such_option", 1)
 
@@ -594,7 +607,8 @@ def test_view_shards_reassemble_the_scene(gpu, oracle):
 
 
 # --------------------------------------------------------------------------------------------- fp16 storage (configs[4])
-@pytest.mark.parametrize("N,C,D,H,W,chunk", [(5, 40, 6, 24, 32, 2), (3, 32, 4, 33, 47, 3), (4, 256, 3, 20, 28, 1)])
+@pytest.mark.parametrize("N,C,D,H,W,chunk", [(5, 40, 6, 24, 32, 2), (3, 32, 4, 33, 47, 3), (4, 256, 3, 20, 28, 1),
+                                               (3, 32, 128, 10, 12, 2), (4, 64, 128, 12, 64, 3)])
 def test_fp16_storage_and_view_chunks(gpu, oracle, N, C, D, H, W, chunk):
     """fp16 feature maps in, fp16 cost volume out, produced in chunks of reference views: the arithmetic is the
     fp32 path's, so the result must equal the oracle's fp32 variance of the (exactly converted) half features,
@@ -632,6 +646,59 @@ def test_fp16_storage_and_view_chunks(gpu, oracle, N, C, D, H, W, chunk):
     vol2, valid2 = hp.lift(feat16.float().to(gpu), packed, geo, ed, en)
     assert torch.equal(valid, valid2)
     np.testing.assert_allclose(vol.cpu().numpy(), vol2.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_stress_config_full_size(gpu, oracle):
+    """BASELINE configs[4] as worded and at its size: 100 views x 128 planes x 240x320 (HxW) maps, C=256, fp16 feature maps
+    in and fp16 cost volume out (503 GB) produced in chunks of 10 reference views (50 GB each) through
+    `cost_volume_chunks(..., half_out=True)` -- the route bench.py times.  Views spread over three chunks are recomputed
+    by the oracle (mode 1) on their 3-view sub-scene {view, neighbour 0, neighbour 1}, 8 channels each, and rounded to
+    fp16 to nearest-even: bit for bit.  One chunk is produced again from doubled features: exactly 4x wherever the
+    fp16 value is normal (fp32 arithmetic scales exactly; fp16 rounding commutes with a power of two outside the
+    subnormal range), finite and non-negative up to rounding everywhere."""
+    free = torch.cuda.mem_get_info(gpu)[0]
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~175 GB of free HBM (three 50 GB chunks + the packed maps)")
+    from mvsdet_amd import ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw, chunk = 100, 256, 128, (240, 320), 10
+    hp = MVSDetHotPath([40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], D)
+    feat16 = synthetic.make_features(N, C, hw, seed=5, device=gpu).half()
+    geo = hp.prepare_scene(synthetic.make_img_meta(N, hw, seed=5), gpu)
+    packed = ops.pack_features(feat16)
+    assert packed.dtype == torch.float32
+    probes = {3: [0, 31, 32, 100, 129, 200, 254, 255], 47: [1, 30, 33, 64, 127, 128, 191, 255], 99: [7, 8, 15, 16, 95, 96, 223, 224]}
+    seen, kept = [], None
+    for first, var in hp.cost_volume_chunks(packed, geo, C, hw[0], hw[1], chunk, half_out=True):
+        assert var.dtype == torch.float16 and var.shape == (min(chunk, N - first), C, D, hw[0], hw[1])
+        for n0, ch in probes.items():
+            if first <= n0 < first + var.shape[0]:
+                nb = geo.neighbor_ids[n0].tolist()
+                sub_feat = feat16[[n0] + nb][:, ch].float().cpu()
+                sub = oracle.plane_sweep_variance(sub_feat, np.array([[1, 2], [0, 2], [0, 1]]), np.stack(
+                    [geo.proj_rel[n0].cpu().numpy()] * 3), geo.depth_values[:3].cpu(), mode=1)
+                with np.errstate(over="ignore"):
+                    ref16 = sub[0].astype(np.float16)
+                got = var[n0 - first, ch].cpu().numpy()
+                np.testing.assert_array_equal(got.view(np.uint16), ref16.view(np.uint16))
+                seen.append(first)
+        if first == 40:
+            kept = var            # the chunk of views 40..49 stays for the scaling property
+        else:
+            assert bool(torch.isfinite(var[::3, ::37, ::5]).all())
+        del var
+    assert sorted(set(seen)) == [0, 40, 90] and kept is not None
+    packed2 = ops.pack_features(feat16 * 2.0)      # exact in fp16 (|f| < 6 sigma)
+    sl = slice(40, 50)
+    var2 = ops.plane_sweep_variance_shard(packed2, geo.neighbor_ids[sl], geo.proj_rel[sl], geo.depth_values[sl], N, 40, C,
+                                          hw[0], hw[1], True)
+    tiny = 2.0 ** -14                              # smallest normal fp16
+    for i in range(chunk):                         # view by view: temporaries of 5 GB
+        a, b = kept[i].float(), var2[i].float()
+        assert bool(torch.isfinite(b).all()) and float(a.min()) > -1e-3
+        normal = a >= tiny
+        assert torch.equal(b[normal], a[normal] * 4.0)
+        assert float((b - a * 4.0).abs().max()) <= 4 * 2.0 ** -24
 
 
 # --------------------------------------------------------------------------------------------- HIP graph capture
@@ -1098,6 +1165,28 @@ def test_batchnorm_relu_training_kernels(gpu, N, C, D, H, W, relu):
     np.testing.assert_allclose(invstd.detach().cpu().numpy(), (1.0 / torch.sqrt(x.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5)).numpy(), rtol=1e-5)
     for got, want in ((xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(want.abs().max())))
+
+
+def test_batchnorm_training_statistics_of_offset_channels(gpu):
+    """Channels whose mean is ~1000x their spread (behind a large bias): E[x^2] - mean^2 on raw fp32 strips would lose the
+    variance entirely; the kernel sums around a per-channel pivot.  Against a float64 evaluation (torch.nn.BatchNorm3d
+    uses Welford and is itself within 1e-4 here)."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(77)
+    N, C, D, H, W = 3, 6, 4, 10, 12
+    off = torch.tensor([1000.0, -1000.0, 300.0, 0.0, 5000.0, -50.0]).view(1, C, 1, 1, 1)
+    x = torch.randn(N, C, D, H, W, generator=g) * torch.tensor([1.0, 0.5, 0.3, 2.0, 4.0, 0.05]).view(1, C, 1, 1, 1) + off
+    wgt, b = torch.ones(C), torch.zeros(C)
+    out, mean, invstd = ops.bn3d_relu_train(x.to(gpu), wgt.to(gpu), b.to(gpu), 1e-5, False)
+    x64 = x.double()
+    m64 = x64.mean(dim=(0, 2, 3, 4))
+    v64 = x64.var(dim=(0, 2, 3, 4), unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), m64.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(v64 + 1e-5)).numpy(), rtol=2e-5)
+    ref = ((x64 - m64.view(1, C, 1, 1, 1)) / torch.sqrt(v64 + 1e-5).view(1, C, 1, 1, 1)).float()
+    # fp32 x * scale + shift at |x| = 5000 carries a few ulp(|x| / std) of absolute error: compare at that scale
+    tol = (x.abs().amax(dim=(0, 2, 3, 4)) * 6e-7 / torch.sqrt(v64.float())).view(1, C, 1, 1, 1) + 1e-5
+    assert bool(((out.cpu() - ref).abs() <= tol).all())
 
 
 def test_cost_network_training_mode_batchnorm(gpu):
