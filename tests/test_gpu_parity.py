@@ -529,6 +529,7 @@ def test_full_size_64_plane_shape(gpu, oracle):
     """BASELINE configs[1] at full size (40 views, 64 planes, 120x160, C=256: a 50 GB cost volume): exact x4
     scaling, finiteness, and a slice (one reference view, 8 channels) recomputed by the oracle on the 3-view
     sub-scene {view, neighbour 0, neighbour 1}."""
+    torch.cuda.empty_cache()
     free = torch.cuda.mem_get_info(gpu)[0]
     if free < 130 * (1 << 30):
         pytest.skip("needs ~110 GB of free HBM")
@@ -656,6 +657,7 @@ def test_stress_config_full_size(gpu, oracle):
     fp16 to nearest-even: bit for bit.  One chunk is produced again from doubled features: exactly 4x wherever the
     fp16 value is normal (fp32 arithmetic scales exactly; fp16 rounding commutes with a power of two outside the
     subnormal range), finite and non-negative up to rounding everywhere."""
+    torch.cuda.empty_cache()   # blocks cached by earlier tests count as used in mem_get_info
     free = torch.cuda.mem_get_info(gpu)[0]
     if free < 200 * (1 << 30):
         pytest.skip("needs ~175 GB of free HBM (three 50 GB chunks + the packed maps)")
