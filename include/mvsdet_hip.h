@@ -323,6 +323,25 @@ int mvsdet_backproject_weigh_mean_bwd_f32(const float* feat, const int64_t* feat
                                           mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The cost network's 3x3x3 convolutions on the bf16 matrix cores, fp32 operands cut into bf16 pieces ("bf16x3":
+ * x*w ~ x_hi*w_hi + x_hi*w_mid + x_mid*w_hi, fp32 accumulation; csrc/costreg_bf16.hip).  Replaces the same layers of
+ * mvs_models/mvsnet.py:76-82,104-108 as mvsdet_conv3d_k3_mfma_f32 does, at 3/16 of the fp32 matrix-core time; results
+ * differ from an fp32 convolution by ~2^-16 of the products' size (logits of the network: 2e-6 .. 4e-6, bar 1e-4).
+ *
+ * "SCL" (split channel-last) activations: xs[piece 2][n][c8 = ceil(C/8)][Dp][Hp][Wp][8] bf16, piece = hi | mid,
+ * (dp,hp,wp) = (d,h,w) + 1 inside a zero border; Dp/Hp/Wp and the size in bytes come from mvsdet_scl_bytes.
+ * mvsdet_scl_pack_f32 cuts an (N,C,D,H,W) fp32 tensor (zero_border != 0: clear the buffer first; a buffer reused for the
+ * same shape needs that once).  weight_split: [Cout/64][c8][14 tap pairs][2 groups of 32 outputs][2 pieces][64 lanes][8]
+ * bf16, lane = 32 * (tap parity) + output % 32, tap 27 and channels >= Cin zero (mvsdet_amd.ops.split_conv_weight).
+ * out (N,Cout,D,H,W) fp32 = [relu]([scale *] conv [+ shift] [+ residual]).  Stride 1, Cout % 64 == 0.
+ * ------------------------------------------------------------------------------------------- */
+size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp /*HOST, may be NULL*/, int* Hp, int* Wp);
+int mvsdet_scl_pack_f32(const float* x, void* xs, int N, int C, int D, int H, int W, int zero_border, mvsdet_stream_t stream);
+int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                            const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                            mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement helper for bench.py: runs `fn`-independent HIP-event timing is done by the caller;
  * this only exposes a device-to-device float4 copy so the achievable HBM ceiling can be calibrated
  * on the same box (SURVEY.md section 8d "Roofline").

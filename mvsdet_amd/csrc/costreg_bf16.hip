@@ -1,0 +1,343 @@
+// 3x3x3 convolutions of the cost regularisation network (mvs_models/mvsnet.py:76-82,104-108) on the bf16 matrix cores
+// with fp32 operands cut into bf16 pieces ("bf16x3"):
+//
+//     x = x_hi + x_mid (+ 2^-16 |x|),  w = w_hi + w_mid (+ ...),   x*w ~ x_hi*w_hi + x_hi*w_mid + x_mid*w_hi
+//
+// Every product of two bf16 pieces is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the three
+// MFMAs leave out only the terms of relative size 2^-16 (x_mid*w_mid, x_lo*w_hi, x_hi*w_lo): measured on the network
+// (tools/study/split_bf16_emulation.py, G8 fixture) 2e-6 .. 4e-6 on the logits, 5e-7 on the depth probabilities -- the
+// north_star bar is 1e-4 -- where plain bf16 operands give 1e-3.  Three bf16 MFMAs cost 3/16 of the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32 runs at the vector rate: MI355X_MICROARCH.md, Matrix cores).
+//
+// Data layout ("split channel-last", SCL): a producer cuts the activations once,
+//     xs[piece][n][c8][dp][hp][wp][8]   bf16, piece = hi | mid, c8 = channel / 8, (dp,hp,wp) = (d,h,w) + 1,
+// with a zero border of one voxel (and up to a tile beyond D, H, W) around every volume, so the convolution reads
+// whole halo tiles without a bounds test.  One voxel's 8 channels of one piece are 16 bytes: one lane of an LDS-DMA
+// (global_load_lds_dwordx4), one ds_read_b128, one MFMA B fragment.
+//
+// Implicit GEMM, D[o][v] += A[o][k] * B[k][v]:  the 16 k of an MFMA are (tap parity, 8 channels): lane half h = lane >> 5
+// reads tap 2p + h of tap pair p -- the 27 taps make 14 pairs, the last one half empty (zero weights): 27/28 of the
+// matrix work is useful and a stage is 8 channels deep, which is what lets two stages of input fit the LDS.
+//   block  = (view, 4 x TH x 16 output voxels, 64 output channels), TH waves: 8 (4x8x16) or 12 (4x12x16: 60 rows = 5 tiles,
+//            three waves on every SIMD; a 6-wave tile would leave two SIMDs with one wave and two with two)
+//   wave   = 64 voxels (4 h-rows x 16 = two column groups of 32) x 64 channels (two row groups) = 4 accumulators 32x32
+//   LDS    = input halo tile of 8 channels, both pieces, double buffered  +  the weights of 5 tap pairs x 64 x 8,
+//            both pieces, double buffered (three weight sub-stages per 8 channels); all of it filled by LDS-DMA
+//   per tap pair and wave: 4 A + 4 B ds_read_b128 feed 12 MFMAs (2 x 2 accumulators x 3 terms)
+// One barrier per weight sub-stage: wait for the own DMAs of the stage, barrier, issue the DMAs of the next stage into
+// the buffers the barrier has just freed, compute.
+#include "common.h"
+
+#include <algorithm>
+
+namespace mvsdet {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+
+constexpr int kBfW = 16;             // tile width (voxels along w): one MFMA column group = 2 h-rows of 16
+constexpr int kBfPairs = 14;         // tap pairs (27 taps + 1 empty)
+constexpr int kBfSubPairs = 5;       // tap pairs per weight sub-stage (5 + 5 + 4)
+constexpr int kBfWSlots = kBfSubPairs * 2 * 2 * 64;   // 16-byte slots of one weight buffer: [pair][row group][piece][lane]
+
+__host__ __device__ constexpr int bf_in_slots(int TD, int TH) {   // 16-byte slots of one piece of one input buffer
+    return ((TD + 2) * (TH + 2) * (kBfW + 2) + 63) / 64 * 64;
+}
+__host__ __device__ constexpr size_t bf_lds_bytes(int TD, int TH) {
+    return (size_t)(2 * 2 * bf_in_slots(TD, TH) + 2 * kBfWSlots) * 16;
+}
+
+// fp32 NCDHW -> SCL (both pieces), interior voxels only: the border stays as the caller zeroed it.
+// thread = one voxel x 8 channels: 8 coalesced channel-row reads, two 16-byte stores.
+__global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restrict__ x, uint4* __restrict__ xs, int C, int C8,
+                                                            int D, int H, int W, int Dp, int Hp, int Wp, size_t piece_stride) {
+    const size_t vol = (size_t)D * H * W;
+    const size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (v >= vol) return;
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    const int d = (int)(v / ((size_t)H * W)), r = (int)(v - (size_t)d * H * W), h = r / W, w = r - h * W;
+    const float* src = x + ((size_t)n * C + (size_t)c8 * 8) * vol + v;
+    unsigned hi[4], mid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float f[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) f[e] = (c8 * 8 + 2 * j + e < C) ? src[(size_t)(2 * j + e) * vol] : 0.0f;
+        unsigned short hb[2], mb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const __bf16 a = (__bf16)f[e];               // round to nearest even (v_cvt_pk_bf16_f32)
+            const __bf16 b = (__bf16)(f[e] - (float)a);  // exact difference, rounded once
+            hb[e] = __builtin_bit_cast(unsigned short, a);
+            mb[e] = __builtin_bit_cast(unsigned short, b);
+        }
+        hi[j] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+        mid[j] = (unsigned)mb[0] | ((unsigned)mb[1] << 16);
+    }
+    const size_t o = (((size_t)n * C8 + c8) * Dp + (d + 1)) * Hp * Wp + (size_t)(h + 1) * Wp + (w + 1);
+    xs[o] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    xs[piece_stride + o] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+}
+
+// tap t of the 3x3x3 kernel as an offset in halo voxels; tap 27 (the empty half of pair 13) aliases tap 26
+template <int HH>
+__host__ __device__ constexpr int bf_tap_off(int t) {
+    const int u = t > 26 ? 26 : t;
+    return ((u / 9) * HH + (u / 3) % 3) * (kBfW + 2) + u % 3;
+}
+
+template <int TD, int TH>
+__global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
+    const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
+    size_t piece_stride, int tiles_w, int relu) {
+    constexpr int NW = TD * TH / 4;                       // waves
+    constexpr int HD = TD + 2, HH = TH + 2, HW = kBfW + 2;
+    constexpr int NVOX = HD * HH * HW;
+    constexpr int INS = bf_in_slots(TD, TH);              // slots per piece
+    constexpr int IN_DMA = INS / 64;                      // wave-instructions per piece and stage
+    constexpr int IN_PER_WAVE = (2 * IN_DMA + NW - 1) / NW;
+    extern __shared__ uint4 s_bf[];   // [2 stages][2 pieces][INS] input, then [2 stages][kBfWSlots] weights
+    uint4* s_in = s_bf;
+    uint4* s_w = s_bf + 2 * 2 * INS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int nob = Cout / 64;
+    const int n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int col = lane & 31, hh = lane >> 5;
+
+    // ---- DMA plans.  Input: wave-instruction i of a stage = (piece i / IN_DMA, slots 64*(i % IN_DMA) ..); the lane's slot
+    // is a halo voxel (dz, hy, wx) -> its address in the padded volume (slots beyond the halo re-read voxel 0).
+    const size_t c8_stride = (size_t)Dp * Hp * Wp;
+    const uint4* xn = xs + ((size_t)n * C8) * c8_stride + ((size_t)d0 * Hp + h0) * Wp + w0;
+    unsigned in_src[IN_PER_WAVE];   // 16-byte units relative to xn (piece and channel group added per stage)
+#pragma unroll
+    for (int k = 0; k < IN_PER_WAVE; ++k) {
+        const int i = wave + k * NW;
+        const int slot = (i % IN_DMA) * 64 + lane;
+        const int sv = slot < NVOX ? slot : 0;
+        const int dz = sv / (HH * HW), r = sv - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
+        in_src[k] = (unsigned)(((size_t)dz * Hp + hy) * Wp + wx);
+    }
+    auto dma_input = [&](int c8, int buf) {
+#pragma unroll
+        for (int k = 0; k < IN_PER_WAVE; ++k) {
+            const int i = wave + k * NW;   // wave-uniform
+            if (i < 2 * IN_DMA) {
+                const int piece = i / IN_DMA;
+                const uint4* src = xn + (size_t)piece * piece_stride + (size_t)c8 * c8_stride + in_src[k];
+                uint4* dst = s_in + (size_t)(buf * 2 + piece) * INS + (i % IN_DMA) * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    // Weights: wq[ob64][c8][pair 14][row group 2][piece 2][lane 64] in 16-byte units; sub-stage s = pairs 5s .. 5s+4
+    const uint4* wn = wq + (size_t)ob64 * C8 * (kBfPairs * 4 * 64);
+    auto dma_weights = [&](int c8, int s, int buf) {
+        const int ninstr = (s == 2 ? kBfPairs - 2 * kBfSubPairs : kBfSubPairs) * 4;
+        const uint4* src0 = wn + ((size_t)c8 * kBfPairs + s * kBfSubPairs) * (4 * 64) + lane;
+        for (int i = wave; i < ninstr; i += NW) {
+            uint4* dst = s_w + (size_t)buf * kBfWSlots + i * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 64),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    // ---- the wave's two column groups: g = 2*wave + b, plane g / (TH/2), h-rows 2*(g % (TH/2)) + {0,1}; column c of a
+    // group = voxel (row c / 16, w = c % 16)
+    int vb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int g = 2 * wave + b;
+        const int dz = g / (TH / 2), hy = 2 * (g % (TH / 2)) + (col >> 4);
+        vb[b] = (dz * HH + hy) * HW + (col & 15);
+    }
+
+    f32x16b acc[2][2];   // [row group (32 output channels)][column group]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const bf16x8* s_in8 = reinterpret_cast<const bf16x8*>(s_in);
+    const bf16x8* s_w8 = reinterpret_cast<const bf16x8*>(s_w);
+
+    auto compute = [&](auto sc, int ibuf, int wbuf) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int np = (s == 2 ? kBfPairs - 2 * kBfSubPairs : kBfSubPairs);
+        const bf16x8* bin = s_in8 + (size_t)(ibuf * 2) * INS;
+        const bf16x8* ain = s_w8 + (size_t)wbuf * kBfWSlots + lane;
+#pragma unroll
+        for (int pl = 0; pl < np; ++pl) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int p = s * kBfSubPairs + pl;
+            const int toff = hh ? bf_tap_off<HH>(2 * p + 1) : bf_tap_off<HH>(2 * p);
+            bf16x8 A[2][2], B[2][2];   // [row / column group][piece]
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) A[a][q] = ain[((pl * 2 + a) * 2 + q) * 64];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb[b] + toff];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], acc[a][b], 0, 0, 0);   // w_mid * x_hi
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], acc[a][b], 0, 0, 0);   // w_hi * x_mid
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], acc[a][b], 0, 0, 0);   // w_hi * x_hi
+                }
+        }
+    };
+
+    // ---- pipeline over the flat stage index q = 3*c8 + s
+    dma_input(0, 0);
+    dma_weights(0, 0, 0);
+    for (int c8 = 0; c8 < C8; ++c8) {
+        const int ibuf = c8 & 1;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int wbuf = (c8 * 3 + s) & 1;
+            // this wave's DMAs of the current stage have landed; after the barrier everybody's have, and everybody is done
+            // reading the buffers the next stage's DMAs (issued right below) overwrite
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) only (expcnt 7, lgkmcnt 15 untouched)
+            __builtin_amdgcn_s_barrier();
+            if (s < 2) {
+                dma_weights(c8, s + 1, wbuf ^ 1);
+            } else if (c8 + 1 < C8) {
+                dma_weights(c8 + 1, 0, wbuf ^ 1);
+            }
+            if (s == 0 && c8 + 1 < C8) dma_input(c8 + 1, ibuf ^ 1);
+            if (s == 0) compute(std::integral_constant<int, 0>{}, ibuf, wbuf);
+            else if (s == 1) compute(std::integral_constant<int, 1>{}, ibuf, wbuf);
+            else compute(std::integral_constant<int, 2>{}, ibuf, wbuf);
+        }
+    }
+
+    // ---- epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (voxel), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int g = 2 * wave + b;
+        const int d = d0 + g / (TH / 2), h = h0 + 2 * (g % (TH / 2)) + (col >> 4), w = w0 + (col & 15);
+        if (d >= D || h >= H || w >= W) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = acc[a][b][r];
+                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+                if (scale) v = fmaf(v, scale[o], shift[o]);
+                if (residual) v = v + residual[idx];
+                if (relu) v = fmaxf(v, 0.0f);
+                out[idx] = v;
+            }
+    }
+}
+
+}  // namespace mvsdet
+
+using namespace mvsdet;
+
+namespace {
+struct BfPlan {
+    int td, th, tiles_d, tiles_h, tiles_w, Dp, Hp, Wp;
+};
+// tile = 4 x TH x 16 with TH = 8 or 12, whichever pads H less (60 rows: 12); padded extents = tiles + the one-voxel border
+BfPlan bf_plan(int D, int H, int W) {
+    BfPlan p;
+    p.td = 4;
+    const int pad8 = (H + 7) / 8 * 8, pad12 = (H + 11) / 12 * 12;
+    p.th = pad12 < pad8 ? 12 : 8;
+    p.tiles_d = (D + p.td - 1) / p.td;
+    p.tiles_h = (H + p.th - 1) / p.th;
+    p.tiles_w = (W + kBfW - 1) / kBfW;
+    p.Dp = p.tiles_d * p.td + 2;
+    p.Hp = p.tiles_h * p.th + 2;
+    p.Wp = p.tiles_w * kBfW + 2;
+    return p;
+}
+}  // namespace
+
+// Geometry of the split channel-last form of an (N,C,D,H,W) activation: padded extents and total bytes (both pieces).
+extern "C" size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp, int* Hp, int* Wp) {
+    if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const BfPlan p = bf_plan(D, H, W);
+    if (Dp) *Dp = p.Dp;
+    if (Hp) *Hp = p.Hp;
+    if (Wp) *Wp = p.Wp;
+    return (size_t)2 * N * ((C + 7) / 8) * p.Dp * p.Hp * p.Wp * 16;
+}
+
+// x (N,C,D,H,W) fp32 -> xs (SCL, mvsdet_scl_bytes).  The border of xs must be zero: `zero_border` != 0 clears the whole
+// buffer first (one memset; a caller that reuses the buffer for the same shape clears it once and passes 0).
+extern "C" int mvsdet_scl_pack_f32(const float* x, void* xs, int N, int C, int D, int H, int W, int zero_border,
+                                   mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && xs, "scl_pack: NULL pointer");
+    MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, "scl_pack: bad shape N=%d C=%d D=%d H=%d W=%d", N, C, D, H, W);
+    MVS_REQUIRE(((uintptr_t)xs & 15u) == 0, "scl_pack: xs must be 16-byte aligned");
+    const BfPlan p = bf_plan(D, H, W);
+    const int C8 = (C + 7) / 8;
+    MVS_REQUIRE(N <= 65535 && C8 <= 65535, "scl_pack: N or C too large");
+    const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_border && hipMemsetAsync(xs, 0, 2 * piece * 16, st) != hipSuccess) {
+        set_error("scl_pack: hipMemsetAsync failed");
+        return MVSDET_ERR_HIP;
+    }
+    const size_t vol = (size_t)D * H * W;
+    dim3 grid((unsigned)((vol + kThreads - 1) / kThreads), (unsigned)C8, (unsigned)N);
+    hipLaunchKernelGGL(scl_pack_kernel, grid, dim3(kThreads), 0, st, x, static_cast<uint4*>(xs), C, C8, D, H, W, p.Dp, p.Hp, p.Wp,
+                       piece);
+    MVS_LAUNCH_CHECK("scl_pack");
+    return MVSDET_OK;
+}
+
+// Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ per-channel affine] [+ residual] [+ ReLU] on the
+// bf16 matrix cores, three-term split (file header).  xs: SCL input (mvsdet_scl_pack_f32); weight_split: the weights cut
+// and permuted by the caller to [Cout/64][Cin8][14 tap pairs][2 row groups][2 pieces][64 lanes][8] bf16 (lane = 32*(tap
+// parity) + output channel % 32; tap 27 zero; channels beyond Cin zero); out: (N,Cout,D,H,W) fp32.
+extern "C" int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                       const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                       mvsdet_stream_t stream) {
+    const char* name = "conv3d_k3_bf16x3";
+    MVS_REQUIRE(xs && weight_split && out, "%s: NULL pointer", name);
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
+    MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
+    MVS_REQUIRE((((uintptr_t)xs | (uintptr_t)weight_split) & 15u) == 0, "%s: xs and weights must be 16-byte aligned", name);
+    const BfPlan p = bf_plan(D, H, W);
+    const int C8 = (Cin + 7) / 8;
+    MVS_REQUIRE((size_t)p.Dp * p.Hp * p.Wp < ((size_t)1 << 31), "%s: one padded channel-group volume exceeds 2^31 voxels", name);
+    MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
+    dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64)));
+    hipStream_t st = (hipStream_t)stream;
+#define MVS_BF_CASE(TD_, TH_)                                                                                               \
+    {                                                                                                                       \
+        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_>;                                                                        \
+        const size_t lds = bf_lds_bytes(TD_, TH_);                                                                          \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+            hipSuccess) {                                                                                                   \
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                  \
+            return MVSDET_ERR_HIP;                                                                                          \
+        }                                                                                                                   \
+        hipLaunchKernelGGL(k, grid, dim3(64 * TD_ * TH_ / 4), lds, st, static_cast<const uint4*>(xs),                       \
+                           static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W, p.Dp,   \
+                           p.Hp, p.Wp, piece, p.tiles_w, relu);                                                             \
+    }
+    if (p.th == 12) MVS_BF_CASE(4, 12) else MVS_BF_CASE(4, 8)
+#undef MVS_BF_CASE
+    MVS_LAUNCH_CHECK(name);
+    return MVSDET_OK;
+}

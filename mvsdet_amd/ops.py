@@ -631,6 +631,100 @@ def _bpm_bwd(ctx, g_mean, g_count):
 backproject_weigh_mean.register_autograd(_bpm_bwd, setup_context=_bpm_setup)
 
 
+# ------------------------------------------------------------------------------------------- cost network on bf16x3 (f-1)
+def split_bf16(t: Tensor):
+    """fp32 -> (hi, mid) bfloat16 pieces: hi = bf16(t), mid = bf16(t - hi), both round-to-nearest-even; t - hi is exact."""
+    hi = t.to(torch.bfloat16)
+    mid = (t - hi.to(torch.float32)).to(torch.bfloat16)
+    return hi, mid
+
+
+def split_conv_weight(weight: Tensor) -> Tensor:
+    """Conv3d weight (Cout = 64*m, Cin, 3,3,3) fp32 -> the layout mvsdet_conv3d_k3_bf16x3 streams into LDS
+    (include/mvsdet_hip.h): [Cout/64][ceil(Cin/8)][14 tap pairs][2 row groups][2 pieces][64 lanes][8 channels] bf16,
+    lane = 32*(tap parity) + output % 32; tap 27 and the channels beyond Cin are zero."""
+    cout, cin = weight.shape[:2]
+    if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"split_conv_weight: weight {tuple(weight.shape)} != (64*m,Cin,3,3,3)")
+    c8 = (cin + 7) // 8
+    w = weight.detach().to(torch.float32).reshape(cout, cin, 27)
+    w = torch.nn.functional.pad(w, (0, 1, 0, c8 * 8 - cin))                      # taps -> 28, channels -> 8*c8
+    pieces = torch.stack(split_bf16(w), 0)                                      # (piece, Cout, C, 28)
+    # (piece, ob, a, r, c8, j, p, h) -> (ob, c8, p, a, piece, h, r, j)
+    pieces = pieces.reshape(2, cout // 64, 2, 32, c8, 8, 14, 2).permute(1, 4, 6, 2, 0, 7, 3, 5)
+    return pieces.contiguous().reshape(cout // 64, c8, 14, 2, 2, 64, 8)
+
+
+class SclTensor:
+    """An activation in the split channel-last form the bf16x3 convolutions read (include/mvsdet_hip.h): `data` is the
+    flat bfloat16 buffer [2][N][ceil(C/8)][Dp][Hp][Wp][8] with a zero border; `shape` the logical (N,C,D,H,W)."""
+
+    def __init__(self, data: Tensor, shape, padded):
+        self.data, self.shape, self.padded = data, tuple(int(v) for v in shape), tuple(int(v) for v in padded)
+
+    def pieces(self):
+        """(hi, mid) as (N, C8*8, D, H, W) bfloat16 tensors (interior only) -- for tests."""
+        n, c, d, h, w = self.shape
+        c8 = (c + 7) // 8
+        dp, hp, wp = self.padded
+        v = self.data.view(2, n, c8, dp, hp, wp, 8)[:, :, :, 1:d + 1, 1:h + 1, 1:w + 1]
+        v = v.permute(0, 1, 2, 6, 3, 4, 5).reshape(2, n, c8 * 8, d, h, w)
+        return v[0], v[1]
+
+
+def scl_geometry(N: int, C: int, D: int, H: int, W: int):
+    """(bytes, (Dp, Hp, Wp)) of the SCL form of an (N,C,D,H,W) activation."""
+    import ctypes
+    dp, hp, wp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    nbytes = _lib.load().mvsdet_scl_bytes(N, C, D, H, W, ctypes.byref(dp), ctypes.byref(hp), ctypes.byref(wp))
+    return int(nbytes), (dp.value, hp.value, wp.value)
+
+
+def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
+    """(N,C,D,H,W) fp32 -> SclTensor.  `out`: a buffer of the same shape to refill (its border is already zero)."""
+    _req(x, "x", dim=5)
+    x = x.contiguous()
+    N, C, D, H, W = x.shape
+    nbytes, padded = scl_geometry(N, C, D, H, W)
+    fresh = out is None or out.shape != tuple(x.shape) or out.data.device != x.device
+    if fresh:
+        out = SclTensor(torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=x.device), x.shape, padded)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_scl_pack_f32(_lib.ptr(x), _lib.ptr(out.data), N, C, D, H, W, int(fresh), _stream(x)),
+                   "scl_pack")
+    return out
+
+
+def conv3d_k3_bf16x3(xs: SclTensor, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
+                     residual: Optional[Tensor] = None) -> Tensor:
+    """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ affine] [+ residual] [+ ReLU] on the bf16
+    matrix cores with three-term split operands (csrc/costreg_bf16.hip): SCL input -> (N,Cout,D,H,W) fp32."""
+    N, Cin, D, H, W = xs.shape
+    if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
+        raise ValueError(f"conv3d_k3_bf16x3: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
+    Cout = weight_split.shape[0] * 64
+    if (scale is None) != (shift is None):
+        raise ValueError("conv3d_k3_bf16x3: scale and shift come together")
+    if scale is not None:
+        _req(scale, "scale", dim=1)
+        _req(shift, "shift", dim=1)
+        if scale.numel() != Cout or shift.numel() != Cout:
+            raise ValueError(f"conv3d_k3_bf16x3: scale / shift must have {Cout} elements")
+        scale, shift = scale.contiguous(), shift.contiguous()
+    out = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=xs.data.device)
+    if residual is not None:
+        _req(residual, "residual", dim=5)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError(f"conv3d_k3_bf16x3: residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+        residual = residual.contiguous()
+    weight_split = weight_split.contiguous()
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().mvsdet_conv3d_k3_bf16x3(_lib.ptr(xs.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
+                                                       _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
+                                                       _stream(out)), "conv3d_k3_bf16x3")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- misc
 def device_copy(src: Tensor, dst: Tensor):
     """float4 device-to-device copy kernel (bench.py's achievable-HBM yardstick)."""

@@ -1,0 +1,79 @@
+"""The cost network's convolutions on the bf16 matrix cores with three-term split operands (csrc/costreg_bf16.hip,
+SURVEY 8 f-1): the kernels against a float64 evaluation of the SAME three products (so the check is independent of the
+split's own truncation: what remains is fp32 accumulation order), and against the plain fp32 convolution within the
+truncation the scheme promises (~2^-16 of the products' size).  Reference layers: mvs_models/mvsnet.py:76-82."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def three_term_conv64(x, w, **kw):
+    """float64 convolution of the pieces the kernel multiplies: x_hi*w_hi + x_hi*w_mid + x_mid*w_hi."""
+    from mvsdet_amd.ops import split_bf16
+    xh, xm = (t.double() for t in split_bf16(x))
+    wh, wm = (t.double() for t in split_bf16(w))
+    return F.conv3d(xh, wh, **kw) + F.conv3d(xh, wm, **kw) + F.conv3d(xm, wh, **kw)
+
+
+def test_scl_pack_pieces_and_border(gpu):
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 13, 5, 7, 19, generator=g) * 3.0
+    x[0, 0, 0, 0, 0] = 0.0
+    x[1, 12, 4, 6, 18] = -1e-30
+    s = ops.scl_pack(x.to(gpu))
+    hi, mid = s.pieces()
+    eh, em = ops.split_bf16(x)
+    assert torch.equal(hi[:, :13].cpu(), eh) and torch.equal(mid[:, :13].cpu(), em)
+    assert float(hi[:, 13:].abs().max()) == 0.0                       # channels beyond C
+    n, c, d, h, w = s.shape
+    dp, hp, wp = s.padded
+    full = s.data.view(2, n, 2, dp, hp, wp, 8).float()
+    inner = torch.zeros_like(full, dtype=torch.bool)
+    inner[:, :, :, 1:d + 1, 1:h + 1, 1:w + 1] = True
+    assert float(full[~inner].abs().max()) == 0.0                     # the zero border
+    # refill of the same buffer with other values: border still zero, interior replaced
+    s2 = ops.scl_pack((x * 0.5).to(gpu), out=s)
+    assert s2 is s and torch.equal(s.pieces()[0][:, :13].cpu(), ops.split_bf16(x * 0.5)[0])
+    assert float(s.data.view(2, n, 2, dp, hp, wp, 8).float()[~inner].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 16, 64, 4, 8, 16), (2, 24, 64, 5, 13, 21), (1, 8, 128, 3, 12, 16),
+                                               (1, 37, 64, 9, 25, 33), (2, 64, 64, 12, 60, 80), (1, 256, 64, 4, 12, 16),
+                                               (1, 5, 64, 1, 1, 1)])
+def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g).abs() * 2.0        # variance-like, >= 0
+    wgt = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, D, H, W, generator=g)
+    xs = ops.scl_pack(x.to(gpu))
+    wq = ops.split_conv_weight(wgt).to(gpu)
+    raw = ops.conv3d_k3_bf16x3(xs, wq, None, None, False).cpu()
+    want = three_term_conv64(x, wgt, padding=1)
+    mag = float(F.conv3d(x.abs().double(), wgt.abs().double(), padding=1).max())     # size of the summed products
+    assert float((raw.double() - want).abs().max()) <= 4e-7 * mag                     # fp32 accumulation of exact products
+    ref32 = F.conv3d(x.double(), wgt.double(), padding=1)
+    assert float((raw.double() - ref32).abs().max()) <= 3 * 2.0 ** -16 * mag          # the dropped terms, worst case
+    # observed truncation is far below the bound: random signs average the dropped terms down
+    assert float((raw.double() - ref32).abs().max()) <= 2e-5 * float(ref32.abs().max()) + 1e-6
+    full = ops.conv3d_k3_bf16x3(xs, wq, scale.to(gpu), shift.to(gpu), True, res.to(gpu)).cpu()
+    wantf = torch.relu(torch.addcmul(shift.view(1, -1, 1, 1, 1), raw, scale.view(1, -1, 1, 1, 1)) + res)
+    np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
+
+
+def test_conv3d_k3_bf16x3_argument_checks(gpu):
+    from mvsdet_amd import ops
+    xs = ops.scl_pack(torch.zeros(1, 8, 2, 2, 2, device=gpu))
+    wq = ops.split_conv_weight(torch.zeros(64, 8, 3, 3, 3)).to(gpu)
+    with pytest.raises(ValueError):
+        ops.conv3d_k3_bf16x3(xs, wq[:, :, :13], None, None, False)
+    with pytest.raises(ValueError):
+        ops.conv3d_k3_bf16x3(xs, wq, torch.ones(64, device=gpu), None, False)
+    with pytest.raises(ValueError):
+        ops.split_conv_weight(torch.zeros(60, 8, 3, 3, 3))
+    assert float(ops.conv3d_k3_bf16x3(xs, wq, None, None, False).abs().max()) == 0.0
