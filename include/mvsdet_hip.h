@@ -336,6 +336,9 @@ int mvsdet_backproject_weigh_mean_bwd_f32(const float* feat, const int64_t* feat
  * out (N,Cout,D,H,W) fp32 = [relu]([scale *] conv [+ shift] [+ residual]).  Stride 1, Cout % 64 == 0.
  * ------------------------------------------------------------------------------------------- */
 size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp /*HOST, may be NULL*/, int* Hp, int* Wp);
+/* weight (Cout = 64*m, Cin, 3,3,3) fp32 -> weight_split (mvsdet_split_conv_weight_bytes) on the device: one small launch */
+size_t mvsdet_split_conv_weight_bytes(int Cout, int Cin);
+int mvsdet_split_conv_weight(const float* weight, void* weight_split, int Cout, int Cin, mvsdet_stream_t stream);
 int mvsdet_scl_pack_f32(const float* x, void* xs, int N, int C, int D, int H, int W, int zero_border, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
                             const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,

@@ -74,10 +74,13 @@ SIGNATURES = {
                                               _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_copy_f32": [_vp, _vp, _sz, _vp],
     "mvsdet_scl_bytes": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "mvsdet_split_conv_weight_bytes": [_i, _i],
+    "mvsdet_split_conv_weight": [_vp, _vp, _i, _i, _vp],
     "mvsdet_scl_pack_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_bf16x3": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
-_RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_scl_bytes": ctypes.c_size_t, "mvsdet_packed_bytes": ctypes.c_size_t,
+_RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_scl_bytes": ctypes.c_size_t,
+            "mvsdet_split_conv_weight_bytes": ctypes.c_size_t, "mvsdet_packed_bytes": ctypes.c_size_t,
             "mvsdet_plane_sweep_scratch_bytes": ctypes.c_size_t, "mvsdet_plane_sweep_workspace_bytes": ctypes.c_size_t,
             "mvsdet_plane_sweep_bwd_workspace_bytes": ctypes.c_size_t,
             "mvsdet_conv3d_k3_dw_partial_bytes": ctypes.c_size_t,

@@ -79,6 +79,30 @@ __global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restr
     xs[piece_stride + o] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
 }
 
+// Conv3d weight (Cout,Cin,27) fp32 -> [Cout/64][c8][14][2 row groups][2 pieces][64 lanes][8] bf16 (see the entry point):
+// thread = one 16-byte unit.  A few hundred thousand elements: run on every call, so the kernel never multiplies a stale
+// copy of weights that were updated in place.
+__global__ __launch_bounds__(kThreads) void split_conv_weight_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin,
+                                                                     int C8, size_t units) {
+    const size_t u = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (u >= units) return;
+    const int lane = (int)(u & 63), piece = (int)((u >> 6) & 1), a = (int)((u >> 7) & 1);
+    const size_t r = u >> 8;
+    const int p = (int)(r % kBfPairs), c8 = (int)((r / kBfPairs) % C8), ob = (int)(r / ((size_t)kBfPairs * C8));
+    const int o = ob * 64 + a * 32 + (lane & 31), t = 2 * p + (lane >> 5);
+    unsigned short b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        const float f = (t < 27 && c < Cin) ? w[((size_t)o * Cin + c) * 27 + t] : 0.0f;
+        const __bf16 hi = (__bf16)f;
+        const __bf16 v = piece ? (__bf16)(f - (float)hi) : hi;
+        b[j] = __builtin_bit_cast(unsigned short, v);
+    }
+    out[u] = make_uint4((unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16),
+                        (unsigned)b[4] | ((unsigned)b[5] << 16), (unsigned)b[6] | ((unsigned)b[7] << 16));
+}
+
 // tap t of the 3x3x3 kernel as an offset in halo voxels; tap 27 (the empty half of pair 13) aliases tap 26
 template <int HH>
 __host__ __device__ constexpr int bf_tap_off(int t) {
@@ -300,6 +324,22 @@ extern "C" int mvsdet_scl_pack_f32(const float* x, void* xs, int N, int C, int D
     hipLaunchKernelGGL(scl_pack_kernel, grid, dim3(kThreads), 0, st, x, static_cast<uint4*>(xs), C, C8, D, H, W, p.Dp, p.Hp, p.Wp,
                        piece);
     MVS_LAUNCH_CHECK("scl_pack");
+    return MVSDET_OK;
+}
+
+// weight (Cout = 64*m, Cin, 3,3,3) fp32 -> weight_split, (Cout/64) * ceil(Cin/8) * 14 * 2 * 2 * 64 * 16 bytes
+extern "C" size_t mvsdet_split_conv_weight_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cout % 64 || Cin <= 0) return 0;
+    return (size_t)(Cout / 64) * ((Cin + 7) / 8) * kBfPairs * 2 * 2 * 64 * 16;
+}
+extern "C" int mvsdet_split_conv_weight(const float* weight, void* weight_split, int Cout, int Cin, mvsdet_stream_t stream) {
+    MVS_REQUIRE(weight && weight_split, "split_conv_weight: NULL pointer");
+    MVS_REQUIRE(Cout > 0 && Cout % 64 == 0 && Cin > 0, "split_conv_weight: Cout=%d must be a positive multiple of 64, Cin=%d > 0", Cout, Cin);
+    MVS_REQUIRE(((uintptr_t)weight_split & 15u) == 0, "split_conv_weight: output must be 16-byte aligned");
+    const size_t units = mvsdet_split_conv_weight_bytes(Cout, Cin) / 16;
+    hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((units + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, weight, static_cast<uint4*>(weight_split), Cin, (Cin + 7) / 8, units);
+    MVS_LAUNCH_CHECK("split_conv_weight");
     return MVSDET_OK;
 }
 

@@ -642,11 +642,18 @@ def split_bf16(t: Tensor):
 def split_conv_weight(weight: Tensor) -> Tensor:
     """Conv3d weight (Cout = 64*m, Cin, 3,3,3) fp32 -> the layout mvsdet_conv3d_k3_bf16x3 streams into LDS
     (include/mvsdet_hip.h): [Cout/64][ceil(Cin/8)][14 tap pairs][2 row groups][2 pieces][64 lanes][8 channels] bf16,
-    lane = 32*(tap parity) + output % 32; tap 27 and the channels beyond Cin are zero."""
+    lane = 32*(tap parity) + output % 32; tap 27 and the channels beyond Cin are zero.  On a ROCm device this is ONE small
+    kernel (run per call: in-place weight updates are always seen); on the CPU the same layout from torch ops (tests)."""
     cout, cin = weight.shape[:2]
     if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3):
         raise ValueError(f"split_conv_weight: weight {tuple(weight.shape)} != (64*m,Cin,3,3,3)")
     c8 = (cin + 7) // 8
+    if weight.is_cuda:
+        w = weight.detach().to(torch.float32).contiguous()
+        out = torch.empty((cout // 64, c8, 14, 2, 2, 64, 8), dtype=torch.bfloat16, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(_lib.load().mvsdet_split_conv_weight(_lib.ptr(w), _lib.ptr(out), cout, cin, _stream(w)), "split_conv_weight")
+        return out
     w = weight.detach().to(torch.float32).reshape(cout, cin, 27)
     w = torch.nn.functional.pad(w, (0, 1, 0, c8 * 8 - cin))                      # taps -> 28, channels -> 8*c8
     pieces = torch.stack(split_bf16(w), 0)                                      # (piece, Cout, C, 28)

@@ -52,7 +52,8 @@ def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
     scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
     res = torch.randn(N, Cout, D, H, W, generator=g)
     xs = ops.scl_pack(x.to(gpu))
-    wq = ops.split_conv_weight(wgt).to(gpu)
+    wq = ops.split_conv_weight(wgt.to(gpu))                           # the device kernel ...
+    assert torch.equal(wq.cpu().view(torch.int16), ops.split_conv_weight(wgt).view(torch.int16))   # ... == the torch-op layout
     raw = ops.conv3d_k3_bf16x3(xs, wq, None, None, False).cpu()
     want = three_term_conv64(x, wgt, padding=1)
     mag = float(F.conv3d(x.abs().double(), wgt.abs().double(), padding=1).max())     # size of the summed products
