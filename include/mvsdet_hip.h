@@ -141,6 +141,16 @@ int mvsdet_plane_sweep_table_f32(const float* proj, const float* depth, void* sc
 int mvsdet_plane_sweep_variance_tabled_f32(const float* packed, const int64_t* nbr, const void* table,
                                            size_t table_bytes, float* var, int N, int K, int C, int D, int H,
                                            int W, mvsdet_stream_t stream);
+/* The same two calls for a PITCHED cost volume: `var` is (N,C,D,H,out_w_pitch) in memory and columns [0, W) of every row are
+ * written (the caller hands out that view; mvsdet.py:467 materialises a contiguous volume -- same values, other strides).
+ * With out_w_pitch a multiple of 32 every row starts on a 128-byte line and the sweep writes whole lines from 32x4 pixel
+ * tiles even when W is no multiple of 32 (the 80-wide maps of the shipped configs: 64-byte runs otherwise).  The geometry
+ * must be built with the pitch it is consumed with. */
+int mvsdet_plane_sweep_table_pitched_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes, int N,
+                                         int K, int D, int H, int W, int out_w_pitch, mvsdet_stream_t stream);
+int mvsdet_plane_sweep_variance_tabled_pitched_f32(const float* packed, const int64_t* nbr, const void* table,
+                                                   size_t table_bytes, float* var, int N, int K, int C, int D, int H, int W,
+                                                   int out_w_pitch, mvsdet_stream_t stream);
 int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,
                                     const float* depth, float* var, void* workspace, size_t workspace_bytes,
                                     int N, int K, int C, int D, int H, int W, mvsdet_stream_t stream);
@@ -330,7 +340,7 @@ int mvsdet_backproject_weigh_mean_bwd_f32(const float* feat, const int64_t* feat
  *
  * "SCL" (split channel-last) activations: xs[piece 2][n][c8 = ceil(C/8)][Dp][Hp][Wp][8] bf16, piece = hi | mid,
  * (dp,hp,wp) = (d,h,w) + 1 inside a zero border; Dp/Hp/Wp and the size in bytes come from mvsdet_scl_bytes.
- * mvsdet_scl_pack_f32 cuts an (N,C,D,H,W) fp32 tensor (zero_border != 0: clear the buffer first; a buffer reused for the
+ * mvsdet_scl_pack_f32 cuts an (N,C,D,H,W) fp32 tensor (possibly row-pitched: mvsdet_plane_sweep_variance_tabled_pitched_f32; zero_border != 0: clear the buffer first; a buffer reused for the
  * same shape needs that once).  weight_split: [Cout/64][c8][14 tap pairs][2 groups of 32 outputs][2 pieces][64 lanes][8]
  * bf16, lane = 32 * (tap parity) + output % 32, tap 27 and channels >= Cin zero (mvsdet_amd.ops.split_conv_weight).
  * out (N,Cout,D,H,W) fp32 = [relu]([scale *] conv [+ shift] [+ residual]).  Stride 1, Cout % 64 == 0.
@@ -339,7 +349,8 @@ size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp /*HOST, may b
 /* weight (Cout = 64*m, Cin, 3,3,3) fp32 -> weight_split (mvsdet_split_conv_weight_bytes) on the device: one small launch */
 size_t mvsdet_split_conv_weight_bytes(int Cout, int Cin);
 int mvsdet_split_conv_weight(const float* weight, void* weight_split, int Cout, int Cin, mvsdet_stream_t stream);
-int mvsdet_scl_pack_f32(const float* x, void* xs, int N, int C, int D, int H, int W, int zero_border, mvsdet_stream_t stream);
+int mvsdet_scl_pack_f32(const float* x, const int64_t* x_strides /*HOST[4] = element strides of n, c, d, h; w stride 1; NULL = contiguous*/,
+                        void* xs, int N, int C, int D, int H, int W, int zero_border, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
                             const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
                             mvsdet_stream_t stream);

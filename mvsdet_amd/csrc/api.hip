@@ -21,7 +21,8 @@ static int env_int(const char* name, int dflt) {
 }
 
 Options& options() {
-    static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1)};
+    static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1),
+                        env_int("MVSDET_SWEEP_DSPLIT", 0), env_int("MVSDET_SWEEP_GROUPS", -1)};
     return o;
 }
 
@@ -31,6 +32,8 @@ static int* option_slot(const char* name) {
     if (!strcmp(name, "sweep_tw")) return &o.sweep_tw;
     if (!strcmp(name, "sweep_boxcap")) return &o.sweep_boxcap;
     if (!strcmp(name, "sweep_xcd")) return &o.sweep_xcd;
+    if (!strcmp(name, "sweep_dsplit")) return &o.sweep_dsplit;
+    if (!strcmp(name, "sweep_groups")) return &o.sweep_groups;
     return nullptr;
 }
 

@@ -18,6 +18,9 @@ struct Options {
     int sweep_tw;      // 0 = by the map width, 16 / 32 force the tile shape (16x8 / 32x4)
     int sweep_boxcap;  // texels of one LDS footprint box (0 forces the global-gather path)
     int sweep_xcd;     // XCD-aware block map for fewer than 8 slabs
+    int sweep_dsplit;  // 0 = by the grid size; n > 0: every block sweeps ceil(D / n) consecutive planes
+    int sweep_groups;  // -1 = by the plane count; 0 / 1 = off; g in [2, kSweepGroups]: a tile's planes are dealt to up to g blocks,
+                       // cut where its footprint boxes are refilled (the near planes)
 };
 Options& options();
 
@@ -27,7 +30,9 @@ struct SweepGeometry {
     unsigned* flags;
     float* proj;
     float* depth;
+    unsigned short* groups;   // [N*tiles][kSweepGroups + 1] plane-group boundaries of every tile (sweep_kernel.h)
 };
+constexpr int kSweepGroups = 6;   // at most this many plane groups (blocks) per (tile, slab)
 SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles);
 
 constexpr int kWave = 64;       // CDNA wavefront

@@ -49,20 +49,23 @@ __host__ __device__ constexpr size_t bf_lds_bytes(int TD, int TH) {
 
 // fp32 NCDHW -> SCL (both pieces), interior voxels only: the border stays as the caller zeroed it.
 // thread = one voxel x 8 channels: 8 coalesced channel-row reads, two 16-byte stores.
-__global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restrict__ x, uint4* __restrict__ xs, int C, int C8,
-                                                            int D, int H, int W, int Dp, int Hp, int Wp, size_t piece_stride) {
+__global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restrict__ x, long long sN, long long sC, long long sD,
+                                                            long long sH, uint4* __restrict__ xs, int C, int C8, int D, int H, int W,
+                                                            int Dp, int Hp, int Wp, size_t piece_stride) {
     const size_t vol = (size_t)D * H * W;
     const size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x;
     if (v >= vol) return;
     const int c8 = blockIdx.y, n = blockIdx.z;
     const int d = (int)(v / ((size_t)H * W)), r = (int)(v - (size_t)d * H * W), h = r / W, w = r - h * W;
-    const float* src = x + ((size_t)n * C + (size_t)c8 * 8) * vol + v;
+    // element (n,c,d,h,w) at x[n*sN + c*sC + d*sD + h*sH + w]: a pitched cost volume (rows padded to whole 128-byte lines)
+    // is read in place
+    const float* src = x + (size_t)n * sN + (size_t)c8 * 8 * sC + (size_t)d * sD + (size_t)h * sH + w;
     unsigned hi[4], mid[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float f[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) f[e] = (c8 * 8 + 2 * j + e < C) ? src[(size_t)(2 * j + e) * vol] : 0.0f;
+        for (int e = 0; e < 2; ++e) f[e] = (c8 * 8 + 2 * j + e < C) ? src[(size_t)(2 * j + e) * sC] : 0.0f;
         unsigned short hb[2], mb[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -303,10 +306,10 @@ extern "C" size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp, i
     return (size_t)2 * N * ((C + 7) / 8) * p.Dp * p.Hp * p.Wp * 16;
 }
 
-// x (N,C,D,H,W) fp32 -> xs (SCL, mvsdet_scl_bytes).  The border of xs must be zero: `zero_border` != 0 clears the whole
+// x (N,C,D,H,W) fp32, element strides xstr = {n, c, d, h} (w stride 1; NULL = contiguous) -> xs (SCL, mvsdet_scl_bytes).  The border of xs must be zero: `zero_border` != 0 clears the whole
 // buffer first (one memset; a caller that reuses the buffer for the same shape clears it once and passes 0).
-extern "C" int mvsdet_scl_pack_f32(const float* x, void* xs, int N, int C, int D, int H, int W, int zero_border,
-                                   mvsdet_stream_t stream) {
+extern "C" int mvsdet_scl_pack_f32(const float* x, const int64_t* xstr, void* xs, int N, int C, int D, int H, int W,
+                                   int zero_border, mvsdet_stream_t stream) {
     MVS_REQUIRE(x && xs, "scl_pack: NULL pointer");
     MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, "scl_pack: bad shape N=%d C=%d D=%d H=%d W=%d", N, C, D, H, W);
     MVS_REQUIRE(((uintptr_t)xs & 15u) == 0, "scl_pack: xs must be 16-byte aligned");
@@ -321,8 +324,11 @@ extern "C" int mvsdet_scl_pack_f32(const float* x, void* xs, int N, int C, int D
     }
     const size_t vol = (size_t)D * H * W;
     dim3 grid((unsigned)((vol + kThreads - 1) / kThreads), (unsigned)C8, (unsigned)N);
-    hipLaunchKernelGGL(scl_pack_kernel, grid, dim3(kThreads), 0, st, x, static_cast<uint4*>(xs), C, C8, D, H, W, p.Dp, p.Hp, p.Wp,
-                       piece);
+    const long long sN = xstr ? xstr[0] : (long long)C * vol, sC = xstr ? xstr[1] : (long long)vol;
+    const long long sD = xstr ? xstr[2] : (long long)H * W, sH = xstr ? xstr[3] : (long long)W;
+    MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= W, "scl_pack: bad strides");
+    hipLaunchKernelGGL(scl_pack_kernel, grid, dim3(kThreads), 0, st, x, sN, sC, sD, sH, static_cast<uint4*>(xs), C, C8, D, H, W,
+                       p.Dp, p.Hp, p.Wp, piece);
     MVS_LAUNCH_CHECK("scl_pack");
     return MVSDET_OK;
 }

@@ -110,9 +110,14 @@ namespace {
 // ceiling).  A width that is a multiple of 16 but not of 32 (the 80-wide maps of the shipped configs) leaves a third column
 // of 32x4 tiles half empty: with many planes per block the wider runs win all the same (50 views x 96 planes, 60x80:
 // 6.6 against 7.1 ms), with the reference's 12 planes the smaller footprints and the fuller grid of the 16x8 tiles do.
-int pick_tile_width(int W, int D) {
+// A PITCHED output (row pitch a multiple of 32 elements, chosen by the caller: every row then starts on a 128-byte line) takes
+// the 32x4 tiles whatever the width: tools/micro/store_pattern_ref.hip, 60x80 maps x 12 planes, stores only: 16x8 tiles on
+// the contiguous volume 0.66 ms (3.5 TB/s: 64-byte runs; 32x4 tiles there straddle two lines on every odd row: 0.55),
+// 32x4 tiles on rows pitched to 96: 0.46 ms.
+int pick_tile_width(int W, int D, int out_pitch = 0) {
     const int tw = options().sweep_tw;  // tuning knob (mvsdet_set_option "sweep_tw"); 0 = by the map shape
     if (tw == 16 || tw == 32) return tw;
+    if (out_pitch > 0 && out_pitch != W && out_pitch % 32 == 0) return 32;
     if (W % 32 == 0 || W % 16 != 0) return 32;
     return D >= 48 ? 32 : 16;
 }
@@ -157,7 +162,8 @@ size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 namespace mvsdet {
 // Sweep geometry in the scratch buffer (built by plane_sweep_coords_kernel, consumed by the slab kernels):
-//   boxes [N*tiles*D*K] int4 | flags [N*tiles*D] u32 | proj copy [N*K*16] f32 | depth copy [N*D] f32
+//   boxes [N*tiles*D*K] int4 | flags [N*tiles*D] u32 | proj copy [N*K*16] f32 | depth copy [N*D] f32 |
+//   plane groups [N*tiles][kSweepGroups+1] u16
 // `tiles` is that of the tile width in force; the size query assumes the larger of the two tile shapes.
 SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles) {
     SweepGeometry g;
@@ -169,6 +175,8 @@ SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles) {
     g.proj = reinterpret_cast<float*>(p);
     p += align16((size_t)N * K * 16 * sizeof(float));
     g.depth = reinterpret_cast<float*>(p);
+    p += align16((size_t)N * D * sizeof(float));
+    g.groups = reinterpret_cast<unsigned short*>(p);
     return g;
 }
 }  // namespace mvsdet
@@ -176,19 +184,19 @@ SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles) {
 namespace {
 template <int KV, int TW, bool FAST, typename OutT>
 int launch_slab(dim3 grid, hipStream_t stream, size_t lds, const float* packed, const float* ref_packed, const int64_t* nbr,
-                const SweepGeometry& geo, OutT* var, int n_src, int C, int S, int D, int H, int W, int tiles_x,
-                int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
+                const SweepGeometry& geo, const unsigned short* groups, OutT* var, int n_src, int C, int S, int D, int H, int W,
+                int Wo, int tiles_x, int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
     auto* k = plane_sweep_variance_kernel<KV, TW, FAST, OutT>;
     if (int rc = allow_dynamic_lds(k, lds)) return rc;
     hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, ref_packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags,
-                       var, n_src, C, S, D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts);
+                       groups, var, n_src, C, S, D, H, W, Wo, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts);
     return MVSDET_OK;
 }
 
 template <int TW>
 int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, const float* depth, void* var_any,
                  void* scratch, int N, int K, int C, int D, int H, int W, hipStream_t stream, int phases, int n_src,
-                 int ref_first, bool half_out) {
+                 int ref_first, bool half_out, int Wo) {
     float* var = static_cast<float*>(var_any);
     __half* var16 = static_cast<__half*>(var_any);  // half_out: same kernel, variance rounded to fp16 at the store
     // phases: bit 0 = build the sweep geometry (coords kernel), bit 1 = run the slab kernel.  N reference views starting at view ref_first of the n_src packed source views (a view shard;
@@ -202,7 +210,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         set_error("plane_sweep_variance: grid too large");
         return MVSDET_ERR_INVALID_ARG;
     }
-    const bool fast = (C % kSlab == 0) && (W % 4 == 0);   // whole float4 stores of whole slabs (see the kernel)
+    const bool fast = (C % kSlab == 0) && (W % 4 == 0) && (Wo % 4 == 0);   // whole float4 stores of whole slabs (see the kernel)
     // A call that only CONSUMES a geometry (phases == 2) cannot know the capacity it was built with -- the staged /
     // refill flags and the union boxes carry it implicitly -- so its LDS slots are sized for the largest capacity any
     // geometry of this (K, tile shape) can have: "sweep_boxcap" may change between the two calls without harm.
@@ -211,7 +219,19 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
     // of planes) unless the grid would be too small to fill 256 CUs x 2 blocks
     int dsplit = 1;
     while (nblocks * dsplit < 1024 && D / (dsplit * 2) >= 2) dsplit *= 2;
+    // Few planes over the whole depth range (the shipped configs' 12 over 0.2-5 m): a third of a block's planes refill a
+    // footprint box -- a block-wide stall -- and a CU's three blocks stall together; about four planes per block give the
+    // CU more, shorter blocks in different phases (60x80 x 12 planes: 0.70 -> 0.66 ms, the store-pattern ceiling of the
+    // 16x8 tiles: tools/micro/store_pattern_ref.hip; more planes per block or 32x4 tiles gain nothing: tools/sweep_pitch_timing.py)
+    if (D <= 16 && TW == 16 && dsplit == 1) dsplit = (D + 3) / 4;
+    if (options().sweep_dsplit > 0) dsplit = std::min(options().sweep_dsplit, D);
     const int d_per_block = (D + dsplit - 1) / dsplit;
+    // plane groups (sweep_kernel.h): worth their extra block start-ups where refills are a large share of a block's planes
+    // -- few planes spanning the whole depth range (the shipped configs' 12)
+    int gmax = options().sweep_groups;
+    if (gmax < 0) gmax = 1;   // measured (tools/sweep_pitch_timing.py): cutting at the refills loses to equal shares of planes
+    gmax = std::min(gmax, kSweepGroups);
+    const bool grouped = K > 0 && gmax >= 2 && dsplit == 1;
     const SweepGeometry geo = sweep_geometry(scratch, N, K, D, tiles);
     dim3 cgrid((unsigned)(N * tiles));
     const int n_bt = N * tiles;
@@ -222,21 +242,24 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         xcd_parts = 8 / S;
         grid_x = 8LL * ((n_bt + xcd_parts - 1) / xcd_parts);
     }
-    dim3 grid((unsigned)grid_x, (D + d_per_block - 1) / d_per_block);
+    // the geometry carries its own cuts (at most kSweepGroups groups, whatever "sweep_groups" said when it was built):
+    // the grid allows for all of them, blocks of absent groups leave at once
+    dim3 grid((unsigned)grid_x, grouped ? kSweepGroups : (D + d_per_block - 1) / d_per_block);
+    const unsigned short* groups = grouped ? geo.groups : nullptr;
     const float* ref_packed = packed ? packed + (size_t)ref_first * S * H * W * kSlab : nullptr;
     const size_t lds = sweep_lds_bytes(K, box_cap);
     int rc = MVSDET_OK;
 #define MVS_SLAB(KV, FV)                                                                                               \
-    (half_out ? launch_slab<KV, TW, FV, __half>(grid, stream, lds, packed, ref_packed, nbr, geo, var16, n_src, C, S,   \
-                                                D, H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts)       \
-              : launch_slab<KV, TW, FV, float>(grid, stream, lds, packed, ref_packed, nbr, geo, var, n_src, C, S, D,   \
-                                               H, W, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts))
+    (half_out ? launch_slab<KV, TW, FV, __half>(grid, stream, lds, packed, ref_packed, nbr, geo, groups, var16, n_src, C, S, \
+                                                D, H, W, Wo, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts)   \
+              : launch_slab<KV, TW, FV, float>(grid, stream, lds, packed, ref_packed, nbr, geo, groups, var, n_src, C, S, D, \
+                                               H, W, Wo, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts))
 #define MVS_SWEEP_CASE(KV)                                                                                            \
     case KV:                                                                                                          \
         if (phases & 1)                                                                                               \
             hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads),                            \
                                (size_t)D * (KV * sizeof(int4) + sizeof(unsigned) + sizeof(float)), stream, proj, depth,               \
-                               geo.boxes, geo.flags, geo.proj, geo.depth, D, H, W, tiles_x, tiles, box_cap);           \
+                               geo.boxes, geo.flags, geo.proj, geo.depth, geo.groups, gmax, D, H, W, tiles_x, tiles, box_cap); \
         if (phases & 2) rc = fast ? MVS_SLAB(KV, true) : MVS_SLAB(KV, false);                                         \
         break;
     switch (K) {
@@ -257,7 +280,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
 }  // namespace
 
 namespace mvsdet {
-int sweep_tile_width(int W, int D) { return pick_tile_width(W, D); }  // shared with planesweep_bwd.hip
+int sweep_tile_width(int W, int D) { return pick_tile_width(W, D, 0); }  // shared with planesweep_bwd.hip
 int sweep_box_cap(int K, int tw) { return effective_box_cap(K, tw); }
 int sweep_max_box_cap(int K, int tw) { return max_box_cap(K, tw); }
 }
@@ -279,13 +302,17 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
     // data; sized for the larger of the two tile shapes so the "sweep_tw" option cannot outgrow it
     const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
     return (size_t)N * tiles * D * K * sizeof(int4) + align16((size_t)N * tiles * D * sizeof(unsigned)) +
-           align16((size_t)N * K * 16 * sizeof(float)) + align16((size_t)N * D * sizeof(float));
+           align16((size_t)N * K * 16 * sizeof(float)) + align16((size_t)N * D * sizeof(float)) +
+           align16((size_t)N * tiles * (kSweepGroups + 1) * sizeof(unsigned short));
 }
 
 static int sweep_entry(const char* name, const float* packed, const int64_t* nbr, const float* proj, const float* depth,
                        void* var, void* scratch, size_t scratch_bytes, int N, int K, int C, int D, int H, int W,
-                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0, bool half_out = false) {
+                       mvsdet_stream_t stream, int phases, int n_src = -1, int ref_first = 0, bool half_out = false,
+                       int out_pitch = 0) {
     if (n_src < 0) n_src = N;
+    const int Wo = out_pitch > 0 ? out_pitch : W;
+    MVS_REQUIRE(Wo >= W, "%s: output row pitch %d < W=%d", name, Wo, W);
     MVS_REQUIRE(ref_first >= 0 && N <= n_src && ref_first <= n_src - N,
                 "%s: reference views [%d, %d) outside the %d packed views", name, ref_first, ref_first + N, n_src);
     MVS_REQUIRE(!(phases & 2) || (packed && var), "%s: NULL pointer", name);
@@ -295,17 +322,17 @@ static int sweep_entry(const char* name, const float* packed, const int64_t* nbr
     MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "%s: bad shape N=%d C=%d D=%d H=%d W=%d", name, N, C, D, H, W);
     MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "%s: K=%d outside [0,%d]", name, K, MVSDET_MAX_NEIGHBORS);
     MVS_REQUIRE(D <= MVSDET_MAX_DEPTH && H < 65535 && W < 65535, "%s: D > %d, or H or W > 65534", name, MVSDET_MAX_DEPTH);
-    MVS_REQUIRE((size_t)8 * D * H * W * sizeof(float) < ((size_t)1 << 32), "%s: 8 channel rows of the cost volume (8*D*H*W floats) exceed 4 GiB", name);
+    MVS_REQUIRE((size_t)8 * D * H * Wo * sizeof(float) < ((size_t)1 << 32), "%s: 8 channel rows of the cost volume (8*D*H*W floats) exceed 4 GiB", name);
     MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "%s: one slab image exceeds 2^31 elements", name);
     if (scratch_bytes < mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)) {
         set_error("%s: scratch %zu B < %zu B", name, scratch_bytes, mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W));
         return MVSDET_ERR_WORKSPACE;
     }
     MVS_REQUIRE(K == 0 || ((uintptr_t)scratch % 16 == 0), "%s: scratch must be 16-byte aligned", name);
-    const int tw = pick_tile_width(W, D);
+    const int tw = pick_tile_width(W, D, Wo);
     hipStream_t st = (hipStream_t)stream;
-    if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
-    return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out);
+    if (tw == 16) return launch_sweep<16>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out, Wo);
+    return launch_sweep<32>(packed, nbr, proj, depth, var, scratch, N, K, C, D, H, W, st, phases, n_src, ref_first, half_out, Wo);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_packed_f32(const float* packed, const int64_t* nbr, const float* proj,
@@ -343,6 +370,22 @@ extern "C" int mvsdet_plane_sweep_variance_tabled_f32(const float* packed, const
                                                       int W, mvsdet_stream_t stream) {
     return sweep_entry("plane_sweep_variance_tabled", packed, nbr, nullptr, nullptr, var, const_cast<void*>(table),
                        table_bytes, N, K, C, D, H, W, stream, 2);
+}
+
+// The two halves again for a PITCHED output: var is (N,C,D,H,out_w_pitch) in memory, of which columns [0, W) are written
+// (the caller hands out the view).  A pitch that is a multiple of 32 puts every row on a 128-byte line and selects the
+// 32x4 tiles (pick_tile_width); the geometry must be built with the same pitch (the tile shape decides its layout).
+extern "C" int mvsdet_plane_sweep_table_pitched_f32(const float* proj, const float* depth, void* scratch, size_t scratch_bytes,
+                                                    int N, int K, int D, int H, int W, int out_w_pitch, mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_table_pitched", nullptr, nullptr, proj, depth, nullptr, scratch, scratch_bytes, N, K, 1, D, H,
+                       W, stream, 1, -1, 0, false, out_w_pitch);
+}
+
+extern "C" int mvsdet_plane_sweep_variance_tabled_pitched_f32(const float* packed, const int64_t* nbr, const void* table,
+                                                              size_t table_bytes, float* var, int N, int K, int C, int D, int H,
+                                                              int W, int out_w_pitch, mvsdet_stream_t stream) {
+    return sweep_entry("plane_sweep_variance_tabled_pitched", packed, nbr, nullptr, nullptr, var, const_cast<void*>(table),
+                       table_bytes, N, K, C, D, H, W, stream, 2, -1, 0, false, out_w_pitch);
 }
 
 extern "C" int mvsdet_plane_sweep_variance_f32(const float* feat, const int64_t* nbr, const float* proj,

@@ -141,8 +141,8 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                                                                        const float* __restrict__ depth,
                                                                        int4* __restrict__ boxes,
                                                                        unsigned* __restrict__ flags, float* __restrict__ proj_copy,
-                                                                       float* __restrict__ depth_copy, int D, int H, int W,
-                                                                       int tiles_x, int tiles, int box_cap) {
+                                                                       float* __restrict__ depth_copy, unsigned short* __restrict__ groups,
+                                                                       int gmax, int D, int H, int W, int tiles_x, int tiles, int box_cap) {
     constexpr int TH = kTilePix / TW;
     extern __shared__ int4 s_geo[];    // [K][D] the tile's boxes of all planes, then [D] flags words, then [D] plane depths
     int4* s_pb = s_geo;
@@ -262,6 +262,19 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     __syncthreads();
     for (int i = tid; i < D * K; i += kThreads) boxes[(size_t)bt * D * K + i] = s_pb[(size_t)(i % K) * D + i / K];
     for (int d = tid; d < D; d += kThreads) flags[(size_t)bt * D + d] = s_fl[d];
+    // Plane groups: the slab kernel deals a tile's planes to up to gmax blocks, cut in front of a plane that refills a box.
+    // The near planes' footprints jump by many texels per plane (12 planes over 0.2-5 m: every one of the first few is a
+    // refill -- a block-wide stall of two barriers and a DMA round trip); as the first plane of its own block a refill is
+    // part of the block's start-up, which the other blocks of the CU cover.  The last group takes all remaining planes.
+    if (tid == 0 && groups) {
+        unsigned short* gr = groups + (size_t)bt * (kSweepGroups + 1);
+        int g = 0;
+        gr[0] = 0;
+        constexpr unsigned kAnyRefill = kFlagRefill | (kFlagRefill << 4) | (kFlagRefill << 8) | (kFlagRefill << 12);
+        for (int d = 1; d < D; ++d)
+            if ((s_fl[d] & kAnyRefill) && g < gmax - 1) gr[++g] = (unsigned short)d;
+        for (++g; g <= kSweepGroups; ++g) gr[g] = (unsigned short)D;
+    }
 }
 
 // DPP helpers.  A wave's lanes are (pixel slot ps = lane >> 3, channel group g = lane & 7): an 8-lane group = two quads.
@@ -299,8 +312,8 @@ template <int K, int TW, bool FAST, typename OutT = float>
 __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
     const float* __restrict__ proj, const float* __restrict__ depth, const int4* __restrict__ boxes,
-    const unsigned* __restrict__ flags, OutT* __restrict__ var, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
+    const unsigned* __restrict__ flags, const unsigned short* __restrict__ groups, OutT* __restrict__ var, int N, int C, int S,
+    int D, int H, int W, int Wo, int tiles_x, int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int NP = (K + 1) / 2;             // decode passes: a lane decodes ONE (pixel-step, neighbour) pair per pass
     constexpr int NPP = NP > 0 ? NP : 1;
@@ -308,6 +321,8 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     extern __shared__ float4 s_box[];  // K slots of (box_cap + kBoxPad) texels (8 float4 each)
 
     const int HW = H * W;
+    const int HWo = H * Wo;   // Wo = row pitch of the OUTPUT in elements (W for a contiguous volume; a multiple of 32 puts every
+                              // row on a 128-byte boundary: 32x4 tiles then write whole lines even when W is no multiple of 32)
     const int id = blockIdx.x;
     int slab = id % S;
     int bt = id / S;  // n*tiles + tile
@@ -322,8 +337,14 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     }
     const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const int d_begin = blockIdx.y * d_per_block;
-    const int d_end = min(D, d_begin + d_per_block);
+    // the block's planes: a fixed share of D, or group blockIdx.y of this tile's plane groups (plane_sweep_coords_kernel)
+    int d_begin = blockIdx.y * d_per_block;
+    int d_end = min(D, d_begin + d_per_block);
+    if (groups) {
+        d_begin = groups[(size_t)bt * (kSweepGroups + 1) + blockIdx.y];
+        d_end = groups[(size_t)bt * (kSweepGroups + 1) + blockIdx.y + 1];
+        if (d_begin >= d_end) return;   // fewer groups than the grid allows for (block-uniform, before any barrier)
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it scalar
@@ -355,9 +376,9 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     }
     // stores: uniform base of (channel 8*i of the slab, plane d) + one 32-bit lane offset (channel g, the pixels)
     // (bytes; the entry point checks that 8 channel rows of the volume stay below 4 GiB)
-    const unsigned st_off = ((unsigned)g * (unsigned)D * (unsigned)HW + (unsigned)(py * W + px0)) * (unsigned)sizeof(OutT);
+    const unsigned st_off = ((unsigned)g * (unsigned)D * (unsigned)HWo + (unsigned)(py * Wo + px0)) * (unsigned)sizeof(OutT);
     const int st_n = (py < H) ? max(0, min(4, W - px0)) : 0;               // how many of the 4 pixels are inside the image
-    const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);  // 16-byte aligned in every channel row
+    const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((Wo & 3) == 0);  // 16-byte aligned in every channel row
 
     // ---- the lane's decode duty.  The sampling position of (pixel, plane, neighbour) does not depend on the channel:
     // in pass p lane (ps, g) computes it for pixel p0 + (g & 3) and neighbour 2p + (g >> 2) -- ONE position, one decode
@@ -416,10 +437,10 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     // stream from evicting the source slabs)
     float vout[4][4];
     int d_pending = -1;
-    OutT* const var_slab = var + ((size_t)n * C + slab * kSlab) * D * HW;   // block-uniform: channel row 0 of the slab, plane 0
-    const size_t row8 = (size_t)8 * D * HW;                                 // 8 channel rows further
+    OutT* const var_slab = var + ((size_t)n * C + slab * kSlab) * D * HWo;  // block-uniform: channel row 0 of the slab, plane 0
+    const size_t row8 = (size_t)8 * D * HWo;                                // 8 channel rows further
     auto flush = [&](int d) {
-        OutT* plane_base = var_slab + (size_t)d * HW;
+        OutT* plane_base = var_slab + (size_t)d * HWo;
         if constexpr (FAST) {
             if (st_n == 4) {
 #pragma unroll

@@ -242,6 +242,48 @@ def _(packed, nbr, table, C, D, H, W):
     return packed.new_empty((nbr.shape[0], C, D, H, W))
 
 
+def sweep_row_pitch(W: int) -> int:
+    """Row pitch (elements) of a cost volume whose rows start on 128-byte lines: W rounded up to a multiple of 32."""
+    return (int(W) + 31) // 32 * 32
+
+
+def plane_sweep_table_pitched(proj: Tensor, depth: Tensor, H: int, W: int, w_pitch: int) -> Tensor:
+    """plane_sweep_table for a cost volume with row pitch `w_pitch` (plane_sweep_variance_tabled_pitched)."""
+    _req(proj, "proj", dim=4)
+    _req(depth, "depth", dim=2)
+    N, K = proj.shape[:2]
+    D = depth.shape[1]
+    lib = _lib.load()
+    sbytes = lib.mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)
+    table = torch.empty(max(sbytes // 4, 4), dtype=torch.float32, device=proj.device)
+    proj, depth = proj.contiguous(), depth.contiguous()
+    with torch.cuda.device(proj.device):
+        _lib.check(lib.mvsdet_plane_sweep_table_pitched_f32(_lib.ptr(proj), _lib.ptr(depth), _lib.ptr(table), sbytes, N, K, D, H,
+                                                            W, int(w_pitch), _stream(proj)), "plane_sweep_table_pitched")
+    return table
+
+
+def plane_sweep_variance_tabled_pitched(packed: Tensor, nbr: Tensor, table: Tensor, C: int, D: int, H: int, W: int,
+                                        w_pitch: int) -> Tensor:
+    """The per-channel half of the sweep into a row-PITCHED volume: returns the (N,C,D,H,W) view of an (N,C,D,H,w_pitch)
+    buffer -- the values of plane_sweep_variance_tabled bit for bit, rows `w_pitch` elements apart (every row on a 128-byte
+    line when w_pitch % 32 == 0: whole-line stores from 32x4 tiles for the 80-wide maps of the shipped configs).
+    Forward only; the pad columns are never written."""
+    _req(packed, "packed", dim=1)
+    _req(nbr, "nbr", dtype=torch.int64, dim=2)
+    _req(table, "table", dim=1)
+    if w_pitch < W:
+        raise ValueError(f"plane_sweep_variance_tabled_pitched: pitch {w_pitch} < W={W}")
+    N, K = nbr.shape
+    nbr = nbr.contiguous()
+    buf = torch.empty((N, C, D, H, int(w_pitch)), dtype=torch.float32, device=packed.device)
+    with torch.cuda.device(packed.device):
+        _lib.check(_lib.load().mvsdet_plane_sweep_variance_tabled_pitched_f32(
+            _lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(table), table.numel() * 4, _lib.ptr(buf), N, K, C, D, H, W, int(w_pitch),
+            _stream(packed)), "plane_sweep_variance_tabled_pitched")
+    return buf[..., :W]
+
+
 @torch.library.custom_op(f"{_NS}::plane_sweep_variance", mutates_args=(), device_types="cuda")
 def plane_sweep_variance(feat: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor) -> Tensor:
     """a3+a4 (mvsdet.py:439-467): feat (N,C,H,W), nbr (N,K) int64, proj (N,K,4,4), depth (N,D) -> (N,C,D,H,W)."""
@@ -688,16 +730,20 @@ def scl_geometry(N: int, C: int, D: int, H: int, W: int):
 
 
 def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
-    """(N,C,D,H,W) fp32 -> SclTensor.  `out`: a buffer of the same shape to refill (its border is already zero)."""
+    """(N,C,D,H,W) fp32 -> SclTensor.  x may be any view whose last dimension has stride 1 (a row-pitched cost volume is
+    read in place).  `out`: a buffer of the same shape to refill (its border is already zero)."""
+    import ctypes
     _req(x, "x", dim=5)
-    x = x.contiguous()
+    if x.stride(4) != 1 or min(x.stride()) < 0:
+        x = x.contiguous()
     N, C, D, H, W = x.shape
     nbytes, padded = scl_geometry(N, C, D, H, W)
     fresh = out is None or out.shape != tuple(x.shape) or out.data.device != x.device
     if fresh:
         out = SclTensor(torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=x.device), x.shape, padded)
+    xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mvsdet_scl_pack_f32(_lib.ptr(x), _lib.ptr(out.data), N, C, D, H, W, int(fresh), _stream(x)),
+        _lib.check(_lib.load().mvsdet_scl_pack_f32(_lib.ptr(x), xstr, _lib.ptr(out.data), N, C, D, H, W, int(fresh), _stream(x)),
                    "scl_pack")
     return out
 

@@ -67,6 +67,14 @@ def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
     np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
 
 
+def test_scl_pack_reads_a_pitched_volume_in_place(gpu):
+    from mvsdet_amd import ops
+    buf = torch.randn(2, 9, 3, 5, 32, device=gpu)
+    view = buf[..., :20]                       # rows 32 elements apart, 20 used: a row-pitched cost volume
+    a, b = ops.scl_pack(view), ops.scl_pack(view.contiguous())
+    assert torch.equal(a.data.view(torch.int16), b.data.view(torch.int16))
+
+
 def test_conv3d_k3_bf16x3_argument_checks(gpu):
     from mvsdet_amd import ops
     xs = ops.scl_pack(torch.zeros(1, 8, 2, 2, 2, device=gpu))

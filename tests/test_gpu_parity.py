@@ -473,11 +473,12 @@ def test_sweep_variants_are_bit_identical(gpu):
     N, C, H, W = feat.shape
     args = (ops.pack_features(feat), dev(g["neighbor_ids"], gpu), dev(g["proj_rel"], gpu), dev(g["depth_values"], gpu), C, H, W)
     ref = ops.plane_sweep_variance_packed(*args)
-    saved = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap", "sweep_xcd")}
+    saved = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap", "sweep_xcd", "sweep_dsplit", "sweep_groups")}
     try:
         for opts in ({"sweep_tw": 16}, {"sweep_tw": 32}, {"sweep_boxcap": 0}, {"sweep_boxcap": 40}, {"sweep_boxcap": 320},
                      {"sweep_tw": 16, "sweep_boxcap": 0}, {"sweep_tw": 32, "sweep_boxcap": 96, "sweep_xcd": 0},
-                     {"sweep_tw": 16, "sweep_boxcap": 64}):
+                     {"sweep_tw": 16, "sweep_boxcap": 64}, {"sweep_dsplit": 1}, {"sweep_dsplit": 3}, {"sweep_dsplit": 8},
+                     {"sweep_groups": 2}, {"sweep_groups": 6, "sweep_dsplit": 1}, {"sweep_groups": 4, "sweep_tw": 32, "sweep_dsplit": 1}):
             for k, v in {**saved, **opts}.items():
                 _lib.set_option(k, v)
             out = ops.plane_sweep_variance_packed(*args)
@@ -498,6 +499,13 @@ def test_sweep_variants_are_bit_identical(gpu):
     finally:
         for k, v in saved.items():
             _lib.set_option(k, v)
+    # the row-pitched volume (rows on 128-byte lines, 32x4 tiles): the same values behind other strides
+    wp = ops.sweep_row_pitch(W)
+    tp = ops.plane_sweep_table_pitched(proj, depth, H, W, wp)
+    pv = ops.plane_sweep_variance_tabled_pitched(packed, nbr, tp, C, D, H, W, wp)
+    assert pv.shape == ref.shape and pv.stride(3) == wp and torch.equal(pv, ref)
+    with pytest.raises(ValueError):
+        ops.plane_sweep_variance_tabled_pitched(packed, nbr, tp, C, D, H, W, W - 1)
     with pytest.raises(ValueError):
         _lib.set_option("no_such_option", 1)
 
