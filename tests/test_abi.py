@@ -74,7 +74,9 @@ def test_argument_checks_do_not_launch(lib):
     assert lib.mvsdet_plane_sweep_variance_packed_f32(one, one, one, one, one, sixteen, 64, 2, 2, 4, 3, 8, 8, None) == 2
     assert b"scratch" in lib.mvsdet_last_error()
     # scratch: one 16-B box per (view, tile, plane, neighbour) + one flags word per (view, tile, plane) + proj / depth copies
-    assert lib.mvsdet_plane_sweep_scratch_bytes(40, 2, 64, 120, 160) == 40 * 150 * 64 * (2 * 16 + 4) + 40 * 2 * 64 + 40 * 64 * 4
+    # + 7 plane-group boundaries (u16) per (view, tile)
+    assert lib.mvsdet_plane_sweep_scratch_bytes(40, 2, 64, 120, 160) == \
+        40 * 150 * 64 * (2 * 16 + 4) + 40 * 2 * 64 + 40 * 64 * 4 + 40 * 150 * 7 * 2
     assert lib.mvsdet_plane_sweep_scratch_bytes(40, 0, 64, 120, 160) == 0
     assert lib.mvsdet_plane_sweep_workspace_bytes(40, 2, 256, 64, 120, 160) == \
         lib.mvsdet_packed_bytes(40, 256, 120, 160) + lib.mvsdet_plane_sweep_scratch_bytes(40, 2, 64, 120, 160)
