@@ -258,6 +258,78 @@ def run_train(args, w, rank, world, device):
     return elapsed, checksum
 
 
+class ShapeOnlyStages:
+    """--launch-check of the view-sharded mode on a machine without a GPU: the device stages replaced by zero tensors of
+    the right shapes, so that the rendezvous, the ONE all-gather of the feature shards and the ONE all-reduce of the
+    (C+1, X*Y*Z) voxel buffer (parallel.forward_scene_view_sharded) run over the chosen backend with their real sizes."""
+
+    def __init__(self, hp):
+        self.hp = hp
+
+    def pack(self, feature):
+        return feature
+
+    def cost_volume_shard(self, packed, geo, first, count, n_src, C, H, W):
+        return packed.new_zeros((count, 1, 1, 1, 1))
+
+    def depth_distribution(self, cost_logits):
+        n, _, d, h, w = cost_logits.shape
+        z = cost_logits.new_zeros
+        return z((n, d, h, w)), z((n, d, h, w)), z((n, 3, h, w)), z((n, 3, h, w)), None, z((n, h, w))
+
+    def lift_sum_shard(self, packed, geo, est_depth, est_dens, first, count, n_src, C, H, W):
+        v = self.hp.n_voxels[0] * self.hp.n_voxels[1] * self.hp.n_voxels[2]
+        return packed.new_full((C, v), float(count)), torch.full((v,), count, dtype=torch.int32)
+
+
+def run_view_sharded(args, w, rank, world, device, dry=False):
+    """ONE scene over all ranks (the intra-scene split): every rank holds the feature maps of its own contiguous
+    shard of the N reference views (as if its 2-D backbone had produced them), one all-gather gives every rank all N maps,
+    stages 1-2 (and the cost network with --with-cost-network) run on the local views, and one all-reduce(SUM) of the
+    (C+1, X*Y*Z) voxel buffer completes a9/a10.  Strong scaling of a single scene: value = scenes/s of the whole job."""
+    from mvsdet_amd import parallel, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    net = None
+    if args.with_cost_network and not dry:
+        from mvsdet_amd.costreg import CostRegNet3DGS
+        torch.manual_seed(0)
+        net = CostRegNet3DGS(w["C"]).to(device).eval()
+    hp = MVSDetHotPath(w.get("voxels", N_VOXELS), VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3, cost_regularization=net)
+    hw = (w["H"], w["W"])
+    first, count = parallel.view_shard(w["N"], rank, world)
+    pool = []
+    for i in range(args.scene_pool):   # every rank draws the same scene and keeps its own views
+        feat = synthetic.make_features(w["N"], w["C"], hw, seed=i, device=device)[first:first + count].contiguous()
+        logits = None if net is not None else synthetic.make_cost_logits(w["N"], w["D"], hw, seed=i, device=device)
+        pool.append((feat, logits))
+    metas = unseen_metas(w, 0, args.warmup + args.steps + 1)   # the same cameras on every rank, new ones every step
+    stages = ShapeOnlyStages(hp) if dry else None
+
+    def step(i):
+        feat, logits = pool[i % len(pool)]
+        if not dry:
+            hp.prefetch_scene(metas[i + 1], device)
+        with torch.no_grad():
+            out = parallel.forward_scene_view_sharded(hp, feat, metas[i], cost_logits=logits, features_are_local=True,
+                                                      stages=stages)
+        return out
+
+    out = None
+    for i in range(args.warmup):
+        out = step(i)
+    parallel.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        out = step(i)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    parallel.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device if device.type == "cuda" else None)
+    return elapsed, float(out["volume"].abs().sum().item()), int(out["valid"].max().item())
+
+
 def full_chain_rate(device, steps=10):
     """a1..a10 with the real CostRegNet_3DGS (random weights, eval mode, no autograd) between a4 and a5 at the shape the
     shipped config runs: what a scene costs end to end on the GPU (the network is ~30x the hot path around it)."""
@@ -507,8 +579,10 @@ def main():
     ap.add_argument("--with-cost-network", action="store_true",
                     help="(default on at N=1 unless --no-extras) scenes/s of a1..a10 with the real cost regularisation "
                          "network in between, reference-true shape, eval mode: our kernels only")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
-                    help="train = configs[2]: fwd + bwd + optimiser step with a stand-in cost network under DDP")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "view-sharded"],
+                    help="train = configs[2]: fwd + bwd + optimiser step with a stand-in cost network under DDP; "
+                         "view-sharded = ONE scene over all ranks (one all-gather of the feature shards + one all-reduce "
+                         "of the voxel buffer per scene: parallel.forward_scene_view_sharded)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -522,6 +596,21 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank number "
                          f"as a {args.gpus}-GPU one")
+    if args.launch_check and args.mode == "view-sharded":
+        # the collectives of the intra-scene split with their real sizes, device stages replaced by zero tensors (CPU, gloo)
+        from mvsdet_amd import parallel
+        if world > 1:
+            parallel.init_distributed(os.environ.get("MVSDET_DIST_BACKEND", "gloo"), None)
+        wn = args.workload if args.workload != "auto" else "tiny_3v_8d_48x64"
+        w = WORKLOADS[wn]
+        elapsed, checksum, vmax = run_view_sharded(args, w, rank, world, torch.device("cpu"), dry=True)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "mode": "view-sharded", "n_gpus": world, "workload": wn, "steps": args.steps,
+                              "views_seen": vmax, "checksum": checksum}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     if args.launch_check:
         return launch_check(args, rank, world)
     if not torch.cuda.is_available():
@@ -540,6 +629,26 @@ def main():
     if name == "auto":
         free = torch.cuda.mem_get_info(device)[0]
         name = "scannet_40v_64d_120x160" if free > 70 * (1 << 30) else "scannet_ref_40v_12d_60x80"
+    if args.mode == "view-sharded":
+        if args.workload == "auto":
+            name = "scannet_ref_40v_12d_60x80"
+        w = WORKLOADS[name]
+        elapsed, checksum, vmax = run_view_sharded(args, w, rank, world, device)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "scenes/sec of ONE scene sharded over the ranks by reference views (a1..a10"
+                          + (" + cost network)" if args.with_cost_network else ", stand-in logits)"),
+                "value": round(args.steps / elapsed, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mode": "view-sharded",
+                "config": {"workload": name, "views": w["N"], "channels": w["C"], "depth_planes": w["D"],
+                           "feat_hw": [w["H"], w["W"]], "voxels": w.get("voxels", N_VOXELS),
+                           "parallelism": f"view-sharded x{world}: 1 all-gather (feature shards) + 1 all-reduce (voxel buffer) per scene"},
+                "roofline": None, "checksum": checksum, "views_in_fullest_voxel": vmax}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     if args.mode == "train":
         if args.workload == "auto":
             name = "scannet_ref_40v_12d_60x80"   # what mvsdet_res50_2x_low_res.py trains on

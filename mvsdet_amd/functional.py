@@ -28,9 +28,35 @@ LAZY_WARP = False
 LAZY_ANY_DEVICE = False   # tests only: defer on CPU tensors too (the fused launches are stubbed there)
 
 
+# (neighbour projection tensor, reference projection tensor) -> proj_rel on the CPU, filled by `collect_proj_for_scene`:
+# the patched MVSDet.collect_proj evaluates the k products of a scene ONCE, from one device-to-host copy of the cameras;
+# `homo_warping` then finds its matrix by the identity of the two tensors it is handed (the entries keep them alive, so
+# an id is never reused while it is in the table).
+_SCENE_PROJ: dict = {}
+
+
 def relative_projection(src_proj: Tensor, ref_proj: Tensor) -> Tensor:
     """module.py:116  proj = src_proj @ inverse(ref_proj), fp32, evaluated with ATen-CPU; result on CPU."""
+    hit = _SCENE_PROJ.get((id(src_proj), id(ref_proj)))
+    if hit is not None and hit[0] is src_proj and hit[1] is ref_proj:
+        return hit[2]
     return torch.matmul(src_proj.detach().float().cpu(), torch.inverse(ref_proj.detach().float().cpu()))
+
+
+def collect_proj_for_scene(w2c: Tensor, intr: Tensor, neighbor_ids: Tensor):
+    """MVSDet.collect_proj (mvsdet.py:249-264) for the patched reference: same return values on the callers' device, and
+    -- from ONE host copy of `w2c` / `intr` -- the k matrices `nei_proj @ inverse(ref_proj)` (module.py:116) that the k
+    `homo_warping` calls of the scene will ask for, so those cost no further synchronisation and no repeated inverse."""
+    dev = w2c.device
+    w2c_h, intr_h, ids_h = w2c.detach().float().cpu(), intr.detach().float().cpu(), neighbor_ids.detach().cpu()
+    proj_h, nei_h = collect_proj(w2c_h, intr_h, ids_h)
+    inv_ref = torch.inverse(proj_h)
+    proj = proj_h.to(dev, non_blocking=True) if dev.type != "cpu" else proj_h
+    nei = tuple((n.to(dev, non_blocking=True) if dev.type != "cpu" else n) for n in nei_h)
+    _SCENE_PROJ.clear()                      # one scene at a time: the reference's loop is sequential
+    for n_dev, n_host in zip(nei, nei_h):
+        _SCENE_PROJ[(id(n_dev), id(proj))] = (n_dev, proj, torch.matmul(n_host, inv_ref))
+    return proj, nei
 
 
 def knn(x: Tensor, ref: Tensor, k: int, maskself: bool = False) -> Tensor:

@@ -41,7 +41,7 @@ def _compute_avg_depth(self, prob_volume, off_pred):
 
 
 def _collect_proj(self, w2c, intr, neighbor_ids):
-    return F_.collect_proj(w2c, intr, neighbor_ids)
+    return F_.collect_proj_for_scene(w2c, intr, neighbor_ids)
 
 
 PATCHED_FUNCTIONS = {

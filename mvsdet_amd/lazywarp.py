@@ -172,12 +172,14 @@ def _try_fused(sq_scaled: LazyVolume, sum_scaled_sq: LazyVolume):
         ids = ids.to(feat.device)
         # the recorded calls must be exactly this scene's: reference volume = features repeated over the planes, its
         # square, and the neighbour maps = features gathered with the noted ids
-        if not (torch.equal(base[:, :, -1], feat) and torch.equal(base_sq[:, :, 0], feat * feat)):
-            return None
+        # (all comparisons are enqueued first and answered by ONE device-to-host read)
         depth = warps[0].payload["depth"]
-        for j, w in enumerate(warps):
-            if not (torch.equal(w.payload["src"], feat[ids[:, j]]) and w.payload["depth"] is depth):
-                return None
+        if any(w.payload["depth"] is not depth or w.payload["src"].shape != feat.shape for w in warps):
+            return None
+        checks = [(base[:, :, -1] == feat).all(), (base_sq[:, :, 0] == feat * feat).all()]
+        checks += [(w.payload["src"] == feat[ids[:, j]]).all() for j, w in enumerate(warps)]
+        if not bool(torch.stack(checks).all()):
+            return None
         proj = torch.stack([w.payload["proj"] for w in warps], dim=1)
         stats["fused"] += 1
         return ops.plane_sweep_variance(feat, ids, proj, depth)

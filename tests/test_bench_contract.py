@@ -64,3 +64,22 @@ def test_training_mode_two_rank_ddp_dry_run(gpu):
     d = _last_json(out.stdout)
     assert d["mode"] == "train" and d["n_gpus"] == 2 and d["value"] > 0 and d["checksum"] > 0
     assert d["config"]["parallelism"].startswith("ddp x2")
+
+
+@pytest.mark.timeout(600)
+def test_view_sharded_mode_two_rank_dry_run(gpu):
+    """--mode view-sharded on the device stages: two ranks share the GPU over gloo, each sweeping its half of the views;
+    one all-gather + one all-reduce per scene."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MVSDET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "view-sharded", "--steps", "2", "--warmup", "1",
+           "--workload", "tiny_3v_8d_48x64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["mode"] == "view-sharded" and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "view-sharded", "--steps", "2", "--warmup", "1",
+                          "--workload", "tiny_3v_8d_48x64"], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = _last_json(one.stdout)
+    assert abs(d1["checksum"] - d["checksum"]) <= 2e-6 * abs(d1["checksum"]) + 1e-6   # the view sum is re-associated

@@ -37,6 +37,21 @@ def test_failing_rank_fails_the_launch():
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
+@pytest.mark.timeout(400)
+def test_view_sharded_mode_two_ranks():
+    """--mode view-sharded: one scene over the ranks (one all-gather of the feature shards + one all-reduce of the voxel
+    buffer per scene, mvsdet_amd.parallel.forward_scene_view_sharded) launched as two gloo ranks; device stages replaced by
+    shape-only stand-ins under --launch-check, so what runs is the launch, the sharding and the two collectives."""
+    out = _run({}, "--gpus", "2", "--mode", "view-sharded", "--launch-check", "--steps", "2", "--warmup", "1",
+               "--workload", "tiny_3v_8d_48x64")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    # the stand-in lifting reports `count` views per voxel on every rank: the all-reduce must add them up to all 3 views
+    assert d["mode"] == "view-sharded" and d["n_gpus"] == 2 and d["views_seen"] == 3
+
+
 def test_mismatched_world_size_is_refused():
     out = _run({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--launch-check")
     assert out.returncode != 0 and "refusing" in out.stderr

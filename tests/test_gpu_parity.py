@@ -1015,6 +1015,64 @@ def test_unmodified_variance_loop_collapses_into_the_fused_kernel(gpu, oracle, t
         F_.LAZY_WARP = old
 
 
+def test_patched_route_with_device_cameras_and_its_wall_time(gpu):
+    """mvsdet.py:419-467 (restated) as the reference runs it: `w2c` and `K` are DEVICE tensors (:419-420), neighbour ids,
+    projections and depth values live on the device.  Under the patch `MVSDet.collect_proj` copies the cameras to the host
+    once and evaluates the k matrices `nei_proj @ inverse(ref_proj)` of the scene there (functional.collect_proj_for_scene),
+    the k `homo_warping` calls look theirs up, and the loop collapses into one fused launch: the result is the fused
+    kernel's, bit for bit, and the wall time of the whole route is recorded beside the fused stage alone (the rest is the
+    reference's own `repeat` / `** 2` of the (N,C,D,H,W) reference volume and the recognition checks)."""
+    import json
+    import os
+    import time
+    from mvsdet_amd import functional as F_, integration, lazywarp, ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    N, C, D, hw = 40, 64, 12, (60, 80)
+    hp = MVSDetHotPath([40, 40, 16], [.16, .16, .2], [0.2, 5.0], D)
+    meta = synthetic.make_img_meta(N, hw, seed=12)
+    geo = hp.prepare_scene(meta, gpu)
+    feature = synthetic.make_features(N, C, hw, seed=12).to(gpu)
+    w2c = torch.tensor(np.array(meta["lidar2img"]["extrinsic"]), device=gpu)
+    K = torch.tensor(np.array(meta["lidar2img"]["intrinsic"]), device=gpu)
+    K_feat = K.clone()
+    K_feat[:2] /= meta["ori_shape"][0] / (meta["img_shape"][0] / 4)
+    expected = ops.plane_sweep_variance(feature, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+
+    class Patched:          # the two patched entry points the block calls, as integration.patch_reference binds them
+        get_nearest_pose_ids = staticmethod(F_.get_nearest_pose_ids)
+        homo_warping = staticmethod(F_.homo_warping)
+        collect_proj = staticmethod(lambda w, k, ids: integration.PATCHED_METHODS["collect_proj"](None, w, k, ids))
+
+    old = F_.LAZY_WARP
+    F_.LAZY_WARP = True
+    try:
+        times = []
+        for rep in range(4):
+            before = dict(lazywarp.stats)
+            torch.cuda.synchronize(gpu)
+            t0 = time.perf_counter()
+            c2w = w2c.inverse()                                             # mvsdet.py:433, on the device
+            var, ids = _reference_style_variance(Patched, feature, c2w, w2c, K_feat, geo.depth_values, False)
+            torch.cuda.synchronize(gpu)
+            times.append((time.perf_counter() - t0) * 1e3)
+            assert lazywarp.stats["fused"] == before["fused"] + 1 and lazywarp.stats["materialized"] == before["materialized"]
+            assert var.is_cuda and torch.equal(var, expected) and torch.equal(ids, geo.neighbor_ids)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.plane_sweep_variance(feature, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+        e1.record()
+        torch.cuda.synchronize(gpu)
+        rec = {"shape": [N, C, D, *hw], "patched_route_ms": [round(t, 3) for t in times], "fused_stage_ms": round(e0.elapsed_time(e1), 3)}
+        print("patched route timing", json.dumps(rec))
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, "patched_route_timing.json"), "w") as fh:
+                json.dump(rec, fh)
+        assert min(times[1:]) < 50.0        # a few ms on an MI355X; the bound only catches a fall-back to k materialised volumes
+    finally:
+        F_.LAZY_WARP = old
+
+
 def test_unmodified_lifting_block_uses_the_fused_kernel(gpu, oracle):
     """mvsdet.py:497-513 on the patched backproject_Weigh: `volume.sum(dim=0)` and `valid.sum(dim=0)` of the deferred
     volumes run ONE fused lifting launch; indexing the volume instead materialises the per-view result."""

@@ -277,3 +277,126 @@ def test_neck_is_pinned_to_the_reference_source_text():
         assert [tuple(t.shape) for t in a] == [(2, 4, 8, 8, 4), (2, 4, 4, 4, 2), (2, 4, 2, 2, 1)]
         for ta, tb in zip(a, b):
             assert torch.equal(ta, tb)
+
+
+def _oracle_backed_ops(monkeypatch, oracle):
+    """The device operators of mvsdet_amd.ops replaced by the CPU oracle / ATen restatements (this container has no GPU):
+    what the patched reference and MVSDetHotPath.forward_scene launch is counted, and computed by the checker."""
+    import numpy as np
+    import torch
+    from mvsdet_amd import functional as F_, ops
+    calls = {"sweep": 0, "lift": 0, "depth": 0}
+
+    def sweep(feat, ids, proj, depth):
+        calls["sweep"] += 1
+        return torch.from_numpy(oracle.plane_sweep_variance(feat.detach(), ids, proj, depth, mode=0))
+
+    def sweep_packed(packed, ids, proj, depth, c, h, w):
+        return sweep(packed, ids, proj, depth)
+
+    def sample(prob, off, near, interval, topk):      # a6 + a7 as SURVEY appendix A states them (bit-exact there)
+        calls["depth"] += 1
+        dens, idx = prob.topk(topk, dim=1)
+        est = idx.float() * np.float32(interval) + np.float32(near) + torch.gather(off, 1, idx) * np.float32(interval)
+        d = torch.arange(prob.shape[1], dtype=torch.float32).view(1, -1, 1, 1)
+        avg = (prob * (np.float32(near) + (d + off) * np.float32(interval))).sum(1)
+        return est, dens, idx.int(), avg
+
+    def depth_prob_topk(cost_reg, off_logit, near, interval, topk):
+        prob, off = torch.softmax(cost_reg, 1), torch.sigmoid(off_logit)
+        est, dens, idx, avg = sample(prob, off, near, interval, topk)
+        return prob, off, est, dens, idx, avg
+
+    def lift_sum(packed, points, projection, est_depth, est_dens, n, first, c, h, w, vz):
+        calls["lift"] += 1
+        o = oracle.backproject_weigh(packed.numpy()[:, :, :est_depth.shape[2], :est_depth.shape[3]], points.reshape(3, -1).numpy(),
+                                     projection.numpy(), est_depth.numpy(), est_dens.numpy(), vz)
+        return torch.from_numpy(o["volume"].sum(0)), torch.from_numpy(o["valid"].sum(0).astype(np.int32))
+
+    def lift_mean(feat, packed, points, projection, est_depth, est_dens, hf, wf, vz):
+        calls["lift"] += 1
+        o = oracle.backproject_weigh_mean(feat.numpy(), points.reshape(3, -1).numpy(), projection.numpy(), est_depth.numpy(),
+                                          est_dens.numpy(), vz)
+        return torch.from_numpy(o["volume_mean"]), torch.from_numpy(o["valid_count"].astype(np.int32))
+
+    monkeypatch.setattr(ops, "plane_sweep_variance", sweep)
+    monkeypatch.setattr(ops, "plane_sweep_variance_packed", sweep_packed)
+    monkeypatch.setattr(ops, "sample_depth_prob", sample)
+    monkeypatch.setattr(ops, "depth_prob_topk", depth_prob_topk)
+    monkeypatch.setattr(ops, "backproject_weigh_sum_shard", lift_sum)
+    monkeypatch.setattr(ops, "backproject_weigh_mean", lift_mean)
+    monkeypatch.setattr(ops, "pack_features", lambda f: f)
+    monkeypatch.setattr(F_, "LAZY_ANY_DEVICE", True)
+    return calls
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_reference_extract_feat_itself_runs_through_the_patch(reference, oracle, monkeypatch, training):
+    """The REAL thing once: an instance of the reference's own `MVSDet` class, its own `extract_feat`
+    (mvsdet.py:336-698) called as it stands -- 2-D backbone / neck, 3-D neck and NVS branch out of the way (stub modules,
+    ray_batch=None), `.cuda()` of the depth-scale helpers (:1283-1313) made a no-op -- first unpatched (pure reference,
+    ATen-CPU), then under `integration.patch_reference` with the device operators backed by the oracle.  The patched run
+    must launch exactly ONE fused sweep and ONE fused lifting per scene and materialise nothing (lazywarp.stats), agree
+    with the pure reference, and equal MVSDetHotPath.forward_scene on the same scene."""
+    from types import SimpleNamespace
+    import numpy as np
+    import torch
+    from mvsdet_amd import integration, lazywarp, synthetic
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    ref, _ = reference
+    N, C, D, hw = 5, 8, 8, (60, 80)
+    meta = synthetic.make_img_meta(N, hw, seed=31)
+    feature = synthetic.make_features(N, C, hw, seed=31)
+    torch.manual_seed(3)
+    net = CostRegNet3DGS(C, base=8).eval()
+    with torch.no_grad():
+        net.prob.weight.mul_(40.0)          # a soft-max with a clear ranking: the top-3 must not hinge on 1e-6
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+
+    def make_detector():
+        det = ref.MVSDet.__new__(ref.MVSDet)                     # the reference class; __init__ needs mmengine's registry
+        torch.nn.Module.__init__(det)
+        det.backbone = lambda img: feature                        # the 2-D stages are not ours: hand out the feature maps
+        det.neck = lambda x: [x]
+        det.neck_3d = lambda x: x
+        det.head_2d = None
+        det.n_voxels, det.voxel_size, det.near_far_range, det.topk = [40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], 3
+        det.gs_cfg = SimpleNamespace(num_monocular_samples=D)
+        det.depth_interval = (5.0 - 0.2) / D                      # mvsdet.py:221-225
+        det.depth_values = np.arange(0.2, 5.0, det.depth_interval, dtype=np.float32)
+        det.cost_regularization = net
+        det.train(training)
+        net.eval()                                                # same BatchNorm behaviour in both runs
+        return det
+
+    inputs = {"imgs": torch.zeros(1, N, 3, 240, 320)}
+    samples = [SimpleNamespace(metainfo=meta)]
+
+    def run(det):
+        with torch.no_grad():
+            return det.extract_feat(inputs, samples, "test" if not training else "train")
+
+    plain = run(make_detector())                                  # the unpatched reference
+    calls = _oracle_backed_ops(monkeypatch, oracle)
+    orig = integration.patch_reference(ref)
+    try:
+        before = dict(lazywarp.stats)
+        got = run(make_detector())
+        assert lazywarp.stats["fused"] == before["fused"] + 2, lazywarp.stats            # one sweep + one lifting
+        assert lazywarp.stats["materialized"] == before["materialized"], lazywarp.stats   # nothing fell back
+        assert calls["sweep"] == 1 and calls["lift"] == 1
+    finally:
+        integration.unpatch_reference(ref, orig)
+    x0, v0 = plain[0][0], plain[1][0]
+    x1, v1 = got[0][0], got[1][0]
+    assert x1.shape == x0.shape == (C, 40, 40, 16) and v1.shape == v0.shape
+    same = (v0 == v1)[0]
+    assert float((~same).float().mean()) < 1e-3 and int((v0 > 0).sum()) > 500           # counts: bit-equal but for near-ties
+    np.testing.assert_allclose(x1[:, same].numpy(), x0[:, same].numpy(), rtol=0, atol=1e-4)
+    # the scene driver on the same operators: the same volume and counts
+    hp = MVSDetHotPath([40, 40, 16], [0.16, 0.16, 0.2], [0.2, 5.0], D, topk=3, cost_regularization=net)
+    with torch.no_grad():
+        out = hp.forward_scene(feature, meta)
+    assert torch.equal(out["valid"].float(), v1)
+    np.testing.assert_allclose(out["volume"].numpy(), x1.numpy(), rtol=0, atol=2e-6)
