@@ -703,12 +703,13 @@ def test_stress_config_full_size(gpu, oracle):
     var2 = ops.plane_sweep_variance_shard(packed2, geo.neighbor_ids[sl], geo.proj_rel[sl], geo.depth_values[sl], N, 40, C,
                                           hw[0], hw[1], True)
     tiny = 2.0 ** -14                              # smallest normal fp16
-    for i in range(chunk):                         # view by view: temporaries of 5 GB
-        a, b = kept[i].float(), var2[i].float()
-        assert bool(torch.isfinite(b).all()) and float(a.min()) > -1e-3
-        normal = a >= tiny
-        assert torch.equal(b[normal], a[normal] * 4.0)
-        assert float((b - a * 4.0).abs().max()) <= 4 * 2.0 ** -24
+    for i in range(chunk):                         # view by view, 64 channels at a time: temporaries of ~2.5 GB
+        for c0 in range(0, C, 64):
+            a, b = kept[i, c0:c0 + 64].float(), var2[i, c0:c0 + 64].float()
+            assert bool(torch.isfinite(b).all()) and float(a.min()) > -1e-3
+            err = (b - a * 4.0).abs()
+            assert float(torch.where(a > tiny, err, torch.zeros_like(err)).max()) == 0.0   # exact where the UNROUNDED value is a normal fp16 (a == 2^-14 may be a rounded-up subnormal)
+            assert float(err.max()) <= 4 * 2.0 ** -24
 
 
 # --------------------------------------------------------------------------------------------- HIP graph capture
@@ -1033,9 +1034,11 @@ def test_patched_route_with_device_cameras_and_its_wall_time(gpu):
     geo = hp.prepare_scene(meta, gpu)
     feature = synthetic.make_features(N, C, hw, seed=12).to(gpu)
     w2c = torch.tensor(np.array(meta["lidar2img"]["extrinsic"]), device=gpu)
-    K = torch.tensor(np.array(meta["lidar2img"]["intrinsic"]), device=gpu)
-    K_feat = K.clone()
+    # feature-level intrinsics evaluated on the host and uploaded: ATen's device kernel divides by a scalar as a multiplication
+    # by its reciprocal -- one ulp in K, 1e-5 in the variance (DESIGN "tolerance budget") -- and this test is about the ROUTE
+    K_feat = torch.tensor(np.array(meta["lidar2img"]["intrinsic"]))
     K_feat[:2] /= meta["ori_shape"][0] / (meta["img_shape"][0] / 4)
+    K_feat = K_feat.to(gpu)
     expected = ops.plane_sweep_variance(feature, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
 
     class Patched:          # the two patched entry points the block calls, as integration.patch_reference binds them
