@@ -354,6 +354,11 @@ int mvsdet_scl_pack_f32(const float* x, const int64_t* x_strides /*HOST[4] = ele
 int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
                             const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
                             mvsdet_stream_t stream);
+/* The same convolution on the fp32 tensor itself (x_strides as for mvsdet_scl_pack_f32): the pieces are cut inside the
+ * kernel while the previous channel group is multiplied -- no packing pass, no SCL copy; results identical bit for bit. */
+int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split,
+                                  const float* scale, const float* shift, const float* residual, float* out, int N, int Cin,
+                                  int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement helper for bench.py: runs `fn`-independent HIP-event timing is done by the caller;

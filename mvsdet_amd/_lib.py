@@ -80,6 +80,7 @@ SIGNATURES = {
     "mvsdet_plane_sweep_table_pitched_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_variance_tabled_pitched_f32": [_vp, _vp, _vp, _sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_bf16x3": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_conv3d_k3_bf16x3_f32in": [_vp, _i64p, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 _RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_scl_bytes": ctypes.c_size_t,
             "mvsdet_split_conv_weight_bytes": ctypes.c_size_t, "mvsdet_packed_bytes": ctypes.c_size_t,

@@ -174,14 +174,6 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # eval route of the stride-1 layers: "bf16x3" = bf16 matrix cores on split operands (logits within 2e-6 .. 4e-6 of
         # fp32: tools/study/split_bf16_emulation.py), "fp32" = the fp32 MFMA kernels (bit-level fp32 FMA sums)
         self.matrix_precision = "bf16x3"
-        self._scl_buffers = {}   # shape -> SclTensor: split inputs are refilled in place (their zero border is kept)
-
-    def _scl(self, x):
-        from . import ops
-        key = (tuple(x.shape), x.device)
-        buf = ops.scl_pack(x, out=self._scl_buffers.get(key))
-        self._scl_buffers[key] = buf
-        return buf
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
@@ -206,7 +198,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             if self.matrix_precision == "bf16x3" and conv.stride == (1, 1, 1):
                 # stride-1 layers (conv0, conv2, conv4: 79 % of the network's FLOP) on the bf16 matrix cores with
                 # three-term split operands (csrc/costreg_bf16.hip): conv0 4.4 ms instead of 15.2 on the fp32 MFMA
-                return ops.conv3d_k3_bf16x3(self._scl(x), ops.split_conv_weight(conv.weight), scale, shift, True)
+                return ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(conv.weight), scale, shift, True)
             wperm = ops.permute_conv_weight(conv.weight)   # a few MB at most, negligible next to the convolution
             return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()

@@ -113,12 +113,19 @@ __host__ __device__ constexpr int bf_tap_off(int t) {
     return ((u / 9) * HH + (u / 3) % 3) * (kBfW + 2) + u % 3;
 }
 
-template <int TD, int TH>
+// F32IN: the input is the fp32 (N,C,D,H,W) tensor itself (element strides sN, sC, sD, sH; w stride 1 -- a row-pitched cost
+// volume included) instead of its SCL form: every thread fetches the 8 channels of its 2-3 halo voxels of the NEXT channel
+// group into registers while the current group is multiplied (coalesced along w), cuts them into the two bf16 pieces and
+// writes the same LDS image the DMA route fills -- no packing pass and no second copy of the activation in HBM (the 2.4 GB
+// variance volume: 1.0 ms of packing and a 3 GB buffer).  Out-of-volume halo voxels are zeros by predicate.
+template <int TD, int TH, bool F32IN>
 __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
-    const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
+    const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu) {
     constexpr int NW = TD * TH / 4;                       // waves
+    constexpr int NT = 64 * NW;                           // threads
     constexpr int HD = TD + 2, HH = TH + 2, HW = kBfW + 2;
     constexpr int NVOX = HD * HH * HW;
     constexpr int INS = bf_in_slots(TD, TH);              // slots per piece
@@ -159,6 +166,59 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
                 uint4* dst = s_in + (size_t)(buf * 2 + piece) * INS + (i % IN_DMA) * 64;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    // ---- fp32 input (F32IN): voxel slots tid, tid + NT, .. of the halo tile; offset inside one channel's volume or -1
+    constexpr int NV = F32IN ? (NVOX + NT - 1) / NT : 1;
+    int f_off[NV];
+    float f_reg[NV][8];
+    const float* xfn = F32IN ? xf + (size_t)n * sN : nullptr;
+    if constexpr (F32IN) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int slot = tid + k * NT;
+            const int dz = slot / (HH * HW), r = slot - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
+            const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
+            const bool ok = slot < NVOX && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
+            f_off[k] = ok ? (int)((long long)d * sD + (long long)h * sH + w) : -1;
+        }
+    }
+    auto fetch_f32 = [&](int c8) {
+        if constexpr (F32IN) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c8 * 8 + j;
+                    f_reg[k][j] = (f_off[k] >= 0 && c < Cin) ? xfn[(size_t)c * sC + f_off[k]] : 0.0f;
+                }
+        }
+    };
+    auto stage_f32 = [&](int buf) {
+        if constexpr (F32IN) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int slot = tid + k * NT;
+                unsigned hi[4], mid[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned short hb[2], mb[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float f = f_reg[k][2 * j + e];
+                        const __bf16 a = (__bf16)f;
+                        const __bf16 b = (__bf16)(f - (float)a);
+                        hb[e] = __builtin_bit_cast(unsigned short, a);
+                        mb[e] = __builtin_bit_cast(unsigned short, b);
+                    }
+                    hi[j] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+                    mid[j] = (unsigned)mb[0] | ((unsigned)mb[1] << 16);
+                }
+                if (slot < NVOX) {
+                    s_in[(size_t)(buf * 2 + 0) * INS + slot] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                    s_in[(size_t)(buf * 2 + 1) * INS + slot] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+                }
             }
         }
     };
@@ -227,15 +287,22 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
     };
 
     // ---- pipeline over the flat stage index q = 3*c8 + s
-    dma_input(0, 0);
+    if constexpr (F32IN) {
+        fetch_f32(0);
+        stage_f32(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes of the first input stage are done
+    } else {
+        dma_input(0, 0);
+    }
     dma_weights(0, 0, 0);
     for (int c8 = 0; c8 < C8; ++c8) {
         const int ibuf = c8 & 1;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int wbuf = (c8 * 3 + s) & 1;
-            // this wave's DMAs of the current stage have landed; after the barrier everybody's have, and everybody is done
-            // reading the buffers the next stage's DMAs (issued right below) overwrite
+            // this wave's DMAs (and, F32IN, register fetches) of the current stage have landed; after the barrier
+            // everybody's have, and everybody is done reading the buffers the next stage's transfers (issued right below)
+            // overwrite
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) only (expcnt 7, lgkmcnt 15 untouched)
             __builtin_amdgcn_s_barrier();
             if (s < 2) {
@@ -243,7 +310,14 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
             } else if (c8 + 1 < C8) {
                 dma_weights(c8 + 1, 0, wbuf ^ 1);
             }
-            if (s == 0 && c8 + 1 < C8) dma_input(c8 + 1, ibuf ^ 1);
+            if constexpr (F32IN) {
+                // next channel group: global -> registers during sub-stage 0, registers -> LDS (cut into pieces) at the
+                // top of sub-stage 1; the LDS reads of sub-stage 1's first tap pair wait for lgkmcnt(0) behind the writes
+                if (s == 0 && c8 + 1 < C8) fetch_f32(c8 + 1);
+                if (s == 1 && c8 + 1 < C8) stage_f32(ibuf ^ 1);
+            } else {
+                if (s == 0 && c8 + 1 < C8) dma_input(c8 + 1, ibuf ^ 1);
+            }
             if (s == 0) compute(std::integral_constant<int, 0>{}, ibuf, wbuf);
             else if (s == 1) compute(std::integral_constant<int, 1>{}, ibuf, wbuf);
             else compute(std::integral_constant<int, 2>{}, ibuf, wbuf);
@@ -353,11 +427,10 @@ extern "C" int mvsdet_split_conv_weight(const float* weight, void* weight_split,
 // bf16 matrix cores, three-term split (file header).  xs: SCL input (mvsdet_scl_pack_f32); weight_split: the weights cut
 // and permuted by the caller to [Cout/64][Cin8][14 tap pairs][2 row groups][2 pieces][64 lanes][8] bf16 (lane = 32*(tap
 // parity) + output channel % 32; tap 27 zero; channels beyond Cin zero); out: (N,Cout,D,H,W) fp32.
-extern "C" int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
-                                       const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
-                                       mvsdet_stream_t stream) {
-    const char* name = "conv3d_k3_bf16x3";
-    MVS_REQUIRE(xs && weight_split && out, "%s: NULL pointer", name);
+static int launch_bf16x3(const char* name, const void* xs, const float* xf, const int64_t* xstr, const void* weight_split,
+                         const float* scale, const float* shift, const float* residual, float* out, int N, int Cin, int Cout,
+                         int D, int H, int W, int relu, mvsdet_stream_t stream) {
+    MVS_REQUIRE((xs || xf) && weight_split && out, "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
@@ -366,24 +439,55 @@ extern "C" int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split,
     const int C8 = (Cin + 7) / 8;
     MVS_REQUIRE((size_t)p.Dp * p.Hp * p.Wp < ((size_t)1 << 31), "%s: one padded channel-group volume exceeds 2^31 voxels", name);
     MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    const size_t vol = (size_t)D * H * W;
+    const long long sN = xstr ? xstr[0] : (long long)Cin * vol, sC = xstr ? xstr[1] : (long long)vol;
+    const long long sD = xstr ? xstr[2] : (long long)H * W, sH = xstr ? xstr[3] : (long long)W;
+    if (xf) {
+        MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= W, "%s: bad strides", name);
+        MVS_REQUIRE((long long)(D - 1) * sD + (long long)(H - 1) * sH + W < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
+    }
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
     dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64)));
     hipStream_t st = (hipStream_t)stream;
-#define MVS_BF_CASE(TD_, TH_)                                                                                               \
+#define MVS_BF_CASE(TD_, TH_, F32_)                                                                                         \
     {                                                                                                                       \
-        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_>;                                                                        \
+        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_>;                                                                  \
         const size_t lds = bf_lds_bytes(TD_, TH_);                                                                          \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
             hipSuccess) {                                                                                                   \
             set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                  \
             return MVSDET_ERR_HIP;                                                                                          \
         }                                                                                                                   \
-        hipLaunchKernelGGL(k, grid, dim3(64 * TD_ * TH_ / 4), lds, st, static_cast<const uint4*>(xs),                       \
-                           static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W, p.Dp,   \
-                           p.Hp, p.Wp, piece, p.tiles_w, relu);                                                             \
+        hipLaunchKernelGGL(k, grid, dim3(64 * TD_ * TH_ / 4), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH,   \
+                           Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W,    \
+                           p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu);                                                       \
     }
-    if (p.th == 12) MVS_BF_CASE(4, 12) else MVS_BF_CASE(4, 8)
+    if (xf) {
+        if (p.th == 12) MVS_BF_CASE(4, 12, true) else MVS_BF_CASE(4, 8, true)
+    } else {
+        if (p.th == 12) MVS_BF_CASE(4, 12, false) else MVS_BF_CASE(4, 8, false)
+    }
 #undef MVS_BF_CASE
     MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
+}
+
+// Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ per-channel affine] [+ residual] [+ ReLU] on the
+// bf16 matrix cores, three-term split (file header).  xs: SCL input (mvsdet_scl_pack_f32); weight_split: the weights cut
+// and permuted (mvsdet_split_conv_weight) to [Cout/64][Cin8][14 tap pairs][2 row groups][2 pieces][64 lanes][8] bf16 (lane =
+// 32*(tap parity) + output channel % 32; tap 27 zero; channels beyond Cin zero); out: (N,Cout,D,H,W) fp32.
+extern "C" int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                       const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                       mvsdet_stream_t stream) {
+    return launch_bf16x3("conv3d_k3_bf16x3", xs, nullptr, nullptr, weight_split, scale, shift, residual, out, N, Cin, Cout, D, H, W,
+                         relu, stream);
+}
+
+// The same convolution reading the fp32 tensor x (N,Cin,D,H,W) directly (x_strides = element strides of n, c, d, h; w
+// stride 1; NULL = contiguous): the operands are cut into their bf16 pieces inside the kernel -- same results bit for bit.
+extern "C" int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_strides, const void* weight_split,
+                                             const float* scale, const float* shift, const float* residual, float* out, int N,
+                                             int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
+    return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, N, Cin, Cout, D,
+                         H, W, relu, stream);
 }

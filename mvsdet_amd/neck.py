@@ -101,7 +101,7 @@ def _conv_k3(x: Tensor, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool, residua
     from . import ops
     scale, shift = _bn_affine(bn)
     if conv.stride[0] == 1 and BF16X3_MIN_VOXELS and x[0, 0].numel() >= BF16X3_MIN_VOXELS:
-        return ops.conv3d_k3_bf16x3(ops.scl_pack(x), _split_weight(conv), scale, shift, relu, residual)
+        return ops.conv3d_k3_bf16x3(x, _split_weight(conv), scale, shift, relu, residual)
     return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(conv.weight), scale, shift, relu, conv.stride[0], residual)
 
 

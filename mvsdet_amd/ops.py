@@ -748,11 +748,23 @@ def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
     return out
 
 
-def conv3d_k3_bf16x3(xs: SclTensor, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
+def conv3d_k3_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
                      residual: Optional[Tensor] = None) -> Tensor:
     """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ affine] [+ residual] [+ ReLU] on the bf16
-    matrix cores with three-term split operands (csrc/costreg_bf16.hip): SCL input -> (N,Cout,D,H,W) fp32."""
-    N, Cin, D, H, W = xs.shape
+    matrix cores with three-term split operands (csrc/costreg_bf16.hip) -> (N,Cout,D,H,W) fp32.
+    x: the fp32 (N,Cin,D,H,W) tensor itself (any view with w stride 1: cut into pieces inside the kernel, no extra pass) or
+    its SclTensor form (scl_pack) -- identical results."""
+    import ctypes
+    scl = isinstance(x, SclTensor)
+    if scl:
+        N, Cin, D, H, W = x.shape
+        dev = x.data.device
+    else:
+        _req(x, "x", dim=5)
+        if x.stride(4) != 1 or min(x.stride()) < 0:
+            x = x.contiguous()
+        N, Cin, D, H, W = x.shape
+        dev = x.device
     if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
         raise ValueError(f"conv3d_k3_bf16x3: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
     Cout = weight_split.shape[0] * 64
@@ -764,17 +776,24 @@ def conv3d_k3_bf16x3(xs: SclTensor, weight_split: Tensor, scale: Optional[Tensor
         if scale.numel() != Cout or shift.numel() != Cout:
             raise ValueError(f"conv3d_k3_bf16x3: scale / shift must have {Cout} elements")
         scale, shift = scale.contiguous(), shift.contiguous()
-    out = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=xs.data.device)
+    out = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=dev)
     if residual is not None:
         _req(residual, "residual", dim=5)
         if tuple(residual.shape) != tuple(out.shape):
             raise ValueError(f"conv3d_k3_bf16x3: residual {tuple(residual.shape)} != output {tuple(out.shape)}")
         residual = residual.contiguous()
     weight_split = weight_split.contiguous()
-    with torch.cuda.device(out.device):
-        _lib.check(_lib.load().mvsdet_conv3d_k3_bf16x3(_lib.ptr(xs.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
-                                                       _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
-                                                       _stream(out)), "conv3d_k3_bf16x3")
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        if scl:
+            _lib.check(lib.mvsdet_conv3d_k3_bf16x3(_lib.ptr(x.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
+                                                   _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
+                                                   _stream(out)), "conv3d_k3_bf16x3")
+        else:
+            xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
+            _lib.check(lib.mvsdet_conv3d_k3_bf16x3_f32in(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
+                                                         _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
+                                                         _stream(out)), "conv3d_k3_bf16x3_f32in")
     return out
 
 

@@ -55,6 +55,8 @@ def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
     wq = ops.split_conv_weight(wgt.to(gpu))                           # the device kernel ...
     assert torch.equal(wq.cpu().view(torch.int16), ops.split_conv_weight(wgt).view(torch.int16))   # ... == the torch-op layout
     raw = ops.conv3d_k3_bf16x3(xs, wq, None, None, False).cpu()
+    direct = ops.conv3d_k3_bf16x3(x.to(gpu), wq, None, None, False).cpu()            # the fp32 tensor itself, cut in the kernel
+    assert torch.equal(direct, raw)
     want = three_term_conv64(x, wgt, padding=1)
     mag = float(F.conv3d(x.abs().double(), wgt.abs().double(), padding=1).max())     # size of the summed products
     assert float((raw.double() - want).abs().max()) <= 4e-7 * mag                     # fp32 accumulation of exact products
@@ -63,6 +65,9 @@ def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
     # observed truncation is far below the bound: random signs average the dropped terms down
     assert float((raw.double() - ref32).abs().max()) <= 2e-5 * float(ref32.abs().max()) + 1e-6
     full = ops.conv3d_k3_bf16x3(xs, wq, scale.to(gpu), shift.to(gpu), True, res.to(gpu)).cpu()
+    pitched = torch.zeros(N, Cin, D, H, W + 11, device=gpu)
+    pitched[..., :W] = x.to(gpu)                                                    # a row-pitched input view, read in place
+    assert torch.equal(ops.conv3d_k3_bf16x3(pitched[..., :W], wq, scale.to(gpu), shift.to(gpu), True, res.to(gpu)).cpu(), full)
     wantf = torch.relu(torch.addcmul(shift.view(1, -1, 1, 1, 1), raw, scale.view(1, -1, 1, 1, 1)) + res)
     np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
 

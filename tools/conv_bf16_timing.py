@@ -34,12 +34,13 @@ def main():
         t32 = timeit(lambda: ops.conv3d_k3_mfma(x, wp, sc, sh, True, 1))
         tpk = timeit(lambda: ops.scl_pack(x, out=xs))
         tbf = timeit(lambda: ops.conv3d_k3_bf16x3(xs, wq, sc, sh, True))
+        tdir = timeit(lambda: ops.conv3d_k3_bf16x3(x, wq, sc, sh, True))
         fl = 2.0 * 27 * Cin * Cout * N * D * H * W
         y32 = ops.conv3d_k3_mfma(x, wp, sc, sh, True, 1)
         ybf = ops.conv3d_k3_bf16x3(xs, wq, sc, sh, True)
         err = float((y32 - ybf).abs().max()) / float(y32.abs().max())
         print(f"{name}: fp32 MFMA {t32:.3f} ms ({fl / t32 / 1e9:.1f} TF)  bf16x3 {tbf:.3f} ms ({fl / tbf / 1e9:.1f} TF useful, "
-              f"{3 * fl / tbf / 1e9:.0f} TF of bf16 MFMA)  pack {tpk:.3f} ms  max rel diff {err:.2e}", flush=True)
+              f"{3 * fl / tbf / 1e9:.0f} TF of bf16 MFMA)  pack {tpk:.3f} ms  fp32-input form {tdir:.3f} ms  max rel diff {err:.2e}", flush=True)
 
 
 if __name__ == "__main__":
