@@ -349,6 +349,10 @@ size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp /*HOST, may b
 /* weight (Cout = 64*m, Cin, 3,3,3) fp32 -> weight_split (mvsdet_split_conv_weight_bytes) on the device: one small launch */
 size_t mvsdet_split_conv_weight_bytes(int Cout, int Cin);
 int mvsdet_split_conv_weight(const float* weight, void* weight_split, int Cout, int Cin, mvsdet_stream_t stream);
+/* order 0 = the stride-1 layout above; 1 = for mvsdet_conv3d_k3_s2_bf16x3_f32in (tap pairs grouped by the parity class of the
+ * input voxel); 2 = for the transposed convolution: `weight` is a ConvTranspose3d weight (Cin,Cout,3,3,3), pairs grouped by the
+ * parity class of the output voxel. */
+int mvsdet_split_conv_weight_ordered(const float* weight, void* weight_split, int Cout, int Cin, int order, mvsdet_stream_t stream);
 int mvsdet_scl_pack_f32(const float* x, const int64_t* x_strides /*HOST[4] = element strides of n, c, d, h; w stride 1; NULL = contiguous*/,
                         void* xs, int N, int C, int D, int H, int W, int zero_border, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
@@ -359,6 +363,12 @@ int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const floa
 int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split,
                                   const float* scale, const float* shift, const float* residual, float* out, int N, int Cin,
                                   int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+
+/* Conv3d(kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] (mvsnet.py:77,79) on the bf16 matrix cores, three-term
+ * split: x (N,Cin,D,H,W) fp32 -> out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1); weight_split of order 1. */
+int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split,
+                                     const float* scale, const float* shift, float* out, int N, int Cin, int Cout, int D, int H,
+                                     int W, int relu, mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement helper for bench.py: runs `fn`-independent HIP-event timing is done by the caller;

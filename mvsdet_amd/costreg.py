@@ -195,10 +195,12 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
                 and conv.out_channels % 64 == 0 and conv.stride in ((1, 1, 1), (2, 2, 2))):
             from . import ops
             scale, shift = _bn_affine(bn)
-            if self.matrix_precision == "bf16x3" and conv.stride == (1, 1, 1):
-                # stride-1 layers (conv0, conv2, conv4: 79 % of the network's FLOP) on the bf16 matrix cores with
-                # three-term split operands (csrc/costreg_bf16.hip): conv0 4.4 ms instead of 15.2 on the fp32 MFMA
-                return ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(conv.weight), scale, shift, True)
+            if self.matrix_precision == "bf16x3":
+                # the bf16 matrix cores with three-term split operands (csrc/costreg_bf16.hip): conv0 4.8 ms instead of 15.2
+                # on the fp32 MFMA; the stride-2 layers as sums over the 8 parity classes of their input
+                if conv.stride == (1, 1, 1):
+                    return ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(conv.weight), scale, shift, True)
+                return ops.conv3d_k3_s2_bf16x3(x, ops.split_conv_weight(conv.weight, 1), scale, shift, True)
             wperm = ops.permute_conv_weight(conv.weight)   # a few MB at most, negligible next to the convolution
             return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()

@@ -85,19 +85,22 @@ __global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restr
 // Conv3d weight (Cout,Cin,27) fp32 -> [Cout/64][c8][14][2 row groups][2 pieces][64 lanes][8] bf16 (see the entry point):
 // thread = one 16-byte unit.  A few hundred thousand elements: run on every call, so the kernel never multiplies a stale
 // copy of weights that were updated in place.
+struct TapTable { signed char t[2 * kBfPairs]; };   // the 3x3x3 tap (0..26) of every half of the 14 tap pairs; -1 = empty half
+
 __global__ __launch_bounds__(kThreads) void split_conv_weight_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin,
-                                                                     int C8, size_t units) {
+                                                                     int C8, size_t units, TapTable taps, long long so, long long sc) {
     const size_t u = (size_t)blockIdx.x * kThreads + threadIdx.x;
     if (u >= units) return;
     const int lane = (int)(u & 63), piece = (int)((u >> 6) & 1), a = (int)((u >> 7) & 1);
     const size_t r = u >> 8;
     const int p = (int)(r % kBfPairs), c8 = (int)((r / kBfPairs) % C8), ob = (int)(r / ((size_t)kBfPairs * C8));
-    const int o = ob * 64 + a * 32 + (lane & 31), t = 2 * p + (lane >> 5);
+    const int o = ob * 64 + a * 32 + (lane & 31), t = taps.t[2 * p + (lane >> 5)];
     unsigned short b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
-        const float f = (t < 27 && c < Cin) ? w[((size_t)o * Cin + c) * 27 + t] : 0.0f;
+        // element (output o, input c, tap t) at w[o*so + c*sc + t]: (Cout,Cin,27) for Conv3d, (Cin,Cout,27) for ConvTranspose3d
+        const float f = (t >= 0 && c < Cin) ? w[(size_t)o * so + (size_t)c * sc + t] : 0.0f;
         const __bf16 hi = (__bf16)f;
         const __bf16 v = piece ? (__bf16)(f - (float)hi) : hi;
         b[j] = __builtin_bit_cast(unsigned short, v);
@@ -184,6 +187,8 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
             f_off[k] = ok ? (int)((long long)d * sD + (long long)h * sH + w) : -1;
         }
     }
+    // ("load or zero" per element: measured faster than unconditional loads from a clamped address with the zeroing moved to
+    // the cut -- 4.79 against 4.91 ms at conv0 -- although hipcc branches around every such load)
     auto fetch_f32 = [&](int c8) {
         if constexpr (F32IN) {
 #pragma unroll
@@ -346,6 +351,221 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-2 convolution (mvsnet.py:77,79: conv1 64 -> 128, conv3 128 -> 256; kernel 3, padding 1) on the same machinery.
+// Output voxel o reads input 2o + k - 1 per dimension: k = 1 reads the EVEN input plane at coarse index o, k = 0 / k = 2
+// the ODD plane at o - 1 / o.  So the input splits into 8 parity classes pi = (pd, ph, pw), each a stride-1 grid of the
+// output's size, and the layer is the sum of 8 small stride-1 convolutions (1, 2, 2, 2, 4, 4, 4, 8 taps = 27) into the same
+// accumulators.  A stage = (8 channels, one parity class): its tile of the class ((4+1) x (8+1) x (16+1) voxels) is
+// fetched from the fp32 tensor (every second element along each odd/even axis), cut into bf16 pieces and written to LDS
+// one stage ahead, the class's 1, 1, 2 or 4 tap pairs of weights arrive by LDS-DMA; 14 tap pairs per 8 channels, exactly
+// the stride-1 kernel's MFMA work per output voxel.  x (N,Cin,Di,Hi,Wi) fp32 -> out (N,Cout,D,H,W), D = (Di-1)/2 + 1, ...
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kS2TD = 4, kS2TH = 8;
+constexpr int kS2HH = kS2TH + 1, kS2HW = kBfW + 1;
+constexpr int kS2Vox = (kS2TD + 1) * kS2HH * kS2HW;          // 765 voxels of one parity-class tile
+constexpr int kS2Ins = (kS2Vox + 63) / 64 * 64;              // 768 slots per piece
+constexpr int kS2WSlots = 4 * 2 * 2 * 64;                    // up to 4 tap pairs per stage
+__host__ __device__ constexpr size_t s2_lds_bytes() { return (size_t)(2 * 2 * kS2Ins + 2 * kS2WSlots) * 16; }
+__host__ __device__ constexpr int s2_pairs(int pi) { return (1 << ((pi >> 2) + ((pi >> 1) & 1) + (pi & 1))) / 2 == 0 ? 1 : (1 << ((pi >> 2) + ((pi >> 1) & 1) + (pi & 1))) / 2; }
+__host__ __device__ constexpr int s2_first_pair(int pi) { int n = 0; for (int q = 0; q < pi; ++q) n += s2_pairs(q); return n; }
+// tap j of class pi as an offset in the class tile: per odd dimension bit 0 -> k = 0 (coarse index o - 1 = tile index o),
+// bit 1 -> k = 2 (coarse index o = tile index o + 1); even dimensions contribute nothing
+__host__ __device__ constexpr int s2_tap_off(int pi, int j) {
+    const int pd = pi >> 2, ph = (pi >> 1) & 1, pw = pi & 1, nt = 1 << (pd + ph + pw);
+    int bits = j < nt ? j : nt - 1, jw = 0, jh = 0, jd = 0;
+    if (pw) { jw = bits & 1; bits >>= 1; }
+    if (ph) { jh = bits & 1; bits >>= 1; }
+    if (pd) { jd = bits & 1; }
+    return (jd * kS2HH + jh) * kS2HW + jw;
+}
+
+__global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_kernel(
+    const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out, int C8, int Cout, int Di, int Hi,
+    int Wi, int D, int H, int W, int tiles_w, int relu) {
+    constexpr int TD = kS2TD, TH = kS2TH, NW = TD * TH / 4, NT = 64 * NW;
+    constexpr int HH = kS2HH, HW = kS2HW, NVOX = kS2Vox, INS = kS2Ins;
+    constexpr int NV = (NVOX + NT - 1) / NT;   // 2 voxel slots per thread and stage
+    extern __shared__ uint4 s_bf[];            // [2 stages][2 pieces][INS] input, then [2 stages][kS2WSlots] weights
+    uint4* s_in = s_bf;
+    uint4* s_w = s_bf + 2 * 2 * INS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int nob = Cout / 64;
+    const int n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int col = lane & 31, hh = lane >> 5;
+    const float* xfn = xf + (size_t)n * sN;
+
+    // the thread's voxel slots of a class tile: tile index (dz, hy, wx) <-> input voxel 2*(d0 + dz) - pd, ... (class pi)
+    int vz[NV], vy[NV], vx[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int slot = tid + k * NT;
+        const int sv = slot < NVOX ? slot : 0;
+        vz[k] = 2 * (d0 + sv / (HH * HW));
+        vy[k] = 2 * (h0 + (sv % (HH * HW)) / HW);
+        vx[k] = 2 * (w0 + sv % HW);
+    }
+    // (A second register set with two stages of flight time was tried: beside an LDS-DMA hipcc drains vmcnt(0) before it uses
+    // an ordinary load's result, so the extra stage is never granted; hiding the DMA in inline assembly cost more than it won.)
+    float f_reg[1][NV][8];
+    auto fetch = [&](auto setc, int c8, int pi) {
+        constexpr int set = decltype(setc)::value;
+        const int pd = pi >> 2, ph = (pi >> 1) & 1, pw = pi & 1;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int d = vz[k] - pd, h = vy[k] - ph, w = vx[k] - pw;
+            const bool ok = (tid + k * NT < NVOX) && d >= 0 && d < Di && h >= 0 && h < Hi && w >= 0 && w < Wi;
+            const size_t off = ok ? (size_t)((long long)d * sD + (long long)h * sH + w) : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c8 * 8 + j;
+                f_reg[set][k][j] = (ok && c < Cin) ? xfn[(size_t)c * sC + off] : 0.0f;
+            }
+        }
+    };
+    auto stage = [&](auto setc, int buf) {
+        constexpr int set = decltype(setc)::value;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int slot = tid + k * NT;
+            unsigned hi[4], mid[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned short hb[2], mb[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float f = f_reg[set][k][2 * j + e];
+                    const __bf16 a = (__bf16)f;
+                    const __bf16 b = (__bf16)(f - (float)a);
+                    hb[e] = __builtin_bit_cast(unsigned short, a);
+                    mb[e] = __builtin_bit_cast(unsigned short, b);
+                }
+                hi[j] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+                mid[j] = (unsigned)mb[0] | ((unsigned)mb[1] << 16);
+            }
+            if (slot < NVOX) {
+                s_in[(size_t)(buf * 2 + 0) * INS + slot] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                s_in[(size_t)(buf * 2 + 1) * INS + slot] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+            }
+        }
+    };
+    // weights: wq[ob64][c8][14 pairs in class order][row group][piece][lane]; stage (c8, pi) = pairs first(pi) .. + pairs(pi)
+    const uint4* wn = wq + (size_t)ob64 * C8 * (kBfPairs * 4 * 64);
+    auto dma_weights = [&](int c8, int pi, int buf) {
+        int first = 0, np = 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q == pi) { first = s2_first_pair(q); np = s2_pairs(q); }
+        const uint4* src0 = wn + ((size_t)c8 * kBfPairs + first) * (4 * 64) + lane;
+        for (int i = wave; i < np * 4; i += NW) {
+            uint4* dst = s_w + (size_t)buf * kS2WSlots + i * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 64),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    int vb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int g = 2 * wave + b;
+        const int dz = g / (TH / 2), hy = 2 * (g % (TH / 2)) + (col >> 4);
+        vb[b] = (dz * HH + hy) * HW + (col & 15);
+    }
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const bf16x8* s_in8 = reinterpret_cast<const bf16x8*>(s_in);
+    const bf16x8* s_w8 = reinterpret_cast<const bf16x8*>(s_w);
+
+    auto compute = [&](auto pc, int buf) {
+        constexpr int pi = decltype(pc)::value;
+        constexpr int np = s2_pairs(pi);
+        const bf16x8* bin = s_in8 + (size_t)(buf * 2) * INS;
+        const bf16x8* ain = s_w8 + (size_t)buf * kS2WSlots + lane;
+#pragma unroll
+        for (int pl = 0; pl < np; ++pl) {
+            const int toff = hh ? s2_tap_off(pi, 2 * pl + 1) : s2_tap_off(pi, 2 * pl);
+            bf16x8 A[2][2], B[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) A[a][q] = ain[((pl * 2 + a) * 2 + q) * 64];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb[b] + toff];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+
+    // pipeline over the flat stage index q = 8*c8 + pi; LDS buffers alternate with q (= with pi).  Stage q: the registers
+    // hold stage q+1's values (fetched during stage q-1): cut them into LDS buffer (q+1)&1 (free since stage q-1 ended),
+    // start the fetch of stage q+2 and the weight DMA of stage q+1, multiply stage q.
+    const int nq = C8 * 8;
+    using S0 = std::integral_constant<int, 0>;
+    fetch(S0{}, 0, 0);
+    stage(S0{}, 0);
+    dma_weights(0, 0, 0);
+    if (nq > 1) fetch(S0{}, 0, 1);
+    auto step = [&](auto pc, int c8) {
+        constexpr int pi = decltype(pc)::value;
+        constexpr int buf = pi & 1;
+        const int q = c8 * 8 + pi;
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) and lgkmcnt(0): own fetches, DMAs and LDS writes are done
+        __builtin_amdgcn_s_barrier();
+        if (q + 1 < nq) {
+            stage(S0{}, buf ^ 1);
+            dma_weights(pi == 7 ? c8 + 1 : c8, (pi + 1) & 7, buf ^ 1);
+        }
+        if (q + 2 < nq) fetch(S0{}, pi >= 6 ? c8 + 1 : c8, (pi + 2) & 7);
+        compute(pc, buf);
+    };
+    for (int c8 = 0; c8 < C8; ++c8) {
+        step(std::integral_constant<int, 0>{}, c8);
+        step(std::integral_constant<int, 1>{}, c8);
+        step(std::integral_constant<int, 2>{}, c8);
+        step(std::integral_constant<int, 3>{}, c8);
+        step(std::integral_constant<int, 4>{}, c8);
+        step(std::integral_constant<int, 5>{}, c8);
+        step(std::integral_constant<int, 6>{}, c8);
+        step(std::integral_constant<int, 7>{}, c8);
+    }
+
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int g = 2 * wave + b;
+        const int d = d0 + g / (TH / 2), h = h0 + 2 * (g % (TH / 2)) + (col >> 4), w = w0 + (col & 15);
+        if (d >= D || h >= H || w >= W) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = acc[a][b][r];
+                if (scale) v = fmaf(v, scale[o], shift[o]);
+                if (relu) v = fmaxf(v, 0.0f);
+                out[((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w] = v;
+            }
+    }
+}
+
 }  // namespace mvsdet
 
 using namespace mvsdet;
@@ -412,21 +632,52 @@ extern "C" size_t mvsdet_split_conv_weight_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cout % 64 || Cin <= 0) return 0;
     return (size_t)(Cout / 64) * ((Cin + 7) / 8) * kBfPairs * 2 * 2 * 64 * 16;
 }
-extern "C" int mvsdet_split_conv_weight(const float* weight, void* weight_split, int Cout, int Cin, mvsdet_stream_t stream) {
+// order: 0 = stride-1 convolution (pair p = taps 2p, 2p+1), 1 = stride-2 convolution (taps grouped by the parity class of the
+// input voxel they read: conv3d_k3_s2_bf16x3_kernel), 2 = transposed convolution (ConvTranspose3d weight (Cin,Cout,3,3,3);
+// taps grouped by the parity class of the OUTPUT voxel: convT3d_k3_s2_bf16x3_kernel)
+static TapTable tap_table(int order) {
+    TapTable tt;
+    if (order == 0) {
+        for (int i = 0; i < 2 * kBfPairs; ++i) tt.t[i] = (signed char)(i < 27 ? i : -1);
+    } else {
+        // per dimension an odd class has two taps (k = 0, k = 2), an even class one (k = 1); classes in the order
+        // pi = 4*pd + 2*ph + pw, inside a class the taps in the order of (jd, jh, jw) over the odd dimensions
+        int n = 0;
+        for (int pi = 0; pi < 8; ++pi) {
+            const int pd = pi >> 2, ph = (pi >> 1) & 1, pw = pi & 1, nt = 1 << (pd + ph + pw);
+            for (int j = 0; j < nt; ++j) {
+                int bits = j, jw = 0, jh = 0, jd = 0;
+                if (pw) { jw = bits & 1; bits >>= 1; }
+                if (ph) { jh = bits & 1; bits >>= 1; }
+                if (pd) { jd = bits & 1; }
+                const int kd = pd ? 2 * jd : 1, kh = ph ? 2 * jh : 1, kw = pw ? 2 * jw : 1;
+                tt.t[n++] = (signed char)((kd * 3 + kh) * 3 + kw);
+            }
+            if (nt == 1) tt.t[n++] = -1;   // the lone tap of the all-even class fills half a pair
+        }
+    }
+    return tt;
+}
+
+extern "C" int mvsdet_split_conv_weight_ordered(const float* weight, void* weight_split, int Cout, int Cin, int order,
+                                                mvsdet_stream_t stream) {
     MVS_REQUIRE(weight && weight_split, "split_conv_weight: NULL pointer");
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0 && Cin > 0, "split_conv_weight: Cout=%d must be a positive multiple of 64, Cin=%d > 0", Cout, Cin);
+    MVS_REQUIRE(order >= 0 && order <= 2, "split_conv_weight: order %d not in {0,1,2}", order);
     MVS_REQUIRE(((uintptr_t)weight_split & 15u) == 0, "split_conv_weight: output must be 16-byte aligned");
     const size_t units = mvsdet_split_conv_weight_bytes(Cout, Cin) / 16;
+    const long long so = order == 2 ? 27 : (long long)Cin * 27, sc = order == 2 ? (long long)Cout * 27 : 27;
     hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((units + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       (hipStream_t)stream, weight, static_cast<uint4*>(weight_split), Cin, (Cin + 7) / 8, units);
+                       (hipStream_t)stream, weight, static_cast<uint4*>(weight_split), Cin, (Cin + 7) / 8, units, tap_table(order),
+                       so, sc);
     MVS_LAUNCH_CHECK("split_conv_weight");
     return MVSDET_OK;
 }
 
-// Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ per-channel affine] [+ residual] [+ ReLU] on the
-// bf16 matrix cores, three-term split (file header).  xs: SCL input (mvsdet_scl_pack_f32); weight_split: the weights cut
-// and permuted by the caller to [Cout/64][Cin8][14 tap pairs][2 row groups][2 pieces][64 lanes][8] bf16 (lane = 32*(tap
-// parity) + output channel % 32; tap 27 zero; channels beyond Cin zero); out: (N,Cout,D,H,W) fp32.
+extern "C" int mvsdet_split_conv_weight(const float* weight, void* weight_split, int Cout, int Cin, mvsdet_stream_t stream) {
+    return mvsdet_split_conv_weight_ordered(weight, weight_split, Cout, Cin, 0, stream);
+}
+
 static int launch_bf16x3(const char* name, const void* xs, const float* xf, const int64_t* xstr, const void* weight_split,
                          const float* scale, const float* shift, const float* residual, float* out, int N, int Cin, int Cout,
                          int D, int H, int W, int relu, mvsdet_stream_t stream) {
@@ -490,4 +741,38 @@ extern "C" int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_st
                                              int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
     return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, N, Cin, Cout, D,
                          H, W, relu, stream);
+}
+
+// Conv3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] of mvsnet.py:77,79 on the bf16 matrix
+// cores, three-term split; x (N,Cin,D,H,W) fp32 (x_strides as above) -> out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1);
+// weight_split from mvsdet_split_conv_weight_ordered(order = 1).
+extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x_strides, const void* weight_split,
+                                                const float* scale, const float* shift, float* out, int N, int Cin, int Cout,
+                                                int Di, int Hi, int Wi, int relu, mvsdet_stream_t stream) {
+    const char* name = "conv3d_k3_s2_bf16x3_f32in";
+    MVS_REQUIRE(x && weight_split && out, "%s: NULL pointer", name);
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
+    MVS_REQUIRE(N > 0 && Cin > 0 && Di > 0 && Hi > 0 && Wi > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, Di, Hi, Wi);
+    MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
+    MVS_REQUIRE(((uintptr_t)weight_split & 15u) == 0, "%s: weights must be 16-byte aligned", name);
+    const int D = (Di - 1) / 2 + 1, H = (Hi - 1) / 2 + 1, W = (Wi - 1) / 2 + 1;
+    const size_t ivol = (size_t)Di * Hi * Wi;
+    const long long sN = x_strides ? x_strides[0] : (long long)Cin * ivol, sC = x_strides ? x_strides[1] : (long long)ivol;
+    const long long sD = x_strides ? x_strides[2] : (long long)Hi * Wi, sH = x_strides ? x_strides[3] : (long long)Wi;
+    MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= Wi, "%s: bad strides", name);
+    MVS_REQUIRE((long long)(Di - 1) * sD + (long long)(Hi - 1) * sH + Wi < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
+    const int tiles_w = (W + kBfW - 1) / kBfW, tiles_h = (H + kS2TH - 1) / kS2TH, tiles_d = (D + kS2TD - 1) / kS2TD;
+    MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    auto* k = conv3d_k3_s2_bf16x3_kernel;
+    const size_t lds = s2_lds_bytes();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
+        return MVSDET_ERR_HIP;
+    }
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 64)));
+    hipLaunchKernelGGL(k, grid, dim3(64 * kS2TD * kS2TH / 4), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,
+                       static_cast<const uint4*>(weight_split), scale, shift, out, (Cin + 7) / 8, Cout, Di, Hi, Wi, D, H, W, tiles_w,
+                       relu);
+    MVS_LAUNCH_CHECK(name);
+    return MVSDET_OK;
 }

@@ -681,24 +681,55 @@ def split_bf16(t: Tensor):
     return hi, mid
 
 
-def split_conv_weight(weight: Tensor) -> Tensor:
-    """Conv3d weight (Cout = 64*m, Cin, 3,3,3) fp32 -> the layout mvsdet_conv3d_k3_bf16x3 streams into LDS
-    (include/mvsdet_hip.h): [Cout/64][ceil(Cin/8)][14 tap pairs][2 row groups][2 pieces][64 lanes][8 channels] bf16,
-    lane = 32*(tap parity) + output % 32; tap 27 and the channels beyond Cin are zero.  On a ROCm device this is ONE small
+def _tap_table(order: int):
+    """The 3x3x3 tap of each half of the 14 tap pairs (-1 = empty), as csrc/costreg_bf16.hip:tap_table builds it."""
+    if order == 0:
+        return [i if i < 27 else -1 for i in range(28)]
+    t = []
+    for pi in range(8):
+        pd, ph, pw = pi >> 2, (pi >> 1) & 1, pi & 1
+        nt = 1 << (pd + ph + pw)
+        for j in range(nt):
+            bits, jw, jh, jd = j, 0, 0, 0
+            if pw:
+                jw, bits = bits & 1, bits >> 1
+            if ph:
+                jh, bits = bits & 1, bits >> 1
+            if pd:
+                jd = bits & 1
+            t.append(((2 * jd if pd else 1) * 3 + (2 * jh if ph else 1)) * 3 + (2 * jw if pw else 1))
+        if nt == 1:
+            t.append(-1)
+    return t
+
+
+def split_conv_weight(weight: Tensor, order: int = 0) -> Tensor:
+    """Conv3d weight (Cout = 64*m, Cin, 3,3,3) fp32 -> the layout the bf16x3 kernels stream into LDS (include/mvsdet_hip.h):
+    [Cout/64][ceil(Cin/8)][14 tap pairs][2 row groups][2 pieces][64 lanes][8 channels] bf16, lane = 32*(half of the pair) +
+    output % 32; empty halves and the channels beyond Cin are zero.  order 0: stride-1 convolution (pair p = taps 2p, 2p+1);
+    1: stride-2 convolution (pairs grouped by the parity class of the input voxel); 2: `weight` is a ConvTranspose3d weight
+    (Cin, Cout = 64*m, 3,3,3), pairs grouped by the parity class of the output voxel.  On a ROCm device this is ONE small
     kernel (run per call: in-place weight updates are always seen); on the CPU the same layout from torch ops (tests)."""
-    cout, cin = weight.shape[:2]
-    if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3):
-        raise ValueError(f"split_conv_weight: weight {tuple(weight.shape)} != (64*m,Cin,3,3,3)")
+    if order == 2:
+        cin, cout = weight.shape[:2]
+    else:
+        cout, cin = weight.shape[:2]
+    if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3) or order not in (0, 1, 2):
+        raise ValueError(f"split_conv_weight: weight {tuple(weight.shape)} (order {order}) has no 64*m output channels / 3x3x3 taps")
     c8 = (cin + 7) // 8
     if weight.is_cuda:
         w = weight.detach().to(torch.float32).contiguous()
         out = torch.empty((cout // 64, c8, 14, 2, 2, 64, 8), dtype=torch.bfloat16, device=w.device)
         with torch.cuda.device(w.device):
-            _lib.check(_lib.load().mvsdet_split_conv_weight(_lib.ptr(w), _lib.ptr(out), cout, cin, _stream(w)), "split_conv_weight")
+            _lib.check(_lib.load().mvsdet_split_conv_weight_ordered(_lib.ptr(w), _lib.ptr(out), cout, cin, order, _stream(w)),
+                       "split_conv_weight")
         return out
-    w = weight.detach().to(torch.float32).reshape(cout, cin, 27)
-    w = torch.nn.functional.pad(w, (0, 1, 0, c8 * 8 - cin))                      # taps -> 28, channels -> 8*c8
-    pieces = torch.stack(split_bf16(w), 0)                                      # (piece, Cout, C, 28)
+    w = weight.detach().to(torch.float32)
+    w = (w.transpose(0, 1) if order == 2 else w).reshape(cout, cin, 27)
+    taps = torch.tensor(_tap_table(order))
+    w = torch.where(taps.view(1, 1, 28) >= 0, w[:, :, taps.clamp(min=0)], torch.zeros(()))   # (Cout, Cin, 28) in pair order
+    w = torch.nn.functional.pad(w, (0, 0, 0, c8 * 8 - cin))                                  # channels -> 8*c8
+    pieces = torch.stack(split_bf16(w), 0)                                                  # (piece, Cout, C, 28)
     # (piece, ob, a, r, c8, j, p, h) -> (ob, c8, p, a, piece, h, r, j)
     pieces = pieces.reshape(2, cout // 64, 2, 32, c8, 8, 14, 2).permute(1, 4, 6, 2, 0, 7, 3, 5)
     return pieces.contiguous().reshape(cout // 64, c8, 14, 2, 2, 64, 8)
@@ -794,6 +825,36 @@ def conv3d_k3_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Op
             _lib.check(lib.mvsdet_conv3d_k3_bf16x3_f32in(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
                                                          _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
                                                          _stream(out)), "conv3d_k3_bf16x3_f32in")
+    return out
+
+
+def conv3d_k3_s2_bf16x3(x: Tensor, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool) -> Tensor:
+    """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] (mvsnet.py:77,79) on the bf16
+    matrix cores, three-term split: x (N,Cin,D,H,W) fp32 (w stride 1) -> (N,Cout,(D-1)//2+1,(H-1)//2+1,(W-1)//2+1);
+    weight_split = split_conv_weight(weight, order=1)."""
+    import ctypes
+    _req(x, "x", dim=5)
+    if x.stride(4) != 1 or min(x.stride()) < 0:
+        x = x.contiguous()
+    N, Cin, D, H, W = x.shape
+    if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
+        raise ValueError(f"conv3d_k3_s2_bf16x3: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
+    Cout = weight_split.shape[0] * 64
+    if (scale is None) != (shift is None):
+        raise ValueError("conv3d_k3_s2_bf16x3: scale and shift come together")
+    if scale is not None:
+        _req(scale, "scale", dim=1)
+        _req(shift, "shift", dim=1)
+        if scale.numel() != Cout or shift.numel() != Cout:
+            raise ValueError(f"conv3d_k3_s2_bf16x3: scale / shift must have {Cout} elements")
+        scale, shift = scale.contiguous(), shift.contiguous()
+    out = torch.empty((N, Cout, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    weight_split = weight_split.contiguous()
+    xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_conv3d_k3_s2_bf16x3_f32in(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale),
+                                                                _lib.ptr(shift), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
+                                                                _stream(x)), "conv3d_k3_s2_bf16x3")
     return out
 
 

@@ -80,6 +80,30 @@ def test_scl_pack_reads_a_pitched_volume_in_place(gpu):
     assert torch.equal(a.data.view(torch.int16), b.data.view(torch.int16))
 
 
+@pytest.mark.parametrize("N,Cin,Cout,Di,Hi,Wi", [(1, 16, 64, 8, 16, 32), (2, 24, 64, 5, 13, 21), (1, 8, 128, 6, 30, 40),
+                                                  (1, 37, 64, 9, 25, 33), (1, 64, 128, 12, 60, 80), (1, 5, 64, 1, 1, 1),
+                                                  (1, 128, 256, 6, 30, 40), (1, 3, 64, 2, 2, 2)])
+def test_conv3d_k3_s2_bf16x3(gpu, N, Cin, Cout, Di, Hi, Wi):
+    """Stride-2 convolution as the sum over the 8 parity classes of its input (conv1 / conv3 of mvsnet.py:77,79)."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin + Wi)
+    x = torch.randn(N, Cin, Di, Hi, Wi, generator=g).abs() * 2.0
+    wgt = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    wq = ops.split_conv_weight(wgt.to(gpu), 1)
+    assert torch.equal(wq.cpu().view(torch.int16), ops.split_conv_weight(wgt, 1).view(torch.int16))
+    raw = ops.conv3d_k3_s2_bf16x3(x.to(gpu), wq, None, None, False).cpu()
+    want = three_term_conv64(x, wgt, padding=1, stride=2)
+    assert raw.shape == want.shape
+    mag = float(F.conv3d(x.abs().double(), wgt.abs().double(), padding=1, stride=2).max())
+    assert float((raw.double() - want).abs().max()) <= 4e-7 * mag
+    ref32 = F.conv3d(x.double(), wgt.double(), padding=1, stride=2)
+    assert float((raw.double() - ref32).abs().max()) <= 2e-5 * float(ref32.abs().max()) + 1e-6
+    full = ops.conv3d_k3_s2_bf16x3(x.to(gpu), wq, scale.to(gpu), shift.to(gpu), True).cpu()
+    wantf = torch.relu(torch.addcmul(shift.view(1, -1, 1, 1, 1), raw, scale.view(1, -1, 1, 1, 1)))
+    np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
+
+
 def test_conv3d_k3_bf16x3_argument_checks(gpu):
     from mvsdet_amd import ops
     xs = ops.scl_pack(torch.zeros(1, 8, 2, 2, 2, device=gpu))

@@ -43,5 +43,24 @@ def main():
               f"{3 * fl / tbf / 1e9:.0f} TF of bf16 MFMA)  pack {tpk:.3f} ms  fp32-input form {tdir:.3f} ms  max rel diff {err:.2e}", flush=True)
 
 
+def stride2():
+    dev = torch.device("cuda:0")
+    for name, N, Cin, Cout, D, H, W in (("conv1", 40, 64, 128, 12, 60, 80), ("conv3", 40, 128, 256, 6, 30, 40)):
+        x = torch.randn(N, Cin, D, H, W, device=dev).abs()
+        w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) / (27 * Cin) ** 0.5
+        sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        wp = ops.permute_conv_weight(w)
+        wq = ops.split_conv_weight(w, 1)
+        t32 = timeit(lambda: ops.conv3d_k3_mfma(x, wp, sc, sh, True, 2))
+        tbf = timeit(lambda: ops.conv3d_k3_s2_bf16x3(x, wq, sc, sh, True))
+        y32 = ops.conv3d_k3_mfma(x, wp, sc, sh, True, 2)
+        ybf = ops.conv3d_k3_s2_bf16x3(x, wq, sc, sh, True)
+        fl = 2.0 * 27 * Cin * Cout * y32[:, 0].numel()
+        err = float((y32 - ybf).abs().max()) / float(y32.abs().max())
+        print(f"{name} (stride 2): fp32 MFMA {t32:.3f} ms ({fl / t32 / 1e9:.1f} TF)  bf16x3 {tbf:.3f} ms ({fl / tbf / 1e9:.1f} TF useful)  "
+              f"max rel diff {err:.2e}", flush=True)
+
+
 if __name__ == "__main__":
+    stride2()
     main()
