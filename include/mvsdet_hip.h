@@ -370,6 +370,13 @@ int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x_strides /*
                                      const float* scale, const float* shift, float* out, int N, int Cin, int Cout, int D, int H,
                                      int W, int relu, mvsdet_stream_t stream);
 
+/* ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine] [+ ReLU] [+ residual, added last]
+ * (mvsnet.py:92-100,110-111) on the bf16 matrix cores, three-term split: xs = SCL form of x (N,Cin,D,H,W); weight_split of
+ * order 2 from the (Cin,Cout,3,3,3) weight; out / residual (N,Cout,2D,2H,2W) fp32, 8-byte aligned. */
+int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                mvsdet_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement helper for bench.py: runs `fn`-independent HIP-event timing is done by the caller;
  * this only exposes a device-to-device float4 copy so the achievable HBM ceiling can be calibrated

@@ -174,6 +174,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # eval route of the stride-1 layers: "bf16x3" = bf16 matrix cores on split operands (logits within 2e-6 .. 4e-6 of
         # fp32: tools/study/split_bf16_emulation.py), "fp32" = the fp32 MFMA kernels (bit-level fp32 FMA sums)
         self.matrix_precision = "bf16x3"
+        self._scl = {}   # shape -> SclTensor of the transposed layers' (coarse) inputs; their zero border is written once
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
@@ -218,8 +219,13 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not self.training
                 and deconv.out_channels % 64 == 0):
             from . import ops
-            wperm = ops.permute_convT_weight(deconv.weight)
             scale, shift = _bn_affine(bn)
+            if self.matrix_precision == "bf16x3":
+                # 8 output parity classes = 8 small stride-1 convolutions over the coarse input (csrc/costreg_bf16.hip)
+                key = (tuple(x.shape), x.device)   # the coarse input in split channel-last form: refilled in place
+                xs = self._scl[key] = ops.scl_pack(x, out=self._scl.get(key))
+                return ops.convT3d_k3_s2_bf16x3(xs, ops.split_conv_weight(deconv.weight, 2), scale, shift, skip, True)
+            wperm = ops.permute_convT_weight(deconv.weight)
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and deconv.out_channels % 64 == 0 and deconv.in_channels % 64 == 0):

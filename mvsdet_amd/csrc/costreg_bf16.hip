@@ -566,6 +566,199 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Transposed convolution (mvsnet.py:92-100: conv9 256 -> 128, conv11 128 -> 64; ConvTranspose3d kernel 3, stride 2, padding 1,
+// output_padding 1) + affine + ReLU, then the skip tensor is added (mvsnet.py:110-111).  Output 2i + p per dimension sees
+// tap k = 1 on input i (p = 0), or k = 0 on input i + 1 and k = 2 on input i (p = 1): each of the 8 output parity classes is
+// a stride-1 convolution over the INPUT grid with 1, 2, 4 or 8 taps.  One block = (coarse tile of 4 x 8 x 16 input voxels,
+// output parity (PD, PH), BOTH w parities, 64 output channels): 8 waves x (2 row groups x 2 column groups x 2 w parities) =
+// 8 accumulators; the two neighbouring outputs of a lane leave as one float2.  A stage = 8 input channels: the halo tile
+// (5 x 9 x 17 voxels, SCL form of the coarse input) and the 2 - 6 tap pairs of the two classes arrive by LDS-DMA, two
+// stages ahead (three LDS buffers, counted vmcnt): the stages are as short as 24 MFMAs per wave.
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int ct_pairs(int pd, int ph) { return s2_pairs(pd * 4 + ph * 2) + s2_pairs(pd * 4 + ph * 2 + 1); }
+constexpr int kCtWSlots = 6 * 2 * 2 * 64;   // up to 6 tap pairs per stage
+__host__ __device__ constexpr size_t ct_lds_bytes() { return (size_t)(3 * 2 * kS2Ins + 3 * kCtWSlots) * 16; }
+// tap j of output class pi as an offset in the halo tile (origin = the tile's first input voxel): per odd dimension bit 0 ->
+// k = 0 reads input i + 1, bit 1 -> k = 2 reads input i
+__host__ __device__ constexpr int ct_tap_off(int pi, int j) {
+    const int pd = pi >> 2, ph = (pi >> 1) & 1, pw = pi & 1, nt = 1 << (pd + ph + pw);
+    int bits = j < nt ? j : nt - 1, jw = 0, jh = 0, jd = 0;
+    if (pw) { jw = bits & 1; bits >>= 1; }
+    if (ph) { jh = bits & 1; bits >>= 1; }
+    if (pd) { jd = bits & 1; }
+    const int od = (pd && !jd) ? 1 : 0, oh = (ph && !jh) ? 1 : 0, ow = (pw && !jw) ? 1 : 0;
+    return (od * kS2HH + oh) * kS2HW + ow;
+}
+
+template <int PD, int PH>
+__device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
+    const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
+    size_t piece_stride, int tiles_w, int relu, int tile_xy) {
+    constexpr int TD = kS2TD, TH = kS2TH, NW = 8;
+    constexpr int HH = kS2HH, HW = kS2HW, NVOX = kS2Vox, INS = kS2Ins;
+    constexpr int IN_DMA = INS / 64;                      // 12 wave-instructions per piece
+    constexpr int IN_PER_WAVE = 2 * IN_DMA / NW;          // 3
+    constexpr int PI0 = PD * 4 + PH * 2, NP0 = s2_pairs(PI0), NP1 = s2_pairs(PI0 + 1), NP = NP0 + NP1;
+    constexpr int W_PER_WAVE = (NP * 4 + NW - 1) / NW;    // weight DMAs per wave and stage (the tail repeats earlier pieces)
+    constexpr int DMA_PER_STAGE = IN_PER_WAVE + W_PER_WAVE;
+    static_assert(2 * IN_DMA % NW == 0, "input DMAs must divide evenly over the waves");
+    extern __shared__ uint4 s_bf[];   // [3 stages][2 pieces][INS] input, then [3 stages][kCtWSlots] weights
+    uint4* s_in = s_bf;
+    uint4* s_w = s_bf + 3 * 2 * INS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bw = tile_xy % tiles_w, bh = tile_xy / tiles_w;
+    const int nob = Cout / 64;
+    const int n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int col = lane & 31, hh = lane >> 5;
+
+    // input DMA plan: halo voxel (dz, hy, wx) = input (d0 + dz, h0 + hy, w0 + wx) = padded (+1, +1, +1)
+    const size_t c8_stride = (size_t)Dp * Hp * Wp;
+    const uint4* xn = xs + ((size_t)n * C8) * c8_stride + ((size_t)(d0 + 1) * Hp + (h0 + 1)) * Wp + (w0 + 1);
+    unsigned in_src[IN_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < IN_PER_WAVE; ++k) {
+        const int i = wave + k * NW;
+        const int slot = (i % IN_DMA) * 64 + lane;
+        const int sv = slot < NVOX ? slot : 0;
+        const int dz = sv / (HH * HW), r = sv - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
+        in_src[k] = (unsigned)(((size_t)dz * Hp + hy) * Wp + wx);
+    }
+    const uint4* wn = wq + (size_t)ob64 * C8 * (kBfPairs * 4 * 64) + (size_t)s2_first_pair(PI0) * (4 * 64) + lane;
+    auto dma_stage = [&](int c8, int buf) {
+#pragma unroll
+        for (int k = 0; k < IN_PER_WAVE; ++k) {
+            const int i = wave + k * NW;
+            const int piece = i / IN_DMA;
+            const uint4* src = xn + (size_t)piece * piece_stride + (size_t)c8 * c8_stride + in_src[k];
+            uint4* dst = s_in + (size_t)(buf * 2 + piece) * INS + (i % IN_DMA) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < W_PER_WAVE; ++k) {
+            const int i = (wave + k * NW) % (NP * 4);   // the tail wraps: every wave issues the same number of DMAs
+            uint4* dst = s_w + (size_t)buf * kCtWSlots + i * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wn + (size_t)c8 * (kBfPairs * 4 * 64) + i * 64),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    int vb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int g = 2 * wave + b;
+        const int dz = g / (TH / 2), hy = 2 * (g % (TH / 2)) + (col >> 4);
+        vb[b] = (dz * HH + hy) * HW + (col & 15);
+    }
+    f32x16b acc[2][2][2];   // [w parity][row group][column group]
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pw][a][b][r] = 0.0f;
+    const bf16x8* s_in8 = reinterpret_cast<const bf16x8*>(s_in);
+    const bf16x8* s_w8 = reinterpret_cast<const bf16x8*>(s_w);
+
+    auto compute = [&](int buf) {
+        const bf16x8* bin = s_in8 + (size_t)(buf * 2) * INS;
+        const bf16x8* ain = s_w8 + (size_t)buf * kCtWSlots + lane;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int pw = pl < NP0 ? 0 : 1;
+            const int pi = PI0 + pw, pj = pw ? pl - NP0 : pl;
+            const int toff = hh ? ct_tap_off(pi, 2 * pj + 1) : ct_tap_off(pi, 2 * pj);
+            bf16x8 A[2][2], B[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) A[a][q] = ain[((pl * 2 + a) * 2 + q) * 64];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb[b] + toff];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[pw][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], acc[pw][a][b], 0, 0, 0);
+                    acc[pw][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], acc[pw][a][b], 0, 0, 0);
+                    acc[pw][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], acc[pw][a][b], 0, 0, 0);
+                }
+        }
+    };
+
+    // three LDS stages: at stage c8 the DMAs of c8+2 are issued (into the buffer stage c8-1 used), and the wait at the top
+    // leaves one stage's DMAs (those of c8+1) in flight
+    dma_stage(0, 0);
+    if (C8 > 1) dma_stage(1, 1);
+    int buf = 0;
+    for (int c8 = 0; c8 < C8; ++c8) {
+        if (c8 + 1 < C8) __builtin_amdgcn_s_waitcnt(0x0f70 | (DMA_PER_STAGE & 15) | ((DMA_PER_STAGE >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+        if (c8 + 2 < C8) dma_stage(c8 + 2, buf == 0 ? 2 : buf - 1);
+        compute(buf);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // epilogue: lane = coarse voxel; the two w parities are neighbouring outputs -> one float2
+    const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int g = 2 * wave + b;
+        const int di = d0 + g / (TH / 2), hi = h0 + 2 * (g % (TH / 2)) + (col >> 4), wi = w0 + (col & 15);
+        if (di >= Di || hi >= Hi || wi >= Wi) continue;
+        const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + 2 * wi;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float2 v = make_float2(acc[0][a][b][r], acc[1][a][b][r]);
+                if (scale) {
+                    const float sc = scale[o], sh = shift[o];
+                    v.x = fmaf(v.x, sc, sh);
+                    v.y = fmaf(v.y, sc, sh);
+                }
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.0f);
+                    v.y = fmaxf(v.y, 0.0f);
+                }
+                const size_t idx = ((size_t)n * Cout + o) * ovol + pos;
+                if (residual) {
+                    const float2 rv = *reinterpret_cast<const float2*>(residual + idx);
+                    v.x = rv.x + v.x;
+                    v.y = rv.y + v.y;
+                }
+                *reinterpret_cast<float2*>(out + idx) = v;
+            }
+    }
+}
+
+// ONE launch for the four (PD, PH) classes: class = blockIdx.x & 3, so the four blocks that read the same input tile are
+// dispatched together (the tile's second to fourth reads hit L2) and the grid has one tail instead of four.
+__global__ __launch_bounds__(512) void convT3d_k3_s2_bf16x3_kernel(
+    const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
+    size_t piece_stride, int tiles_w, int relu) {
+    const int cls = blockIdx.x & 3, tile_xy = blockIdx.x >> 2;
+    if (cls == 0) convT3d_k3_s2_bf16x3_body<1, 1>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else if (cls == 1) convT3d_k3_s2_bf16x3_body<1, 0>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else if (cls == 2) convT3d_k3_s2_bf16x3_body<0, 1>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else convT3d_k3_s2_bf16x3_body<0, 0>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+}
+
 }  // namespace mvsdet
 
 using namespace mvsdet;
@@ -584,7 +777,7 @@ BfPlan bf_plan(int D, int H, int W) {
     p.tiles_h = (H + p.th - 1) / p.th;
     p.tiles_w = (W + kBfW - 1) / kBfW;
     p.Dp = p.tiles_d * p.td + 2;
-    p.Hp = p.tiles_h * p.th + 2;
+    p.Hp = std::max(pad8, pad12) + 2;   // covers the 4x8x16 tiles of the transposed convolution as well
     p.Wp = p.tiles_w * kBfW + 2;
     return p;
 }
@@ -773,6 +966,43 @@ extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x
     hipLaunchKernelGGL(k, grid, dim3(64 * kS2TD * kS2TH / 4), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,
                        static_cast<const uint4*>(weight_split), scale, shift, out, (Cin + 7) / 8, Cout, Di, Hi, Wi, D, H, W, tiles_w,
                        relu);
+    MVS_LAUNCH_CHECK(name);
+    return MVSDET_OK;
+}
+
+// ConvTranspose3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine] [+ ReLU] [+ residual,
+// added last] of mvsnet.py:92-100,110-111 on the bf16 matrix cores, three-term split.  xs: SCL form of the input (N,Cin,D,H,W)
+// (mvsdet_scl_pack_f32); weight_split: mvsdet_split_conv_weight_ordered(order = 2) of the (Cin,Cout,3,3,3) weight;
+// out / residual (N,Cout,2D,2H,2W) fp32, 8-byte aligned.
+extern "C" int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                           const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W,
+                                           int relu, mvsdet_stream_t stream) {
+    const char* name = "convT3d_k3_s2_bf16x3";
+    MVS_REQUIRE(xs && weight_split && out, "%s: NULL pointer", name);
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
+    MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
+    MVS_REQUIRE((((uintptr_t)xs | (uintptr_t)weight_split) & 15u) == 0, "%s: xs and weights must be 16-byte aligned", name);
+    MVS_REQUIRE(((uintptr_t)out & 7u) == 0 && (residual == nullptr || ((uintptr_t)residual & 7u) == 0),
+                "%s: out and residual must be 8-byte aligned", name);
+    const BfPlan p = bf_plan(D, H, W);   // the padded extents of the SCL input (its tile height may be 12: the extents only grow)
+    const int C8 = (Cin + 7) / 8;
+    const int tiles_w = (W + kBfW - 1) / kBfW, tiles_h = (H + kS2TH - 1) / kS2TH, tiles_d = (D + kS2TD - 1) / kS2TD;
+    // the halo tile reaches one voxel past the last tile: padded index tiles*T + 1 must exist
+    MVS_REQUIRE(tiles_d * kS2TD + 2 <= p.Dp && tiles_h * kS2TH + 2 <= p.Hp && tiles_w * kBfW + 2 <= p.Wp,
+                "%s: the SCL padding does not cover the 4x8x16 tiles", name);
+    MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
+    dim3 grid((unsigned)(tiles_w * tiles_h * 4), (unsigned)tiles_d, (unsigned)(N * (Cout / 64)));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ct_lds_bytes();
+    auto* k = convT3d_k3_s2_bf16x3_kernel;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
+        return MVSDET_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split), scale,
+                       shift, residual, out, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, relu);
     MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
 }

@@ -858,6 +858,39 @@ def conv3d_k3_s2_bf16x3(x: Tensor, weight_split: Tensor, scale: Optional[Tensor]
     return out
 
 
+def convT3d_k3_s2_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor],
+                         residual: Optional[Tensor], relu: bool) -> Tensor:
+    """ConvTranspose3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine] [+ ReLU]
+    [+ residual, added last] (mvsnet.py:92-100,110-111) on the bf16 matrix cores, three-term split: x (N,Cin,D,H,W) fp32 (or
+    its SclTensor) -> (N,Cout,2D,2H,2W); weight_split = split_conv_weight(weight (Cin,Cout,3,3,3), order=2)."""
+    xs = x if isinstance(x, SclTensor) else scl_pack(x)
+    N, Cin, D, H, W = xs.shape
+    if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
+        raise ValueError(f"convT3d_k3_s2_bf16x3: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
+    Cout = weight_split.shape[0] * 64
+    if (scale is None) != (shift is None):
+        raise ValueError("convT3d_k3_s2_bf16x3: scale and shift come together")
+    dev = xs.data.device
+    if scale is not None:
+        _req(scale, "scale", dim=1)
+        _req(shift, "shift", dim=1)
+        if scale.numel() != Cout or shift.numel() != Cout:
+            raise ValueError(f"convT3d_k3_s2_bf16x3: scale / shift must have {Cout} elements")
+        scale, shift = scale.contiguous(), shift.contiguous()
+    out = torch.empty((N, Cout, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=dev)
+    if residual is not None:
+        _req(residual, "residual", dim=5)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError(f"convT3d_k3_s2_bf16x3: residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+        residual = residual.contiguous()
+    weight_split = weight_split.contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mvsdet_convT3d_k3_s2_bf16x3(_lib.ptr(xs.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
+                                                           _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
+                                                           _stream(out)), "convT3d_k3_s2_bf16x3")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- misc
 def device_copy(src: Tensor, dst: Tensor):
     """float4 device-to-device copy kernel (bench.py's achievable-HBM yardstick)."""

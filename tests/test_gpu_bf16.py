@@ -104,6 +104,34 @@ def test_conv3d_k3_s2_bf16x3(gpu, N, Cin, Cout, Di, Hi, Wi):
     np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 16, 64, 4, 8, 16), (2, 24, 64, 3, 7, 11), (1, 256, 128, 3, 15, 20),
+                                               (1, 128, 64, 6, 30, 40), (1, 5, 64, 1, 1, 1), (1, 40, 64, 5, 60, 17)])
+def test_convT3d_k3_s2_bf16x3(gpu, N, Cin, Cout, D, H, W):
+    """Transposed convolution as 8 output parity classes over the coarse input (conv9 / conv11 of mvsnet.py:92-100), with
+    the affine, the ReLU and the skip tensor added last (mvsnet.py:110-111)."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + Cin + W)
+    x = torch.randn(N, Cin, D, H, W, generator=g).abs() * 2.0
+    wgt = torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (27 * Cin / 8) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    res = torch.randn(N, Cout, 2 * D, 2 * H, 2 * W, generator=g)
+    wq = ops.split_conv_weight(wgt.to(gpu), 2)
+    assert torch.equal(wq.cpu().view(torch.int16), ops.split_conv_weight(wgt, 2).view(torch.int16))
+    raw = ops.convT3d_k3_s2_bf16x3(x.to(gpu), wq, None, None, None, False).cpu()
+    kw = dict(stride=2, padding=1, output_padding=1)
+    xh, xm = (t.double() for t in ops.split_bf16(x))
+    wh, wm = (t.double() for t in ops.split_bf16(wgt))
+    want = F.conv_transpose3d(xh, wh, **kw) + F.conv_transpose3d(xh, wm, **kw) + F.conv_transpose3d(xm, wh, **kw)
+    assert raw.shape == want.shape
+    mag = float(F.conv_transpose3d(x.abs().double(), wgt.abs().double(), **kw).max())
+    assert float((raw.double() - want).abs().max()) <= 4e-7 * mag
+    ref32 = F.conv_transpose3d(x.double(), wgt.double(), **kw)
+    assert float((raw.double() - ref32).abs().max()) <= 2e-5 * float(ref32.abs().max()) + 1e-6
+    full = ops.convT3d_k3_s2_bf16x3(x.to(gpu), wq, scale.to(gpu), shift.to(gpu), res.to(gpu), True).cpu()
+    wantf = res + torch.relu(torch.addcmul(shift.view(1, -1, 1, 1, 1), raw, scale.view(1, -1, 1, 1, 1)))
+    np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
+
+
 def test_conv3d_k3_bf16x3_argument_checks(gpu):
     from mvsdet_amd import ops
     xs = ops.scl_pack(torch.zeros(1, 8, 2, 2, 2, device=gpu))

@@ -61,6 +61,26 @@ def stride2():
               f"max rel diff {err:.2e}", flush=True)
 
 
+def transposed():
+    dev = torch.device("cuda:0")
+    for name, N, Cin, Cout, D, H, W in (("conv9", 40, 256, 128, 3, 15, 20), ("conv11", 40, 128, 64, 6, 30, 40)):
+        x = torch.randn(N, Cin, D, H, W, device=dev).abs()
+        w = torch.randn(Cin, Cout, 3, 3, 3, device=dev) / (27 * Cin / 8) ** 0.5
+        skip = torch.randn(N, Cout, 2 * D, 2 * H, 2 * W, device=dev)
+        sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        wp = ops.permute_convT_weight(w)
+        wq = ops.split_conv_weight(w, 2)
+        t32 = timeit(lambda: ops.convT3d_k3_s2_mfma(x, wp, sc, sh, skip, True))
+        tbf = timeit(lambda: ops.convT3d_k3_s2_bf16x3(x, wq, sc, sh, skip, True))
+        y32 = ops.convT3d_k3_s2_mfma(x, wp, sc, sh, skip, True)
+        ybf = ops.convT3d_k3_s2_bf16x3(x, wq, sc, sh, skip, True)
+        fl = 2.0 * 27 * Cin * Cout * x[:, 0].numel()
+        err = float((y32 - ybf).abs().max()) / float(y32.abs().max())
+        print(f"{name} (transposed): fp32 MFMA {t32:.3f} ms ({fl / t32 / 1e9:.1f} TF)  bf16x3 incl. packing {tbf:.3f} ms "
+              f"({fl / tbf / 1e9:.1f} TF useful)  max rel diff {err:.2e}", flush=True)
+
+
 if __name__ == "__main__":
+    transposed()
     stride2()
     main()
