@@ -7,7 +7,8 @@ mkdir -p $out
 export TMPDIR=/tmp
 cd $root
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o costreg -- python3 tools/costreg_layers_hip.py > $out/kt.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc -o pmc -- python3 tools/costreg_layers_hip.py > $out/pmc.log 2>&1
+rocprofv3 -L 2>/dev/null | grep -o "SQ_INSTS_VALU_MFMA_MOPS_[A-Z0-9]*" | sort -u > $out/mfma_counters.txt
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc -o pmc -- python3 tools/costreg_layers_hip.py > $out/pmc.log 2>&1
 find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 # the 3-D neck (eval) and one training step of the cost network (forward + backward on our kernels)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_neck -o neck -- python3 tools/neck_timing.py > $out/kt_neck.log 2>&1
