@@ -8,7 +8,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 cd $root
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-seconds 0 > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python3 bench.py --steps 20 --warmup 5 --no-extras --cpu-seconds 0 > $out/bench_under_rocprof.log 2>&1
 find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bwd -o kt -- python3 tools/profile_bwd.py > $out/kt_bwd.log 2>&1
 find $out/kt_bwd -name "*kernel_stats.csv" -exec cp {} $out/bwd_scannet_ref_40v_12d_60x80_kernel_stats.csv \;
