@@ -267,8 +267,6 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
         const bf16x8* ain = s_w8 + (size_t)wbuf * kBfWSlots + lane;
 #pragma unroll
         for (int pl = 0; pl < np; ++pl) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int p = s * kBfSubPairs + pl;
             const int toff = hh ? bf_tap_off<HH>(2 * p + 1) : bf_tap_off<HH>(2 * p);
             bf16x8 A[2][2], B[2][2];   // [row / column group][piece]
@@ -672,8 +670,6 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
         const bf16x8* ain = s_w8 + (size_t)buf * kCtWSlots + lane;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int pw = pl < NP0 ? 0 : 1;
             const int pi = PI0 + pw, pj = pw ? pl - NP0 : pl;
             const int toff = hh ? ct_tap_off(pi, 2 * pj + 1) : ct_tap_off(pi, 2 * pj);
