@@ -30,9 +30,12 @@ class _ConvK3S1(torch.autograd.Function):
     reference-true shape, these kernels 15 + 15 + 22 ms."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bf16x3=False):
         from . import ops
         ctx.save_for_backward(x, weight)
+        ctx.bf16x3 = bool(bf16x3)
+        if ctx.bf16x3:   # forward and input gradient on the bf16 matrix cores, three-term split (csrc/costreg_bf16.hip)
+            return ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(weight), None, None, False)
         return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(weight), None, None, False)
 
     @staticmethod
@@ -43,10 +46,13 @@ class _ConvK3S1(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             wflip = weight.detach().transpose(0, 1).flip(2, 3, 4).contiguous()      # (Cin, Cout, 3,3,3)
-            gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(wflip), None, None, False)
+            if ctx.bf16x3 and wflip.shape[0] % 64 == 0:
+                gx = ops.conv3d_k3_bf16x3(gy, ops.split_conv_weight(wflip), None, None, False)
+            else:
+                gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(wflip), None, None, False)
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_k3_dw(x, gy)
-        return gx, gw
+        return gx, gw, None
 
 
 class _ConvK3S2(torch.autograd.Function):
@@ -56,9 +62,12 @@ class _ConvK3S2(torch.autograd.Function):
     `ops.conv3d_k3_dw(stride=2)`.  D, H, W even (the network asks for multiples of 4)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bf16x3=False):
         from . import ops
         ctx.save_for_backward(x, weight)
+        ctx.bf16x3 = bool(bf16x3)
+        if ctx.bf16x3:
+            return ops.conv3d_k3_s2_bf16x3(x, ops.split_conv_weight(weight, 1), None, None, False)
         return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(weight), None, None, False, 2)
 
     @staticmethod
@@ -68,10 +77,13 @@ class _ConvK3S2(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = ops.convT3d_k3_s2_mfma(gy, ops.permute_convT_weight(weight.detach()), None, None, None, False)
+            if ctx.bf16x3 and weight.shape[1] % 64 == 0:   # the (Cout,Cin,3,3,3) tensor read as a ConvTranspose3d weight
+                gx = ops.convT3d_k3_s2_bf16x3(gy, ops.split_conv_weight(weight.detach(), 2), None, None, None, False)
+            else:
+                gx = ops.convT3d_k3_s2_mfma(gy, ops.permute_convT_weight(weight.detach()), None, None, None, False)
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_k3_dw(x, gy, 0, 2)
-        return gx, gw
+        return gx, gw, None
 
 
 class _ConvT3S2(torch.autograd.Function):
@@ -81,9 +93,12 @@ class _ConvT3S2(torch.autograd.Function):
     weight-gradient kernel with the two tensors exchanged."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bf16x3=False):
         from . import ops
         ctx.save_for_backward(x, weight)
+        ctx.bf16x3 = bool(bf16x3)
+        if ctx.bf16x3:
+            return ops.convT3d_k3_s2_bf16x3(x, ops.split_conv_weight(weight, 2), None, None, None, False)
         return ops.convT3d_k3_s2_mfma(x, ops.permute_convT_weight(weight), None, None, None, False)
 
     @staticmethod
@@ -93,10 +108,13 @@ class _ConvT3S2(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(weight.detach()), None, None, False, 2)
+            if ctx.bf16x3 and weight.shape[0] % 64 == 0:   # the (Cin,Cout,3,3,3) tensor read as a Conv3d weight
+                gx = ops.conv3d_k3_s2_bf16x3(gy, ops.split_conv_weight(weight.detach(), 1), None, None, False)
+            else:
+                gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(weight.detach()), None, None, False, 2)
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_k3_dw(gy, x, 0, 2)
-        return gx, gw
+        return gx, gw, None
 
 
 def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor) -> torch.Tensor:
@@ -208,7 +226,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
                 and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
             # autograd: convolution forward / backward on our kernels; BatchNorm + ReLU too when it uses batch statistics
             fn = _ConvK3S1 if conv.stride == (1, 1, 1) else _ConvK3S2
-            y = fn.apply(x, conv.weight)
+            y = fn.apply(x, conv.weight, self.matrix_precision == "bf16x3")
             return _bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y))
         return layer(x)
 
@@ -229,7 +247,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and deconv.out_channels % 64 == 0 and deconv.in_channels % 64 == 0):
-            y = _ConvT3S2.apply(x, deconv.weight)
+            y = _ConvT3S2.apply(x, deconv.weight, self.matrix_precision == "bf16x3")
             return skip + (_bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y)))
         return skip + seq(x)
 

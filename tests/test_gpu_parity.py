@@ -1177,6 +1177,7 @@ def test_cost_network_training_gradients_hip_vs_torch(gpu):
     # BatchNorm on its running statistics: with batch statistics over the few quarter-resolution voxels of this small
     # volume the summation-order noise of two correct convolutions is amplified beyond any useful tolerance
     net = CostRegNet3DGS(256).to(gpu).eval()
+    net.matrix_precision = "fp32"     # bit-level fp32 FMA sums on both routes: no ReLU decision differs (bf16x3: next test)
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm3d):
             m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
@@ -1196,6 +1197,47 @@ def test_cost_network_training_gradients_hip_vs_torch(gpu):
     torch.testing.assert_close(gx1, gx0, rtol=0, atol=1e-4 * float(gx0.abs().max()))
     for k in gp0:
         torch.testing.assert_close(gp1[k], gp0[k], rtol=0, atol=1e-4 * max(float(gp0[k].abs().max()), 1e-12), msg=k)
+
+
+def test_cost_network_training_on_bf16x3(gpu):
+    """Under autograd with `matrix_precision = "bf16x3"` (the default) forward and input gradient of every 3x3x3 layer run
+    on the bf16 matrix cores with three-term split operands, the weight gradients on the fp32 kernels.  Every layer pass is
+    within 5e-6 of its fp32 counterpart (checked per autograd Function); through the network a forward difference of that
+    size flips the ReLU decision of the few activations that sit within it of zero, so gradients are compared in norm."""
+    from mvsdet_amd import costreg as CR
+    torch.manual_seed(5)
+    for fn, xs, ws in ((CR._ConvK3S1, (2, 256, 8, 12, 32), (64, 256, 3, 3, 3)), (CR._ConvK3S2, (2, 64, 8, 12, 32), (128, 64, 3, 3, 3)),
+                       (CR._ConvT3S2, (2, 128, 4, 6, 16), (128, 64, 3, 3, 3))):
+        x, w = torch.randn(*xs, device=gpu), torch.randn(*ws, device=gpu) / 30
+        res = {}
+        for bf in (False, True):
+            xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = fn.apply(xi, wi, bf)
+            y.backward(torch.randn(y.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(1)))
+            res[bf] = (y.detach(), xi.grad, wi.grad)
+        for a, b in zip(res[False], res[True]):
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), fn.__name__
+    net = CR.CostRegNet3DGS(256).to(gpu).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(2, 256, 8, 12, 32, device=gpu)
+    target = torch.randn(2, 2, 8, 12, 32, device=gpu)
+    grads = {}
+    for prec in ("bf16x3", "fp32"):
+        net.matrix_precision = prec
+        net.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        out = net(xin)
+        ((out - target) ** 2).mean().backward()
+        grads[prec] = (out.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+    o1, gx1, gp1 = grads["bf16x3"]
+    o0, gx0, gp0 = grads["fp32"]
+    torch.testing.assert_close(o1, o0, rtol=0, atol=2e-5 * float(o0.abs().max()))
+    rel = lambda a, b: float((a - b).norm()) / max(float(b.norm()), 1e-30)   # noqa: E731
+    assert rel(gx1, gx0) < 2e-3
+    for k in gp0:
+        assert rel(gp1[k], gp0[k]) < 2e-3, k
 
 
 @pytest.mark.parametrize("N,Cin,D,H,W", [(2, 64, 12, 20, 40), (1, 6, 5, 7, 33), (1, 3, 1, 1, 1)])
