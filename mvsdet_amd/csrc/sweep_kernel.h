@@ -162,9 +162,52 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
         for (int i = tid; i < K * 16; i += kThreads) proj_copy[(size_t)n * K * 16 + i] = proj[(size_t)n * K * 16 + i];
         for (int d = tid; d < D; d += kThreads) depth_copy[(size_t)n * D + d] = depth[(size_t)n * D + d];
     }
-    // A (plane, neighbour) footprint is the work of ONE wave: its lanes take the tile's pixels lane and lane + 64 (two
-    // independent positions in flight per lane), one wave reduction gives the box, lane 0 files it -- no block barrier
-    // and no cross-wave merge per plane.  Wave w takes the planes w, w + 4, ... of every neighbour.
+    // ---- fast path: one THREAD per (neighbour, plane).  For a fixed plane the sample position is a linear-fractional function
+    // of the pixel; where its denominator Z keeps one sign over the tile (checked at the four corner pixels: Z is affine in the
+    // pixel), each coordinate takes its extremes over the tile at a corner.  So the footprint of all 128 pixels lies inside
+    // the box spanned by the corners' positions -- 4 positions per (tile, plane, neighbour) instead of 128.  The box may
+    // exceed the exact one (taps outside the image are clipped by the rectangle, not one by one) and carries a margin of
+    // 1e-3 px against the rounding noise of positions computed at interior pixels (the chain is good to ~2e-4 px:
+    // DESIGN "tolerance budget"); a larger box only costs LDS, results never depend on it.  Anything else -- Z changing
+    // sign or vanishing, a non-finite position -- is left to the exact wave-wide scan below.
+    constexpr int kSlowMark = INT32_MIN + 2;   // boxes[].w of a (plane, neighbour) that needs the exact scan
+    {
+        const int xa = tx0, xb = min(tx0 + TW, W) - 1, ya = ty0, yb = min(ty0 + TH, H) - 1;
+        for (int task = tid; task < K * D; task += kThreads) {
+            const int j = task / D, d = task - j * D;
+            const float* P = proj + ((size_t)n * K + j) * 16;
+            const float t0 = P[3], t1 = P[7], t2 = P[11];
+            const float dval = s_dv[d];
+            float ixmin = INFINITY, ixmax = -INFINITY, iymin = INFINITY, iymax = -INFINITY;
+            bool ok = xb >= xa && yb >= ya;
+            int zpos = 0, zneg = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const SampleRay r = sample_ray(P, (float)((c & 1) ? xb : xa), (float)((c & 2) ? yb : ya));
+                const float Z = r.rz * dval + t2;                       // the denominator inside sample_at, same arithmetic
+                const float2 e = sample_at(r, t0, t1, t2, dval, H, W);
+                ok = ok && isfinite(Z) && isfinite(e.x) && isfinite(e.y);
+                zpos += Z > 0.0f;
+                zneg += Z < 0.0f;
+                ixmin = fminf(ixmin, e.x); ixmax = fmaxf(ixmax, e.x);
+                iymin = fminf(iymin, e.y); iymax = fmaxf(iymax, e.y);
+            }
+            ok = ok && (zpos == 4 || zneg == 4);
+            int4 bx = make_int4(0, 0, 0, kSlowMark);
+            if (ok) {
+                // taps of a position ix are floor(ix), floor(ix) + 1; clipped to the image (and clamped before the conversion)
+                const float fx0 = fmaxf(floorf(ixmin - 1e-3f), 0.0f), fx1 = fminf(floorf(ixmax + 1e-3f) + 1.0f, (float)(W - 1));
+                const float fy0 = fmaxf(floorf(iymin - 1e-3f), 0.0f), fy1 = fminf(floorf(iymax + 1e-3f) + 1.0f, (float)(H - 1));
+                if (fx1 < fx0 || fy1 < fy0) bx = make_int4(INT32_MAX, INT32_MIN, INT32_MAX, kBoxSkip);   // all taps outside, all finite
+                else bx = make_int4((int)fx0, (int)fx1, (int)fy0, (int)fy1);
+            }
+            s_pb[(size_t)j * D + d] = bx;
+        }
+    }
+    __syncthreads();
+    // ---- exact scan of the marked (plane, neighbour) pairs.  A footprint is the work of ONE wave: its lanes take the tile's
+    // pixels lane and lane + 64 (two independent positions in flight per lane), one wave reduction gives the box, lane 0
+    // files it -- no block barrier and no cross-wave merge per plane.  Wave w takes the planes w, w + 4, ... of every neighbour.
     bool inside[2];
     SampleRay ray[K > 0 ? K : 1][2];   // the pixel rays (plane-independent)
 #pragma unroll
@@ -180,6 +223,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
         const float* P = proj + ((size_t)n * K + j) * 16;
         const float t0 = P[3], t1 = P[7], t2 = P[11];
         for (int d = wave; d < D; d += kThreads / 64) {
+            if (s_pb[(size_t)j * D + d].w != kSlowMark) continue;   // wave-uniform (LDS broadcast)
             const float dval = s_dv[d];
             int xlo = INT32_MAX, xhi = INT32_MIN, ylo = INT32_MAX, yhi = INT32_MIN;
             int fin = 1;
