@@ -181,6 +181,11 @@ class MVSDetHotPath:
         self._points_cache: dict = {}
         self._geo_streams: dict = {}
         self._geometry = _GeometryWorker(self)
+        # "auto": the tabled sweep of forward_scene writes a ROW-PITCHED volume (rows on 128-byte lines, handed out as the
+        # (N,C,D,H,W) view of an (N,C,D,H,pitch) buffer: same values, `stride(3)` = pitch) where that pays -- maps whose
+        # width is a multiple of 16 but not of 32 swept with the 32x4 tiles (48 planes or more): 6.1 against 6.5 ms at 50 views x
+        # 96 planes x 60x80.  The cost network and the depth distribution read such views in place.  False: always contiguous.
+        self.pitched_variance = "auto"
 
     # ---- reference-named methods (mvsdet.py:249, 266, 298) -------------------------------------------
     def collect_proj(self, w2c, intr, neighbor_ids):
@@ -285,7 +290,11 @@ class MVSDetHotPath:
             if events:   # bench.py: timing events on the stream the kernel launches on
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(side)
-            table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
+            pitch = self.variance_row_pitch(W)
+            if pitch != W:
+                table = ops.plane_sweep_table_pitched(geo.proj_rel, geo.depth_values, H, W, pitch)
+            else:
+                table = ops.plane_sweep_table(geo.proj_rel, geo.depth_values, H, W)
             if events:
                 t1.record(side)
             done = torch.cuda.Event()
@@ -293,10 +302,19 @@ class MVSDetHotPath:
         table.record_stream(cur)   # allocated under the side stream, consumed on the current one
         return (table, done, t0, t1) if events else (table, done)
 
+    def variance_row_pitch(self, W: int) -> int:
+        """Row pitch (elements) of the variance volume `forward_scene` produces for maps of width W (W itself: contiguous)."""
+        if self.pitched_variance == "auto" and W % 32 != 0 and W % 16 == 0 and self.num_depth >= 48:
+            return ops.sweep_row_pitch(W)
+        return int(W)
+
     def cost_volume_tabled(self, packed: Tensor, geo: SceneGeometry, table_and_event, C: int, H: int, W: int) -> Tensor:
         """a3+a4 from the packed maps and a geometry built by `sweep_geometry_async` (forward only)."""
         table, done = table_and_event
         torch.cuda.current_stream(packed.device).wait_event(done)
+        pitch = self.variance_row_pitch(W)
+        if pitch != W:   # the geometry was built for this pitch (sweep_geometry_async)
+            return ops.plane_sweep_variance_tabled_pitched(packed, geo.neighbor_ids, table, C, self.num_depth, H, W, pitch)
         return ops.plane_sweep_variance_tabled(packed, geo.neighbor_ids, table, C, self.num_depth, H, W)
 
     def cost_volume(self, feature: Tensor, geo: SceneGeometry, packed: Optional[Tensor] = None) -> Tensor:
