@@ -252,6 +252,11 @@ int mvsdet_convT3d_k3_s2_mfma_f32(const float* x, const float* weight_perm, cons
 size_t mvsdet_conv3d_k3_dw_partial_bytes(int Cin, int Cout, int nsplit);
 int mvsdet_conv3d_k3_dw_mfma_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
                                  int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
+/* The same sum on the bf16 matrix cores with three-term split operands (the arithmetic of mvsdet_conv3d_k3_bf16x3: both
+ * fp32 tensors are cut into bf16 pieces on the way into the LDS, products accumulate in fp32; relative error of a product
+ * 2^-16).  Same arguments and partial layout. */
+int mvsdet_conv3d_k3_dw_bf16x3(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
+                               int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
 /* The same for the stride-2 layers (mvsnet.py:77,80: conv1, conv3): x (N,Cin,D,H,W) with even D, H, W, grad_out
  * (N,Cout,D/2,H/2,W/2); dW[o][c][tap] = sum grad_out[n][o][v] * x[n][c][2v + tap - 1].  With the two tensors exchanged --
  * x := the layer's grad_out (fine), grad_out := the layer's input (coarse) -- the result is the (Cin,Cout,3,3,3) weight

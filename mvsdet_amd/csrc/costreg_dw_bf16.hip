@@ -1,0 +1,258 @@
+// Weight gradient of Conv3d(kernel 3, stride 1, padding 1) of the cost regularisation network (mvs_models/mvsnet.py:76-82)
+// on the bf16 matrix cores with three-term split operands (see costreg_bf16.hip for the arithmetic):
+//
+//     dW[o][c][kd,kh,kw] = sum over views and voxels (d,h,w) of  dY[n,o,d,h,w] * X[n,c,d+kd-1,h+kh-1,w+kw-1]
+//
+// A GEMM per tap with the VOXELS as the reduction: D[o][c] += A[o][k] * B[k][c], the 16 k of v_mfma_f32_32x32x16_bf16 being
+// 16 consecutive voxels of one row.  Both operands arrive as fp32 NCDHW, are cut into bf16 pieces on the way into the LDS
+// and are stored voxel-contiguous, so that a lane's fragment (8 voxels of one channel) is one ds_read_b128.
+//   block = 32 output x 32 input channels, 9 waves = the 9 (kd,kh); each wave keeps the accumulators of its 3 kw
+//   tile  = 4 rows x 16 voxels of dY and the 3 x 6 x 18 halo of X; the columns of tiles are walked along d as one stream of
+//           planes with a ring of four X planes and two dY buffers (see the kernel)
+//   loads : rows as float4 (W a multiple of 4), two steps ahead in registers; the two voxels either side of the 16 of a
+//           row by three extra waves; padding read from a zero word so that no load sits under a branch
+//   kw    : a lane reads its 8 voxels, the other half's and the edge pairs (three ds_read_b128, conflict-free at the channel
+//           pitch) and forms the shifted fragments with five v_alignbit_b32
+//   per row of the tile and wave: 2 A + 6 B ds_read_b128 feed 9 MFMAs
+// partial[split][o][c][27] as the fp32 kernel: the caller adds the splits up.
+#include "common.h"
+
+namespace mvsdet {
+
+typedef short dwb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float dwb_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned dwb_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDbTH = 4, kDbTW = 16;
+constexpr int kDbWaves = 9, kDbThreads = kDbWaves * 64;
+constexpr int kDbXRowB = 48;                                      // [w0..w0+7][w0+8..w0+15][w0-2,w0-1 | w0+16,w0+17][pad 8]
+constexpr int kDbXPlaneB = (kDbTH + 2) * kDbXRowB;                // 288
+constexpr int kDbXChanB = 4 * kDbXPlaneB + 16;                    // 1168 B = 292 words = 36 mod 64: conflict-free b128 reads
+constexpr int kDbXPieceB = 32 * kDbXChanB;
+constexpr int kDbYChanB = kDbTH * 32 + 16;                        // 144 B = 36 words: conflict-free b128 reads
+constexpr int kDbYPieceB = 32 * kDbYChanB;
+constexpr int kDbYBufB = 2 * kDbYPieceB;
+constexpr int kDbLdsB = 2 * kDbXPieceB + 2 * kDbYBufB;            // 93184: one block of 9 waves per CU
+constexpr int kDbMainThreads = 32 * (kDbTH + 2) * 2;              // 384: one group of 8 voxels of (channel, halo row) each
+static_assert(kDbMainThreads + 32 * (kDbTH + 2) == kDbThreads, "waves 6..8: the two edge pairs of one (channel, halo row) each");
+static_assert(32 * kDbTH * 2 <= kDbMainThreads && kDbMainThreads % 64 == 0, "dY roles on whole waves");
+
+__device__ float4 g_dwb_zero;   // zero-initialised: the source of every padding element
+
+__device__ __forceinline__ unsigned dwb_pack(__bf16 a, __bf16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// two fp32 -> the packed bf16 pair of their leading pieces and of their remainders
+__device__ __forceinline__ void dwb_split2(float f0, float f1, unsigned& hi, unsigned& mid) {
+    const __bf16 a0 = (__bf16)f0, a1 = (__bf16)f1;                       // round to nearest even
+    hi = dwb_pack(a0, a1);
+    mid = dwb_pack((__bf16)(f0 - (float)a0), (__bf16)(f1 - (float)a1));  // exact difference, rounded once
+}
+
+// The columns of a split are walked as ONE stream of planes: position q = (column i, plane pos), pos = 0 .. D, where the
+// plane pos = D is all zero and serves as plane D of column i and as plane -1 of column i+1.  Every step commits one X plane
+// (two ahead of the one being multiplied) into a ring of four and one dY tile into one of two buffers, fetches the ones
+// two steps further into registers and multiplies planes q-1, q, q+1: one barrier per step, no start-up cost per column,
+// two steps of global loads in flight (a step is shorter than the memory latency).
+__global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                         float* __restrict__ partial, int N, int Cin, int Cout,
+                                                                         int D, int H, int W, int tiles_w, int tiles_h, int ncols,
+                                                                         int nsplit) {
+    extern __shared__ uint4 s_dwb[];
+    char* const sx = reinterpret_cast<char*>(s_dwb);
+    char* const sy = sx + 2 * kDbXPieceB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int kd = wave / 3, kh = wave - 3 * kd;
+    const int split = blockIdx.x, c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
+    const size_t vol = (size_t)D * H * W;
+    const int HW = H * W;
+    const float* const zero = reinterpret_cast<const float*>(&g_dwb_zero);
+
+    dwb_f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    // staging roles (whole waves): waves 0..5 -- X, 8 voxels of (channel, halo row) as two float4; waves 6..8 -- X, the four
+    // voxels beside the tile of (channel, halo row); waves 0..3 also dY, 8 voxels of (channel, row)
+    const bool xmain = tid < kDbMainThreads, ythread = tid < 32 * kDbTH * 2;
+    const int et = tid - kDbMainThreads;
+    const int xc = xmain ? tid / 12 : et / 6;
+    const int xrow = xmain ? (tid % 12) >> 1 : et % 6;
+    const int xgrp = tid & 1;
+    const int x_lds = xc * kDbXChanB + xrow * kDbXRowB + (xmain ? xgrp * 16 : 32);
+    const int yo = (tid >> 3) & 31, yrow = (tid >> 1) & 3, ygrp = tid & 1;
+    const int y_lds = yo * kDbYChanB + yrow * 32 + ygrp * 16;
+
+    const int cols_per_view = tiles_h * tiles_w;
+    const int mine = split < ncols ? (ncols - split + nsplit - 1) / nsplit : 0;   // columns of this split
+    const int Q = mine * (D + 1);                                                 // stream positions
+
+    struct Regs { float4 xa, xb, ya, yb; };
+    Regs sets[2];
+    // Padding comes from a zero word in global memory (an address select, then an unconditional load): a load whose value
+    // is selected under a condition is moved under a branch by the compiler, each with its own s_waitcnt, and a mask on
+    // the loaded value would wait for the load inside the step that issued it.
+    // stream position q -> (view, tile origin, plane); plane == D or q beyond the stream: zeros
+    auto fetch = [&](Regs& g, int qx, int qy) {
+        {
+            const int i = qx / (D + 1), dd = qx - i * (D + 1);
+            const int cidx = min(split + i * nsplit, ncols - 1), n = cidx / cols_per_view, t2 = cidx - n * cols_per_view;
+            const int h0 = (t2 / tiles_w) * kDbTH, w0 = (t2 % tiles_w) * kDbTW;
+            const int h = h0 - 1 + xrow;
+            const bool ok = qx < Q && c0 + xc < Cin && dd < D && h >= 0 && h < H;
+            const float* row = x + ((size_t)n * Cin + min(c0 + xc, Cin - 1)) * vol + (size_t)min(dd, D - 1) * HW + min(max(h, 0), H - 1) * W;
+            if (xmain) {
+                const int w = w0 + 8 * xgrp;
+                g.xa = *reinterpret_cast<const float4*>((ok && w < W) ? row + w : zero);
+                g.xb = *reinterpret_cast<const float4*>((ok && w + 4 < W) ? row + w + 4 : zero);
+            } else {
+                g.xa.x = *((ok && w0 > 0) ? row + w0 - 2 : zero);
+                g.xa.y = *((ok && w0 > 0) ? row + w0 - 1 : zero);
+                g.xa.z = *((ok && w0 + 16 < W) ? row + w0 + 16 : zero);
+                g.xa.w = *((ok && w0 + 17 < W) ? row + w0 + 17 : zero);
+            }
+        }
+        if (ythread) {
+            const int i = qy / (D + 1), d = qy - i * (D + 1);
+            const int cidx = min(split + i * nsplit, ncols - 1), n = cidx / cols_per_view, t2 = cidx - n * cols_per_view;
+            const int h0 = (t2 / tiles_w) * kDbTH, w0 = (t2 % tiles_w) * kDbTW;
+            const int h = h0 + yrow, w = w0 + 8 * ygrp;
+            const bool ok = qy < Q && d < D && o0 + yo < Cout && h < H;
+            const float* row = gy + ((size_t)n * Cout + min(o0 + yo, Cout - 1)) * vol + (size_t)min(d, D - 1) * HW + min(h, H - 1) * W;
+            g.ya = *reinterpret_cast<const float4*>((ok && w < W) ? row + w : zero);
+            g.yb = *reinterpret_cast<const float4*>((ok && w + 4 < W) ? row + w + 4 : zero);
+        }
+    };
+    auto put8 = [&](char* dst, int piece_stride, const float4& a, const float4& b) {
+        uint4 hi, mid;
+        dwb_split2(a.x, a.y, hi.x, mid.x);
+        dwb_split2(a.z, a.w, hi.y, mid.y);
+        dwb_split2(b.x, b.y, hi.z, mid.z);
+        dwb_split2(b.z, b.w, hi.w, mid.w);
+        *reinterpret_cast<uint4*>(dst) = hi;
+        *reinterpret_cast<uint4*>(dst + piece_stride) = mid;
+    };
+    auto commit = [&](const Regs& g, int slot, int ybuf) {
+        char* dx = sx + x_lds + slot * kDbXPlaneB;
+        if (xmain) {
+            put8(dx, kDbXPieceB, g.xa, g.xb);
+        } else {
+            uint2 hi, mid;
+            dwb_split2(g.xa.x, g.xa.y, hi.x, mid.x);
+            dwb_split2(g.xa.z, g.xa.w, hi.y, mid.y);
+            *reinterpret_cast<uint2*>(dx) = hi;
+            *reinterpret_cast<uint2*>(dx + kDbXPieceB) = mid;
+        }
+        if (ythread) put8(sy + ybuf * kDbYBufB + y_lds, kDbYPieceB, g.ya, g.yb);
+    };
+
+    const char* const ya = sy + r32 * kDbYChanB + hh * 16;
+    const char* const xbase = sx + r32 * kDbXChanB + kh * kDbXRowB;
+    const int own_off = hh * 16, oth_off = 16 - hh * 16;
+
+    if (Q > 0) {
+        // plane -1 of the first column (slot 3) is zero; planes 0, 1 and the first dY tile are committed before the loop
+        sets[0].xa = sets[0].xb = sets[0].ya = sets[0].yb = make_float4(0.f, 0.f, 0.f, 0.f);
+        commit(sets[0], 3, 1);
+        fetch(sets[0], 0, 0);
+        commit(sets[0], 0, 0);
+        fetch(sets[0], 1, Q);
+        commit(sets[0], 1, 1);
+        fetch(sets[0], 2, 1);
+        fetch(sets[1], 3, 2);
+    }
+    int pos = 0;
+    auto step = [&](int q, Regs& g) {
+        __syncthreads();   // step q-1 fully consumed (its oldest plane and its dY buffer may be replaced); commits of q-1 visible
+        commit(g, (q + 2) & 3, (q + 1) & 1);
+        fetch(g, q + 4, q + 3);
+        if (q < Q && pos < D) {
+            const char* xs = xbase + ((q + kd + 3) & 3) * kDbXPlaneB;
+            const char* ys = ya + (q & 1) * kDbYBufB;
+#pragma unroll
+            for (int r = 0; r < kDbTH; ++r) {
+                const dwb_bf16x8 a_hi = *reinterpret_cast<const dwb_bf16x8*>(ys + r * 32);
+                const dwb_bf16x8 a_mid = *reinterpret_cast<const dwb_bf16x8*>(ys + kDbYPieceB + r * 32);
+                dwb_bf16x8 bq[3][2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const char* rowp = xs + p * kDbXPieceB + r * kDbXRowB;
+                    const dwb_u32x4 own = *reinterpret_cast<const dwb_u32x4*>(rowp + own_off);   // this half's 8 voxels
+                    dwb_u32x4 oth = *reinterpret_cast<const dwb_u32x4*>(rowp + oth_off);         // the other half's
+                    dwb_u32x4 edg = *reinterpret_cast<const dwb_u32x4*>(rowp + 32);              // (w0-2,w0-1), (w0+16,w0+17)
+                    // one word of each is used: keep the whole ds_read_b128 (conflict-free at this channel pitch) -- narrowed
+                    // to a ds_read_b32 it banks modulo 32 and the 32 channels of a half wave fall on 8 banks
+                    asm volatile("" : "+v"(oth));
+                    asm volatile("" : "+v"(edg));
+                    const unsigned L = hh ? oth.w : edg.x;     // high half = the voxel before own
+                    const unsigned R = hh ? edg.y : oth.x;     // low half = the voxel after own
+                    const unsigned t1 = __builtin_amdgcn_alignbit(own.y, own.x, 16), t2 = __builtin_amdgcn_alignbit(own.z, own.y, 16),
+                                   t3 = __builtin_amdgcn_alignbit(own.w, own.z, 16);
+                    bq[0][p] = __builtin_bit_cast(dwb_bf16x8, (dwb_u32x4{__builtin_amdgcn_alignbit(own.x, L, 16), t1, t2, t3}));   // w-1
+                    bq[1][p] = __builtin_bit_cast(dwb_bf16x8, own);                                                               // w
+                    bq[2][p] = __builtin_bit_cast(dwb_bf16x8, (dwb_u32x4{t1, t2, t3, __builtin_amdgcn_alignbit(R, own.w, 16)}));   // w+1
+                }
+                // consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bq[kw][0], acc[kw], 0, 0, 0);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bq[kw][1], acc[kw], 0, 0, 0);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, bq[kw][0], acc[kw], 0, 0, 0);
+            }
+        }
+        pos = pos == D ? 0 : pos + 1;
+    };
+    for (int q = 0; q < Q; q += 2) {
+        step(q, sets[0]);
+        step(q + 1, sets[1]);
+    }
+    // partial[split][o][c][tap]; C/D map: column = lane & 31 (c), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (o)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int t = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * hh, c = c0 + r32;
+            if (o < Cout && c < Cin) partial[(((size_t)split * Cout + o) * Cin + c) * 27 + t] = acc[kw][r];
+        }
+    }
+}
+
+}  // namespace mvsdet
+
+using namespace mvsdet;
+
+extern "C" size_t mvsdet_conv3d_k3_dw_partial_bytes(int Cin, int Cout, int nsplit);
+
+extern "C" int mvsdet_conv3d_k3_dw_bf16x3(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
+                                          int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && grad_out && partial, "conv3d_k3_dw_bf16x3: NULL pointer");
+    MVS_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_dw_bf16x3: bad shape");
+    MVS_REQUIRE(nsplit > 0 && nsplit <= 65535, "conv3d_k3_dw_bf16x3: nsplit=%d outside [1,65535]", nsplit);
+    MVS_REQUIRE((long long)D * H * W < INT32_MAX, "conv3d_k3_dw_bf16x3: one channel volume exceeds 2^31 elements");
+    MVS_REQUIRE(W % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)grad_out % 16 == 0,
+                "conv3d_k3_dw_bf16x3: rows are read as float4 (W=%d must be a multiple of 4, tensors 16-byte aligned)", W);
+    if (partial_bytes < mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)) {
+        set_error("conv3d_k3_dw_bf16x3: partial buffer %zu B < %zu B", partial_bytes,
+                  mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit));
+        return MVSDET_ERR_WORKSPACE;
+    }
+    const int tiles_w = (W + kDbTW - 1) / kDbTW, tiles_h = (H + kDbTH - 1) / kDbTH;
+    const long long ncols = (long long)N * tiles_h * tiles_w;   // (view, h-tile, w-tile) columns, walked along d
+    MVS_REQUIRE(ncols < INT32_MAX, "conv3d_k3_dw_bf16x3: too many tiles");
+    dim3 grid((unsigned)nsplit, (unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
+    MVS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "conv3d_k3_dw_bf16x3: too many channel blocks");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_dw_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kDbLdsB) != hipSuccess) {
+        set_error("conv3d_k3_dw_bf16x3: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        return MVSDET_ERR_HIP;
+    }
+    hipLaunchKernelGGL(conv3d_k3_dw_bf16x3_kernel, grid, dim3(kDbThreads), kDbLdsB, (hipStream_t)stream, x, grad_out, partial, N, Cin, Cout,
+                       D, H, W, tiles_w, tiles_h, (int)ncols, nsplit);
+    MVS_LAUNCH_CHECK("conv3d_k3_dw_bf16x3");
+    return MVSDET_OK;
+}

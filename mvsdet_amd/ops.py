@@ -1039,16 +1039,21 @@ def _(x, weight_perm, scale, shift, residual, relu):
 
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_dw", mutates_args=(), device_types="cuda")
-def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1) -> Tensor:
+def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1, bf16x3: bool = False) -> Tensor:
     """Weight gradient of Conv3d(kernel 3, stride 1 or 2, padding 1): x (N,Cin,D,H,W), grad_out (N,Cout,D/s,H/s,W/s) ->
     (Cout,Cin,3,3,3), on the fp32 matrix cores; `nsplit` voxel splits are accumulated separately and summed
     (0 = automatic: up to 128 splits, fewer when Cin*Cout is large so that the partial sums stay below 256 MB).
     With stride 2 and the tensors exchanged (x = grad of the output, grad_out = the input) this is the weight gradient of
-    ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1) in its own (Cin,Cout,3,3,3) layout."""
+    ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1) in its own (Cin,Cout,3,3,3) layout.
+    bf16x3 (stride 1 only): the sum runs on the bf16 matrix cores with three-term split operands (csrc/costreg_dw_bf16.hip)."""
     _req(x, "x", dim=5)
     _req(grad_out, "grad_out", dim=5)
     if stride not in (1, 2):
         raise ValueError(f"conv3d_k3_dw: stride {stride} not in (1, 2)")
+    if bf16x3 and stride != 1:
+        raise ValueError("conv3d_k3_dw: the bf16x3 kernel covers stride 1")
+    if bf16x3 and x.shape[-1] % 4:
+        raise ValueError(f"conv3d_k3_dw: the bf16x3 kernel reads rows as float4, W={x.shape[-1]} is not a multiple of 4")
     N, Cin, D, H, W = x.shape
     Cout = grad_out.shape[1]
     if any(v % stride for v in (D, H, W)) or tuple(grad_out.shape) != (N, Cout, D // stride, H // stride, W // stride):
@@ -1060,6 +1065,8 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1) 
     pbytes = lib.mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)
     partial = torch.empty((nsplit, Cout, Cin, 27), dtype=torch.float32, device=x.device)
     fn = lib.mvsdet_conv3d_k3_dw_mfma_f32 if stride == 1 else lib.mvsdet_conv3d_k3_s2_dw_mfma_f32
+    if bf16x3:
+        fn = lib.mvsdet_conv3d_k3_dw_bf16x3
     with torch.cuda.device(x.device):
         _lib.check(fn(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), pbytes, nsplit, N, Cin, Cout, D, H, W, _stream(x)),
                    "conv3d_k3_dw")
@@ -1067,7 +1074,7 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1) 
 
 
 @conv3d_k3_dw.register_fake
-def _(x, grad_out, nsplit=0, stride=1):
+def _(x, grad_out, nsplit=0, stride=1, bf16x3=False):
     return x.new_empty((grad_out.shape[1], x.shape[1], 3, 3, 3))
 
 

@@ -143,3 +143,36 @@ def test_conv3d_k3_bf16x3_argument_checks(gpu):
     with pytest.raises(ValueError):
         ops.split_conv_weight(torch.zeros(60, 8, 3, 3, 3))
     assert float(ops.conv3d_k3_bf16x3(xs, wq, None, None, False).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,nsplit", [(2, 32, 64, 3, 8, 16, 4), (1, 40, 70, 2, 5, 20, 3), (2, 5, 3, 1, 1, 4, 2),
+                                                     (1, 64, 32, 4, 9, 36, 200), (2, 64, 64, 12, 60, 80, 0),
+                                                     (1, 33, 31, 5, 7, 24, 7), (3, 8, 8, 2, 3, 12, 1)])
+def test_conv3d_k3_dw_bf16x3(gpu, N, Cin, Cout, D, H, W, nsplit):
+    """Weight gradient of the stride-1 layers on the bf16 matrix cores (csrc/costreg_dw_bf16.hip): against the float64 sum
+    of the same three piece products, and against ATen's fp32 conv3d_weight within the scheme's truncation."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    gy = torch.randn(N, Cout, D, H, W, generator=g)
+    shape = (Cout, Cin, 3, 3, 3)
+    xh, xm = (t.double() for t in ops.split_bf16(x))
+    yh, ym = (t.double() for t in ops.split_bf16(gy))
+    cw = lambda a, b: torch.nn.grad.conv3d_weight(a, shape, b, padding=1)
+    want = cw(xh, yh) + cw(xh, ym) + cw(xm, yh)
+    got = ops.conv3d_k3_dw(x.to(gpu), gy.to(gpu), nsplit, 1, True).cpu()
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    # fp32 accumulation of N*D*H*W products per element, in splits
+    np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=0, atol=2e-6 * scale * max(1.0, (N * D * H * W) ** 0.5 / 8))
+    full = cw(x.double(), gy.double())
+    assert float((got.double() - full).abs().max()) <= 1e-4 * scale
+    fp32 = ops.conv3d_k3_dw(x.to(gpu), gy.to(gpu), nsplit).cpu()
+    assert float((got - fp32).abs().max()) <= 1e-4 * scale
+
+
+def test_conv3d_k3_dw_bf16x3_needs_rows_of_whole_float4(gpu):
+    from mvsdet_amd import ops
+    x = torch.randn(1, 8, 2, 4, 18, device=gpu)
+    with pytest.raises(ValueError, match="multiple of 4"):
+        ops.conv3d_k3_dw(x, x.clone(), 0, 1, True)
