@@ -50,8 +50,8 @@ class _ConvK3S1(torch.autograd.Function):
                 gx = ops.conv3d_k3_bf16x3(gy, ops.split_conv_weight(wflip), None, None, False)
             else:
                 gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(wflip), None, None, False)
-        if ctx.needs_input_grad[1]:
-            gw = ops.conv3d_k3_dw(x, gy)
+        if ctx.needs_input_grad[1]:   # bf16x3: csrc/costreg_dw_bf16.hip (rows read as float4)
+            gw = ops.conv3d_k3_dw(x, gy, 0, 1, ctx.bf16x3 and x.shape[-1] % 4 == 0)
         return gx, gw, None
 
 

@@ -16,12 +16,16 @@
 //   per row of the tile and wave: 2 A + 6 B ds_read_b128 feed 9 MFMAs
 // partial[split][o][c][27] as the fp32 kernel: the caller adds the splits up.
 #include "common.h"
+#ifndef DWB_EXP
+#define DWB_EXP 0
+#endif
 
 namespace mvsdet {
 
 typedef short dwb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float dwb_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned dwb_u32x4 __attribute__((ext_vector_type(4)));
+typedef float dwb_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDbTH = 4, kDbTW = 16;
 constexpr int kDbWaves = 9, kDbThreads = kDbWaves * 64;
@@ -32,10 +36,13 @@ constexpr int kDbXPieceB = 32 * kDbXChanB;
 constexpr int kDbYChanB = kDbTH * 32 + 16;                        // 144 B = 36 words: conflict-free b128 reads
 constexpr int kDbYPieceB = 32 * kDbYChanB;
 constexpr int kDbYBufB = 2 * kDbYPieceB;
-constexpr int kDbLdsB = 2 * kDbXPieceB + 2 * kDbYBufB;            // 93184: one block of 9 waves per CU
+constexpr int kDbTabCap = 4096;                                   // columns of one split (host: nsplit >= ncols / 4096)
+constexpr int kDbTabOff = 2 * kDbXPieceB + 2 * kDbYBufB;          // 93184
+constexpr int kDbLdsB = kDbTabOff + kDbTabCap * 8;                // 125952: one block of 9 waves per CU
 constexpr int kDbMainThreads = 32 * (kDbTH + 2) * 2;              // 384: one group of 8 voxels of (channel, halo row) each
+constexpr int kDbYThreads = 32 * kDbTH * 4;                       // 512: one float4 of (channel, row) each
 static_assert(kDbMainThreads + 32 * (kDbTH + 2) == kDbThreads, "waves 6..8: the two edge pairs of one (channel, halo row) each");
-static_assert(32 * kDbTH * 2 <= kDbMainThreads && kDbMainThreads % 64 == 0, "dY roles on whole waves");
+static_assert(kDbThreads - kDbYThreads == 64, "the last wave parks its dY store in the 32 x 16 bytes of channel padding");
 
 __device__ float4 g_dwb_zero;   // zero-initialised: the source of every padding element
 
@@ -54,6 +61,13 @@ __device__ __forceinline__ void dwb_split2(float f0, float f1, unsigned& hi, uns
 // (two ahead of the one being multiplied) into a ring of four and one dY tile into one of two buffers, fetches the ones
 // two steps further into registers and multiplies planes q-1, q, q+1: one barrier per step, no start-up cost per column,
 // two steps of global loads in flight (a step is shorter than the memory latency).
+//
+// A step is straight-line code, the same for every wave: the zero plane between two columns (and the positions beyond the
+// stream) carry a zero dY tile and are multiplied like any other (1/(D+1) more matrix work); every thread issues the same
+// three float4 loads (padding and idle roles read a zero word: a branch on the role would hide from the compiler how many
+// loads are in flight and it would wait for all of them) and the same four LDS stores; the stream position is advanced
+// without a division (the columns of the split are decoded once, into a table in the LDS).  So the vector instructions of
+// the staging run between the MFMAs of the step instead of before them.
 __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                          float* __restrict__ partial, int N, int Cin, int Cout,
                                                                          int D, int H, int W, int tiles_w, int tiles_h, int ncols,
@@ -61,10 +75,23 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
     extern __shared__ uint4 s_dwb[];
     char* const sx = reinterpret_cast<char*>(s_dwb);
     char* const sy = sx + 2 * kDbXPieceB;
+    int2* const tab = reinterpret_cast<int2*>(sx + kDbTabOff);   // column i of this split -> (view, tile origin h0 << 16 | w0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, hh = lane >> 5;
     const int kd = wave / 3, kh = wave - 3 * kd;
-    const int split = blockIdx.x, c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
+    // The blocks of one split (all channel blocks) read the same dY tiles and, per input-channel block, the same X planes at
+    // the same time: they are placed on ONE XCD (block id modulo 8 picks the XCD), so that its L2 serves all but the first.
+    const int ncb = (Cin + 31) / 32, nob = (Cout + 31) / 32, J = ncb * nob;
+    int split, j;
+    if (nsplit % 8 == 0) {
+        const int k = blockIdx.x >> 3;
+        j = k % J;
+        split = (k / J) * 8 + (blockIdx.x & 7);
+    } else {
+        j = blockIdx.x % J;
+        split = blockIdx.x / J;
+    }
+    const int c0 = (j / nob) * 32, o0 = (j % nob) * 32;
     const size_t vol = (size_t)D * H * W;
     const int HW = H * W;
     const float* const zero = reinterpret_cast<const float*>(&g_dwb_zero);
@@ -75,136 +102,144 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    // staging roles (whole waves): waves 0..5 -- X, 8 voxels of (channel, halo row) as two float4; waves 6..8 -- X, the four
-    // voxels beside the tile of (channel, halo row); waves 0..3 also dY, 8 voxels of (channel, row)
-    const bool xmain = tid < kDbMainThreads, ythread = tid < 32 * kDbTH * 2;
+    // staging roles: X -- waves 0..5: 8 voxels of (channel, halo row) as two float4; waves 6..8: the float4 before and the one
+    // after the tile of (channel, halo row), for the two voxels either side; dY -- waves 0..7: one float4 of (channel, row)
+    const bool xmain = tid < kDbMainThreads, ythread = tid < kDbYThreads;
     const int et = tid - kDbMainThreads;
     const int xc = xmain ? tid / 12 : et / 6;
     const int xrow = xmain ? (tid % 12) >> 1 : et % 6;
     const int xgrp = tid & 1;
+    const int xoff_a = xmain ? 8 * xgrp : -4, xoff_b = xmain ? 8 * xgrp + 4 : 16;
     const int x_lds = xc * kDbXChanB + xrow * kDbXRowB + (xmain ? xgrp * 16 : 32);
-    const int yo = (tid >> 3) & 31, yrow = (tid >> 1) & 3, ygrp = tid & 1;
-    const int y_lds = yo * kDbYChanB + yrow * 32 + ygrp * 16;
+    const int yo = (tid >> 4) & 31, yrow = (tid >> 2) & 3, yq = tid & 3;
+    const int y_lds = ythread ? yo * kDbYChanB + yrow * 32 + yq * 8 : ((tid - kDbYThreads) >> 1) * kDbYChanB + 128 + (tid & 1) * 8;
+    const float* const xchan = x + (size_t)min(c0 + xc, Cin - 1) * vol;
+    const float* const ychan = gy + (size_t)min(o0 + yo, Cout - 1) * vol;
+    const bool xc_ok = c0 + xc < Cin, yo_ok = ythread && o0 + yo < Cout;
 
     const int cols_per_view = tiles_h * tiles_w;
-    const int mine = split < ncols ? (ncols - split + nsplit - 1) / nsplit : 0;   // columns of this split
+    const int mine = split < ncols ? (ncols - split + nsplit - 1) / nsplit : 0;   // columns of this split (host: <= kDbTabCap)
     const int Q = mine * (D + 1);                                                 // stream positions
+    for (int i = tid; i < mine; i += kDbThreads) {
+        const int cidx = split + i * nsplit, n = cidx / cols_per_view, t2 = cidx - n * cols_per_view;
+        tab[i] = make_int2(n, ((t2 / tiles_w) * kDbTH) << 16 | ((t2 % tiles_w) * kDbTW));
+    }
+    __syncthreads();
 
-    struct Regs { float4 xa, xb, ya, yb; };
+    struct Regs { dwb_f32x4 xa, xb, ya; };
+    struct Pos { int i, d; };   // column of the split, plane (d == D: the zero plane)
     Regs sets[2];
-    // Padding comes from a zero word in global memory (an address select, then an unconditional load): a load whose value
-    // is selected under a condition is moved under a branch by the compiler, each with its own s_waitcnt, and a mask on
-    // the loaded value would wait for the load inside the step that issued it.
-    // stream position q -> (view, tile origin, plane); plane == D or q beyond the stream: zeros
-    auto fetch = [&](Regs& g, int qx, int qy) {
+    // X plane at stream position px and dY tile at position py (a position beyond the stream or a plane D: zeros)
+    auto fetch = [&](Regs& g, Pos px, Pos py) {
         {
-            const int i = qx / (D + 1), dd = qx - i * (D + 1);
-            const int cidx = min(split + i * nsplit, ncols - 1), n = cidx / cols_per_view, t2 = cidx - n * cols_per_view;
-            const int h0 = (t2 / tiles_w) * kDbTH, w0 = (t2 % tiles_w) * kDbTW;
+            const int2 e = tab[min(px.i, mine - 1)];
+            const int h0 = e.y >> 16, w0 = e.y & 0xffff;
             const int h = h0 - 1 + xrow;
-            const bool ok = qx < Q && c0 + xc < Cin && dd < D && h >= 0 && h < H;
-            const float* row = x + ((size_t)n * Cin + min(c0 + xc, Cin - 1)) * vol + (size_t)min(dd, D - 1) * HW + min(max(h, 0), H - 1) * W;
-            if (xmain) {
-                const int w = w0 + 8 * xgrp;
-                g.xa = *reinterpret_cast<const float4*>((ok && w < W) ? row + w : zero);
-                g.xb = *reinterpret_cast<const float4*>((ok && w + 4 < W) ? row + w + 4 : zero);
-            } else {
-                g.xa.x = *((ok && w0 > 0) ? row + w0 - 2 : zero);
-                g.xa.y = *((ok && w0 > 0) ? row + w0 - 1 : zero);
-                g.xa.z = *((ok && w0 + 16 < W) ? row + w0 + 16 : zero);
-                g.xa.w = *((ok && w0 + 17 < W) ? row + w0 + 17 : zero);
-            }
+            const bool ok = (px.i < mine) & (px.d < D) & xc_ok & (h >= 0) & (h < H);   // '&': no short-circuit branches in a step
+            const float* row = xchan + (size_t)e.x * Cin * vol + (size_t)min(px.d, D - 1) * HW + min(max(h, 0), H - 1) * W;
+            const int wa = w0 + xoff_a, wb = w0 + xoff_b;
+            g.xa = *reinterpret_cast<const dwb_f32x4*>((ok & (wa >= 0) & (wa < W)) ? row + wa : zero);
+            g.xb = *reinterpret_cast<const dwb_f32x4*>((ok & (wb < W)) ? row + wb : zero);
         }
-        if (ythread) {
-            const int i = qy / (D + 1), d = qy - i * (D + 1);
-            const int cidx = min(split + i * nsplit, ncols - 1), n = cidx / cols_per_view, t2 = cidx - n * cols_per_view;
-            const int h0 = (t2 / tiles_w) * kDbTH, w0 = (t2 % tiles_w) * kDbTW;
-            const int h = h0 + yrow, w = w0 + 8 * ygrp;
-            const bool ok = qy < Q && d < D && o0 + yo < Cout && h < H;
-            const float* row = gy + ((size_t)n * Cout + min(o0 + yo, Cout - 1)) * vol + (size_t)min(d, D - 1) * HW + min(h, H - 1) * W;
-            g.ya = *reinterpret_cast<const float4*>((ok && w < W) ? row + w : zero);
-            g.yb = *reinterpret_cast<const float4*>((ok && w + 4 < W) ? row + w + 4 : zero);
+        {
+            const int2 e = tab[min(py.i, mine - 1)];
+            const int h0 = e.y >> 16, w0 = e.y & 0xffff;
+            const int h = h0 + yrow, w = w0 + 4 * yq;
+            const bool ok = (py.i < mine) & (py.d < D) & yo_ok & (h < H) & (w < W);
+            const float* row = ychan + (size_t)e.x * Cout * vol + (size_t)min(py.d, D - 1) * HW + min(h, H - 1) * W;
+            g.ya = *reinterpret_cast<const dwb_f32x4*>(ok ? row + w : zero);
         }
     };
-    auto put8 = [&](char* dst, int piece_stride, const float4& a, const float4& b) {
+    auto commit = [&](Regs& g, int slot, int ybuf) {
+        // the values pass through an opaque statement here, after the barrier: otherwise the compiler cuts them into pieces
+        // right after the loads (fewer registers) and so waits for every load inside the step that issued it
+        asm volatile("" : "+v"(g.xa), "+v"(g.xb), "+v"(g.ya));
+        // edge role: (w0-2, w0-1) = xa.zw, (w0+16, w0+17) = xb.xy; its 16-byte store covers the edge pairs and the row's padding
+        const dwb_f32x4 a = xmain ? g.xa : dwb_f32x4{g.xa.z, g.xa.w, g.xb.x, g.xb.y};
         uint4 hi, mid;
         dwb_split2(a.x, a.y, hi.x, mid.x);
         dwb_split2(a.z, a.w, hi.y, mid.y);
-        dwb_split2(b.x, b.y, hi.z, mid.z);
-        dwb_split2(b.z, b.w, hi.w, mid.w);
-        *reinterpret_cast<uint4*>(dst) = hi;
-        *reinterpret_cast<uint4*>(dst + piece_stride) = mid;
-    };
-    auto commit = [&](const Regs& g, int slot, int ybuf) {
+        dwb_split2(g.xb.x, g.xb.y, hi.z, mid.z);
+        dwb_split2(g.xb.z, g.xb.w, hi.w, mid.w);
         char* dx = sx + x_lds + slot * kDbXPlaneB;
-        if (xmain) {
-            put8(dx, kDbXPieceB, g.xa, g.xb);
-        } else {
-            uint2 hi, mid;
-            dwb_split2(g.xa.x, g.xa.y, hi.x, mid.x);
-            dwb_split2(g.xa.z, g.xa.w, hi.y, mid.y);
-            *reinterpret_cast<uint2*>(dx) = hi;
-            *reinterpret_cast<uint2*>(dx + kDbXPieceB) = mid;
-        }
-        if (ythread) put8(sy + ybuf * kDbYBufB + y_lds, kDbYPieceB, g.ya, g.yb);
+        *reinterpret_cast<uint4*>(dx) = hi;
+        *reinterpret_cast<uint4*>(dx + kDbXPieceB) = mid;
+        uint2 yh, ym;
+        dwb_split2(g.ya.x, g.ya.y, yh.x, ym.x);
+        dwb_split2(g.ya.z, g.ya.w, yh.y, ym.y);
+        char* dy = sy + ybuf * kDbYBufB + y_lds;
+        *reinterpret_cast<uint2*>(dy) = yh;
+        *reinterpret_cast<uint2*>(dy + kDbYPieceB) = ym;
     };
+    auto at = [&](int q) { return Pos{q / (D + 1), q % (D + 1)}; };
+    auto next = [&](Pos p) { return p.d == D ? Pos{p.i + 1, 0} : Pos{p.i, p.d + 1}; };
 
     const char* const ya = sy + r32 * kDbYChanB + hh * 16;
     const char* const xbase = sx + r32 * kDbXChanB + kh * kDbXRowB;
     const int own_off = hh * 16, oth_off = 16 - hh * 16;
 
+    // one row of the tile: 8 ds_read_b128, 10 v_alignbit, 9 MFMAs
+    auto row_mfma = [&](const char* xs, const char* ys, int r) {
+        const dwb_bf16x8 a_hi = *reinterpret_cast<const dwb_bf16x8*>(ys + r * 32);
+        const dwb_bf16x8 a_mid = *reinterpret_cast<const dwb_bf16x8*>(ys + kDbYPieceB + r * 32);
+        dwb_bf16x8 bq[3][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const char* rowp = xs + p * kDbXPieceB + r * kDbXRowB;
+            const dwb_u32x4 own = *reinterpret_cast<const dwb_u32x4*>(rowp + own_off);   // this half's 8 voxels
+            dwb_u32x4 oth = *reinterpret_cast<const dwb_u32x4*>(rowp + oth_off);         // the other half's
+            dwb_u32x4 edg = *reinterpret_cast<const dwb_u32x4*>(rowp + 32);              // (w0-2,w0-1), (w0+16,w0+17)
+            // one word of each is used: keep the whole ds_read_b128 (conflict-free at this channel pitch) -- narrowed
+            // to a ds_read_b32 it banks modulo 32 and the 32 channels of a half wave fall on 8 banks
+            asm volatile("" : "+v"(oth));
+            asm volatile("" : "+v"(edg));
+            const unsigned L = hh ? oth.w : edg.x;     // high half = the voxel before own
+            const unsigned R = hh ? edg.y : oth.x;     // low half = the voxel after own
+            const unsigned t1 = __builtin_amdgcn_alignbit(own.y, own.x, 16), t2 = __builtin_amdgcn_alignbit(own.z, own.y, 16),
+                           t3 = __builtin_amdgcn_alignbit(own.w, own.z, 16);
+            bq[0][p] = __builtin_bit_cast(dwb_bf16x8, (dwb_u32x4{__builtin_amdgcn_alignbit(own.x, L, 16), t1, t2, t3}));   // w-1
+            bq[1][p] = __builtin_bit_cast(dwb_bf16x8, own);                                                               // w
+            bq[2][p] = __builtin_bit_cast(dwb_bf16x8, (dwb_u32x4{t1, t2, t3, __builtin_amdgcn_alignbit(R, own.w, 16)}));   // w+1
+        }
+        // consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bq[kw][0], acc[kw], 0, 0, 0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bq[kw][1], acc[kw], 0, 0, 0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, bq[kw][0], acc[kw], 0, 0, 0);
+    };
+
+    Pos fx = at(4), fy = at(3);   // the positions the first step fetches
     if (Q > 0) {
         // plane -1 of the first column (slot 3) is zero; planes 0, 1 and the first dY tile are committed before the loop
-        sets[0].xa = sets[0].xb = sets[0].ya = sets[0].yb = make_float4(0.f, 0.f, 0.f, 0.f);
+        sets[0].xa = sets[0].xb = sets[0].ya = dwb_f32x4{0.f, 0.f, 0.f, 0.f};
         commit(sets[0], 3, 1);
-        fetch(sets[0], 0, 0);
+        fetch(sets[0], at(0), at(0));
         commit(sets[0], 0, 0);
-        fetch(sets[0], 1, Q);
+        fetch(sets[0], at(1), Pos{mine, 0});
         commit(sets[0], 1, 1);
-        fetch(sets[0], 2, 1);
-        fetch(sets[1], 3, 2);
+        fetch(sets[0], at(2), at(1));
+        fetch(sets[1], at(3), at(2));
     }
-    int pos = 0;
     auto step = [&](int q, Regs& g) {
         __syncthreads();   // step q-1 fully consumed (its oldest plane and its dY buffer may be replaced); commits of q-1 visible
+        const char* xs = xbase + ((q + kd + 3) & 3) * kDbXPlaneB;
+        const char* ys = ya + (q & 1) * kDbYBufB;
+#if DWB_EXP != 1
+        row_mfma(xs, ys, 0);
+        row_mfma(xs, ys, 1);
+#endif
+#if DWB_EXP != 2
         commit(g, (q + 2) & 3, (q + 1) & 1);
-        fetch(g, q + 4, q + 3);
-        if (q < Q && pos < D) {
-            const char* xs = xbase + ((q + kd + 3) & 3) * kDbXPlaneB;
-            const char* ys = ya + (q & 1) * kDbYBufB;
-#pragma unroll
-            for (int r = 0; r < kDbTH; ++r) {
-                const dwb_bf16x8 a_hi = *reinterpret_cast<const dwb_bf16x8*>(ys + r * 32);
-                const dwb_bf16x8 a_mid = *reinterpret_cast<const dwb_bf16x8*>(ys + kDbYPieceB + r * 32);
-                dwb_bf16x8 bq[3][2];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const char* rowp = xs + p * kDbXPieceB + r * kDbXRowB;
-                    const dwb_u32x4 own = *reinterpret_cast<const dwb_u32x4*>(rowp + own_off);   // this half's 8 voxels
-                    dwb_u32x4 oth = *reinterpret_cast<const dwb_u32x4*>(rowp + oth_off);         // the other half's
-                    dwb_u32x4 edg = *reinterpret_cast<const dwb_u32x4*>(rowp + 32);              // (w0-2,w0-1), (w0+16,w0+17)
-                    // one word of each is used: keep the whole ds_read_b128 (conflict-free at this channel pitch) -- narrowed
-                    // to a ds_read_b32 it banks modulo 32 and the 32 channels of a half wave fall on 8 banks
-                    asm volatile("" : "+v"(oth));
-                    asm volatile("" : "+v"(edg));
-                    const unsigned L = hh ? oth.w : edg.x;     // high half = the voxel before own
-                    const unsigned R = hh ? edg.y : oth.x;     // low half = the voxel after own
-                    const unsigned t1 = __builtin_amdgcn_alignbit(own.y, own.x, 16), t2 = __builtin_amdgcn_alignbit(own.z, own.y, 16),
-                                   t3 = __builtin_amdgcn_alignbit(own.w, own.z, 16);
-                    bq[0][p] = __builtin_bit_cast(dwb_bf16x8, (dwb_u32x4{__builtin_amdgcn_alignbit(own.x, L, 16), t1, t2, t3}));   // w-1
-                    bq[1][p] = __builtin_bit_cast(dwb_bf16x8, own);                                                               // w
-                    bq[2][p] = __builtin_bit_cast(dwb_bf16x8, (dwb_u32x4{t1, t2, t3, __builtin_amdgcn_alignbit(R, own.w, 16)}));   // w+1
-                }
-                // consecutive MFMAs go to different accumulators
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bq[kw][0], acc[kw], 0, 0, 0);
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bq[kw][1], acc[kw], 0, 0, 0);
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, bq[kw][0], acc[kw], 0, 0, 0);
-            }
-        }
-        pos = pos == D ? 0 : pos + 1;
+        fetch(g, fx, fy);
+        fy = fx;
+        fx = next(fx);
+#endif
+#if DWB_EXP != 1
+        row_mfma(xs, ys, 2);
+        row_mfma(xs, ys, 3);
+#endif
     };
     for (int q = 0; q < Q; q += 2) {
         step(q, sets[0]);
@@ -244,8 +279,12 @@ extern "C" int mvsdet_conv3d_k3_dw_bf16x3(const float* x, const float* grad_out,
     const int tiles_w = (W + kDbTW - 1) / kDbTW, tiles_h = (H + kDbTH - 1) / kDbTH;
     const long long ncols = (long long)N * tiles_h * tiles_w;   // (view, h-tile, w-tile) columns, walked along d
     MVS_REQUIRE(ncols < INT32_MAX, "conv3d_k3_dw_bf16x3: too many tiles");
-    dim3 grid((unsigned)nsplit, (unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32));
-    MVS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "conv3d_k3_dw_bf16x3: too many channel blocks");
+    MVS_REQUIRE((ncols + nsplit - 1) / nsplit <= kDbTabCap, "conv3d_k3_dw_bf16x3: %lld tile columns need nsplit >= %lld", ncols,
+                (ncols + kDbTabCap - 1) / kDbTabCap);
+    MVS_REQUIRE(H < 32768 && W < 65536, "conv3d_k3_dw_bf16x3: H=%d, W=%d too large", H, W);
+    const long long nblocks = (long long)nsplit * ((Cin + 31) / 32) * ((Cout + 31) / 32);
+    MVS_REQUIRE(nblocks < INT32_MAX, "conv3d_k3_dw_bf16x3: too many blocks");
+    dim3 grid((unsigned)nblocks);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_dw_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kDbLdsB) != hipSuccess) {
         set_error("conv3d_k3_dw_bf16x3: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");

@@ -1062,6 +1062,10 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1, 
     lib = _lib.load()
     if nsplit <= 0:
         nsplit = max(8, min(128, (256 << 20) // (Cout * Cin * 108)))
+        if bf16x3:   # one block of 9 waves per CU: 256 / (channel blocks) splits, a multiple of 8 (one split = one XCD)
+            nsplit = max(8, min(64, (256 // (((Cin + 31) // 32) * ((Cout + 31) // 32))) // 8 * 8))
+    if bf16x3:       # the kernel keeps the columns of a split in a 4096-entry table
+        nsplit = max(nsplit, -(-(N * ((H + 3) // 4) * ((W + 15) // 16)) // 4096))
     pbytes = lib.mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)
     partial = torch.empty((nsplit, Cout, Cin, 27), dtype=torch.float32, device=x.device)
     fn = lib.mvsdet_conv3d_k3_dw_mfma_f32 if stride == 1 else lib.mvsdet_conv3d_k3_s2_dw_mfma_f32
