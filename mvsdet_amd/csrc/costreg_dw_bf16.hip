@@ -16,9 +16,6 @@
 //   per row of the tile and wave: 2 A + 6 B ds_read_b128 feed 9 MFMAs
 // partial[split][o][c][27] as the fp32 kernel: the caller adds the splits up.
 #include "common.h"
-#ifndef DWB_EXP
-#define DWB_EXP 0
-#endif
 
 namespace mvsdet {
 
@@ -226,20 +223,14 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
         __syncthreads();   // step q-1 fully consumed (its oldest plane and its dY buffer may be replaced); commits of q-1 visible
         const char* xs = xbase + ((q + kd + 3) & 3) * kDbXPlaneB;
         const char* ys = ya + (q & 1) * kDbYBufB;
-#if DWB_EXP != 1
         row_mfma(xs, ys, 0);
         row_mfma(xs, ys, 1);
-#endif
-#if DWB_EXP != 2
         commit(g, (q + 2) & 3, (q + 1) & 1);
         fetch(g, fx, fy);
         fy = fx;
         fx = next(fx);
-#endif
-#if DWB_EXP != 1
         row_mfma(xs, ys, 2);
         row_mfma(xs, ys, 3);
-#endif
     };
     for (int q = 0; q < Q; q += 2) {
         step(q, sets[0]);

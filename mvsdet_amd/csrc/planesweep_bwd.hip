@@ -51,7 +51,12 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     extern __shared__ double s_grad[];  // K slots of (box_cap + kBoxPad) texels x 16 doubles: gradient images of the resident boxes
 
     const int HW = H * W;
-    const int id = blockIdx.x;
+    // HALF == 2: both halves in one launch; blocks 16k .. 16k+7 are the lower halves of eight (view, tile, slab) units and
+    // blocks 16k+8 .. 16k+15 the upper halves of the same eight, so a unit's two halves run on the same XCD (block id modulo
+    // 8) at about the same time and the second finds the 128-byte texel lines of the first in its L2
+    const int half = HALF == 2 ? (int)((blockIdx.x >> 3) & 1) : HALF;
+    const int id = HALF == 2 ? (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7)) : (int)blockIdx.x;
+    if (HALF == 2 && id >= N * tiles * S) return;
     const int slab = id % S;
     const int bt = id / S;
     const int tile = bt % tiles, n = bt / tiles;
@@ -61,15 +66,15 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     const int g = lane & 7, ps = lane >> 3;
     const size_t slab_stride = (size_t)HW * kSlab;
     // float2 views of the slab images, already at the lane's two floats: texel t is element 16 * t
-    const float2* ref_img = reinterpret_cast<const float2*>(packed + ((size_t)n * S + slab) * slab_stride) + 8 * HALF + g;
+    const float2* ref_img = reinterpret_cast<const float2*>(packed + ((size_t)n * S + slab) * slab_stride) + 8 * half + g;
     const float2* nb_img[KK];
     float* nb_grad[KK];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         int64_t v = nbr[(size_t)n * K + j];
         v = v < 0 ? 0 : (v >= N ? N - 1 : v);
-        nb_img[j] = reinterpret_cast<const float2*>(packed + ((size_t)v * S + slab) * slab_stride) + 8 * HALF + g;
-        nb_grad[j] = gpacked + ((size_t)v * S + slab) * slab_stride + kHalfSlab * HALF;
+        nb_img[j] = reinterpret_cast<const float2*>(packed + ((size_t)v * S + slab) * slab_stride) + 8 * half + g;
+        nb_grad[j] = gpacked + ((size_t)v * S + slab) * slab_stride + kHalfSlab * half;
     }
     const float r = 1.0f / (float)(K + 1);
     const float two_r = 2.0f * r, two_r2 = 2.0f * r * r;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     bool g_ok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int c = slab * kSlab + 16 * (g & 1) + 8 * i + 4 * HALF + (g >> 1);
+        const int c = slab * kSlab + 16 * (g & 1) + 8 * i + 4 * half + (g >> 1);
         g_ok[i] = (c < C) && (st_n > 0);
         g_off[i] = ((size_t)n * C + min(c, C - 1)) * D * HW + (size_t)py * W + px0;
     }
@@ -264,8 +269,8 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             for (int i = 0; i < 2; ++i)
                 if (pok[s]) gref[s][i] = fmaf(go[s][i], two_r * f[s][i] - two_r2 * S_[s][i], gref[s][i]);
         // ---- pass 2: tap gradients of every live neighbour
-#define MVS_GRAD_STEP(SS, ADD)                                                                                        \
-        if (pok[SS]) {                                                                                                \
+#define MVS_GRAD_STEP(SS, ADD, COND)                                                                                  \
+        if (!COND || pok[SS]) {                                                                                       \
             int to[4];                                                                                                \
             float tw[4];                                                                                              \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
@@ -273,11 +278,14 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
                 tw[t] = __int_as_float(quad_bcast<SS>(rw[t]));                                                        \
             }                                                                                                         \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
-                const float gw = go[SS][i] * (two_r * wv[j][SS][i] - two_r2 * S_[SS][i]);                             \
+                float gw = go[SS][i] * (two_r * wv[j][SS][i] - two_r2 * S_[SS][i]);                                   \
+                if (!COND) gw = pok[SS] ? gw : 0.0f;                                                                  \
                 _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
-                    if (tw[t] != 0.0f) ADD(to[t], i, gw * tw[t]);                                                     \
+                    if (!COND || tw[t] != 0.0f) ADD(to[t], i, gw * tw[t]);                                            \
             }                                                                                                         \
         }
+        // LDS adds are unconditional: an invalid tap (weight 0) and a pixel outside the map (gradient 0) add 0.0 to a clamped
+        // texel of the box -- a test per tap would put every one of the 64 ds_add_f64 of a plane under its own branch.
         // LDS: ds_add_f64 on the swizzled gradient image (s_grad is used directly: a select between an LDS and a global
         // address would make hipcc emit flat atomics); larger than the box: one global fp32 atomic per tap
 #define MVS_ADD_LDS(O, I, V) \
@@ -294,11 +302,11 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
                     rw[t] = from_quad<QQ>(__float_as_int(dwx[p][t]));                                                 \
                 }                                                                                                     \
                 if (fj & kFlagStaged) {                                                                               \
-                    MVS_GRAD_STEP(0, MVS_ADD_LDS) MVS_GRAD_STEP(1, MVS_ADD_LDS)                                       \
-                    MVS_GRAD_STEP(2, MVS_ADD_LDS) MVS_GRAD_STEP(3, MVS_ADD_LDS)                                       \
+                    MVS_GRAD_STEP(0, MVS_ADD_LDS, false) MVS_GRAD_STEP(1, MVS_ADD_LDS, false)                         \
+                    MVS_GRAD_STEP(2, MVS_ADD_LDS, false) MVS_GRAD_STEP(3, MVS_ADD_LDS, false)                         \
                 } else {                                                                                              \
-                    MVS_GRAD_STEP(0, MVS_ADD_GLB) MVS_GRAD_STEP(1, MVS_ADD_GLB)                                       \
-                    MVS_GRAD_STEP(2, MVS_ADD_GLB) MVS_GRAD_STEP(3, MVS_ADD_GLB)                                       \
+                    MVS_GRAD_STEP(0, MVS_ADD_GLB, true) MVS_GRAD_STEP(1, MVS_ADD_GLB, true)                           \
+                    MVS_GRAD_STEP(2, MVS_ADD_GLB, true) MVS_GRAD_STEP(3, MVS_ADD_GLB, true)                           \
                 }                                                                                                     \
             }                                                                                                         \
         }
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < K; ++j)
         if (have[j]) flush_box(j);
-    float* gr = gpacked + ((size_t)n * S + slab) * slab_stride + kHalfSlab * HALF;
+    float* gr = gpacked + ((size_t)n * S + slab) * slab_stride + kHalfSlab * half;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         if (pok[s]) {
@@ -381,7 +389,7 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     const int HW = H * W;
     const int tiles_x = (W + tw - 1) / tw, tiles = tiles_x * ((H + th - 1) / th);
     const long long nblocks = (long long)N * tiles * S;
-    MVS_REQUIRE(nblocks <= INT32_MAX, "plane_sweep_variance_bwd: grid too large");
+    MVS_REQUIRE(nblocks <= INT32_MAX / 2 - 16, "plane_sweep_variance_bwd: grid too large");
     const SweepGeometry geo = sweep_geometry(scratch, N, K, D, tiles);
     const int box_cap = sweep_box_cap(K, tw);
     const size_t lds = sweep_lds_bytes(K, box_cap);
@@ -401,8 +409,11 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     }
 #define MVS_BWD_LAUNCH(KV, TWV)                        \
     {                                                  \
-        MVS_BWD_LAUNCH1(KV, TWV, 0)                    \
-        if (C > 4) MVS_BWD_LAUNCH1(KV, TWV, 1)         \
+        if (C > 4) {                                   \
+            grid = dim3((unsigned)((nblocks + 7) / 8 * 16)); \
+            MVS_BWD_LAUNCH1(KV, TWV, 2)                \
+        } else                                         \
+            MVS_BWD_LAUNCH1(KV, TWV, 0)                \
     }
 #define MVS_BWD_CASE(KV)                     \
     case KV:                                 \
