@@ -368,12 +368,29 @@ int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const floa
 int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split,
                                   const float* scale, const float* shift, const float* residual, float* out, int N, int Cin,
                                   int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* Small volumes (the 3-D neck's 20x20x8 and 10x10x4 levels: a handful of tiles): the input channels are split over blocks so
+ * that the grid fills the chip, raw partial sums go to `workspace` and a second kernel adds them (ascending split order)
+ * before the affine, the residual and the ReLU.  workspace_bytes from mvsdet_conv3d_k3_bf16x3_workspace_bytes (0: the grid
+ * is large enough unsplit); NULL or too small a workspace: unsplit, same results up to the order of the fp32 sums. */
+size_t mvsdet_conv3d_k3_bf16x3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
+int mvsdet_conv3d_k3_bf16x3_ws(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                               const float* residual, float* out, void* workspace, size_t workspace_bytes, int N, int Cin, int Cout,
+                               int D, int H, int W, int relu, mvsdet_stream_t stream);
+int mvsdet_conv3d_k3_bf16x3_f32in_ws(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split,
+                                     const float* scale, const float* shift, const float* residual, float* out, void* workspace,
+                                     size_t workspace_bytes, int N, int Cin, int Cout, int D, int H, int W, int relu,
+                                     mvsdet_stream_t stream);
 
 /* Conv3d(kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] (mvsnet.py:77,79) on the bf16 matrix cores, three-term
  * split: x (N,Cin,D,H,W) fp32 -> out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1); weight_split of order 1. */
 int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split,
                                      const float* scale, const float* shift, float* out, int N, int Cin, int Cout, int D, int H,
                                      int W, int relu, mvsdet_stream_t stream);
+/* The stride-2 layer with a workspace for small volumes (as mvsdet_conv3d_k3_bf16x3_f32in_ws). */
+size_t mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
+int mvsdet_conv3d_k3_s2_bf16x3_f32in_ws(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split,
+                                        const float* scale, const float* shift, float* out, void* workspace, size_t workspace_bytes,
+                                        int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
 
 /* ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine] [+ ReLU] [+ residual, added last]
  * (mvsnet.py:92-100,110-111) on the bf16 matrix cores, three-term split: xs = SCL form of x (N,Cin,D,H,W); weight_split of

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
     const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
     const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
-    size_t piece_stride, int tiles_w, int relu) {
+    size_t piece_stride, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
     constexpr int NW = TD * TH / 4;                       // waves
     constexpr int NT = 64 * NW;                           // threads
     constexpr int HD = TD + 2, HH = TH + 2, HW = kBfW + 2;
@@ -141,8 +141,13 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    // blockIdx.z = (view, block of 64 output channels, split of the channel groups): a small volume (the 3-D neck's 20x20x8 and
+    // 10x10x4 levels: 1-12 tiles) is split over the input channels so that the grid fills the chip; each split writes raw
+    // partial sums that splitk_epilogue_kernel adds up (ascending split order) before the affine, residual and ReLU
     const int nob = Cout / 64;
-    const int n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
+    const int n = zo / nob, ob64 = zo % nob;
+    const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
     const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
     const int col = lane & 31, hh = lane >> 5;
 
@@ -290,19 +295,21 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
     };
 
     // ---- pipeline over the flat stage index q = 3*c8 + s
-    if constexpr (F32IN) {
-        fetch_f32(0);
-        stage_f32(0);
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes of the first input stage are done
-    } else {
-        dma_input(0, 0);
+    if (c8_begin < c8_end) {
+        if constexpr (F32IN) {
+            fetch_f32(c8_begin);
+            stage_f32(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes of the first input stage are done
+        } else {
+            dma_input(c8_begin, 0);
+        }
+        dma_weights(c8_begin, 0, 0);
     }
-    dma_weights(0, 0, 0);
-    for (int c8 = 0; c8 < C8; ++c8) {
-        const int ibuf = c8 & 1;
+    for (int c8 = c8_begin; c8 < c8_end; ++c8) {
+        const int ibuf = (c8 - c8_begin) & 1;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const int wbuf = (c8 * 3 + s) & 1;
+            const int wbuf = ((c8 - c8_begin) * 3 + s) & 1;
             // this wave's DMAs (and, F32IN, register fetches) of the current stage have landed; after the barrier
             // everybody's have, and everybody is done reading the buffers the next stage's transfers (issued right below)
             // overwrite
@@ -310,16 +317,16 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
             __builtin_amdgcn_s_barrier();
             if (s < 2) {
                 dma_weights(c8, s + 1, wbuf ^ 1);
-            } else if (c8 + 1 < C8) {
+            } else if (c8 + 1 < c8_end) {
                 dma_weights(c8 + 1, 0, wbuf ^ 1);
             }
             if constexpr (F32IN) {
                 // next channel group: global -> registers during sub-stage 0, registers -> LDS (cut into pieces) at the
                 // top of sub-stage 1; the LDS reads of sub-stage 1's first tap pair wait for lgkmcnt(0) behind the writes
-                if (s == 0 && c8 + 1 < C8) fetch_f32(c8 + 1);
-                if (s == 1 && c8 + 1 < C8) stage_f32(ibuf ^ 1);
+                if (s == 0 && c8 + 1 < c8_end) fetch_f32(c8 + 1);
+                if (s == 1 && c8 + 1 < c8_end) stage_f32(ibuf ^ 1);
             } else {
-                if (s == 0 && c8 + 1 < C8) dma_input(c8 + 1, ibuf ^ 1);
+                if (s == 0 && c8 + 1 < c8_end) dma_input(c8 + 1, ibuf ^ 1);
             }
             if (s == 0) compute(std::integral_constant<int, 0>{}, ibuf, wbuf);
             else if (s == 1) compute(std::integral_constant<int, 1>{}, ibuf, wbuf);
@@ -341,6 +348,10 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
                 const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = acc[a][b][r];
                 const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+                if (nsplit > 1) {
+                    partial[(size_t)split * total + idx] = v;
+                    continue;
+                }
                 if (scale) v = fmaf(v, scale[o], shift[o]);
                 if (residual) v = v + residual[idx];
                 if (relu) v = fmaxf(v, 0.0f);
@@ -381,7 +392,7 @@ __host__ __device__ constexpr int s2_tap_off(int pi, int j) {
 __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_kernel(
     const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out, int C8, int Cout, int Di, int Hi,
-    int Wi, int D, int H, int W, int tiles_w, int relu) {
+    int Wi, int D, int H, int W, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
     constexpr int TD = kS2TD, TH = kS2TH, NW = TD * TH / 4, NT = 64 * NW;
     constexpr int HH = kS2HH, HW = kS2HW, NVOX = kS2Vox, INS = kS2Ins;
     constexpr int NV = (NVOX + NT - 1) / NT;   // 2 voxel slots per thread and stage
@@ -393,7 +404,10 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
     const int nob = Cout / 64;
-    const int n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
+    // blockIdx.z = (view, block of 64 output channels, split of the channel groups): see conv3d_k3_bf16x3_kernel
+    const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
+    const int n = zo / nob, ob64 = zo % nob;
+    const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
     const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
     const int col = lane & 31, hh = lane >> 5;
     const float* xfn = xf + (size_t)n * sN;
@@ -515,16 +529,18 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
     // pipeline over the flat stage index q = 8*c8 + pi; LDS buffers alternate with q (= with pi).  Stage q: the registers
     // hold stage q+1's values (fetched during stage q-1): cut them into LDS buffer (q+1)&1 (free since stage q-1 ended),
     // start the fetch of stage q+2 and the weight DMA of stage q+1, multiply stage q.
-    const int nq = C8 * 8;
+    const int nq = (c8_end - c8_begin) * 8;
     using S0 = std::integral_constant<int, 0>;
-    fetch(S0{}, 0, 0);
-    stage(S0{}, 0);
-    dma_weights(0, 0, 0);
-    if (nq > 1) fetch(S0{}, 0, 1);
+    if (nq > 0) {
+        fetch(S0{}, c8_begin, 0);
+        stage(S0{}, 0);
+        dma_weights(c8_begin, 0, 0);
+        fetch(S0{}, c8_begin, 1);
+    }
     auto step = [&](auto pc, int c8) {
         constexpr int pi = decltype(pc)::value;
         constexpr int buf = pi & 1;
-        const int q = c8 * 8 + pi;
+        const int q = (c8 - c8_begin) * 8 + pi;
         __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) and lgkmcnt(0): own fetches, DMAs and LDS writes are done
         __builtin_amdgcn_s_barrier();
         if (q + 1 < nq) {
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
         if (q + 2 < nq) fetch(S0{}, pi >= 6 ? c8 + 1 : c8, (pi + 2) & 7);
         compute(pc, buf);
     };
-    for (int c8 = 0; c8 < C8; ++c8) {
+    for (int c8 = c8_begin; c8 < c8_end; ++c8) {
         step(std::integral_constant<int, 0>{}, c8);
         step(std::integral_constant<int, 1>{}, c8);
         step(std::integral_constant<int, 2>{}, c8);
@@ -557,9 +573,14 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = acc[a][b][r];
+                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+                if (nsplit > 1) {
+                    partial[(size_t)split * total + idx] = v;
+                    continue;
+                }
                 if (scale) v = fmaf(v, scale[o], shift[o]);
                 if (relu) v = fmaxf(v, 0.0f);
-                out[((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w] = v;
+                out[idx] = v;
             }
     }
 }
@@ -867,9 +888,29 @@ extern "C" int mvsdet_split_conv_weight(const float* weight, void* weight_split,
     return mvsdet_split_conv_weight_ordered(weight, weight_split, Cout, Cin, 0, stream);
 }
 
+namespace mvsdet {
+void launch_splitk_epilogue(const float* partial, int nsplit, size_t total, const float* scale, const float* shift,
+                            const float* residual, float* out, int Cout, size_t vol, int relu, hipStream_t st);   // costreg_conv0.hip
+}
+
+// splits of the channel groups for a grid of `blocks` blocks (one 8-12 wave block per CU): up to ~2 rounds of the chip, at
+// least 4 channel groups (12 weight sub-stages) per split
+static int bf_nsplit(long long blocks, int C8) {
+    if (blocks >= 192) return 1;
+    return (int)std::max(1LL, std::min<long long>((512 + blocks - 1) / blocks, C8 / 4));
+}
+
+extern "C" size_t mvsdet_conv3d_k3_bf16x3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Cout % 64 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const BfPlan p = bf_plan(D, H, W);
+    const int ns = bf_nsplit((long long)p.tiles_w * p.tiles_h * p.tiles_d * N * (Cout / 64), (Cin + 7) / 8);
+    return ns > 1 ? (size_t)ns * N * Cout * D * H * W * sizeof(float) : 0;
+}
+
 static int launch_bf16x3(const char* name, const void* xs, const float* xf, const int64_t* xstr, const void* weight_split,
                          const float* scale, const float* shift, const float* residual, float* out, int N, int Cin, int Cout,
-                         int D, int H, int W, int relu, mvsdet_stream_t stream) {
+                         int D, int H, int W, int relu, mvsdet_stream_t stream, void* workspace = nullptr,
+                         size_t workspace_bytes = 0) {
     MVS_REQUIRE((xs || xf) && weight_split && out, "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
@@ -878,8 +919,11 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     const BfPlan p = bf_plan(D, H, W);
     const int C8 = (Cin + 7) / 8;
     MVS_REQUIRE((size_t)p.Dp * p.Hp * p.Wp < ((size_t)1 << 31), "%s: one padded channel-group volume exceeds 2^31 voxels", name);
-    MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
-    const size_t vol = (size_t)D * H * W;
+    const size_t vol = (size_t)D * H * W, total = (size_t)N * Cout * vol;
+    // without (enough) workspace the convolution runs unsplit
+    int nsplit = bf_nsplit((long long)p.tiles_w * p.tiles_h * p.tiles_d * N * (Cout / 64), C8);
+    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float)) nsplit = 1;
+    MVS_REQUIRE((long long)N * (Cout / 64) * nsplit <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     const long long sN = xstr ? xstr[0] : (long long)Cin * vol, sC = xstr ? xstr[1] : (long long)vol;
     const long long sD = xstr ? xstr[2] : (long long)H * W, sH = xstr ? xstr[3] : (long long)W;
     if (xf) {
@@ -887,7 +931,7 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
         MVS_REQUIRE((long long)(D - 1) * sD + (long long)(H - 1) * sH + W < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
     }
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
-    dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64)));
+    dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
     hipStream_t st = (hipStream_t)stream;
 #define MVS_BF_CASE(TD_, TH_, F32_)                                                                                         \
     {                                                                                                                       \
@@ -900,7 +944,7 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
         }                                                                                                                   \
         hipLaunchKernelGGL(k, grid, dim3(64 * TD_ * TH_ / 4), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH,   \
                            Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W,    \
-                           p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu);                                                       \
+                           p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total);        \
     }
     if (xf) {
         if (p.th == 12) MVS_BF_CASE(4, 12, true) else MVS_BF_CASE(4, 8, true)
@@ -909,6 +953,10 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     }
 #undef MVS_BF_CASE
     MVS_LAUNCH_CHECK(name);
+    if (nsplit > 1) {
+        launch_splitk_epilogue(static_cast<const float*>(workspace), nsplit, total, scale, shift, residual, out, Cout, vol, relu, st);
+        MVS_LAUNCH_CHECK(name);
+    }
     return MVSDET_OK;
 }
 
@@ -932,12 +980,36 @@ extern "C" int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_st
                          H, W, relu, stream);
 }
 
+// The two forms with a workspace (mvsdet_conv3d_k3_bf16x3_workspace_bytes; NULL or too small: unsplit) for small volumes.
+extern "C" int mvsdet_conv3d_k3_bf16x3_ws(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                          const float* residual, float* out, void* workspace, size_t workspace_bytes, int N, int Cin,
+                                          int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
+    return launch_bf16x3("conv3d_k3_bf16x3", xs, nullptr, nullptr, weight_split, scale, shift, residual, out, N, Cin, Cout, D, H, W,
+                         relu, stream, workspace, workspace_bytes);
+}
+
+extern "C" int mvsdet_conv3d_k3_bf16x3_f32in_ws(const float* x, const int64_t* x_strides, const void* weight_split,
+                                                const float* scale, const float* shift, const float* residual, float* out,
+                                                void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int D, int H,
+                                                int W, int relu, mvsdet_stream_t stream) {
+    return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, N, Cin, Cout, D,
+                         H, W, relu, stream, workspace, workspace_bytes);
+}
+
 // Conv3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] of mvsnet.py:77,79 on the bf16 matrix
 // cores, three-term split; x (N,Cin,D,H,W) fp32 (x_strides as above) -> out (N,Cout,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1);
 // weight_split from mvsdet_split_conv_weight_ordered(order = 1).
-extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x_strides, const void* weight_split,
-                                                const float* scale, const float* shift, float* out, int N, int Cin, int Cout,
-                                                int Di, int Hi, int Wi, int relu, mvsdet_stream_t stream) {
+extern "C" size_t mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes(int N, int Cin, int Cout, int Di, int Hi, int Wi) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || Cout % 64 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;
+    const int D = (Di - 1) / 2 + 1, H = (Hi - 1) / 2 + 1, W = (Wi - 1) / 2 + 1;
+    const long long tiles = (long long)((W + kBfW - 1) / kBfW) * ((H + kS2TH - 1) / kS2TH) * ((D + kS2TD - 1) / kS2TD);
+    const int ns = bf_nsplit(tiles * N * (Cout / 64), (Cin + 7) / 8);
+    return ns > 1 ? (size_t)ns * N * Cout * D * H * W * sizeof(float) : 0;
+}
+
+static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void* weight_split, const float* scale,
+                            const float* shift, float* out, void* workspace, size_t workspace_bytes, int N, int Cin, int Cout,
+                            int Di, int Hi, int Wi, int relu, mvsdet_stream_t stream) {
     const char* name = "conv3d_k3_s2_bf16x3_f32in";
     MVS_REQUIRE(x && weight_split && out, "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
@@ -951,19 +1023,42 @@ extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x
     MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= Wi, "%s: bad strides", name);
     MVS_REQUIRE((long long)(Di - 1) * sD + (long long)(Hi - 1) * sH + Wi < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
     const int tiles_w = (W + kBfW - 1) / kBfW, tiles_h = (H + kS2TH - 1) / kS2TH, tiles_d = (D + kS2TD - 1) / kS2TD;
-    MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    const size_t total = (size_t)N * Cout * D * H * W;
+    int nsplit = bf_nsplit((long long)tiles_w * tiles_h * tiles_d * N * (Cout / 64), (Cin + 7) / 8);
+    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float)) nsplit = 1;   // unsplit without (enough) workspace
+    MVS_REQUIRE((long long)N * (Cout / 64) * nsplit <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     auto* k = conv3d_k3_s2_bf16x3_kernel;
     const size_t lds = s2_lds_bytes();
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
         return MVSDET_ERR_HIP;
     }
-    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 64)));
+    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
     hipLaunchKernelGGL(k, grid, dim3(64 * kS2TD * kS2TH / 4), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,
                        static_cast<const uint4*>(weight_split), scale, shift, out, (Cin + 7) / 8, Cout, Di, Hi, Wi, D, H, W, tiles_w,
-                       relu);
+                       relu, nsplit, static_cast<float*>(workspace), total);
     MVS_LAUNCH_CHECK(name);
+    if (nsplit > 1) {
+        launch_splitk_epilogue(static_cast<const float*>(workspace), nsplit, total, scale, shift, nullptr, out, Cout,
+                               (size_t)D * H * W, relu, (hipStream_t)stream);
+        MVS_LAUNCH_CHECK(name);
+    }
     return MVSDET_OK;
+}
+
+extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x_strides, const void* weight_split,
+                                                const float* scale, const float* shift, float* out, int N, int Cin, int Cout,
+                                                int Di, int Hi, int Wi, int relu, mvsdet_stream_t stream) {
+    return launch_s2_bf16x3(x, x_strides, weight_split, scale, shift, out, nullptr, 0, N, Cin, Cout, Di, Hi, Wi, relu, stream);
+}
+
+// with a workspace (mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes; NULL or too small: unsplit) for small volumes
+extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in_ws(const float* x, const int64_t* x_strides, const void* weight_split,
+                                                   const float* scale, const float* shift, float* out, void* workspace,
+                                                   size_t workspace_bytes, int N, int Cin, int Cout, int Di, int Hi, int Wi, int relu,
+                                                   mvsdet_stream_t stream) {
+    return launch_s2_bf16x3(x, x_strides, weight_split, scale, shift, out, workspace, workspace_bytes, N, Cin, Cout, Di, Hi, Wi, relu,
+                            stream);
 }
 
 // ConvTranspose3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine] [+ ReLU] [+ residual,

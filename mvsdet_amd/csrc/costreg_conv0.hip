@@ -197,6 +197,13 @@ __global__ __launch_bounds__(kThreads) void splitk_epilogue_kernel(const float* 
     out[i] = v;
 }
 
+// host-side launch for the other translation units (costreg_bf16.hip)
+void launch_splitk_epilogue(const float* partial, int nsplit, size_t total, const float* scale, const float* shift,
+                            const float* residual, float* out, int Cout, size_t vol, int relu, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, partial,
+                       nsplit, total, scale, shift, residual, out, Cout, vol, relu);
+}
+
 }  // namespace mvsdet
 
 using namespace mvsdet;

@@ -78,20 +78,23 @@ def _hip_ok(x: Tensor, module: nn.Module) -> bool:
 
 
 # Stride-1 3x3x3 convolutions on volumes of at least this many voxels go to the bf16 matrix cores with three-term split
-# operands (csrc/costreg_bf16.hip; outputs within ~1e-5 of the fp32 sums' scale); smaller volumes (the 20x20x8 and 10x10x4
-# levels pad its 4x8x16 tiles 2.4x and 7.7x) and stride 2 stay on the fp32-MFMA kernel.  0 disables the bf16 route.
-BF16X3_MIN_VOXELS = 16384
+# operands (csrc/costreg_bf16.hip; outputs within ~1e-5 of the fp32 sums' scale).  The 20x20x8 and 10x10x4 levels are a
+# handful of tiles (padded 1.9x): there the kernel splits the 512 / 1024 input channels over blocks and a second kernel
+# adds the partial sums (neck 4.05 -> 3.10 ms).  The two stride-2 layers stay on the fp32-MFMA kernel: measured on the
+# bf16x3 stride-2 kernel with the same split 0.72 against 0.64 ms (its stages of one input parity class are a few hundred
+# cycles of MFMA, shorter than the latency of the fetch they wait for).  0 disables the bf16 route.
+BF16X3_MIN_VOXELS = 256
 
 
 def _split_weight(conv: nn.Conv3d) -> Tensor:
-    """The weight cut into bf16 pieces in the bf16x3 kernel's layout, kept on the module (the neck's weights are 300 MB:
-    not re-split per call) until the weight tensor changes or `drop_derived_tensors` runs."""
+    """The weight cut into bf16 pieces in the bf16x3 kernel's layout (tap order of the layer's stride), kept on the module
+    (the neck's weights are 300 MB: not re-split per call) until the weight tensor changes or `drop_derived_tensors` runs."""
     from . import ops
     w = conv.weight
     key = (w.data_ptr(), w._version, w.device)
     cached = conv.__dict__.get("_mvs_wsplit")
     if cached is None or cached[0] != key:
-        cached = (key, ops.split_conv_weight(w))
+        cached = (key, ops.split_conv_weight(w, order=1 if conv.stride[0] == 2 else 0))
         conv.__dict__["_mvs_wsplit"] = cached
     return cached[1]
 
@@ -100,7 +103,7 @@ def _conv_k3(x: Tensor, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool, residua
     """Conv3d(k=3, p=1, stride 1|2) + BN(eval) [+ residual] [+ ReLU] in one MFMA kernel."""
     from . import ops
     scale, shift = _bn_affine(bn)
-    if conv.stride[0] == 1 and BF16X3_MIN_VOXELS and x[0, 0].numel() >= BF16X3_MIN_VOXELS:
+    if conv.stride[0] == 1 and BF16X3_MIN_VOXELS and x[0, 0].numel() >= BF16X3_MIN_VOXELS and conv.out_channels % 64 == 0:
         return ops.conv3d_k3_bf16x3(x, _split_weight(conv), scale, shift, relu, residual)
     return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(conv.weight), scale, shift, relu, conv.stride[0], residual)
 

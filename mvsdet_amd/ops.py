@@ -815,16 +815,19 @@ def conv3d_k3_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Op
         residual = residual.contiguous()
     weight_split = weight_split.contiguous()
     lib = _lib.load()
+    # small volumes: partial sums of the input-channel splits (0 bytes: the grid fills the chip unsplit)
+    wbytes = lib.mvsdet_conv3d_k3_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W)
+    ws = torch.empty((wbytes // 4,), dtype=torch.float32, device=dev) if wbytes else None
     with torch.cuda.device(dev):
         if scl:
-            _lib.check(lib.mvsdet_conv3d_k3_bf16x3(_lib.ptr(x.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
-                                                   _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
-                                                   _stream(out)), "conv3d_k3_bf16x3")
+            _lib.check(lib.mvsdet_conv3d_k3_bf16x3_ws(_lib.ptr(x.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
+                                                      _lib.ptr(residual), _lib.ptr(out), _lib.ptr(ws), wbytes, N, Cin, Cout, D, H, W,
+                                                      int(relu), _stream(out)), "conv3d_k3_bf16x3")
         else:
             xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
-            _lib.check(lib.mvsdet_conv3d_k3_bf16x3_f32in(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
-                                                         _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
-                                                         _stream(out)), "conv3d_k3_bf16x3_f32in")
+            _lib.check(lib.mvsdet_conv3d_k3_bf16x3_f32in_ws(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale),
+                                                            _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(out), _lib.ptr(ws), wbytes,
+                                                            N, Cin, Cout, D, H, W, int(relu), _stream(out)), "conv3d_k3_bf16x3_f32in")
     return out
 
 
@@ -851,10 +854,13 @@ def conv3d_k3_s2_bf16x3(x: Tensor, weight_split: Tensor, scale: Optional[Tensor]
     out = torch.empty((N, Cout, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
     weight_split = weight_split.contiguous()
     xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
+    lib = _lib.load()
+    wbytes = lib.mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W)   # small volumes: input-channel splits
+    ws = torch.empty((wbytes // 4,), dtype=torch.float32, device=x.device) if wbytes else None
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mvsdet_conv3d_k3_s2_bf16x3_f32in(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale),
-                                                                _lib.ptr(shift), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
-                                                                _stream(x)), "conv3d_k3_s2_bf16x3")
+        _lib.check(lib.mvsdet_conv3d_k3_s2_bf16x3_f32in_ws(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale),
+                                                           _lib.ptr(shift), _lib.ptr(out), _lib.ptr(ws), wbytes, N, Cin, Cout, D, H, W,
+                                                           int(relu), _stream(x)), "conv3d_k3_s2_bf16x3")
     return out
 
 

@@ -82,7 +82,8 @@ def test_scl_pack_reads_a_pitched_volume_in_place(gpu):
 
 @pytest.mark.parametrize("N,Cin,Cout,Di,Hi,Wi", [(1, 16, 64, 8, 16, 32), (2, 24, 64, 5, 13, 21), (1, 8, 128, 6, 30, 40),
                                                   (1, 37, 64, 9, 25, 33), (1, 64, 128, 12, 60, 80), (1, 5, 64, 1, 1, 1),
-                                                  (1, 128, 256, 6, 30, 40), (1, 3, 64, 2, 2, 2)])
+                                                  (1, 128, 256, 6, 30, 40), (1, 3, 64, 2, 2, 2),
+                                                  (1, 512, 128, 8, 20, 20)])   # the last one: split over the input channels
 def test_conv3d_k3_s2_bf16x3(gpu, N, Cin, Cout, Di, Hi, Wi):
     """Stride-2 convolution as the sum over the 8 parity classes of its input (conv1 / conv3 of mvsnet.py:77,79)."""
     from mvsdet_amd import ops

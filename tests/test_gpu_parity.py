@@ -1201,9 +1201,10 @@ def test_cost_network_training_gradients_hip_vs_torch(gpu):
 
 def test_cost_network_training_on_bf16x3(gpu):
     """Under autograd with `matrix_precision = "bf16x3"` (the default) forward and input gradient of every 3x3x3 layer run
-    on the bf16 matrix cores with three-term split operands, the weight gradients on the fp32 kernels.  Every layer pass is
-    within 5e-6 of its fp32 counterpart (checked per autograd Function); through the network a forward difference of that
-    size flips the ReLU decision of the few activations that sit within it of zero, so gradients are compared in norm."""
+    on the bf16 matrix cores with three-term split operands, and so do the weight gradients of the stride-1 layers.  Every
+    layer pass is within 1e-5 of its fp32 counterpart (checked per autograd Function); through the network a forward
+    difference of that size flips the ReLU decision of the few activations that sit within it of zero, so gradients are
+    compared in norm: a few 1e-3, set by how many activations flip, not by the arithmetic of a layer (2.4e-3 at this shape)."""
     from mvsdet_amd import costreg as CR
     torch.manual_seed(5)
     for fn, xs, ws in ((CR._ConvK3S1, (2, 256, 8, 12, 32), (64, 256, 3, 3, 3)), (CR._ConvK3S2, (2, 64, 8, 12, 32), (128, 64, 3, 3, 3)),
@@ -1235,9 +1236,9 @@ def test_cost_network_training_on_bf16x3(gpu):
     o0, gx0, gp0 = grads["fp32"]
     torch.testing.assert_close(o1, o0, rtol=0, atol=2e-5 * float(o0.abs().max()))
     rel = lambda a, b: float((a - b).norm()) / max(float(b.norm()), 1e-30)   # noqa: E731
-    assert rel(gx1, gx0) < 2e-3
+    assert rel(gx1, gx0) < 5e-3
     for k in gp0:
-        assert rel(gp1[k], gp0[k]) < 2e-3, k
+        assert rel(gp1[k], gp0[k]) < 5e-3, k
 
 
 @pytest.mark.parametrize("N,Cin,D,H,W", [(2, 64, 12, 20, 40), (1, 6, 5, 7, 33), (1, 3, 1, 1, 1)])
