@@ -61,7 +61,7 @@ __global__ void copy_tail_kernel(const float* __restrict__ src, float* __restric
 
 using namespace mvsdet;
 
-extern "C" int mvsdet_version(void) { return 3001; }
+extern "C" int mvsdet_version(void) { return 3002; }
 
 extern "C" int mvsdet_set_option(const char* name, int value) {
     int* slot = option_slot(name);

@@ -6,11 +6,12 @@
 // A GEMM per tap with the VOXELS as the reduction: D[o][c] += A[o][k] * B[k][c], the 16 k of v_mfma_f32_32x32x16_bf16 being
 // 16 consecutive voxels of one row.  Both operands arrive as fp32 NCDHW, are cut into bf16 pieces on the way into the LDS
 // and are stored voxel-contiguous, so that a lane's fragment (8 voxels of one channel) is one ds_read_b128.
-//   block = 32 output x 32 input channels, 9 waves = the 9 (kd,kh); each wave keeps the accumulators of its 3 kw
+//   block = 32 output x 32 input channels; 9 multiplying waves = the 9 (kd,kh), each with the accumulators of its 3 kw, and 3
+//           staging waves (global loads, cut into pieces, LDS stores)
 //   tile  = 4 rows x 16 voxels of dY and the 3 x 6 x 18 halo of X; the columns of tiles are walked along d as one stream of
 //           planes with a ring of four X planes and two dY buffers (see the kernel)
-//   loads : rows as float4 (W a multiple of 4), two steps ahead in registers; the two voxels either side of the 16 of a
-//           row by three extra waves; padding read from a zero word so that no load sits under a branch
+//   loads : rows as float4 (W a multiple of 4), two steps ahead in registers; padding read from a zero word so that no load
+//           sits under a branch
 //   kw    : a lane reads its 8 voxels, the other half's and the edge pairs (three ds_read_b128, conflict-free at the channel
 //           pitch) and forms the shifted fragments with five v_alignbit_b32
 //   per row of the tile and wave: 2 A + 6 B ds_read_b128 feed 9 MFMAs
@@ -25,7 +26,9 @@ typedef unsigned dwb_u32x4 __attribute__((ext_vector_type(4)));
 typedef float dwb_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDbTH = 4, kDbTW = 16;
-constexpr int kDbWaves = 9, kDbThreads = kDbWaves * 64;
+constexpr int kDbComputeWaves = 9, kDbLoaderWaves = 3;
+constexpr int kDbComputeThreads = kDbComputeWaves * 64, kDbLoaders = kDbLoaderWaves * 64;
+constexpr int kDbThreads = kDbComputeThreads + kDbLoaders;       // 768
 constexpr int kDbXRowB = 48;                                      // [w0..w0+7][w0+8..w0+15][w0-2,w0-1 | w0+16,w0+17][pad 8]
 constexpr int kDbXPlaneB = (kDbTH + 2) * kDbXRowB;                // 288
 constexpr int kDbXChanB = 4 * kDbXPlaneB + 16;                    // 1168 B = 292 words = 36 mod 64: conflict-free b128 reads
@@ -35,11 +38,9 @@ constexpr int kDbYPieceB = 32 * kDbYChanB;
 constexpr int kDbYBufB = 2 * kDbYPieceB;
 constexpr int kDbTabCap = 4096;                                   // columns of one split (host: nsplit >= ncols / 4096)
 constexpr int kDbTabOff = 2 * kDbXPieceB + 2 * kDbYBufB;          // 93184
-constexpr int kDbLdsB = kDbTabOff + kDbTabCap * 8;                // 125952: one block of 9 waves per CU
-constexpr int kDbMainThreads = 32 * (kDbTH + 2) * 2;              // 384: one group of 8 voxels of (channel, halo row) each
-constexpr int kDbYThreads = 32 * kDbTH * 4;                       // 512: one float4 of (channel, row) each
-static_assert(kDbMainThreads + 32 * (kDbTH + 2) == kDbThreads, "waves 6..8: the two edge pairs of one (channel, halo row) each");
-static_assert(kDbThreads - kDbYThreads == 64, "the last wave parks its dY store in the 32 x 16 bytes of channel padding");
+constexpr int kDbLdsB = kDbTabOff + kDbTabCap * 8;                // 125952: one block of 12 waves per CU
+static_assert(kDbLoaders == 32 * (kDbTH + 2), "one loader thread per (input channel, halo row)");
+static_assert(32 * kDbTH <= kDbLoaders, "one loader thread per (output channel, row)");
 
 __device__ float4 g_dwb_zero;   // zero-initialised: the source of every padding element
 
@@ -52,19 +53,29 @@ __device__ __forceinline__ void dwb_split2(float f0, float f1, unsigned& hi, uns
     hi = dwb_pack(a0, a1);
     mid = dwb_pack((__bf16)(f0 - (float)a0), (__bf16)(f1 - (float)a1));  // exact difference, rounded once
 }
+__device__ __forceinline__ void dwb_split8(const dwb_f32x4& a, const dwb_f32x4& b, uint4& hi, uint4& mid) {
+    dwb_split2(a.x, a.y, hi.x, mid.x);
+    dwb_split2(a.z, a.w, hi.y, mid.y);
+    dwb_split2(b.x, b.y, hi.z, mid.z);
+    dwb_split2(b.z, b.w, hi.w, mid.w);
+}
 
 // The columns of a split are walked as ONE stream of planes: position q = (column i, plane pos), pos = 0 .. D, where the
-// plane pos = D is all zero and serves as plane D of column i and as plane -1 of column i+1.  Every step commits one X plane
-// (two ahead of the one being multiplied) into a ring of four and one dY tile into one of two buffers, fetches the ones
-// two steps further into registers and multiplies planes q-1, q, q+1: one barrier per step, no start-up cost per column,
-// two steps of global loads in flight (a step is shorter than the memory latency).
+// plane pos = D is all zero and serves as plane D of column i and as plane -1 of column i+1.  Every step one X plane (two
+// ahead of the one being multiplied) is committed into a ring of four and one dY tile into one of two buffers, the ones two
+// steps further are fetched into registers, and planes q-1, q, q+1 are multiplied: one barrier per step, no start-up cost
+// per column, two steps of global loads in flight (a step is shorter than the memory latency).
 //
-// A step is straight-line code, the same for every wave: the zero plane between two columns (and the positions beyond the
-// stream) carry a zero dY tile and are multiplied like any other (1/(D+1) more matrix work); every thread issues the same
-// three float4 loads (padding and idle roles read a zero word: a branch on the role would hide from the compiler how many
-// loads are in flight and it would wait for all of them) and the same four LDS stores; the stream position is advanced
-// without a division (the columns of the split are decoded once, into a table in the LDS).  So the vector instructions of
-// the staging run between the MFMAs of the step instead of before them.
+// Waves 0..8 only multiply (the zero plane between two columns carries a zero dY tile and is multiplied like any other:
+// 1/(D+1) more matrix work, no branch).  Waves 9..11 only stage: a SIMD's vector issue is shared by its waves (an MFMA holds
+// it for 8 of its 32 cycles), and with the staging on the multiplying waves a step took the SUM of the two (6.3 ms at the
+// conv0 shape for 2.5 ms of staging and 4.4 ms of MFMAs with their fragment reads).  Round-robin placement puts the three
+// loaders on the SIMDs that carry two multiplying waves.  A loader thread owns one (input channel, halo row): six float4
+// loads = the 24 voxels w0-4 .. w0+19, of which w0-2 .. w0+17 make the 48-byte LDS row; threads 0..127 also one (output
+// channel, row) of dY.  The staging step is straight-line: padding and idle roles read a zero word (a load whose value is only
+// selected under a condition is moved under a branch with its own s_waitcnt; a branch on the role hides from the compiler how
+// many loads are in flight), the conversion is pinned behind the barrier (else hipcc converts right after the load to save
+// registers and waits for it there), the stream position advances without a division (column table in the LDS).
 __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                          float* __restrict__ partial, int N, int Cin, int Cout,
                                                                          int D, int H, int W, int tiles_w, int tiles_h, int ncols,
@@ -73,7 +84,9 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
     char* const sx = reinterpret_cast<char*>(s_dwb);
     char* const sy = sx + 2 * kDbXPieceB;
     int2* const tab = reinterpret_cast<int2*>(sx + kDbTabOff);   // column i of this split -> (view, tile origin h0 << 16 | w0)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= kDbComputeWaves;
     const int r32 = lane & 31, hh = lane >> 5;
     const int kd = wave / 3, kh = wave - 3 * kd;
     // The blocks of one split (all channel blocks) read the same dY tiles and, per input-channel block, the same X planes at
@@ -93,27 +106,6 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
     const int HW = H * W;
     const float* const zero = reinterpret_cast<const float*>(&g_dwb_zero);
 
-    dwb_f32x16 acc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
-    // staging roles: X -- waves 0..5: 8 voxels of (channel, halo row) as two float4; waves 6..8: the float4 before and the one
-    // after the tile of (channel, halo row), for the two voxels either side; dY -- waves 0..7: one float4 of (channel, row)
-    const bool xmain = tid < kDbMainThreads, ythread = tid < kDbYThreads;
-    const int et = tid - kDbMainThreads;
-    const int xc = xmain ? tid / 12 : et / 6;
-    const int xrow = xmain ? (tid % 12) >> 1 : et % 6;
-    const int xgrp = tid & 1;
-    const int xoff_a = xmain ? 8 * xgrp : -4, xoff_b = xmain ? 8 * xgrp + 4 : 16;
-    const int x_lds = xc * kDbXChanB + xrow * kDbXRowB + (xmain ? xgrp * 16 : 32);
-    const int yo = (tid >> 4) & 31, yrow = (tid >> 2) & 3, yq = tid & 3;
-    const int y_lds = ythread ? yo * kDbYChanB + yrow * 32 + yq * 8 : ((tid - kDbYThreads) >> 1) * kDbYChanB + 128 + (tid & 1) * 8;
-    const float* const xchan = x + (size_t)min(c0 + xc, Cin - 1) * vol;
-    const float* const ychan = gy + (size_t)min(o0 + yo, Cout - 1) * vol;
-    const bool xc_ok = c0 + xc < Cin, yo_ok = ythread && o0 + yo < Cout;
-
     const int cols_per_view = tiles_h * tiles_w;
     const int mine = split < ncols ? (ncols - split + nsplit - 1) / nsplit : 0;   // columns of this split (host: <= kDbTabCap)
     const int Q = mine * (D + 1);                                                 // stream positions
@@ -123,54 +115,115 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
     }
     __syncthreads();
 
-    struct Regs { dwb_f32x4 xa, xb, ya; };
-    struct Pos { int i, d; };   // column of the split, plane (d == D: the zero plane)
-    Regs sets[2];
-    // X plane at stream position px and dY tile at position py (a position beyond the stream or a plane D: zeros)
-    auto fetch = [&](Regs& g, Pos px, Pos py) {
-        {
-            const int2 e = tab[min(px.i, mine - 1)];
-            const int h0 = e.y >> 16, w0 = e.y & 0xffff;
-            const int h = h0 - 1 + xrow;
-            const bool ok = (px.i < mine) & (px.d < D) & xc_ok & (h >= 0) & (h < H);   // '&': no short-circuit branches in a step
-            const float* row = xchan + (size_t)e.x * Cin * vol + (size_t)min(px.d, D - 1) * HW + min(max(h, 0), H - 1) * W;
-            const int wa = w0 + xoff_a, wb = w0 + xoff_b;
-            g.xa = *reinterpret_cast<const dwb_f32x4*>((ok & (wa >= 0) & (wa < W)) ? row + wa : zero);
-            g.xb = *reinterpret_cast<const dwb_f32x4*>((ok & (wb < W)) ? row + wb : zero);
-        }
-        {
-            const int2 e = tab[min(py.i, mine - 1)];
-            const int h0 = e.y >> 16, w0 = e.y & 0xffff;
-            const int h = h0 + yrow, w = w0 + 4 * yq;
-            const bool ok = (py.i < mine) & (py.d < D) & yo_ok & (h < H) & (w < W);
-            const float* row = ychan + (size_t)e.x * Cout * vol + (size_t)min(py.d, D - 1) * HW + min(h, H - 1) * W;
-            g.ya = *reinterpret_cast<const dwb_f32x4*>(ok ? row + w : zero);
-        }
-    };
-    auto commit = [&](Regs& g, int slot, int ybuf) {
-        // the values pass through an opaque statement here, after the barrier: otherwise the compiler cuts them into pieces
-        // right after the loads (fewer registers) and so waits for every load inside the step that issued it
-        asm volatile("" : "+v"(g.xa), "+v"(g.xb), "+v"(g.ya));
-        // edge role: (w0-2, w0-1) = xa.zw, (w0+16, w0+17) = xb.xy; its 16-byte store covers the edge pairs and the row's padding
-        const dwb_f32x4 a = xmain ? g.xa : dwb_f32x4{g.xa.z, g.xa.w, g.xb.x, g.xb.y};
-        uint4 hi, mid;
-        dwb_split2(a.x, a.y, hi.x, mid.x);
-        dwb_split2(a.z, a.w, hi.y, mid.y);
-        dwb_split2(g.xb.x, g.xb.y, hi.z, mid.z);
-        dwb_split2(g.xb.z, g.xb.w, hi.w, mid.w);
-        char* dx = sx + x_lds + slot * kDbXPlaneB;
-        *reinterpret_cast<uint4*>(dx) = hi;
-        *reinterpret_cast<uint4*>(dx + kDbXPieceB) = mid;
-        uint2 yh, ym;
-        dwb_split2(g.ya.x, g.ya.y, yh.x, ym.x);
-        dwb_split2(g.ya.z, g.ya.w, yh.y, ym.y);
-        char* dy = sy + ybuf * kDbYBufB + y_lds;
-        *reinterpret_cast<uint2*>(dy) = yh;
-        *reinterpret_cast<uint2*>(dy + kDbYPieceB) = ym;
-    };
-    auto at = [&](int q) { return Pos{q / (D + 1), q % (D + 1)}; };
-    auto next = [&](Pos p) { return p.d == D ? Pos{p.i + 1, 0} : Pos{p.i, p.d + 1}; };
+    if (loader) {
+        // ---------------------------------------------------------------------------------------------- staging waves
+        const int lt = tid - kDbComputeThreads;
+        const int xc = lt / (kDbTH + 2), xrow = lt - xc * (kDbTH + 2);
+        const bool ythread = lt < 32 * kDbTH;
+        const int yo = (lt >> 2) & 31, yrow = lt & 3;
+        const int x_lds = xc * kDbXChanB + xrow * kDbXRowB;
+        // idle dY roles park their store in the 16 bytes of padding of a channel (two threads per channel, 8 bytes each ... twice)
+        const int y_lds = ythread ? yo * kDbYChanB + yrow * 32 : -1;
+        const float* const xchan = x + (size_t)min(c0 + xc, Cin - 1) * vol;
+        const float* const ychan = gy + (size_t)min(o0 + yo, Cout - 1) * vol;
+        const bool xc_ok = c0 + xc < Cin, yo_ok = ythread && o0 + yo < Cout;
 
+        struct Regs { dwb_f32x4 xv[6], yv[4]; };
+        struct Pos { int i, d; };   // column of the split, plane (d == D: the zero plane)
+        Regs sets[2];
+        // X plane at stream position px and dY tile at position py (a position beyond the stream or a plane D: zeros)
+        auto fetch = [&](Regs& g, Pos px, Pos py) {
+            {
+                const int2 e = tab[min(px.i, mine - 1)];
+                const int h0 = e.y >> 16, w0 = e.y & 0xffff;
+                const int h = h0 - 1 + xrow;
+                const bool ok = (px.i < mine) & (px.d < D) & xc_ok & (h >= 0) & (h < H);   // '&': no short-circuit branches
+                const float* row = xchan + (size_t)e.x * Cin * vol + (size_t)min(px.d, D - 1) * HW + min(max(h, 0), H - 1) * W;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int w = w0 - 4 + 4 * k;
+                    g.xv[k] = *reinterpret_cast<const dwb_f32x4*>((ok & (w >= 0) & (w < W)) ? row + w : zero);
+                }
+            }
+            {
+                const int2 e = tab[min(py.i, mine - 1)];
+                const int h0 = e.y >> 16, w0 = e.y & 0xffff;
+                const int h = h0 + yrow;
+                const bool ok = (py.i < mine) & (py.d < D) & yo_ok & (h < H);
+                const float* row = ychan + (size_t)e.x * Cout * vol + (size_t)min(py.d, D - 1) * HW + min(h, H - 1) * W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int w = w0 + 4 * k;
+                    g.yv[k] = *reinterpret_cast<const dwb_f32x4*>((ok & (w < W)) ? row + w : zero);
+                }
+            }
+        };
+        auto commit = [&](Regs& g, int slot, int ybuf) {
+            // the values pass through an opaque statement here, after the barrier (see the kernel's comment)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(g.xv[k]));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(g.yv[k]));
+            char* dx = sx + x_lds + slot * kDbXPlaneB;
+            uint4 hi, mid;
+            dwb_split8(g.xv[1], g.xv[2], hi, mid);
+            *reinterpret_cast<uint4*>(dx) = hi;
+            *reinterpret_cast<uint4*>(dx + kDbXPieceB) = mid;
+            dwb_split8(g.xv[3], g.xv[4], hi, mid);
+            *reinterpret_cast<uint4*>(dx + 16) = hi;
+            *reinterpret_cast<uint4*>(dx + kDbXPieceB + 16) = mid;
+            // (w0-2, w0-1) = xv[0].zw, (w0+16, w0+17) = xv[5].xy; the 16-byte store also covers the row's padding
+            dwb_split8(dwb_f32x4{g.xv[0].z, g.xv[0].w, g.xv[5].x, g.xv[5].y}, dwb_f32x4{0.f, 0.f, 0.f, 0.f}, hi, mid);
+            *reinterpret_cast<uint4*>(dx + 32) = hi;
+            *reinterpret_cast<uint4*>(dx + kDbXPieceB + 32) = mid;
+            if (ythread) {
+                char* dy = sy + ybuf * kDbYBufB + y_lds;
+                dwb_split8(g.yv[0], g.yv[1], hi, mid);
+                *reinterpret_cast<uint4*>(dy) = hi;
+                *reinterpret_cast<uint4*>(dy + kDbYPieceB) = mid;
+                dwb_split8(g.yv[2], g.yv[3], hi, mid);
+                *reinterpret_cast<uint4*>(dy + 16) = hi;
+                *reinterpret_cast<uint4*>(dy + kDbYPieceB + 16) = mid;
+            }
+        };
+        auto at = [&](int q) { return Pos{q / (D + 1), q % (D + 1)}; };
+        auto next = [&](Pos p) { return p.d == D ? Pos{p.i + 1, 0} : Pos{p.i, p.d + 1}; };
+
+        Pos fx = at(4), fy = at(3);   // the positions the first step fetches
+        if (Q > 0) {
+            // plane -1 of the first column (slot 3) is zero; planes 0, 1 and the first dY tile are committed before the loop
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sets[0].xv[k] = dwb_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sets[0].yv[k] = dwb_f32x4{0.f, 0.f, 0.f, 0.f};
+            commit(sets[0], 3, 1);
+            fetch(sets[0], at(0), at(0));
+            commit(sets[0], 0, 0);
+            fetch(sets[0], at(1), Pos{mine, 0});
+            commit(sets[0], 1, 1);
+            fetch(sets[0], at(2), at(1));
+            fetch(sets[1], at(3), at(2));
+        }
+        auto step = [&](int q, Regs& g) {
+            __syncthreads();   // step q-1 fully consumed (its oldest plane and its dY buffer may be replaced); commits of q-1 visible
+            commit(g, (q + 2) & 3, (q + 1) & 1);
+            fetch(g, fx, fy);
+            fy = fx;
+            fx = next(fx);
+        };
+        for (int q = 0; q < Q; q += 2) {
+            step(q, sets[0]);
+            step(q + 1, sets[1]);
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------------------------------------- multiplying waves
+    dwb_f32x16 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const char* const ya = sy + r32 * kDbYChanB + hh * 16;
     const char* const xbase = sx + r32 * kDbXChanB + kh * kDbXRowB;
     const int own_off = hh * 16, oth_off = 16 - hh * 16;
@@ -206,35 +259,12 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, bq[kw][0], acc[kw], 0, 0, 0);
     };
-
-    Pos fx = at(4), fy = at(3);   // the positions the first step fetches
-    if (Q > 0) {
-        // plane -1 of the first column (slot 3) is zero; planes 0, 1 and the first dY tile are committed before the loop
-        sets[0].xa = sets[0].xb = sets[0].ya = dwb_f32x4{0.f, 0.f, 0.f, 0.f};
-        commit(sets[0], 3, 1);
-        fetch(sets[0], at(0), at(0));
-        commit(sets[0], 0, 0);
-        fetch(sets[0], at(1), Pos{mine, 0});
-        commit(sets[0], 1, 1);
-        fetch(sets[0], at(2), at(1));
-        fetch(sets[1], at(3), at(2));
-    }
-    auto step = [&](int q, Regs& g) {
-        __syncthreads();   // step q-1 fully consumed (its oldest plane and its dY buffer may be replaced); commits of q-1 visible
+    for (int q = 0; q < ((Q + 1) & ~1); ++q) {
+        __syncthreads();   // the loaders' commits of step q-1 are visible
         const char* xs = xbase + ((q + kd + 3) & 3) * kDbXPlaneB;
         const char* ys = ya + (q & 1) * kDbYBufB;
-        row_mfma(xs, ys, 0);
-        row_mfma(xs, ys, 1);
-        commit(g, (q + 2) & 3, (q + 1) & 1);
-        fetch(g, fx, fy);
-        fy = fx;
-        fx = next(fx);
-        row_mfma(xs, ys, 2);
-        row_mfma(xs, ys, 3);
-    };
-    for (int q = 0; q < Q; q += 2) {
-        step(q, sets[0]);
-        step(q + 1, sets[1]);
+#pragma unroll
+        for (int r = 0; r < kDbTH; ++r) row_mfma(xs, ys, r);
     }
     // partial[split][o][c][tap]; C/D map: column = lane & 31 (c), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (o)
 #pragma unroll
