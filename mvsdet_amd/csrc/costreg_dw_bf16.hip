@@ -6,8 +6,8 @@
 // A GEMM per tap with the VOXELS as the reduction: D[o][c] += A[o][k] * B[k][c], the 16 k of v_mfma_f32_32x32x16_bf16 being
 // 16 consecutive voxels of one row.  Both operands arrive as fp32 NCDHW, are cut into bf16 pieces on the way into the LDS
 // and are stored voxel-contiguous, so that a lane's fragment (8 voxels of one channel) is one ds_read_b128.
-//   block = 32 output x 32 input channels; 9 multiplying waves = the 9 (kd,kh), each with the accumulators of its 3 kw, and 3
-//           staging waves (global loads, cut into pieces, LDS stores)
+//   block = 32 output x 32 input channels; 8 multiplying waves = 8 of the 9 (kd,kh) with their 3 kw each, the ninth pair's
+//           three taps on waves 0..2; 4 staging waves (global loads, cut into pieces, LDS stores), one per SIMD
 //   tile  = 4 rows x 16 voxels of dY and the 3 x 6 x 18 halo of X; the columns of tiles are walked along d as one stream of
 //           planes with a ring of four X planes and two dY buffers (see the kernel)
 //   loads : rows as float4 (W a multiple of 4), two steps ahead in registers; padding read from a zero word so that no load
@@ -26,7 +26,7 @@ typedef unsigned dwb_u32x4 __attribute__((ext_vector_type(4)));
 typedef float dwb_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDbTH = 4, kDbTW = 16;
-constexpr int kDbComputeWaves = 9, kDbLoaderWaves = 3;
+constexpr int kDbComputeWaves = 8, kDbLoaderWaves = 4;
 constexpr int kDbComputeThreads = kDbComputeWaves * 64, kDbLoaders = kDbLoaderWaves * 64;
 constexpr int kDbThreads = kDbComputeThreads + kDbLoaders;       // 768
 constexpr int kDbXRowB = 48;                                      // [w0..w0+7][w0+8..w0+15][w0-2,w0-1 | w0+16,w0+17][pad 8]
@@ -36,11 +36,12 @@ constexpr int kDbXPieceB = 32 * kDbXChanB;
 constexpr int kDbYChanB = kDbTH * 32 + 16;                        // 144 B = 36 words: conflict-free b128 reads
 constexpr int kDbYPieceB = 32 * kDbYChanB;
 constexpr int kDbYBufB = 2 * kDbYPieceB;
+constexpr int kDbDepth = 2;                                       // steps of global loads in flight
 constexpr int kDbTabCap = 4096;                                   // columns of one split (host: nsplit >= ncols / 4096)
 constexpr int kDbTabOff = 2 * kDbXPieceB + 2 * kDbYBufB;          // 93184
 constexpr int kDbLdsB = kDbTabOff + kDbTabCap * 8;                // 125952: one block of 12 waves per CU
-static_assert(kDbLoaders == 32 * (kDbTH + 2), "one loader thread per (input channel, halo row)");
-static_assert(32 * kDbTH <= kDbLoaders, "one loader thread per (output channel, row)");
+constexpr int kDbXRoles = 32 * (kDbTH + 2), kDbYRoles = 32 * kDbTH;   // 192 (input channel, halo row), 128 (output channel, row)
+static_assert(kDbXRoles <= kDbLoaders && kDbYRoles <= kDbLoaders, "one loader thread per row of either operand");
 
 __device__ float4 g_dwb_zero;   // zero-initialised: the source of every padding element
 
@@ -66,16 +67,18 @@ __device__ __forceinline__ void dwb_split8(const dwb_f32x4& a, const dwb_f32x4& 
 // steps further are fetched into registers, and planes q-1, q, q+1 are multiplied: one barrier per step, no start-up cost
 // per column, two steps of global loads in flight (a step is shorter than the memory latency).
 //
-// Waves 0..8 only multiply (the zero plane between two columns carries a zero dY tile and is multiplied like any other:
-// 1/(D+1) more matrix work, no branch).  Waves 9..11 only stage: a SIMD's vector issue is shared by its waves (an MFMA holds
-// it for 8 of its 32 cycles), and with the staging on the multiplying waves a step took the SUM of the two (6.3 ms at the
-// conv0 shape for 2.5 ms of staging and 4.4 ms of MFMAs with their fragment reads).  Round-robin placement puts the three
-// loaders on the SIMDs that carry two multiplying waves.  A loader thread owns one (input channel, halo row): six float4
-// loads = the 24 voxels w0-4 .. w0+19, of which w0-2 .. w0+17 make the 48-byte LDS row; threads 0..127 also one (output
-// channel, row) of dY.  The staging step is straight-line: padding and idle roles read a zero word (a load whose value is only
-// selected under a condition is moved under a branch with its own s_waitcnt; a branch on the role hides from the compiler how
-// many loads are in flight), the conversion is pinned behind the barrier (else hipcc converts right after the load to save
-// registers and waits for it there), the stream position advances without a division (column table in the LDS).
+// Waves 0..7 only multiply (the zero plane between two columns carries a zero dY tile and is multiplied like any other:
+// 1/(D+1) more matrix work, no branch): wave w owns the (kd,kh) pair number w with its three kw, and waves 0..2 one kw each
+// of the ninth pair -- a workgroup's waves go to the SIMDs round-robin (w, w+4, w+8 share one: tools/micro/wave_simd.hip), so
+// every SIMD multiplies 7, 7, 7 or 6 of the 27 taps.  Waves 8..11 only stage, one per SIMD: a SIMD's vector issue is shared
+// by its waves (an MFMA holds it for 8 of its 32 cycles), and with the staging on the multiplying waves a step took the SUM
+// of the two (6.3 ms at the conv0 shape for 2.5 ms of staging and 4.4 ms of MFMAs with their fragment reads).  A loader thread
+// owns one (input channel, halo row) -- six float4 loads = the 24 voxels w0-4 .. w0+19, of which w0-2 .. w0+17 make the
+// 48-byte LDS row -- and / or one (output channel, row) of dY.  The staging step is straight-line: padding and idle roles read
+// a zero word (a load whose value is only selected under a condition is moved under a branch with its own s_waitcnt; a branch
+// on the role hides from the compiler how many loads are in flight), the conversion is pinned behind the barrier (else hipcc
+// converts right after the load to save registers and waits for it there), the stream position advances without a division
+// (column table in the LDS).
 __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                          float* __restrict__ partial, int N, int Cin, int Cout,
                                                                          int D, int H, int W, int tiles_w, int tiles_h, int ncols,
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= kDbComputeWaves;
     const int r32 = lane & 31, hh = lane >> 5;
-    const int kd = wave / 3, kh = wave - 3 * kd;
+    const int kd = wave / 3, kh = wave - 3 * kd;   // multiplying waves: the (kd,kh) pair number `wave`
     // The blocks of one split (all channel blocks) read the same dY tiles and, per input-channel block, the same X planes at
     // the same time: they are placed on ONE XCD (block id modulo 8 picks the XCD), so that its L2 serves all but the first.
     const int ncb = (Cin + 31) / 32, nob = (Cout + 31) / 32, J = ncb * nob;
@@ -118,19 +121,19 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
     if (loader) {
         // ---------------------------------------------------------------------------------------------- staging waves
         const int lt = tid - kDbComputeThreads;
-        const int xc = lt / (kDbTH + 2), xrow = lt - xc * (kDbTH + 2);
-        const bool ythread = lt < 32 * kDbTH;
-        const int yo = (lt >> 2) & 31, yrow = lt & 3;
+        const bool xthread = lt < kDbXRoles, ythread = lt >= kDbLoaders - kDbYRoles;   // threads 128..191 carry both roles
+        const int xl = min(lt, kDbXRoles - 1), yl = max(lt - (kDbLoaders - kDbYRoles), 0);
+        const int xc = xl / (kDbTH + 2), xrow = xl - xc * (kDbTH + 2);
+        const int yo = (yl >> 2) & 31, yrow = yl & 3;
         const int x_lds = xc * kDbXChanB + xrow * kDbXRowB;
-        // idle dY roles park their store in the 16 bytes of padding of a channel (two threads per channel, 8 bytes each ... twice)
-        const int y_lds = ythread ? yo * kDbYChanB + yrow * 32 : -1;
+        const int y_lds = yo * kDbYChanB + yrow * 32;
         const float* const xchan = x + (size_t)min(c0 + xc, Cin - 1) * vol;
         const float* const ychan = gy + (size_t)min(o0 + yo, Cout - 1) * vol;
-        const bool xc_ok = c0 + xc < Cin, yo_ok = ythread && o0 + yo < Cout;
+        const bool xc_ok = xthread && c0 + xc < Cin, yo_ok = ythread && o0 + yo < Cout;
 
         struct Regs { dwb_f32x4 xv[6], yv[4]; };
         struct Pos { int i, d; };   // column of the split, plane (d == D: the zero plane)
-        Regs sets[2];
+        Regs sets[kDbDepth];
         // X plane at stream position px and dY tile at position py (a position beyond the stream or a plane D: zeros)
         auto fetch = [&](Regs& g, Pos px, Pos py) {
             {
@@ -164,19 +167,21 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
             for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(g.xv[k]));
 #pragma unroll
             for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(g.yv[k]));
-            char* dx = sx + x_lds + slot * kDbXPlaneB;
             uint4 hi, mid;
-            dwb_split8(g.xv[1], g.xv[2], hi, mid);
-            *reinterpret_cast<uint4*>(dx) = hi;
-            *reinterpret_cast<uint4*>(dx + kDbXPieceB) = mid;
-            dwb_split8(g.xv[3], g.xv[4], hi, mid);
-            *reinterpret_cast<uint4*>(dx + 16) = hi;
-            *reinterpret_cast<uint4*>(dx + kDbXPieceB + 16) = mid;
-            // (w0-2, w0-1) = xv[0].zw, (w0+16, w0+17) = xv[5].xy; the 16-byte store also covers the row's padding
-            dwb_split8(dwb_f32x4{g.xv[0].z, g.xv[0].w, g.xv[5].x, g.xv[5].y}, dwb_f32x4{0.f, 0.f, 0.f, 0.f}, hi, mid);
-            *reinterpret_cast<uint4*>(dx + 32) = hi;
-            *reinterpret_cast<uint4*>(dx + kDbXPieceB + 32) = mid;
-            if (ythread) {
+            if (xthread) {   // whole waves: 8, 9, 10
+                char* dx = sx + x_lds + slot * kDbXPlaneB;
+                dwb_split8(g.xv[1], g.xv[2], hi, mid);
+                *reinterpret_cast<uint4*>(dx) = hi;
+                *reinterpret_cast<uint4*>(dx + kDbXPieceB) = mid;
+                dwb_split8(g.xv[3], g.xv[4], hi, mid);
+                *reinterpret_cast<uint4*>(dx + 16) = hi;
+                *reinterpret_cast<uint4*>(dx + kDbXPieceB + 16) = mid;
+                // (w0-2, w0-1) = xv[0].zw, (w0+16, w0+17) = xv[5].xy; the 16-byte store also covers the row's padding
+                dwb_split8(dwb_f32x4{g.xv[0].z, g.xv[0].w, g.xv[5].x, g.xv[5].y}, dwb_f32x4{0.f, 0.f, 0.f, 0.f}, hi, mid);
+                *reinterpret_cast<uint4*>(dx + 32) = hi;
+                *reinterpret_cast<uint4*>(dx + kDbXPieceB + 32) = mid;
+            }
+            if (ythread) {   // whole waves: 10, 11
                 char* dy = sy + ybuf * kDbYBufB + y_lds;
                 dwb_split8(g.yv[0], g.yv[1], hi, mid);
                 *reinterpret_cast<uint4*>(dy) = hi;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
         auto at = [&](int q) { return Pos{q / (D + 1), q % (D + 1)}; };
         auto next = [&](Pos p) { return p.d == D ? Pos{p.i + 1, 0} : Pos{p.i, p.d + 1}; };
 
-        Pos fx = at(4), fy = at(3);   // the positions the first step fetches
+        Pos fx = at(2 + kDbDepth), fy = at(1 + kDbDepth);   // the positions the first step fetches
         if (Q > 0) {
             // plane -1 of the first column (slot 3) is zero; planes 0, 1 and the first dY tile are committed before the loop
 #pragma unroll
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
             commit(sets[0], 0, 0);
             fetch(sets[0], at(1), Pos{mine, 0});
             commit(sets[0], 1, 1);
-            fetch(sets[0], at(2), at(1));
-            fetch(sets[1], at(3), at(2));
+#pragma unroll
+            for (int k = 0; k < kDbDepth; ++k) fetch(sets[k], at(2 + k), at(1 + k));
         }
         auto step = [&](int q, Regs& g) {
             __syncthreads();   // step q-1 fully consumed (its oldest plane and its dY buffer may be replaced); commits of q-1 visible
@@ -211,25 +216,29 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
             fy = fx;
             fx = next(fx);
         };
-        for (int q = 0; q < Q; q += 2) {
-            step(q, sets[0]);
-            step(q + 1, sets[1]);
+        for (int q = 0; q < Q; q += kDbDepth) {
+#pragma unroll
+            for (int k = 0; k < kDbDepth; ++k) step(q + k, sets[k]);
         }
         return;
     }
 
     // -------------------------------------------------------------------------------------------------- multiplying waves
-    dwb_f32x16 acc[3];
+    dwb_f32x16 acc[4];   // the three kw of the wave's (kd,kh) pair; waves 0..2: tap kw = wave of the pair (2,2)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const bool extra = wave < 3;
     const char* const ya = sy + r32 * kDbYChanB + hh * 16;
     const char* const xbase = sx + r32 * kDbXChanB + kh * kDbXRowB;
     const int own_off = hh * 16, oth_off = 16 - hh * 16;
+    // the extra tap (2,2,kw = wave): its row of the X plane after the current one, and the one neighbour word it needs
+    const char* const xbase22 = sx + r32 * kDbXChanB + 2 * kDbXRowB;
+    const int side_off = wave == 0 ? (hh ? 0 : 32) : (hh ? 32 : 16);   // kw = 0: the voxel before own; kw = 2: the one after
 
     // one row of the tile: 8 ds_read_b128, 10 v_alignbit, 9 MFMAs
-    auto row_mfma = [&](const char* xs, const char* ys, int r) {
+    auto row_mfma = [&](const char* xs, const char* xs22, const char* ys, int r) {
         const dwb_bf16x8 a_hi = *reinterpret_cast<const dwb_bf16x8*>(ys + r * 32);
         const dwb_bf16x8 a_mid = *reinterpret_cast<const dwb_bf16x8*>(ys + kDbYPieceB + r * 32);
         dwb_bf16x8 bq[3][2];
@@ -258,13 +267,33 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
         for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bq[kw][1], acc[kw], 0, 0, 0);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, bq[kw][0], acc[kw], 0, 0, 0);
+        if (extra) {   // wave-uniform
+            dwb_bf16x8 be[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const char* rowp = xs22 + p * kDbXPieceB + r * kDbXRowB;
+                const dwb_u32x4 own = *reinterpret_cast<const dwb_u32x4*>(rowp + own_off);
+                dwb_u32x4 side = *reinterpret_cast<const dwb_u32x4*>(rowp + side_off);
+                asm volatile("" : "+v"(side));
+                const unsigned t1 = __builtin_amdgcn_alignbit(own.y, own.x, 16), t2 = __builtin_amdgcn_alignbit(own.z, own.y, 16),
+                               t3 = __builtin_amdgcn_alignbit(own.w, own.z, 16);
+                dwb_u32x4 v = own;                                                                      // kw = 1
+                if (wave == 0) v = dwb_u32x4{__builtin_amdgcn_alignbit(own.x, hh ? side.w : side.x, 16), t1, t2, t3};   // w-1
+                if (wave == 2) v = dwb_u32x4{t1, t2, t3, __builtin_amdgcn_alignbit(hh ? side.y : side.x, own.w, 16)};   // w+1
+                be[p] = __builtin_bit_cast(dwb_bf16x8, v);
+            }
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, be[0], acc[3], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, be[1], acc[3], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, be[0], acc[3], 0, 0, 0);
+        }
     };
-    for (int q = 0; q < ((Q + 1) & ~1); ++q) {
+    for (int q = 0; q < (Q + kDbDepth - 1) / kDbDepth * kDbDepth; ++q) {   // as many barriers as the staging waves run
         __syncthreads();   // the loaders' commits of step q-1 are visible
         const char* xs = xbase + ((q + kd + 3) & 3) * kDbXPlaneB;
+        const char* xs22 = xbase22 + ((q + 1) & 3) * kDbXPlaneB;   // kd = 2: the plane after the current one
         const char* ys = ya + (q & 1) * kDbYBufB;
 #pragma unroll
-        for (int r = 0; r < kDbTH; ++r) row_mfma(xs, ys, r);
+        for (int r = 0; r < kDbTH; ++r) row_mfma(xs, xs22, ys, r);
     }
     // partial[split][o][c][tap]; C/D map: column = lane & 31 (c), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (o)
 #pragma unroll
@@ -274,6 +303,13 @@ __global__ __launch_bounds__(kDbThreads) void conv3d_k3_dw_bf16x3_kernel(const f
         for (int r = 0; r < 16; ++r) {
             const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * hh, c = c0 + r32;
             if (o < Cout && c < Cin) partial[(((size_t)split * Cout + o) * Cin + c) * 27 + t] = acc[kw][r];
+        }
+    }
+    if (extra) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * hh, c = c0 + r32;
+            if (o < Cout && c < Cin) partial[(((size_t)split * Cout + o) * Cin + c) * 27 + 24 + wave] = acc[3][r];
         }
     }
 }

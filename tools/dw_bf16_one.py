@@ -6,5 +6,5 @@ dev = torch.device("cuda:0")
 x = torch.randn(40, 256, 12, 60, 80, device=dev)
 gy = torch.randn(40, 64, 12, 60, 80, device=dev)
 for _ in range(3):
-    ops.conv3d_k3_dw(x, gy, 32, 1, True)
+    ops.conv3d_k3_dw(x, gy, 16, 1, True)
 torch.cuda.synchronize()
