@@ -4,7 +4,10 @@
 Random shapes (ragged tiles in d, h and w, channel counts that are no multiple of 8, single-voxel volumes, 64 / 128 / 192
 output channels), the three layer kinds (stride 1 on the SCL form, on the fp32 tensor and on a row-pitched view of it; stride 2;
 transposed), with and without affine / ReLU / residual -- each against a float64 evaluation of the SAME three products
-(x_hi*w_hi + x_hi*w_mid + x_mid*w_hi): what remains is fp32 accumulation order, bounded by 4e-7 of the summed products."""
+(x_hi*w_hi + x_hi*w_mid + x_mid*w_hi): what remains is fp32 accumulation order, bounded by 4e-7 of the summed products.
+Every fourth case is the stride-1 WEIGHT GRADIENT (csrc/costreg_dw_bf16.hip): W a multiple of 4, any channel counts, any
+number of splits; and every eighth forward case has 256-1024 input channels on a small volume, so that the kernels split
+the input channels over blocks (partial sums + epilogue kernel)."""
 import os
 import sys
 
@@ -30,16 +33,38 @@ def main():
     for seed in range(first, first + cases):
         rng = np.random.default_rng(90000 + seed)
         g = torch.Generator().manual_seed(90000 + seed)
-        kind = ("s1", "s2", "t")[seed % 3]
+        kind = ("s1", "s2", "t", "dw")[seed % 4]
         N = int(rng.integers(1, 4))
         Cin = int(rng.choice([1, 3, 8, 13, 16, 24, 40, 64, 100]))
         Cout = int(rng.choice([64, 64, 128, 192]))
         D, H, W = int(rng.integers(1, 11)), int(rng.integers(1, 30)), int(rng.integers(1, 40))
+        if kind != "dw" and seed % 8 >= 4:   # few tiles, many input channels: the split form
+            N, Cin = 1, int(rng.choice([256, 384, 512, 1024]))
+            D, H, W = int(rng.integers(1, 5)), int(rng.integers(1, 13)), int(rng.integers(1, 17))
+        if kind == "dw":
+            W = 4 * int(rng.integers(1, 12))
+            Cout = int(rng.choice([1, 2, 31, 32, 33, 64, 70]))
         x = torch.randn(N, Cin, D, H, W, generator=g) * float(rng.uniform(0.1, 4.0))
         affine, relu, resid = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         scale = (torch.rand(Cout, generator=g) + 0.5) if affine else None
         shift = (torch.randn(Cout, generator=g) * 0.1) if affine else None
         dv = lambda t: None if t is None else t.to(dev)   # noqa: E731
+        if kind == "dw":
+            gy = torch.randn(N, Cout, D, H, W, generator=g) * float(rng.uniform(0.1, 4.0))
+            shape = (Cout, Cin, 3, 3, 3)
+            cw = lambda a, b: torch.nn.grad.conv3d_weight(a, shape, b, padding=1)   # noqa: E731
+            xh, xm = (t.double() for t in ops.split_bf16(x))
+            yh, ym = (t.double() for t in ops.split_bf16(gy))
+            ref = cw(xh, yh) + cw(xh, ym) + cw(xm, yh)
+            mag = float(cw(x.abs().double(), gy.abs().double()).max())
+            nsplit = int(rng.choice([0, 1, 2, 5, 8, 16, 40]))
+            got = ops.conv3d_k3_dw(x.to(dev), gy.to(dev), nsplit, 1, True)
+            err = float((got.cpu().double() - ref).abs().max())
+            tol = 4e-7 * mag + 1e-30
+            if not (got.shape == ref.shape and err <= tol):
+                bad += 1
+                print(f"seed {seed} dw N={N} Cin={Cin} Cout={Cout} {D}x{H}x{W} nsplit={nsplit}: err {err:.3e} tol {tol:.3e}", flush=True)
+            continue
         if kind == "s1":
             w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
             want = three_terms(F.conv3d, x, w, padding=1)
