@@ -40,11 +40,11 @@ constexpr int kBfPairs = 14;         // tap pairs (27 taps + 1 empty)
 constexpr int kBfSubPairs = 5;       // tap pairs per weight sub-stage (5 + 5 + 4)
 constexpr int kBfWSlots = kBfSubPairs * 2 * 2 * 64;   // 16-byte slots of one weight buffer: [pair][row group][piece][lane]
 
-__host__ __device__ constexpr int bf_in_slots(int TD, int TH) {   // 16-byte slots of one piece of one input buffer
-    return ((TD + 2) * (TH + 2) * (kBfW + 2) + 63) / 64 * 64;
+__host__ __device__ constexpr int bf_in_slots(int TD, int TH, int TW = kBfW) {   // 16-byte slots of one piece of one input buffer
+    return ((TD + 2) * (TH + 2) * (TW + 2) + 63) / 64 * 64;
 }
-__host__ __device__ constexpr size_t bf_lds_bytes(int TD, int TH) {
-    return (size_t)(2 * 2 * bf_in_slots(TD, TH) + 2 * kBfWSlots) * 16;
+__host__ __device__ constexpr size_t bf_lds_bytes(int TD, int TH, int TW = kBfW) {
+    return (size_t)(2 * 2 * bf_in_slots(TD, TH, TW) + 2 * kBfWSlots) * 16;
 }
 
 // fp32 NCDHW -> SCL (both pieces), interior voxels only: the border stays as the caller zeroed it.
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(kThreads) void split_conv_weight_kernel(const float
 }
 
 // tap t of the 3x3x3 kernel as an offset in halo voxels; tap 27 (the empty half of pair 13) aliases tap 26
-template <int HH>
+template <int HH, int HW = kBfW + 2>
 __host__ __device__ constexpr int bf_tap_off(int t) {
     const int u = t > 26 ? 26 : t;
-    return ((u / 9) * HH + (u / 3) % 3) * (kBfW + 2) + u % 3;
+    return ((u / 9) * HH + (u / 3) % 3) * HW + u % 3;
 }
 
 // F32IN: the input is the fp32 (N,C,D,H,W) tensor itself (element strides sN, sC, sD, sH; w stride 1 -- a row-pitched cost
@@ -121,17 +121,23 @@ __host__ __device__ constexpr int bf_tap_off(int t) {
 // group into registers while the current group is multiplied (coalesced along w), cuts them into the two bf16 pieces and
 // writes the same LDS image the DMA route fills -- no packing pass and no second copy of the activation in HBM (the 2.4 GB
 // variance volume: 1.0 ms of packing and a 3 GB buffer).  Out-of-volume halo voxels are zeros by predicate.
-template <int TD, int TH, bool F32IN>
-__global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
+// TW: tile width.  16: an MFMA column group (32 voxels) = 2 h-rows of 16; 8 (fp32-input form only): 4 h-rows of 8 -- the tiles
+// 3 x 16 x 8 and 4 x 8 x 8 fit the half- and quarter-resolution volumes of the cost network (6 x 30 x 40, 3 x 15 x 20) and the
+// neck's 40 x 40 x 16 level, which 4 x 8 x 16 tiles pad 1.7x, 2.3x and 1.2x.
+template <int TD, int TH, bool F32IN, int TW = kBfW>
+__global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
     const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
-    constexpr int NW = TD * TH / 4;                       // waves
+    static_assert(TW == 16 || (TW == 8 && F32IN), "8-wide tiles: fp32-input form only");
+    constexpr int RG = 32 / TW;                           // h-rows of one column group
+    static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
+    constexpr int NW = TD * TH * TW / 64;                 // waves
     constexpr int NT = 64 * NW;                           // threads
-    constexpr int HD = TD + 2, HH = TH + 2, HW = kBfW + 2;
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     constexpr int NVOX = HD * HH * HW;
-    constexpr int INS = bf_in_slots(TD, TH);              // slots per piece
+    constexpr int INS = bf_in_slots(TD, TH, TW);          // slots per piece
     constexpr int IN_DMA = INS / 64;                      // wave-instructions per piece and stage
     constexpr int IN_PER_WAVE = (2 * IN_DMA + NW - 1) / NW;
     extern __shared__ uint4 s_bf[];   // [2 stages][2 pieces][INS] input, then [2 stages][kBfWSlots] weights
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
     const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
     const int n = zo / nob, ob64 = zo % nob;
     const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
-    const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
     const int col = lane & 31, hh = lane >> 5;
 
     // ---- DMA plans.  Input: wave-instruction i of a stage = (piece i / IN_DMA, slots 64*(i % IN_DMA) ..); the lane's slot
@@ -244,14 +250,14 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
         }
     };
 
-    // ---- the wave's two column groups: g = 2*wave + b, plane g / (TH/2), h-rows 2*(g % (TH/2)) + {0,1}; column c of a
-    // group = voxel (row c / 16, w = c % 16)
+    // ---- the wave's two column groups: g = 2*wave + b, plane g / (TH/RG), h-rows RG*(g % (TH/RG)) + {0..RG-1}; column c of a
+    // group = voxel (row c / TW, w = c % TW)
     int vb[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int g = 2 * wave + b;
-        const int dz = g / (TH / 2), hy = 2 * (g % (TH / 2)) + (col >> 4);
-        vb[b] = (dz * HH + hy) * HW + (col & 15);
+        const int dz = g / (TH / RG), hy = RG * (g % (TH / RG)) + col / TW;
+        vb[b] = (dz * HH + hy) * HW + col % TW;
     }
 
     f32x16b acc[2][2];   // [row group (32 output channels)][column group]
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
 #pragma unroll
         for (int pl = 0; pl < np; ++pl) {
             const int p = s * kBfSubPairs + pl;
-            const int toff = hh ? bf_tap_off<HH>(2 * p + 1) : bf_tap_off<HH>(2 * p);
+            const int toff = hh ? bf_tap_off<HH, HW>(2 * p + 1) : bf_tap_off<HH, HW>(2 * p);
             bf16x8 A[2][2], B[2][2];   // [row / column group][piece]
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(64 * TD * TH / 4) void conv3d_k3_bf16x3_kernel(
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int g = 2 * wave + b;
-        const int d = d0 + g / (TH / 2), h = h0 + 2 * (g % (TH / 2)) + (col >> 4), w = w0 + (col & 15);
+        const int d = d0 + g / (TH / RG), h = h0 + RG * (g % (TH / RG)) + col / TW, w = w0 + col % TW;
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -375,26 +381,35 @@ constexpr int kS2HH = kS2TH + 1, kS2HW = kBfW + 1;
 constexpr int kS2Vox = (kS2TD + 1) * kS2HH * kS2HW;          // 765 voxels of one parity-class tile
 constexpr int kS2Ins = (kS2Vox + 63) / 64 * 64;              // 768 slots per piece
 constexpr int kS2WSlots = 4 * 2 * 2 * 64;                    // up to 4 tap pairs per stage
-__host__ __device__ constexpr size_t s2_lds_bytes() { return (size_t)(2 * 2 * kS2Ins + 2 * kS2WSlots) * 16; }
+__host__ __device__ constexpr int s2_ins(int TD, int TH, int TW) { return ((TD + 1) * (TH + 1) * (TW + 1) + 63) / 64 * 64; }
+__host__ __device__ constexpr size_t s2_lds_bytes(int TD = kS2TD, int TH = kS2TH, int TW = kBfW) {
+    return (size_t)(2 * 2 * s2_ins(TD, TH, TW) + 2 * kS2WSlots) * 16;
+}
 __host__ __device__ constexpr int s2_pairs(int pi) { return (1 << ((pi >> 2) + ((pi >> 1) & 1) + (pi & 1))) / 2 == 0 ? 1 : (1 << ((pi >> 2) + ((pi >> 1) & 1) + (pi & 1))) / 2; }
 __host__ __device__ constexpr int s2_first_pair(int pi) { int n = 0; for (int q = 0; q < pi; ++q) n += s2_pairs(q); return n; }
 // tap j of class pi as an offset in the class tile: per odd dimension bit 0 -> k = 0 (coarse index o - 1 = tile index o),
 // bit 1 -> k = 2 (coarse index o = tile index o + 1); even dimensions contribute nothing
+template <int HH = kS2HH, int HW = kS2HW>
 __host__ __device__ constexpr int s2_tap_off(int pi, int j) {
     const int pd = pi >> 2, ph = (pi >> 1) & 1, pw = pi & 1, nt = 1 << (pd + ph + pw);
     int bits = j < nt ? j : nt - 1, jw = 0, jh = 0, jd = 0;
     if (pw) { jw = bits & 1; bits >>= 1; }
     if (ph) { jh = bits & 1; bits >>= 1; }
     if (pd) { jd = bits & 1; }
-    return (jd * kS2HH + jh) * kS2HW + jw;
+    return (jd * HH + jh) * HW + jw;
 }
 
-__global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_kernel(
+// Output tile TD x TH x TW: 4 x 8 x 16, or 3 x 16 x 8 (column group = 4 h-rows of 8) for the outputs 6 x 30 x 40 and 3 x 15 x 20 of
+// the cost network, which the former pads 1.7x and 2.3x.
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
     const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out, int C8, int Cout, int Di, int Hi,
     int Wi, int D, int H, int W, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
-    constexpr int TD = kS2TD, TH = kS2TH, NW = TD * TH / 4, NT = 64 * NW;
-    constexpr int HH = kS2HH, HW = kS2HW, NVOX = kS2Vox, INS = kS2Ins;
+    constexpr int RG = 32 / TW;                // h-rows of one column group
+    static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
+    constexpr int NW = TD * TH * TW / 64, NT = 64 * NW;
+    constexpr int HH = TH + 1, HW = TW + 1, NVOX = (TD + 1) * HH * HW, INS = s2_ins(TD, TH, TW);
     constexpr int NV = (NVOX + NT - 1) / NT;   // 2 voxel slots per thread and stage
     extern __shared__ uint4 s_bf[];            // [2 stages][2 pieces][INS] input, then [2 stages][kS2WSlots] weights
     uint4* s_in = s_bf;
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
     const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
     const int n = zo / nob, ob64 = zo % nob;
     const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
-    const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
     const int col = lane & 31, hh = lane >> 5;
     const float* xfn = xf + (size_t)n * sN;
 
@@ -485,8 +500,8 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int g = 2 * wave + b;
-        const int dz = g / (TH / 2), hy = 2 * (g % (TH / 2)) + (col >> 4);
-        vb[b] = (dz * HH + hy) * HW + (col & 15);
+        const int dz = g / (TH / RG), hy = RG * (g % (TH / RG)) + col / TW;
+        vb[b] = (dz * HH + hy) * HW + col % TW;
     }
     f32x16b acc[2][2];
 #pragma unroll
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
         const bf16x8* ain = s_w8 + (size_t)buf * kS2WSlots + lane;
 #pragma unroll
         for (int pl = 0; pl < np; ++pl) {
-            const int toff = hh ? s2_tap_off(pi, 2 * pl + 1) : s2_tap_off(pi, 2 * pl);
+            const int toff = hh ? s2_tap_off<HH, HW>(pi, 2 * pl + 1) : s2_tap_off<HH, HW>(pi, 2 * pl);
             bf16x8 A[2][2], B[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(64 * kS2TD * kS2TH / 4) void conv3d_k3_s2_bf16x3_ke
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int g = 2 * wave + b;
-        const int d = d0 + g / (TH / 2), h = h0 + 2 * (g % (TH / 2)) + (col >> 4), w = w0 + (col & 15);
+        const int d = d0 + g / (TH / RG), h = h0 + RG * (g % (TH / RG)) + col / TW, w = w0 + col % TW;
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -782,7 +797,7 @@ using namespace mvsdet;
 
 namespace {
 struct BfPlan {
-    int td, th, tiles_d, tiles_h, tiles_w, Dp, Hp, Wp;
+    int td, th, tiles_d, tiles_h, tiles_w, Dp, Hp, Wp, tw = kBfW;
 };
 // tile = 4 x TH x 16 with TH = 8 or 12, whichever pads H less (60 rows: 12); padded extents = tiles + the one-voxel border
 BfPlan bf_plan(int D, int H, int W) {
@@ -797,6 +812,23 @@ BfPlan bf_plan(int D, int H, int W) {
     p.Hp = std::max(pad8, pad12) + 2;   // covers the 4x8x16 tiles of the transposed convolution as well
     p.Wp = p.tiles_w * kBfW + 2;
     return p;
+}
+// The fp32-input form is free of the SCL layout: the tile of {4x12x16, 4x8x16, 3x16x8} that pads (D, H, W) least
+// (first = preferred at equal padding: larger tiles, wider rows)
+BfPlan bf_plan_f32(int D, int H, int W) {
+    static const int cand[][3] = {{4, 12, 16}, {4, 8, 16}, {3, 16, 8}};
+    BfPlan best = bf_plan(D, H, W);
+    long long best_vol = -1;
+    for (const auto& c : cand) {
+        const int td = c[0], th = c[1], tw = c[2];
+        const int nd = (D + td - 1) / td, nh = (H + th - 1) / th, nw = (W + tw - 1) / tw;
+        const long long v = (long long)nd * td * nh * th * nw * tw;
+        if (best_vol < 0 || v < best_vol) {
+            best_vol = v;
+            best.td = td; best.th = th; best.tw = tw; best.tiles_d = nd; best.tiles_h = nh; best.tiles_w = nw;
+        }
+    }
+    return best;   // Dp, Hp, Wp: those of the SCL form, unused by the fp32-input kernels
 }
 }  // namespace
 
@@ -916,12 +948,14 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
     MVS_REQUIRE((((uintptr_t)xs | (uintptr_t)weight_split) & 15u) == 0, "%s: xs and weights must be 16-byte aligned", name);
-    const BfPlan p = bf_plan(D, H, W);
+    const BfPlan p = xf ? bf_plan_f32(D, H, W) : bf_plan(D, H, W);
     const int C8 = (Cin + 7) / 8;
     MVS_REQUIRE((size_t)p.Dp * p.Hp * p.Wp < ((size_t)1 << 31), "%s: one padded channel-group volume exceeds 2^31 voxels", name);
     const size_t vol = (size_t)D * H * W, total = (size_t)N * Cout * vol;
-    // without (enough) workspace the convolution runs unsplit
-    int nsplit = bf_nsplit((long long)p.tiles_w * p.tiles_h * p.tiles_d * N * (Cout / 64), C8);
+    // without (enough) workspace the convolution runs unsplit.  The number of splits follows from the 4 x TH x 16 tiling for
+    // BOTH input forms (the fp32-input form may tile differently), so that the two forms add up the same partial sums
+    const BfPlan ps = bf_plan(D, H, W);
+    int nsplit = bf_nsplit((long long)ps.tiles_w * ps.tiles_h * ps.tiles_d * N * (Cout / 64), C8);
     if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float)) nsplit = 1;
     MVS_REQUIRE((long long)N * (Cout / 64) * nsplit <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     const long long sN = xstr ? xstr[0] : (long long)Cin * vol, sC = xstr ? xstr[1] : (long long)vol;
@@ -933,21 +967,24 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
     dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
     hipStream_t st = (hipStream_t)stream;
-#define MVS_BF_CASE(TD_, TH_, F32_)                                                                                         \
+#define MVS_BF_CASE(TD_, TH_, F32_, ...)                                                                                    \
     {                                                                                                                       \
-        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_>;                                                                  \
-        const size_t lds = bf_lds_bytes(TD_, TH_);                                                                          \
+        constexpr int TW_ = (0, ##__VA_ARGS__) ? (0, ##__VA_ARGS__) : kBfW;                                                 \
+        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_, TW_>;                                                             \
+        const size_t lds = bf_lds_bytes(TD_, TH_, TW_);                                                                     \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
             hipSuccess) {                                                                                                   \
             set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                  \
             return MVSDET_ERR_HIP;                                                                                          \
         }                                                                                                                   \
-        hipLaunchKernelGGL(k, grid, dim3(64 * TD_ * TH_ / 4), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH,   \
+        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH,      \
                            Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W,    \
                            p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total);        \
     }
     if (xf) {
-        if (p.th == 12) MVS_BF_CASE(4, 12, true) else MVS_BF_CASE(4, 8, true)
+        if (p.tw == 8) MVS_BF_CASE(3, 16, true, 8)
+        else if (p.th == 12) MVS_BF_CASE(4, 12, true)
+        else MVS_BF_CASE(4, 8, true)
     } else {
         if (p.th == 12) MVS_BF_CASE(4, 12, false) else MVS_BF_CASE(4, 8, false)
     }
@@ -1022,21 +1059,33 @@ static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void
     const long long sD = x_strides ? x_strides[2] : (long long)Hi * Wi, sH = x_strides ? x_strides[3] : (long long)Wi;
     MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= Wi, "%s: bad strides", name);
     MVS_REQUIRE((long long)(Di - 1) * sD + (long long)(Hi - 1) * sH + Wi < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
-    const int tiles_w = (W + kBfW - 1) / kBfW, tiles_h = (H + kS2TH - 1) / kS2TH, tiles_d = (D + kS2TD - 1) / kS2TD;
+    // output tile 4 x 8 x 16 or 3 x 16 x 8, whichever pads (D, H, W) less; the number of splits follows from the former
+    const long long tiles416 = (long long)((W + kBfW - 1) / kBfW) * ((H + kS2TH - 1) / kS2TH) * ((D + kS2TD - 1) / kS2TD);
+    const long long pad416 = tiles416 * (kS2TD * kS2TH * kBfW);
+    const long long tiles38 = (long long)((W + 7) / 8) * ((H + 15) / 16) * ((D + 2) / 3), pad38 = tiles38 * (3 * 16 * 8);
+    const bool t38 = pad38 < pad416;
+    const int ttd = t38 ? 3 : kS2TD, tth = t38 ? 16 : kS2TH, ttw = t38 ? 8 : kBfW;
+    const int tiles_w = (W + ttw - 1) / ttw, tiles_h = (H + tth - 1) / tth, tiles_d = (D + ttd - 1) / ttd;
     const size_t total = (size_t)N * Cout * D * H * W;
-    int nsplit = bf_nsplit((long long)tiles_w * tiles_h * tiles_d * N * (Cout / 64), (Cin + 7) / 8);
+    int nsplit = bf_nsplit(tiles416 * N * (Cout / 64), (Cin + 7) / 8);
     if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float)) nsplit = 1;   // unsplit without (enough) workspace
     MVS_REQUIRE((long long)N * (Cout / 64) * nsplit <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
-    auto* k = conv3d_k3_s2_bf16x3_kernel;
-    const size_t lds = s2_lds_bytes();
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
-        return MVSDET_ERR_HIP;
-    }
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
-    hipLaunchKernelGGL(k, grid, dim3(64 * kS2TD * kS2TH / 4), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,
-                       static_cast<const uint4*>(weight_split), scale, shift, out, (Cin + 7) / 8, Cout, Di, Hi, Wi, D, H, W, tiles_w,
-                       relu, nsplit, static_cast<float*>(workspace), total);
+#define MVS_S2_CASE(TD_, TH_, TW_)                                                                                           \
+    {                                                                                                                        \
+        auto* k = conv3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_>;                                                                 \
+        const size_t lds = s2_lds_bytes(TD_, TH_, TW_);                                                                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
+            hipSuccess) {                                                                                                    \
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                   \
+            return MVSDET_ERR_HIP;                                                                                           \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,                 \
+                           static_cast<const uint4*>(weight_split), scale, shift, out, (Cin + 7) / 8, Cout, Di, Hi, Wi, D, H, W, \
+                           tiles_w, relu, nsplit, static_cast<float*>(workspace), total);                                    \
+    }
+    if (t38) MVS_S2_CASE(3, 16, 8) else MVS_S2_CASE(kS2TD, kS2TH, kBfW)
+#undef MVS_S2_CASE
     MVS_LAUNCH_CHECK(name);
     if (nsplit > 1) {
         launch_splitk_epilogue(static_cast<const float*>(workspace), nsplit, total, scale, shift, nullptr, out, Cout,
