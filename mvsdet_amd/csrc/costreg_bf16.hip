@@ -378,8 +378,6 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kS2TD = 4, kS2TH = 8;
 constexpr int kS2HH = kS2TH + 1, kS2HW = kBfW + 1;
-constexpr int kS2Vox = (kS2TD + 1) * kS2HH * kS2HW;          // 765 voxels of one parity-class tile
-constexpr int kS2Ins = (kS2Vox + 63) / 64 * 64;              // 768 slots per piece
 constexpr int kS2WSlots = 4 * 2 * 2 * 64;                    // up to 4 tap pairs per stage
 __host__ __device__ constexpr int s2_ins(int TD, int TH, int TW) { return ((TD + 1) * (TH + 1) * (TW + 1) + 63) / 64 * 64; }
 __host__ __device__ constexpr size_t s2_lds_bytes(int TD = kS2TD, int TH = kS2TH, int TW = kBfW) {
@@ -612,9 +610,18 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int ct_pairs(int pd, int ph) { return s2_pairs(pd * 4 + ph * 2) + s2_pairs(pd * 4 + ph * 2 + 1); }
 constexpr int kCtWSlots = 6 * 2 * 2 * 64;   // up to 6 tap pairs per stage
-__host__ __device__ constexpr size_t ct_lds_bytes() { return (size_t)(3 * 2 * kS2Ins + 3 * kCtWSlots) * 16; }
+// slots of one piece of one input stage: the halo tile, rounded up until the 2 * INS / 64 DMAs of a stage divide evenly over the waves
+__host__ __device__ constexpr int ct_ins(int TD, int TH, int TW) {
+    int ins = ((TD + 1) * (TH + 1) * (TW + 1) + 63) / 64 * 64;
+    while ((2 * ins / 64) % (TD * TH * TW / 64)) ins += 64;
+    return ins;
+}
+__host__ __device__ constexpr size_t ct_lds_bytes(int TD = kS2TD, int TH = kS2TH, int TW = kBfW) {
+    return (size_t)(3 * 2 * ct_ins(TD, TH, TW) + 3 * kCtWSlots) * 16;
+}
 // tap j of output class pi as an offset in the halo tile (origin = the tile's first input voxel): per odd dimension bit 0 ->
 // k = 0 reads input i + 1, bit 1 -> k = 2 reads input i
+template <int HH = kS2HH, int HW = kS2HW>
 __host__ __device__ constexpr int ct_tap_off(int pi, int j) {
     const int pd = pi >> 2, ph = (pi >> 1) & 1, pw = pi & 1, nt = 1 << (pd + ph + pw);
     int bits = j < nt ? j : nt - 1, jw = 0, jh = 0, jd = 0;
@@ -622,18 +629,20 @@ __host__ __device__ constexpr int ct_tap_off(int pi, int j) {
     if (ph) { jh = bits & 1; bits >>= 1; }
     if (pd) { jd = bits & 1; }
     const int od = (pd && !jd) ? 1 : 0, oh = (ph && !jh) ? 1 : 0, ow = (pw && !jw) ? 1 : 0;
-    return (od * kS2HH + oh) * kS2HW + ow;
+    return (od * HH + oh) * HW + ow;
 }
 
-template <int PD, int PH>
+template <int PD, int PH, int TD, int TH, int TW>
 __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu, int tile_xy) {
-    constexpr int TD = kS2TD, TH = kS2TH, NW = 8;
-    constexpr int HH = kS2HH, HW = kS2HW, NVOX = kS2Vox, INS = kS2Ins;
+    constexpr int RG = 32 / TW;                           // h-rows of one column group
+    static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
+    constexpr int NW = TD * TH * TW / 64;
+    constexpr int HH = TH + 1, HW = TW + 1, NVOX = (TD + 1) * HH * HW, INS = ct_ins(TD, TH, TW);
     constexpr int IN_DMA = INS / 64;                      // 12 wave-instructions per piece
-    constexpr int IN_PER_WAVE = 2 * IN_DMA / NW;          // 3
+    constexpr int IN_PER_WAVE = 2 * IN_DMA / NW;          // 3 (8 waves) or 4 (6 waves)
     constexpr int PI0 = PD * 4 + PH * 2, NP0 = s2_pairs(PI0), NP1 = s2_pairs(PI0 + 1), NP = NP0 + NP1;
     constexpr int W_PER_WAVE = (NP * 4 + NW - 1) / NW;    // weight DMAs per wave and stage (the tail repeats earlier pieces)
     constexpr int DMA_PER_STAGE = IN_PER_WAVE + W_PER_WAVE;
@@ -647,7 +656,7 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
     const int bw = tile_xy % tiles_w, bh = tile_xy / tiles_w;
     const int nob = Cout / 64;
     const int n = blockIdx.z / nob, ob64 = blockIdx.z % nob;
-    const int w0 = bw * kBfW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
     const int col = lane & 31, hh = lane >> 5;
 
     // input DMA plan: halo voxel (dz, hy, wx) = input (d0 + dz, h0 + hy, w0 + wx) = padded (+1, +1, +1)
@@ -686,8 +695,8 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int g = 2 * wave + b;
-        const int dz = g / (TH / 2), hy = 2 * (g % (TH / 2)) + (col >> 4);
-        vb[b] = (dz * HH + hy) * HW + (col & 15);
+        const int dz = g / (TH / RG), hy = RG * (g % (TH / RG)) + col / TW;
+        vb[b] = (dz * HH + hy) * HW + col % TW;
     }
     f32x16b acc[2][2][2];   // [w parity][row group][column group]
 #pragma unroll
@@ -708,7 +717,7 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
         for (int pl = 0; pl < NP; ++pl) {
             const int pw = pl < NP0 ? 0 : 1;
             const int pi = PI0 + pw, pj = pw ? pl - NP0 : pl;
-            const int toff = hh ? ct_tap_off(pi, 2 * pj + 1) : ct_tap_off(pi, 2 * pj);
+            const int toff = hh ? ct_tap_off<HH, HW>(pi, 2 * pj + 1) : ct_tap_off<HH, HW>(pi, 2 * pj);
             bf16x8 A[2][2], B[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -749,7 +758,7 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int g = 2 * wave + b;
-        const int di = d0 + g / (TH / 2), hi = h0 + 2 * (g % (TH / 2)) + (col >> 4), wi = w0 + (col & 15);
+        const int di = d0 + g / (TH / RG), hi = h0 + RG * (g % (TH / RG)) + col / TW, wi = w0 + col % TW;
         if (di >= Di || hi >= Hi || wi >= Wi) continue;
         const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + 2 * wi;
 #pragma unroll
@@ -780,15 +789,16 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
 
 // ONE launch for the four (PD, PH) classes: class = blockIdx.x & 3, so the four blocks that read the same input tile are
 // dispatched together (the tile's second to fourth reads hit L2) and the grid has one tail instead of four.
-__global__ __launch_bounds__(512) void convT3d_k3_s2_bf16x3_kernel(
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(TD * TH * TW) void convT3d_k3_s2_bf16x3_kernel(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu) {
     const int cls = blockIdx.x & 3, tile_xy = blockIdx.x >> 2;
-    if (cls == 0) convT3d_k3_s2_bf16x3_body<1, 1>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
-    else if (cls == 1) convT3d_k3_s2_bf16x3_body<1, 0>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
-    else if (cls == 2) convT3d_k3_s2_bf16x3_body<0, 1>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
-    else convT3d_k3_s2_bf16x3_body<0, 0>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    if (cls == 0) convT3d_k3_s2_bf16x3_body<1, 1, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else if (cls == 1) convT3d_k3_s2_bf16x3_body<1, 0, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else if (cls == 2) convT3d_k3_s2_bf16x3_body<0, 1, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else convT3d_k3_s2_bf16x3_body<0, 0, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
 }
 
 }  // namespace mvsdet
@@ -1127,22 +1137,34 @@ extern "C" int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_sp
                 "%s: out and residual must be 8-byte aligned", name);
     const BfPlan p = bf_plan(D, H, W);   // the padded extents of the SCL input (its tile height may be 12: the extents only grow)
     const int C8 = (Cin + 7) / 8;
-    const int tiles_w = (W + kBfW - 1) / kBfW, tiles_h = (H + kS2TH - 1) / kS2TH, tiles_d = (D + kS2TD - 1) / kS2TD;
+    // input tile 4 x 8 x 16, or 3 x 16 x 8 where that pads (D, H, W) less and the SCL padding covers it
+    const long long pad416 = (long long)((W + kBfW - 1) / kBfW) * kBfW * ((H + kS2TH - 1) / kS2TH) * kS2TH * ((D + kS2TD - 1) / kS2TD) * kS2TD;
+    const long long pad38 = (long long)((W + 7) / 8) * 8 * ((H + 15) / 16) * 16 * ((D + 2) / 3) * 3;
+    const bool t38 = pad38 < pad416 && (D + 2) / 3 * 3 + 2 <= p.Dp && (H + 15) / 16 * 16 + 2 <= p.Hp && (W + 7) / 8 * 8 + 2 <= p.Wp;
+    const int ttd = t38 ? 3 : kS2TD, tth = t38 ? 16 : kS2TH, ttw = t38 ? 8 : kBfW;
+    const int tiles_w = (W + ttw - 1) / ttw, tiles_h = (H + tth - 1) / tth, tiles_d = (D + ttd - 1) / ttd;
     // the halo tile reaches one voxel past the last tile: padded index tiles*T + 1 must exist
-    MVS_REQUIRE(tiles_d * kS2TD + 2 <= p.Dp && tiles_h * kS2TH + 2 <= p.Hp && tiles_w * kBfW + 2 <= p.Wp,
-                "%s: the SCL padding does not cover the 4x8x16 tiles", name);
+    MVS_REQUIRE(tiles_d * ttd + 2 <= p.Dp && tiles_h * tth + 2 <= p.Hp && tiles_w * ttw + 2 <= p.Wp,
+                "%s: the SCL padding does not cover the tiles", name);
     MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
     dim3 grid((unsigned)(tiles_w * tiles_h * 4), (unsigned)tiles_d, (unsigned)(N * (Cout / 64)));
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = ct_lds_bytes();
-    auto* k = convT3d_k3_s2_bf16x3_kernel;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
-        return MVSDET_ERR_HIP;
+#define MVS_CT_CASE(TD_, TH_, TW_)                                                                                           \
+    {                                                                                                                        \
+        const size_t lds = ct_lds_bytes(TD_, TH_, TW_);                                                                      \
+        auto* k = convT3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_>;                                                                \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
+            hipSuccess) {                                                                                                    \
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                   \
+            return MVSDET_ERR_HIP;                                                                                           \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, st, static_cast<const uint4*>(xs),                           \
+                           static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W, p.Dp, p.Hp, \
+                           p.Wp, piece, tiles_w, relu);                                                                      \
     }
-    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split), scale,
-                       shift, residual, out, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, relu);
+    if (t38) MVS_CT_CASE(3, 16, 8) else MVS_CT_CASE(kS2TD, kS2TH, kBfW)
+#undef MVS_CT_CASE
     MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
 }
