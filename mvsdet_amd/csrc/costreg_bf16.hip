@@ -122,7 +122,7 @@ __host__ __device__ constexpr int bf_tap_off(int t) {
 // writes the same LDS image the DMA route fills -- no packing pass and no second copy of the activation in HBM (the 2.4 GB
 // variance volume: 1.0 ms of packing and a 3 GB buffer).  Out-of-volume halo voxels are zeros by predicate.
 // TW: tile width.  16: an MFMA column group (32 voxels) = 2 h-rows of 16; 8 (fp32-input form only): 4 h-rows of 8 -- the tiles
-// 3 x 16 x 8 and 4 x 8 x 8 fit the half- and quarter-resolution volumes of the cost network (6 x 30 x 40, 3 x 15 x 20) and the
+// 3 x 16 x 8 and 8 x 8 x 8 fit the half- and quarter-resolution volumes of the cost network (6 x 30 x 40, 3 x 15 x 20) and the
 // neck's 40 x 40 x 16 level, which 4 x 8 x 16 tiles pad 1.7x, 2.3x and 1.2x.
 template <int TD, int TH, bool F32IN, int TW = kBfW>
 __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
@@ -823,10 +823,10 @@ BfPlan bf_plan(int D, int H, int W) {
     p.Wp = p.tiles_w * kBfW + 2;
     return p;
 }
-// The fp32-input form is free of the SCL layout: the tile of {4x12x16, 4x8x16, 3x16x8} that pads (D, H, W) least
+// The fp32-input form is free of the SCL layout: the tile of {4x12x16, 4x8x16, 3x16x8, 8x8x8} that pads (D, H, W) least
 // (first = preferred at equal padding: larger tiles, wider rows)
 BfPlan bf_plan_f32(int D, int H, int W) {
-    static const int cand[][3] = {{4, 12, 16}, {4, 8, 16}, {3, 16, 8}};
+    static const int cand[][3] = {{4, 12, 16}, {4, 8, 16}, {3, 16, 8}, {8, 8, 8}};
     BfPlan best = bf_plan(D, H, W);
     long long best_vol = -1;
     for (const auto& c : cand) {
@@ -992,7 +992,8 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
                            p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total);        \
     }
     if (xf) {
-        if (p.tw == 8) MVS_BF_CASE(3, 16, true, 8)
+        if (p.tw == 8 && p.td == 3) MVS_BF_CASE(3, 16, true, 8)
+        else if (p.tw == 8) MVS_BF_CASE(8, 8, true, 8)
         else if (p.th == 12) MVS_BF_CASE(4, 12, true)
         else MVS_BF_CASE(4, 8, true)
     } else {
