@@ -348,7 +348,20 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
         const int d = d0 + g / (TH / RG), h = h0 + RG * (g % (TH / RG)) + col / TW, w = w0 + col % TW;
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            // affine and residual of the 16 outputs are requested together, ahead of the stores: loads and stores share one
+            // in-order counter, so a load issued behind a store waits for the store's round trip as well (one element at a
+            // time this epilogue was a chain of 64 memory round trips per lane)
+            float sc[16], sh[16], rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+                const bool fin = nsplit == 1;
+                sc[r] = (fin && scale) ? scale[o] : 1.0f;
+                sh[r] = (fin && scale) ? shift[o] : 0.0f;
+                rv[r] = (fin && residual) ? residual[idx] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -358,11 +371,12 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
                     partial[(size_t)split * total + idx] = v;
                     continue;
                 }
-                if (scale) v = fmaf(v, scale[o], shift[o]);
-                if (residual) v = v + residual[idx];
+                if (scale) v = fmaf(v, sc[r], sh[r]);
+                if (residual) v = v + rv[r];
                 if (relu) v = fmaxf(v, 0.0f);
                 out[idx] = v;
             }
+        }
     }
 }
 
@@ -581,7 +595,14 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
         const int d = d0 + g / (TH / RG), h = h0 + RG * (g % (TH / RG)) + col / TW, w = w0 + col % TW;
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            float sc[16], sh[16];   // requested ahead of the stores (see conv3d_k3_bf16x3_kernel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                sc[r] = (nsplit == 1 && scale) ? scale[o] : 1.0f;
+                sh[r] = (nsplit == 1 && scale) ? shift[o] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -591,10 +612,11 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
                     partial[(size_t)split * total + idx] = v;
                     continue;
                 }
-                if (scale) v = fmaf(v, scale[o], shift[o]);
+                if (scale) v = fmaf(v, sc[r], sh[r]);
                 if (relu) v = fmaxf(v, 0.0f);
                 out[idx] = v;
             }
+        }
     }
 }
 
@@ -762,28 +784,38 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
         if (di >= Di || hi >= Hi || wi >= Wi) continue;
         const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + 2 * wi;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            // the 16 skip values of this (row group, column group) are requested together, ahead of the stores: loads and
+            // stores share one in-order counter, so a load issued behind a store waits for the store's round trip as well
+            // -- one value at a time, the epilogue took half of the layer's time
+            float2 rv[16];
+            float sc[16], sh[16];   // (the affine too: a load between two stores waits for the first store)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                rv[r] = residual ? *reinterpret_cast<const float2*>(residual + ((size_t)n * Cout + o) * ovol + pos) : make_float2(0.f, 0.f);
+                sc[r] = scale ? scale[o] : 1.0f;
+                sh[r] = scale ? shift[o] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float2 v = make_float2(acc[0][a][b][r], acc[1][a][b][r]);
                 if (scale) {
-                    const float sc = scale[o], sh = shift[o];
-                    v.x = fmaf(v.x, sc, sh);
-                    v.y = fmaf(v.y, sc, sh);
+                    v.x = fmaf(v.x, sc[r], sh[r]);
+                    v.y = fmaf(v.y, sc[r], sh[r]);
                 }
                 if (relu) {
                     v.x = fmaxf(v.x, 0.0f);
                     v.y = fmaxf(v.y, 0.0f);
                 }
-                const size_t idx = ((size_t)n * Cout + o) * ovol + pos;
                 if (residual) {
-                    const float2 rv = *reinterpret_cast<const float2*>(residual + idx);
-                    v.x = rv.x + v.x;
-                    v.y = rv.y + v.y;
+                    v.x = rv[r].x + v.x;
+                    v.y = rv[r].y + v.y;
                 }
-                *reinterpret_cast<float2*>(out + idx) = v;
+                *reinterpret_cast<float2*>(out + ((size_t)n * Cout + o) * ovol + pos) = v;
             }
+        }
     }
 }
 
