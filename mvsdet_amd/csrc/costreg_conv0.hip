@@ -163,7 +163,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
         const int d = d0 + dz0, h = h0 + hy0 + rb * kRowsPerCol + chy;
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int ob = 0; ob < 2; ++ob) {
+            // affine and residual of the 16 outputs are requested together, ahead of the stores: loads and stores share one
+            // in-order counter, so a load issued behind a store waits for the store's round trip as well
+            float sc[16], sh[16], rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+                const bool fin = nsplit == 1;
+                sc[r] = (fin && scale) ? scale[o] : 1.0f;
+                sh[r] = (fin && scale) ? shift[o] : 0.0f;
+                rv[r] = (fin && residual) ? residual[idx] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
@@ -173,11 +185,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_k3_mfma_kernel(
                     partial[(size_t)split * partial_stride + idx] = v;
                     continue;
                 }
-                if (scale) v = fmaf(v, scale[o], shift[o]);
-                if (residual) v = v + residual[idx];   // ResModule: x = act(bn(conv(h)) + identity), imvoxel_neck.py:227-229
+                if (scale) v = fmaf(v, sc[r], sh[r]);
+                if (residual) v = v + rv[r];   // ResModule: x = act(bn(conv(h)) + identity), imvoxel_neck.py:227-229
                 if (relu) v = fmaxf(v, 0.0f);
                 out[idx] = v;
             }
+        }
     }
 }
 
@@ -485,28 +498,35 @@ __global__ __launch_bounds__(kThreads, 2) void convT3d_k3_s2_mfma_kernel(
         if (di >= Di || hi >= Hi || wi >= Wi) continue;
         const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + 2 * wi;   // even: 8-byte aligned
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int ob = 0; ob < 2; ++ob) {
+            float sc[16], sh[16];   // requested ahead of the stores (see conv3d_k3_mfma_kernel)
+            float2 rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                sc[r] = scale ? scale[o] : 1.0f;
+                sh[r] = scale ? shift[o] : 0.0f;
+                rv[r] = residual ? *reinterpret_cast<const float2*>(residual + ((size_t)n * Cout + o) * ovol + pos) : make_float2(0.f, 0.f);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ob64 * kC0Out + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 float2 v = make_float2(acc[0][ob][rb][r], acc[1][ob][rb][r]);
                 if (scale) {
-                    const float sc = scale[o], sh = shift[o];
-                    v.x = fmaf(v.x, sc, sh);
-                    v.y = fmaf(v.y, sc, sh);
+                    v.x = fmaf(v.x, sc[r], sh[r]);
+                    v.y = fmaf(v.y, sc[r], sh[r]);
                 }
                 if (relu) {
                     v.x = fmaxf(v.x, 0.0f);
                     v.y = fmaxf(v.y, 0.0f);
                 }
-                const size_t idx = ((size_t)n * Cout + o) * ovol + pos;
                 if (residual) {
-                    const float2 rv = *reinterpret_cast<const float2*>(residual + idx);
-                    v.x = rv.x + v.x;
-                    v.y = rv.y + v.y;
+                    v.x = rv[r].x + v.x;
+                    v.y = rv[r].y + v.y;
                 }
-                *reinterpret_cast<float2*>(out + idx) = v;
+                *reinterpret_cast<float2*>(out + ((size_t)n * Cout + o) * ovol + pos) = v;
             }
+        }
     }
 }
 
