@@ -449,8 +449,10 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
         vy[k] = 2 * (h0 + (sv % (HH * HW)) / HW);
         vx[k] = 2 * (w0 + sv % HW);
     }
-    // (A second register set with two stages of flight time was tried: beside an LDS-DMA hipcc drains vmcnt(0) before it uses
-    // an ordinary load's result, so the extra stage is never granted; hiding the DMA in inline assembly cost more than it won.)
+    // (A second register set with two stages of flight time was tried twice: beside an LDS-DMA hipcc drains vmcnt(0) before it uses
+    // an ordinary load's result, so the extra stage is never granted; with the DMA hidden in inline assembly, every load
+    // unconditional (padding from a zero word) and a counted wait at the top of the step the compiler's waits are counted, and
+    // the layer is slower: conv1 1.03 against 0.92 ms.)
     float f_reg[1][NV][8];
     auto fetch = [&](auto setc, int c8, int pi) {
         constexpr int set = decltype(setc)::value;
