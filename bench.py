@@ -400,12 +400,12 @@ def full_chain_rate(device, steps=10):
         torch.cuda.synchronize(device)
     neck_ms = e0.elapsed_time(e1) / 3
     ntfl = IndoorImVoxelNeck.flops(1, N_VOXELS, wr["C"], 128) / 1e12
-    # the stride-1 3x3x3 layers (all but ~6 % of the work) run on bf16 MFMA with three terms per product: 3 x useful FLOP
+    # the 3x3x3 layers (all but ~2 % of the work) run on bf16 MFMA with three terms per product: 3 x useful FLOP
     # against the dense bf16 peak
     neck_roof = {"bound": "mfma", "achieved": round(3 * ntfl / neck_ms * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s",
                  "frac": round(3 * ntfl / neck_ms * 1e3 / 2500.0, 4), "useful_TFLOPs": round(ntfl / neck_ms * 1e3, 1),
-                 "kernel": "IndoorImVoxelNeck forward (stride-1 3x3x3 layers on bf16x3, the small levels split over the input "
-                           "channels; stride-2 layers on fp32 MFMA, 1x1x1 / transposed 2x2x2 layers as GEMMs)",
+                 "kernel": "IndoorImVoxelNeck forward (3x3x3 layers on bf16x3, the small levels split over the input channels; "
+                           "1x1x1 / transposed 2x2x2 layers as GEMMs)",
                  "kernel_ms": round(neck_ms, 3)}
     return {"workload": "scannet_ref_40v_12d_60x80", "chain": "a1..a10 + CostRegNet_3DGS + IndoorImVoxelNeck + head convolutions, eval",
             "scenes_per_sec": round(steps / el, 3), "cost_network_roofline": roof, "neck_roofline": neck_roof,

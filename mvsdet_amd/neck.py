@@ -80,10 +80,11 @@ def _hip_ok(x: Tensor, module: nn.Module) -> bool:
 # Stride-1 3x3x3 convolutions on volumes of at least this many voxels go to the bf16 matrix cores with three-term split
 # operands (csrc/costreg_bf16.hip; outputs within ~1e-5 of the fp32 sums' scale).  The 20x20x8 and 10x10x4 levels are a
 # handful of tiles (padded 1.9x): there the kernel splits the 512 / 1024 input channels over blocks and a second kernel
-# adds the partial sums (neck 4.05 -> 3.10 ms).  The two stride-2 layers stay on the fp32-MFMA kernel: measured on the
-# bf16x3 stride-2 kernel with the same split 0.72 against 0.64 ms (its stages of one input parity class are a few hundred
-# cycles of MFMA, shorter than the latency of the fetch they wait for).  0 disables the bf16 route.
+# adds the partial sums (neck 4.05 -> 3.10 ms).  0 disables the bf16 route.
 BF16X3_MIN_VOXELS = 256
+# the two stride-2 layers on the bf16x3 stride-2 kernel (its 3x16x8 tiles fit their outputs: neck 2.77 -> 2.58 ms; on 4x8x16 tiles
+# it lost to the fp32 kernel, 0.72 against 0.64 ms)
+S2_BF16X3 = True
 
 
 def _split_weight(conv: nn.Conv3d) -> Tensor:
@@ -105,6 +106,8 @@ def _conv_k3(x: Tensor, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool, residua
     scale, shift = _bn_affine(bn)
     if conv.stride[0] == 1 and BF16X3_MIN_VOXELS and x[0, 0].numel() >= BF16X3_MIN_VOXELS and conv.out_channels % 64 == 0:
         return ops.conv3d_k3_bf16x3(x, _split_weight(conv), scale, shift, relu, residual)
+    if S2_BF16X3 and conv.stride[0] == 2 and residual is None and conv.out_channels % 64 == 0:
+        return ops.conv3d_k3_s2_bf16x3(x, _split_weight(conv), scale, shift, relu)
     return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(conv.weight), scale, shift, relu, conv.stride[0], residual)
 
 
