@@ -37,6 +37,11 @@ class Scale(nn.Module):
         return x * self.scale
 
 
+# The fused 128 -> 25 (padded to 64) convolution of a level on the bf16 matrix cores with three-term split operands
+# (outputs within ~1e-5 of the fp32 sums' scale; the small levels split over the input channels) instead of the fp32 MFMA.
+HEAD_BF16X3 = True
+
+
 class NerfDetHeadConvs(DerivedTensorsMixin, nn.Module):
     """The learnable layers of NerfDetHead and their forward pass (nerfdet_head.py:94-118)."""
 
@@ -62,18 +67,22 @@ class NerfDetHeadConvs(DerivedTensorsMixin, nn.Module):
         from . import ops
         ws = (self.conv_center.weight, self.conv_reg.weight, self.conv_cls.weight)
         key = tuple((w.data_ptr(), w._version, w.device) for w in ws)
-        if self._fused is None or self._fused[0] != key:
+        if self._fused is None or self._fused[0] != key or self._fused[2] != HEAD_BF16X3:
             w = torch.cat([t.detach() for t in ws], 0)
             pad = (-w.shape[0]) % 64
             if pad:
                 w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
-            self._fused = (key, ops.permute_conv_weight(w))
+            # cut into bf16 pieces in the bf16x3 kernel's layout (csrc/costreg_bf16.hip; HEAD_BF16X3), or permuted for the fp32 MFMA
+            self._fused = (key, ops.split_conv_weight(w) if HEAD_BF16X3 else ops.permute_conv_weight(w), HEAD_BF16X3)
         return self._fused[1]
 
     def _forward_single(self, x: Tensor, scale: Scale) -> Tuple[Tensor, Tensor, Tensor]:
         if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not self.training:
             from . import ops
-            y = ops.conv3d_k3_mfma(x, self._fused_weight(), None, None, False)
+            if HEAD_BF16X3:
+                y = ops.conv3d_k3_bf16x3(x, self._fused_weight(), None, None, False)
+            else:
+                y = ops.conv3d_k3_mfma(x, self._fused_weight(), None, None, False)
             r, c = self.n_reg_outs, self.n_classes
             center = y[:, :1].contiguous()
             cls = y[:, 1 + r:1 + r + c] + self.conv_cls.bias.detach().view(1, -1, 1, 1, 1)
