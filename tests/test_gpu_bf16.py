@@ -43,7 +43,11 @@ def test_scl_pack_pieces_and_border(gpu):
 
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 16, 64, 4, 8, 16), (2, 24, 64, 5, 13, 21), (1, 8, 128, 3, 12, 16),
                                                (1, 37, 64, 9, 25, 33), (2, 64, 64, 12, 60, 80), (1, 256, 64, 4, 12, 16),
-                                               (1, 5, 64, 1, 1, 1)])
+                                               (1, 5, 64, 1, 1, 1),
+                                               # the fp32-input form on its other tiles: 3x16x8 (half / quarter resolution of the
+                                               # cost network), 8x8x8 (the neck's 40x40x16-like and 20x20x8 volumes)
+                                               (1, 24, 64, 6, 30, 40), (1, 16, 64, 3, 15, 20), (1, 16, 64, 16, 40, 40),
+                                               (1, 40, 128, 8, 20, 20)])
 def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
     from mvsdet_amd import ops
     g = torch.Generator().manual_seed(N * 1000 + Cin)
