@@ -18,9 +18,10 @@
 // Implicit GEMM, D[o][v] += A[o][k] * B[k][v]:  the 16 k of an MFMA are (tap parity, 8 channels): lane half h = lane >> 5
 // reads tap 2p + h of tap pair p -- the 27 taps make 14 pairs, the last one half empty (zero weights): 27/28 of the
 // matrix work is useful and a stage is 8 channels deep, which is what lets two stages of input fit the LDS.
-//   block  = (view, 4 x TH x 16 output voxels, 64 output channels), TH waves: 8 (4x8x16) or 12 (4x12x16: 60 rows = 5 tiles,
-//            three waves on every SIMD; a 6-wave tile would leave two SIMDs with one wave and two with two)
-//   wave   = 64 voxels (4 h-rows x 16 = two column groups of 32) x 64 channels (two row groups) = 4 accumulators 32x32
+//   block  = (view, TD x TH x TW output voxels, 64 output channels), TD*TH*TW/64 waves: 4x8x16 (8 waves), 4x12x16 (12: 60 rows =
+//            5 tiles, three waves on every SIMD); the fp32-input form also 3x16x8 (6) and 8x8x8 (8), the stride-2 and transposed
+//            kernels 3x16x8 -- whichever pads the volume least (6x30x40 and 3x15x20 are padded 1.7x and 2.3x by 4x8x16)
+//   wave   = 64 voxels (two column groups of 32 = 2 h-rows x 16 or 4 h-rows x 8) x 64 channels (two row groups) = 4 accumulators 32x32
 //   LDS    = input halo tile of 8 channels, both pieces, double buffered  +  the weights of 5 tap pairs x 64 x 8,
 //            both pieces, double buffered (three weight sub-stages per 8 channels); all of it filled by LDS-DMA
 //   per tap pair and wave: 4 A + 4 B ds_read_b128 feed 12 MFMAs (2 x 2 accumulators x 3 terms)
