@@ -254,21 +254,50 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
     }
     // Runs: consecutive live planes of one neighbour whose union box holds at most box_cap texels all get that union
     // box (greedy; out-of-view planes in between do not break a run -- the resident box stays valid across them -- a
-    // footprint larger than the cap does).  Thread j walks its neighbour's boxes in LDS, then publishes per plane its
+    // footprint larger than the cap does).  Wave j walks its neighbour's boxes, then publishes per plane its
     // nibble of the flags word: kFlagLive (taps run), kFlagStaged (from the LDS box), kFlagRefill (the box differs from
     // the one the previous staged plane of this neighbour left resident).  (Cutting the runs of all neighbours together,
     // so that their refills share one stall, was tried: fewer stalls, more box traffic, no net gain.)
     __syncthreads();  // the zeroed flags words, the last plane's boxes
-    if (tid < K) {
-        int4* bj = s_pb + (size_t)tid * D;
+    // Wave j walks neighbour j.  The walk is sequential (greedy), so the boxes of 64 planes at a time sit in the lanes'
+    // registers and the walk reads them with v_readlane (a few cycles) instead of one LDS round trip per plane; closing a
+    // run rewrites its planes' boxes 64 at a time.  (With one thread per neighbour reading LDS plane by plane this pass was
+    // 60 % of the kernel at 128 planes.)
+    if (wave < K) {
+        int4* bj = s_pb + (size_t)wave * D;
+        const unsigned sh = 4 * wave;
+        auto lane_box = [&](const int4& v, int i) {
+            return make_int4(__builtin_amdgcn_readlane(v.x, i), __builtin_amdgcn_readlane(v.y, i),
+                             __builtin_amdgcn_readlane(v.z, i), __builtin_amdgcn_readlane(v.w, i));
+        };
+        // planes first .. last-1 take the union box u; their flags: staged, and the first one refills the slot unless the
+        // previous run left the very same box resident (all planes of a run carry one box, so only its first can differ)
+        auto close_run = [&](int first, int last, const int4& u, bool differs) {
+            for (int e0 = first; e0 < last; e0 += 64) {
+                const int e = e0 + lane;
+                if (e < last) {
+                    const int4 o = bj[e];
+                    if (box_nonempty(o) && box_area(o) <= box_cap) {
+                        bj[e] = u;
+                        atomicOr(s_fl + e, (kFlagStaged | ((e == first && differs) ? kFlagRefill : 0u)) << sh);
+                    }
+                }
+            }
+        };
         int run_first = -1;
-        int4 u = make_int4(0, 0, 0, 0);
-        for (int d = 0; d <= D && box_cap > 0; ++d) {
-            bool close = (d == D);
-            int4 b = make_int4(0, -1, 0, -1);
-            if (d < D) {
-                b = bj[d];
-                if (!box_nonempty(b)) continue;
+        int4 u = make_int4(0, 0, 0, 0), res = make_int4(0, -1, 0, -1);   // res: what the sweep holds resident in this slot
+        for (int base = 0; base < D; base += 64) {
+            const int4 mine = base + lane < D ? bj[base + lane] : make_int4(0, -1, 0, -1);
+            const bool live = box_nonempty(mine);
+            // live: the taps run; an empty footprint with a non-finite position too (from global memory, giving NaN)
+            if (base + lane < D && (live || mine.w != kBoxSkip)) atomicOr(s_fl + base + lane, kFlagLive << sh);
+            unsigned long long todo = box_cap > 0 ? __ballot(live) : 0ull;   // the walk only visits non-empty footprints
+            while (todo) {
+                const int i = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int d = base + i;
+                const int4 b = lane_box(mine, i);
+                bool close = false;
                 if (box_area(b) > box_cap) {
                     close = true;
                 } else if (run_first >= 0) {
@@ -276,32 +305,15 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
                     if (box_area(c) <= box_cap) { u = c; continue; }
                     close = true;
                 }
-            }
-            if (close && run_first >= 0) {
-                for (int e = run_first; e < d; ++e) {
-                    const int4 o = bj[e];
-                    if (box_nonempty(o) && box_area(o) <= box_cap) bj[e] = u;
+                if (close && run_first >= 0) {
+                    close_run(run_first, d, u, u.x != res.x || u.y != res.y || u.z != res.z || u.w != res.w);
+                    res = u;
+                    run_first = -1;
                 }
-                run_first = -1;
+                if (box_area(b) <= box_cap) { run_first = d; u = b; }
             }
-            if (d < D && box_area(b) <= box_cap) { run_first = d; u = b; }
         }
-        int4 res = make_int4(0, -1, 0, -1);  // what the sweep holds resident in this neighbour's slot
-        for (int d = 0; d < D; ++d) {
-            const int4 b = bj[d];
-            unsigned f = 0;
-            if (box_nonempty(b)) {
-                f = kFlagLive;
-                if (box_area(b) <= box_cap) {
-                    f |= kFlagStaged;
-                    if (b.x != res.x || b.y != res.y || b.z != res.z || b.w != res.w) f |= kFlagRefill;
-                    res = b;
-                }
-            } else if (b.w != kBoxSkip) {
-                f = kFlagLive;  // empty footprint with a non-finite position: the taps run (from global memory) and give NaN
-            }
-            if (f) atomicOr(s_fl + d, f << (4 * tid));
-        }
+        if (run_first >= 0) close_run(run_first, D, u, u.x != res.x || u.y != res.y || u.z != res.z || u.w != res.w);
     }
     __syncthreads();
     for (int i = tid; i < D * K; i += kThreads) boxes[(size_t)bt * D * K + i] = s_pb[(size_t)(i % K) * D + i / K];
