@@ -17,6 +17,8 @@ on the GPU it, not the plane sweep, is what a scene costs.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -191,8 +193,13 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         self.hip_backward = True
         # eval route of the stride-1 layers: "bf16x3" = bf16 matrix cores on split operands (logits within 2e-6 .. 4e-6 of
         # fp32: tools/study/split_bf16_emulation.py), "fp32" = the fp32 MFMA kernels (bit-level fp32 FMA sums)
-        self.matrix_precision = "bf16x3"
-        self._scl = {}   # shape -> SclTensor of the transposed layers' (coarse) inputs; their zero border is written once
+        # MVSDET_COSTREG_PRECISION=fp32 makes the fp32 route the default of new modules
+        self.matrix_precision = os.environ.get("MVSDET_COSTREG_PRECISION", "bf16x3")
+        if self.matrix_precision not in ("bf16x3", "fp32"):
+            raise ValueError(f"MVSDET_COSTREG_PRECISION must be 'bf16x3' or 'fp32', got {self.matrix_precision!r}")
+        # (shape, device, stream) -> SclTensor of the transposed layers' (coarse) inputs; their zero border is written once.
+        # Keyed by the stream as well: the buffer is refilled in place, outside the allocator's per-stream reuse tracking
+        self._scl = {}
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
@@ -240,8 +247,12 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             scale, shift = _bn_affine(bn)
             if self.matrix_precision == "bf16x3":
                 # 8 output parity classes = 8 small stride-1 convolutions over the coarse input (csrc/costreg_bf16.hip)
-                key = (tuple(x.shape), x.device)   # the coarse input in split channel-last form: refilled in place
-                xs = self._scl[key] = ops.scl_pack(x, out=self._scl.get(key))
+                # the coarse input in split channel-last form: refilled in place
+                key = (tuple(x.shape), x.device, torch.cuda.current_stream(x.device).cuda_stream)
+                out = self._scl.pop(key, None)
+                while len(self._scl) >= 8:   # varying view counts: least recently used first
+                    self._scl.pop(next(iter(self._scl)))
+                xs = self._scl[key] = ops.scl_pack(x, out=out)
                 return ops.convT3d_k3_s2_bf16x3(xs, ops.split_conv_weight(deconv.weight, 2), scale, shift, skip, True)
             wperm = ops.permute_convT_weight(deconv.weight)
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)

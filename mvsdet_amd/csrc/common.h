@@ -26,12 +26,16 @@ Options& options();
 
 // where plane_sweep_coords_kernel leaves the sweep geometry inside the scratch buffer (planesweep.hip)
 struct SweepGeometry {
+    int4* header;   // {kGeoMagic, tile width, W, (D << 8) | K} written by plane_sweep_coords_kernel: the layout below hangs on the
+                    // tile shape, so a consumer whose own choice differs (a pitched table fed to the contiguous call, another
+                    // "sweep_tw") must not touch it -- the slab kernel checks the header and fills its output with NaN instead
     int4* boxes;
     unsigned* flags;
     float* proj;
     float* depth;
     unsigned short* groups;   // [N*tiles][kSweepGroups + 1] plane-group boundaries of every tile (sweep_kernel.h)
 };
+constexpr int kGeoMagic = 0x4d565347;   // "MVSG"
 constexpr int kSweepGroups = 6;   // at most this many plane groups (blocks) per (tile, slab)
 SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles);
 

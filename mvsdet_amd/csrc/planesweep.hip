@@ -162,12 +162,14 @@ size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 namespace mvsdet {
 // Sweep geometry in the scratch buffer (built by plane_sweep_coords_kernel, consumed by the slab kernels):
-//   boxes [N*tiles*D*K] int4 | flags [N*tiles*D] u32 | proj copy [N*K*16] f32 | depth copy [N*D] f32 |
+//   header int4 | boxes [N*tiles*D*K] int4 | flags [N*tiles*D] u32 | proj copy [N*K*16] f32 | depth copy [N*D] f32 |
 //   plane groups [N*tiles][kSweepGroups+1] u16
 // `tiles` is that of the tile width in force; the size query assumes the larger of the two tile shapes.
 SweepGeometry sweep_geometry(void* scratch, int N, int K, int D, int tiles) {
     SweepGeometry g;
     char* p = static_cast<char*>(scratch);
+    g.header = reinterpret_cast<int4*>(p);   // first, so that its place does not depend on the tile shape
+    p += sizeof(int4);
     g.boxes = reinterpret_cast<int4*>(p);
     p += (size_t)N * tiles * D * K * sizeof(int4);
     g.flags = reinterpret_cast<unsigned*>(p);
@@ -188,7 +190,7 @@ int launch_slab(dim3 grid, hipStream_t stream, size_t lds, const float* packed, 
                 int Wo, int tiles_x, int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
     auto* k = plane_sweep_variance_kernel<KV, TW, FAST, OutT>;
     if (int rc = allow_dynamic_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, ref_packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags,
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, ref_packed, nbr, geo.header, geo.proj, geo.depth, geo.boxes, geo.flags,
                        groups, var, n_src, C, S, D, H, W, Wo, tiles_x, tiles, d_per_block, box_cap, n_bt, xcd_parts);
     return MVSDET_OK;
 }
@@ -259,7 +261,7 @@ int launch_sweep(const float* packed, const int64_t* nbr, const float* proj, con
         if (phases & 1)                                                                                               \
             hipLaunchKernelGGL((plane_sweep_coords_kernel<KV, TW>), cgrid, dim3(kThreads),                            \
                                (size_t)D * (KV * sizeof(int4) + sizeof(unsigned) + sizeof(float)), stream, proj, depth,               \
-                               geo.boxes, geo.flags, geo.proj, geo.depth, geo.groups, gmax, D, H, W, tiles_x, tiles, box_cap); \
+                               geo.header, geo.boxes, geo.flags, geo.proj, geo.depth, geo.groups, gmax, D, H, W, tiles_x, tiles, box_cap); \
         if (phases & 2) rc = fast ? MVS_SLAB(KV, true) : MVS_SLAB(KV, false);                                         \
         break;
     switch (K) {
@@ -301,7 +303,7 @@ extern "C" size_t mvsdet_plane_sweep_scratch_bytes(int N, int K, int D, int H, i
     // footprint boxes (16 B per view, tile, plane, neighbour) + flags (4 B per view, tile, plane) + copies of the camera
     // data; sized for the larger of the two tile shapes so the "sweep_tw" option cannot outgrow it
     const size_t tiles = (size_t)std::max(num_tiles(H, W, 16), num_tiles(H, W, 32));
-    return (size_t)N * tiles * D * K * sizeof(int4) + align16((size_t)N * tiles * D * sizeof(unsigned)) +
+    return sizeof(int4) + (size_t)N * tiles * D * K * sizeof(int4) + align16((size_t)N * tiles * D * sizeof(unsigned)) +
            align16((size_t)N * K * 16 * sizeof(float)) + align16((size_t)N * D * sizeof(float)) +
            align16((size_t)N * tiles * (kSweepGroups + 1) * sizeof(unsigned short));
 }

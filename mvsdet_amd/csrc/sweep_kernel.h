@@ -139,7 +139,7 @@ __device__ __forceinline__ int box_area(const int4& b) { return (b.y - b.x + 1) 
 template <int K, int TW>
 __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const float* __restrict__ proj,
                                                                        const float* __restrict__ depth,
-                                                                       int4* __restrict__ boxes,
+                                                                       int4* __restrict__ header, int4* __restrict__ boxes,
                                                                        unsigned* __restrict__ flags, float* __restrict__ proj_copy,
                                                                        float* __restrict__ depth_copy, unsigned short* __restrict__ groups,
                                                                        int gmax, int D, int H, int W, int tiles_x, int tiles, int box_cap) {
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
         s_dv[d] = depth[(size_t)n * D + d];   // one global round trip for all planes instead of one per plane
     }
     __syncthreads();
+    if (bt == 0 && tid == 0) *header = make_int4(kGeoMagic, TW, W, (D << 8) | K);   // what this layout was built for
     if (tile == 0) {  // the slab kernel reads the camera data from the scratch buffer (the tabled entry point has no other)
         for (int i = tid; i < K * 16; i += kThreads) proj_copy[(size_t)n * K * 16 + i] = proj[(size_t)n * K * 16 + i];
         for (int d = tid; d < D; d += kThreads) depth_copy[(size_t)n * D + d] = depth[(size_t)n * D + d];
@@ -367,7 +368,7 @@ __host__ __device__ constexpr size_t sweep_lds_bytes(int K, int box_cap) { retur
 template <int K, int TW, bool FAST, typename OutT = float>
 __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
-    const float* __restrict__ proj, const float* __restrict__ depth, const int4* __restrict__ boxes,
+    const int4* __restrict__ header, const float* __restrict__ proj, const float* __restrict__ depth, const int4* __restrict__ boxes,
     const unsigned* __restrict__ flags, const unsigned short* __restrict__ groups, OutT* __restrict__ var, int N, int C, int S,
     int D, int H, int W, int Wo, int tiles_x, int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
     constexpr int KK = K > 0 ? K : 1;
@@ -376,6 +377,20 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     constexpr int TH = kTilePix / TW;
     extern __shared__ float4 s_box[];  // K slots of (box_cap + kBoxPad) texels (8 float4 each)
 
+    if constexpr (K > 0) {
+        // The geometry's layout hangs on the tile shape it was built for: one that was built for another (a pitched table handed
+        // to the contiguous call or the other way round, another "sweep_tw") holds boxes of other tiles -- or nothing at all --
+        // where this kernel would look.  Nothing of it is touched: the whole output becomes NaN instead (block-uniform exit
+        // before any barrier).
+        const int4 hd = *header;
+        if (hd.x != kGeoMagic || hd.y != TW || hd.z != W || hd.w != ((D << 8) | K)) {
+            const size_t total = (size_t)(n_bt / tiles) * C * D * H * Wo;
+            const size_t step = (size_t)gridDim.x * gridDim.y * kThreads;
+            for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; i < total; i += step)
+                var[i] = (OutT)__builtin_nanf("");
+            return;
+        }
+    }
     const int HW = H * W;
     const int HWo = H * Wo;   // Wo = row pitch of the OUTPUT in elements (W for a contiguous volume; a multiple of 32 puts every
                               // row on a 128-byte boundary: 32x4 tiles then write whole lines even when W is no multiple of 32)

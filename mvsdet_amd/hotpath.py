@@ -302,9 +302,17 @@ class MVSDetHotPath:
         table.record_stream(cur)   # allocated under the side stream, consumed on the current one
         return (table, done, t0, t1) if events else (table, done)
 
+    def _consumer_reads_strided(self) -> bool:
+        """A pitched volume is a non-contiguous view: a consumer that calls `.view` on it raises, one that calls `.reshape` /
+        `.contiguous` silently copies gigabytes.  Only None (the caller gets `variance` back and the stand-in logits are used)
+        and this package's cost network, which reads pitched rows in place, are known to be safe."""
+        from .costreg import CostRegNet3DGS
+        return self.cost_regularization is None or isinstance(self.cost_regularization, CostRegNet3DGS)
+
     def variance_row_pitch(self, W: int) -> int:
         """Row pitch (elements) of the variance volume `forward_scene` produces for maps of width W (W itself: contiguous)."""
-        if self.pitched_variance == "auto" and W % 32 != 0 and W % 16 == 0 and self.num_depth >= 48:
+        if (self.pitched_variance == "auto" and W % 32 != 0 and W % 16 == 0 and self.num_depth >= 48
+                and self._consumer_reads_strided()):
             return ops.sweep_row_pitch(W)
         return int(W)
 
@@ -379,7 +387,10 @@ class MVSDetHotPath:
     def forward_scene(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor] = None,
                       geo: Optional[SceneGeometry] = None) -> dict:
         """One scene through a1..a10.  `cost_logits` (N,2,D,Hf,Wf) stands in for the cost regularisation
-        network's output when `self.cost_regularization` is None (benchmarks / parity tests)."""
+        network's output when `self.cost_regularization` is None (benchmarks / parity tests).
+        With `pitched_variance = "auto"` (default) `out["variance"]` may be a NON-CONTIGUOUS (N,C,D,H,W) view of a buffer whose
+        rows are `variance_row_pitch(W)` elements apart (same values; only for widths 16 mod 32 with 48+ planes, and only when
+        the consumer is None or `CostRegNet3DGS`): `.view()` on it raises; set `pitched_variance = False` for a contiguous one."""
         if geo is None:
             geo = self.prepare_scene(img_meta, feature.device)
         if feature.is_cuda and not (feature.requires_grad and torch.is_grad_enabled()) and geo.neighbor_ids.shape[1] > 0:

@@ -176,6 +176,9 @@ def _try_fused(sq_scaled: LazyVolume, sum_scaled_sq: LazyVolume):
         depth = warps[0].payload["depth"]
         if any(w.payload["depth"] is not depth or w.payload["src"].shape != feat.shape for w in warps):
             return None
+        # `==` broadcasts (or raises) where torch.equal answered False: shapes first
+        if base_sq.shape != base.shape or base[:, :, -1].shape != feat.shape:
+            return None
         checks = [(base[:, :, -1] == feat).all(), (base_sq[:, :, 0] == feat * feat).all()]
         checks += [(w.payload["src"] == feat[ids[:, j]]).all() for j, w in enumerate(warps)]
         if not bool(torch.stack(checks).all()):

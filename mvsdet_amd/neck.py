@@ -49,11 +49,17 @@ def drop_derived_tensors(root: nn.Module) -> None:
                 m.__dict__[name] = None
 
 
+def _drop_after_load(module: nn.Module, incompatible_keys) -> None:
+    # module-level (not a lambda or a closure): the hook is stored on the module and must pickle with it
+    # (torch.save(model), mp.spawn)
+    drop_derived_tensors(module)
+
+
 class DerivedTensorsMixin:
     """nn.Module mixin of the modules that own derived-tensor caches: mode switches and state-dict loads drop them."""
 
     def _init_derived_hooks(self):
-        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: drop_derived_tensors(module))
+        self.register_load_state_dict_post_hook(_drop_after_load)
 
     def train(self, mode: bool = True):
         drop_derived_tensors(self)

@@ -114,3 +114,79 @@ def load_reference():
     _load("refpkg.mvs_models.homography", os.path.join(_NERFDET, "mvs_models", "homography.py"))
     mvsdet = _load("refpkg.mvsdet", os.path.join(_NERFDET, "mvsdet.py"))
     return mvsdet, module
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Row f-3: the 3-D neck and the detection heads' convolutions.  Their files import mmcv / mmdet /
+# mmengine at the top, none of which is installed here, so the CLASS TEXT is taken from the reference file where it lies
+# and executed with the three helpers it uses spelled out (what each does in the configuration the shipped configs ask
+# for); nothing of the reference is stored.
+# ---------------------------------------------------------------------------------------------------------------
+def load_reference_neck():
+    """`IndoorImVoxelNeck` (and `ResModule`) of mmdet3d/models/necks/imvoxel_neck.py:68-231 as executable classes."""
+    import textwrap
+    from torch import nn
+    path = os.path.join(REF_ROOT, "mmdet3d", "models", "necks", "imvoxel_neck.py")
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    src = open(path).read().splitlines()
+    first = next(i for i, l in enumerate(src) if l.startswith("class IndoorImVoxelNeck("))
+    block = textwrap.dedent("\n".join(src[first:]))
+
+    class ConvModule(nn.Module):   # mmcv.cnn.ConvModule for conv_cfg Conv3d, norm_cfg BN3d, act_cfg ReLU | None
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None, norm_cfg=None, act_cfg=None):
+            super().__init__()
+            assert conv_cfg == dict(type='Conv3d') and norm_cfg == dict(type='BN3d')
+            self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False)
+            self.bn = nn.BatchNorm3d(out_channels)
+            self.with_activation = act_cfg is not None
+            if self.with_activation:
+                self.activate = nn.ReLU(inplace=act_cfg.get('inplace', True))
+
+        def forward(self, x):
+            x = self.bn(self.conv(x))
+            return self.activate(x) if self.with_activation else x
+
+    ns = dict(nn=nn, ConvModule=ConvModule, BaseModule=nn.Module)
+    exec(compile(block, path, "exec"), ns)
+    return ns["IndoorImVoxelNeck"]
+
+
+def load_reference_head(cls_name: str):
+    """`_init_layers` / `_forward_single` / `forward` of NerfDetHead (nerfdet_head.py:90-118) or ImVoxelHead_ARKit (:663-700)
+    as methods of a bare nn.Module: RefHead(n_channels, n_reg_outs, n_classes, n_levels)."""
+    import textwrap
+    import torch
+    from torch import nn, Tensor
+    path = os.path.join(_NERFDET, "nerfdet_head.py")
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    src = open(path).read().splitlines()
+    cls_line = next(i for i, l in enumerate(src) if l.startswith(f"class {cls_name}("))
+    first = next(i for i in range(cls_line, len(src)) if src[i].startswith("    def _init_layers"))
+    last = next(i for i in range(first, len(src)) if src[i].startswith("    def loss("))
+    block = textwrap.dedent("\n".join(src[first:last]))
+
+    class Scale(nn.Module):                      # mmcv.cnn.Scale: a learnable scalar factor
+        def __init__(self, scale=1.0):
+            super().__init__()
+            self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+        def forward(self, x):
+            return x * self.scale
+
+    def multi_apply(func, *args):                # mmdet.models.utils.multi_apply without its kwargs
+        return tuple(map(list, zip(*map(func, *args))))
+
+    ns = dict(nn=nn, torch=torch, Tensor=Tensor, Scale=Scale, multi_apply=multi_apply, normal_init=lambda *a, **k: None,
+              bias_init_with_prob=lambda p: 0.0)
+    exec(compile(block, path, "exec"), ns)
+
+    class RefHead(nn.Module):
+        _init_layers, _forward_single, forward = ns["_init_layers"], ns["_forward_single"], ns["forward"]
+
+        def __init__(self, n_channels, n_reg_outs, n_classes, n_levels):
+            super().__init__()
+            self._init_layers(n_channels, n_reg_outs, n_classes, n_levels)
+
+    return RefHead

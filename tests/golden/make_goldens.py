@@ -408,9 +408,94 @@ def g9_depth_scale():
     save("g9_depth_scale", img_shape=np.array(meta["img_shape"]), ori_shape=np.array(meta["ori_shape"]), inline_restated=1, **out)
 
 
+def g10_neck():
+    """mmdet3d/models/necks/imvoxel_neck.py:70-231 IndoorImVoxelNeck in the shipped configuration (in_channels 256,
+    out_channels 128, n_blocks [1,1,1]: mvsdet_res50_2x_low_res_depth.py:33-37), eval mode, LCG weights and an LCG input on the
+    shipped (1,256,40,40,16) grid.  The class text is executed where it lies (_ref_loader.load_reference_neck); only strided
+    samples of the reference's three output levels are stored (and of the first residual block, to localise a failure)."""
+    from _ref_loader import load_reference_neck
+    from lcg import lcg_fill_state, lcg_uniform
+    torch.manual_seed(0)
+    net = load_reference_neck()(256, 128, [1, 1, 1]).eval()
+    with torch.no_grad():
+        lcg_fill_state(net, 10)
+        x = torch.from_numpy(lcg_uniform(256 * 40 * 40 * 16, 100)).reshape(1, 256, 40, 40, 16)
+        # the voxel volume of a scene is sparse (~10 % of the voxels non-empty, SURVEY appendix A): empty columns as the mean
+        # volume has them, from a second LCG stream
+        keep = torch.from_numpy(lcg_uniform(40 * 40 * 16, 101)).reshape(1, 1, 40, 40, 16) > 0.6
+        x = x * keep
+        block0 = net.down_layer_0(x)
+        outs = net(x)
+    assert [tuple(o.shape) for o in outs] == [(1, 128, 40, 40, 16), (1, 128, 20, 20, 8), (1, 128, 10, 10, 4)]
+    save("g10_neck", weight_seed=10, input_seed=100, mask_seed=101, mask_threshold=np.float32(0.6), in_shape=np.array(x.shape),
+         level0=outs[0][:, ::2, ::2, ::2, ::2], level1=outs[1][:, ::2], level2=outs[2], block0=block0[:, ::4, ::2, ::2, ::2],
+         level_scales=np.array([float(o.abs().max()) for o in outs]), keys=np.array(sorted(net.state_dict())))
+    print("g10 levels", [float(o.abs().max()) for o in outs], "non-zero share of the input", float(keep.float().mean()))
+
+
+def g11_heads():
+    """nerfdet_head.py:90-118 NerfDetHead (6 distances, 18 classes) and :663-700 ImVoxelHead_ARKit (7 regression outputs, 17
+    classes) -- `_init_layers`, `_forward_single`, `forward` executed from the file where it lies -- on LCG weights, scales
+    0.5 / 0.75 / 1.0 and LCG inputs of the neck's three level shapes.  Stored: the (centerness, bbox, class) maps of every level
+    (level 0 sub-sampled by 2 per axis)."""
+    from _ref_loader import load_reference_head
+    from lcg import lcg_fill_state, lcg_uniform
+    out = {}
+    for tag, cls_name, (ch, n_reg, n_cls, n_lvl) in (("scannet", "NerfDetHead", (128, 6, 18, 3)),
+                                                     ("arkit", "ImVoxelHead_ARKit", (128, 7, 17, 3))):
+        torch.manual_seed(0)
+        head = load_reference_head(cls_name)(ch, n_reg, n_cls, n_lvl).eval()
+        with torch.no_grad():
+            lcg_fill_state(head, 11)
+            for i, s in enumerate(head.scales):
+                s.scale.fill_(0.5 + 0.25 * i)
+            xs = [torch.from_numpy(lcg_uniform(ch * (40 >> i) * (40 >> i) * (16 >> i), 110 + i)).reshape(1, ch, 40 >> i, 40 >> i, 16 >> i)
+                  for i in range(n_lvl)]
+            centers, regs, clss = head(xs)
+        for i in range(n_lvl):
+            sl = (slice(None), slice(None), slice(None, None, 2), slice(None, None, 2), slice(None, None, 2)) if i == 0 else ()
+            out.update({f"{tag}_center{i}": centers[i][sl], f"{tag}_reg{i}": regs[i][sl], f"{tag}_cls{i}": clss[i][sl]})
+        print("g11", tag, [tuple(t.shape) for t in regs], float(max(t.abs().max() for t in regs)))
+    save("g11_heads", weight_seed=11, input_seed=110, **out)
+
+
+def g12_cost_regularisation_grads():
+    """mvs_models/mvsnet.py:73-113 CostRegNet_3DGS in TRAIN mode (BatchNorm on batch statistics) under autograd: LCG weights,
+    LCG input (2,256,4,8,16), loss = sum(logits * R) with LCG R.  Stored: the logits, the gradient of the input (sample) and of
+    EVERY parameter -- small tensors whole, large ones as every `stride`-th element of the flattened tensor plus their float64
+    sum of squares -- and the BatchNorm running statistics after the step."""
+    from lcg import lcg_fill_state, lcg_uniform
+    mvsnet = sys.modules["refpkg.mvs_models.mvsnet"]
+    torch.manual_seed(0)
+    net = mvsnet.CostRegNet_3DGS().train()
+    shape = (2, 256, 4, 8, 16)
+    with torch.no_grad():
+        lcg_fill_state(net, 12)
+    x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), 120)).reshape(shape).abs().requires_grad_(True)
+    y = net(x)
+    R = torch.from_numpy(lcg_uniform(y.numel(), 121)).reshape(y.shape)
+    (y * R).sum().backward()
+    out = dict(logits=y, grad_input=x.grad.reshape(-1)[::97].clone())
+    keys = []
+    for k, p in sorted(net.named_parameters()):
+        g = p.grad.reshape(-1)
+        stride = max(1, g.numel() // 8192)
+        keys.append(k)
+        out["g:" + k] = g[::stride].clone()
+        out["n:" + k] = np.float64((g.double() ** 2).sum())
+        out["s:" + k] = np.int64(stride)
+    for k, b in net.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["b:" + k] = b.clone()
+    save("g12_cost_regularisation_grads", weight_seed=12, input_seed=120, r_seed=121, in_shape=np.array(shape),
+         param_keys=np.array(keys), **out)
+    print("g12 logits", tuple(y.shape), float(y.abs().max()), "max |grad|", max(float(p.grad.abs().max()) for p in net.parameters()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = dict(g1=g1_homo_warping, g2=g2_variance, g3=g3_knn, g4=g4_depth_prob, g5=g5_backproject,
-               g6=g6_backward, g7=g7_end_to_end, g8=g8_cost_regularisation, g9=g9_depth_scale)
+               g6=g6_backward, g7=g7_end_to_end, g8=g8_cost_regularisation, g9=g9_depth_scale, g10=g10_neck, g11=g11_heads,
+               g12=g12_cost_regularisation_grads)
     for w in which:
         fns[w]()

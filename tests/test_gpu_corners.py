@@ -383,3 +383,32 @@ def test_ray_depth_vs_reference(gpu, tag):
     assert scale.shape == g[f"{tag}_scale"].shape and ray.shape == g[f"{tag}_est_ray_depth"].shape
     np.testing.assert_allclose(scale.cpu().numpy(), g[f"{tag}_scale"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(ray.cpu().numpy(), g[f"{tag}_est_ray_depth"], rtol=1e-6, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------- geometry header
+def test_geometry_of_another_tile_shape_is_refused(gpu, oracle):
+    """A sweep geometry is laid out for ONE tile shape.  At W = 16 (mod 32) with fewer than 48 planes the contiguous call
+    sweeps 16x8 tiles and the pitched one 32x4: feeding either's table to the other must not read it (boxes of other tiles,
+    or unwritten memory) -- the kernel checks the header the geometry kernel left and answers with NaN everywhere."""
+    from mvsdet_amd import ops
+    N, K, C, D, H, W = 3, 2, 32, 4, 16, 48
+    feat, nbr, proj_rel, depth = _scene(oracle, N, K, C, D, H, W, seed=5)
+    packed = ops.pack_features(feat.to(gpu))
+    nb, pr, dp = torch.as_tensor(nbr).to(gpu), proj_rel.to(gpu), depth.to(gpu)
+    pitch = ops.sweep_row_pitch(W)
+    assert pitch != W
+    t_plain = ops.plane_sweep_table(pr, dp, H, W)
+    t_pitch = ops.plane_sweep_table_pitched(pr, dp, H, W, pitch)
+    good = ops.plane_sweep_variance_tabled(packed, nb, t_plain, C, D, H, W)
+    good_p = ops.plane_sweep_variance_tabled_pitched(packed, nb, t_pitch, C, D, H, W, pitch)
+    ref = oracle.plane_sweep_variance(feat, nbr, proj_rel, depth, mode=1)
+    assert np.array_equal(good.cpu().numpy(), ref) and np.array_equal(good_p.cpu().numpy(), ref)
+    bad = ops.plane_sweep_variance_tabled(packed, nb, t_pitch, C, D, H, W)
+    bad_p = ops.plane_sweep_variance_tabled_pitched(packed, nb, t_plain, C, D, H, W, pitch)
+    torch.cuda.synchronize()
+    assert torch.isnan(bad).all() and torch.isnan(bad_p).all()
+    # a table of another plane count
+    t_d = ops.plane_sweep_table(pr, dp[:, :2].contiguous(), H, W)
+    t_big = torch.zeros_like(t_plain)
+    t_big[:t_d.numel()] = t_d
+    assert torch.isnan(ops.plane_sweep_variance_tabled(packed, nb, t_big, C, D, H, W)).all()
