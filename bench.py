@@ -153,6 +153,7 @@ def run_gpu(args, w, rank, world, device):
     checksum = float(out[1].abs().sum().item()) + float(out[0][0, 0, 0].abs().sum().item())
     del out
     # (table ms, slab-kernel ms) per launch; the chunked workload's shard entry point enqueues both behind one pair
+    hp.sweep_ms_each = [m.elapsed_time(e) for _, _, m, e in ev] if ev and len(ev[0]) == 4 else [a.elapsed_time(b) for a, b in ev]
     if ev and len(ev[0]) == 4:
         sweep_ms = (float(np.mean([a.elapsed_time(b) for a, b, _, _ in ev])), float(np.mean([m.elapsed_time(e) for _, _, m, e in ev])))
     elif ev:
@@ -256,6 +257,69 @@ def run_train(args, w, rank, world, device):
     if world > 1:
         elapsed = parallel.max_over_ranks(elapsed, device)
     return elapsed, checksum
+
+
+def backward_rooflines(w, device, reps=5):
+    """HIP-event timings of the two kernels a training step of configs[2] spends most of its time in, at workload `w`:
+    the backward of the plane sweep (mvsdet.py:439-467 under autograd) against HBM, and the weight gradient of the cost
+    network's first layer (mvsnet.py:76) on the bf16 matrix cores against the dense bf16 peak.  Events are recorded on the
+    current stream, which is the stream both operators launch on."""
+    from mvsdet_amd import ops
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3)
+    s = SceneInputs(w, seed=5, device=device)
+    geo = hp.prepare_scene(s.meta, device)
+    N, C, D, H, W = w["N"], w["C"], w["D"], w["H"], w["W"]
+    gvar = torch.randn((N, C, D, H, W), device=device)
+
+    def timed(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            ts.append(e0.elapsed_time(e1))
+        return float(np.mean(ts)), float(np.min(ts))
+
+    bwd_ms, bwd_min = timed(lambda: ops.plane_sweep_variance_backward(s.features, geo.neighbor_ids, geo.proj_rel, geo.depth_values, gvar))
+    # dL/dvar is read once, the features once, dL/dfeat written once (float atomics on a packed copy, then unpacked)
+    bwd_bytes = N * C * D * H * W * 4 + 2 * N * C * H * W * 4
+    out = {"backward_sweep": {"bound": "hbm", "achieved": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                              "unit": "GB/s", "frac": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "kernel": "plane_sweep_variance_bwd_kernel<K,TW,HALF> (+ geometry kernel, memset and unpack of the "
+                                        "packed gradient: the whole operator between two HIP events)",
+                              "kernel_ms": round(bwd_ms, 4), "min_ms": round(bwd_min, 4), "algorithmic_bytes_per_launch": bwd_bytes,
+                              "bytes_formula": "N*C*D*H*W*4 (dL/dvar read once) + 2*N*C*H*W*4 (features read, gradient written)"}}
+    x = gvar                                             # the variance-shaped input of conv0 (values do not matter to the timing)
+    gy = torch.randn((N, 64, D, H, W), device=device)
+    dw_ms, dw_min = timed(lambda: ops.conv3d_k3_dw(x, gy, 0, 1, True))
+    fl = 2.0 * 27 * C * 64 * N * D * H * W
+    out["weight_gradient_conv0"] = {"bound": "mfma", "achieved": round(3 * fl / (dw_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
+                                    "unit": "TFLOP/s", "frac": round(3 * fl / (dw_ms * 1e-3) / 1e12 / 2500.0, 4),
+                                    "kernel": "conv3d_k3_dw_bf16x3_kernel (conv0 256 -> 64; 3 bf16 MFMAs per fp32-equivalent product)",
+                                    "kernel_ms": round(dw_ms, 4), "min_ms": round(dw_min, 4), "useful_TFLOPs": round(fl / (dw_ms * 1e-3) / 1e12, 1)}
+    del gvar, gy, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def training_block(device):
+    """BASELINE.json configs[2] at N=1 in the driver's default line: a training step of the hot path at the shape the shipped
+    config trains on (tools/train.py:76-153; mvsdet_res50_2x_low_res.py:129: one scene per GPU), with the stand-in and with
+    the real cost network, new cameras every step, plus the rooflines of its two dominant kernels."""
+    wr = WORKLOADS["scannet_ref_40v_12d_60x80"]
+    out = {"workload": "scannet_ref_40v_12d_60x80",
+           "step": "fwd a1..a10 + loss + bwd through the ops' autograd + SGD step, new cameras every step (prefetch only)"}
+    for key, real, steps in (("stand_in_cost_network", False, 10), ("real_cost_network", True, 5)):
+        a = argparse.Namespace(steps=steps, warmup=2, scene_pool=2, with_cost_network=real)
+        el, _ = run_train(a, wr, 0, 1, device)
+        out[key] = {"ms_per_step": round(el / steps * 1e3, 3), "scenes_per_sec": round(steps / el, 3), "steps": steps}
+        torch.cuda.empty_cache()
+    out["roofline"] = backward_rooflines(wr, device)
+    return out
 
 
 class ShapeOnlyStages:
@@ -463,6 +527,35 @@ def hbm_copy_ceiling(device, gib=2.0, reps=5):
     return 2 * n * 4 / (min(ts) * 1e-3) / 1e9
 
 
+def store_pattern_ceiling(w, device, reps=5):
+    """What the sweep's OUTPUT LAYOUT allows on this box: the kernel's store stream alone (same block -> address map, same
+    tile width and planes per block, non-temporal 16-byte stores, no taps, no arithmetic: mvsdet_store_pattern_probe_f32)
+    timed on a volume of the workload's size.  A device-to-device copy (5 TB/s) is no ceiling of a write-only stream; this is."""
+    from mvsdet_amd import _lib, ops
+    if w["C"] % 32 or w["W"] % 4 or w.get("half"):
+        return None
+    tw, th, _ = _lib.sweep_tile_shape(2, w["D"], w["H"], w["W"])
+    n = min(w["N"], w.get("chunk") or w["N"])
+    dpb = 0
+    if w["D"] <= 16 and tw == 16:
+        dpb = (w["D"] + (w["D"] + 3) // 4 - 1) // ((w["D"] + 3) // 4)   # the sweep's "about four planes per block" (planesweep.hip)
+    var = torch.empty((n, w["C"], w["D"], w["H"], w["W"]), dtype=torch.float32, device=device)
+    ops.store_pattern_probe(var, w["W"], tw, dpb)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.store_pattern_probe(var, w["W"], tw, dpb)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ts.append(e0.elapsed_time(e1))
+    nbytes = var.numel() * 4
+    del var
+    torch.cuda.empty_cache()
+    return {"GBps": round(nbytes / (float(np.median(ts)) * 1e-3) / 1e9, 1), "ms": round(float(np.median(ts)), 4), "tile": [tw, th],
+            "planes_per_block": dpb or w["D"], "bytes": nbytes}
+
+
 def cpu_baseline(w, budget_s):
     """Stage 1 (the dominant stage, ~94 % of the reference's CPU time: BASELINE.md section 2) on the host cores,
     bounded sample: a 3-view scene (k=2) at the workload's full C, D, H, W."""
@@ -521,6 +614,9 @@ def spawn_ranks(n, argv):
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env["MVSDET_BENCH_SPAWNED"] = "1"
+    print("bench.py: starting %d ranks: %s | %s" % (n, " ".join(cmd[1:8]), " ".join(
+        f"{k}={env[k]}" for k in _ENV_KEYS if k in env)), file=sys.stderr, flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
     lines = []
     for ln in proc.stdout.splitlines():
@@ -533,6 +629,28 @@ def spawn_ranks(n, argv):
         return 1
     print(lines[0], flush=True)
     return 0
+
+
+_ENV_KEYS = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "RCCL_MSCCL_ENABLE", "NCCL_SOCKET_IFNAME", "HIP_VISIBLE_DEVICES",
+             "ROCR_VISIBLE_DEVICES", "MASTER_ADDR", "MASTER_PORT", "MVSDET_DIST_BACKEND", "MVSDET_BENCH_SPAWNED")
+
+
+def launch_env():
+    """The RCCL / HSA environment this rank runs under, for the record: a wrong guess (the IPC mode, a rank that never
+    joined) must be visible in the JSON line itself the day the multi-GPU runs happen."""
+    env = {k: os.environ[k] for k in _ENV_KEYS if k in os.environ}
+    env["backend"] = (torch.distributed.get_backend() if torch.distributed.is_available() and torch.distributed.is_initialized()
+                      else None)
+    return env
+
+
+def count_ranks(world, device=None):
+    """How many ranks really take part: every rank adds 1 through the process group (1 without one)."""
+    if world <= 1:
+        return 1
+    from mvsdet_amd import parallel
+    on_device = torch.distributed.get_backend() == "nccl"   # RCCL reduces device tensors only
+    return int(round(parallel.sum_over_ranks(1.0, device if on_device else None)))
 
 
 def launch_check(args, rank, world):
@@ -657,6 +775,7 @@ def main():
             name = "scannet_ref_40v_12d_60x80"
         w = WORKLOADS[name]
         elapsed, checksum, vmax = run_view_sharded(args, w, rank, world, device)
+        ranks_seen = count_ranks(world, device)
         if rank == 0:
             print(json.dumps({
                 "metric": "scenes/sec of ONE scene sharded over the ranks by reference views (a1..a10"
@@ -667,7 +786,8 @@ def main():
                 "config": {"workload": name, "views": w["N"], "channels": w["C"], "depth_planes": w["D"],
                            "feat_hw": [w["H"], w["W"]], "voxels": w.get("voxels", N_VOXELS),
                            "parallelism": f"view-sharded x{world}: 1 all-gather (feature shards) + 1 all-reduce (voxel buffer) per scene"},
-                "roofline": None, "checksum": checksum, "views_in_fullest_voxel": vmax}), flush=True)
+                "roofline": None, "ranks_seen": ranks_seen, "launch_env": launch_env(), "checksum": checksum,
+                "views_in_fullest_voxel": vmax}), flush=True)
         if world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -677,6 +797,7 @@ def main():
             name = "scannet_ref_40v_12d_60x80"   # what mvsdet_res50_2x_low_res.py trains on
         w = WORKLOADS[name]
         elapsed, checksum = run_train(args, w, rank, world, device)
+        ranks_seen = count_ranks(world, device)
         if rank == 0:
             print(json.dumps({
                 "metric": "training scenes/sec through the hot path (fwd a1..a10 + bwd + optimiser step, "
@@ -687,7 +808,8 @@ def main():
                 "config": {"workload": name, "views": w["N"], "channels": w["C"], "depth_planes": w["D"],
                            "feat_hw": [w["H"], w["W"]], "scenes_per_step_per_gpu": 1,
                            "parallelism": f"ddp x{world}, gradient all-reduce only"},
-                "roofline": None, "checksum": checksum}), flush=True)
+                "roofline": backward_rooflines(w, device)["backward_sweep"], "ranks_seen": ranks_seen,
+                "launch_env": launch_env(), "checksum": checksum}), flush=True)
         if world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -695,6 +817,7 @@ def main():
     w = WORKLOADS[name]
 
     elapsed, (table_ms, sweep_ms), checksum, hp, scenes = run_gpu(args, w, rank, world, device)
+    ranks_seen = count_ranks(world, device)
     n_cv = w["N"] * args.steps * world
     value = n_cv / elapsed
     # one launch = the reference views of one scene, or of one view chunk for the chunked workload (there the
@@ -719,9 +842,11 @@ def main():
                      "traffic_source": committed_traffic(name)[1],
                      "kernel": SWEEP_KERNEL_NAME,
                      "kernel_ms": round(sweep_ms, 4), "table_kernel_ms": round(table_ms, 4),
+                     # per launch of the timed region (first = the launch after the warm-up's last): the spread between launches
+                     "kernel_ms_min_median_max": [round(float(f(hp.sweep_ms_each)), 4) for f in (np.min, np.median, np.max)],
                      "stage1_frac_incl_table": round(stage1 / HBM_PEAK_GBPS, 4),
                      "algorithmic_bytes_per_launch": bytes_launch},
-        "checksum": checksum,
+        "ranks_seen": ranks_seen, "launch_env": launch_env(), "checksum": checksum,
     }
     if w.get("chunk"):
         line["config"]["views_per_launch"] = w["chunk"]
@@ -732,8 +857,14 @@ def main():
     del scenes, hp
     torch.cuda.empty_cache()
     if extras:
-        line["hbm_copy_ceiling_GBps"] = round(hbm_copy_ceiling(device), 1)
-        line["roofline"]["frac_of_copy_ceiling"] = round(achieved / line["hbm_copy_ceiling_GBps"], 4)
+        line["hbm_copy_ceiling_GBps"] = round(hbm_copy_ceiling(device), 1)   # a read+write stream: reported, not a yardstick
+        sp = store_pattern_ceiling(w, device)
+        if sp is not None:
+            # the sweep writes 0.955 of its algorithmic bytes (D / (D + K + 1) at D = 64): its write stream against what the
+            # same store pattern reaches alone on this box
+            line["roofline"]["store_pattern_ceiling"] = sp
+            wbytes = w["C"] * w["D"] * w["H"] * w["W"] * 4 * (w.get("chunk") or w["N"])
+            line["roofline"]["frac_of_store_pattern_ceiling"] = round(wbytes / (sweep_ms * 1e-3) / 1e9 / sp["GBps"], 4)
         if name != "scannet_ref_40v_12d_60x80":
             # the shape the shipped config really runs, reported beside the headline
             wr = WORKLOADS["scannet_ref_40v_12d_60x80"]
@@ -748,6 +879,11 @@ def main():
                                             "frac": round(br / (sm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                             "geometry_cache": hp_r.geometry_stats,
                                             "stage_ms": stage_breakdown(wr, hp_r, sc_r[0], device)}
+            spr = store_pattern_ceiling(wr, device)
+            if spr is not None:
+                line["reference_true_shape"]["store_pattern_ceiling"] = spr
+                line["reference_true_shape"]["frac_of_store_pattern_ceiling"] = round(
+                    wr["N"] * wr["C"] * wr["D"] * wr["H"] * wr["W"] * 4 / (sm * 1e-3) / 1e9 / spr["GBps"], 4)
             del sc_r, hp_r
             torch.cuda.empty_cache()
         if name == "scannet_40v_64d_120x160":
@@ -758,6 +894,8 @@ def main():
                                         "stress_100v_128d_240x320_c256_f16")}
     if rank == 0 and world == 1 and (args.with_cost_network or extras):
         line["with_cost_network"] = full_chain_rate(device)
+    if extras:
+        line["training"] = training_block(device)   # BASELINE.json configs[2] at N = 1
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and not w.get("half"):
         line["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)

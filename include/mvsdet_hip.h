@@ -406,6 +406,13 @@ int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_split, const 
  * ------------------------------------------------------------------------------------------- */
 int mvsdet_copy_f32(const float* src, float* dst, size_t n_floats, mvsdet_stream_t stream);
 
+/* The plane sweep's store stream alone: the block -> address map of the fused variance kernel (mvsdet.py:467's volume,
+ * (N,C,D,H,out_w_pitch) fp32; C % 32 == 0, W % 4 == 0), tile width 16 or 32, `planes_per_block` planes per block (0 = all),
+ * non-temporal 16-byte stores and nothing else.  bench.py times it to report what the output LAYOUT allows on the box at hand
+ * (`frac_of_store_pattern_ceiling`); `var` is overwritten with arbitrary values. */
+int mvsdet_store_pattern_probe_f32(float* var, int N, int C, int D, int H, int W, int out_w_pitch, int tile_w,
+                                   int planes_per_block, mvsdet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

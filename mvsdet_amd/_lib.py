@@ -74,6 +74,7 @@ SIGNATURES = {
     "mvsdet_backproject_weigh_mean_bwd_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp,
                                               _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_copy_f32": [_vp, _vp, _sz, _vp],
+    "mvsdet_store_pattern_probe_f32": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_scl_bytes": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mvsdet_split_conv_weight_bytes": [_i, _i],
     "mvsdet_split_conv_weight": [_vp, _vp, _i, _i, _vp],

@@ -1,6 +1,7 @@
 // Library-level entry points: version, error string, HBM-ceiling copy kernel.
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -57,11 +58,63 @@ __global__ void copy_tail_kernel(const float* __restrict__ src, float* __restric
     if (i < n) dst[i] = src[i];
 }
 
+// The plane sweep's WRITE pattern alone (no taps, no LDS, no arithmetic): block = (view, TW x 128/TW pixel tile, 32-channel
+// slab) loops over the planes; per plane each wave issues four non-temporal stores of 8 channel rows x 16 B per lane -- the
+// block -> address map of plane_sweep_variance_kernel's FAST form on an (N,C,D,H,Wo) volume.  What this pattern reaches is the
+// ceiling of the sweep's store stream on the box at hand (a device-to-device copy is not: DESIGN.md 4.1).
+template <int TW>
+__global__ __launch_bounds__(kThreads) void store_pattern_kernel(float* __restrict__ var, int C, int D, int H, int W, int Wo,
+                                                                  int tiles_x, int tiles, int d_per_block) {
+    constexpr int TH = 128 / TW;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int S = C / 32;
+    const size_t HWo = (size_t)H * Wo;
+    const int id = blockIdx.x;
+    const int slab = id % S, bt = id / S;
+    const int tile = bt % tiles, n = bt / tiles;
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane & 7, ps = lane >> 3;
+    const int p0 = 32 * wave + 4 * ps;
+    const int px0 = tx0 + p0 % TW, py = ty0 + p0 / TW;
+    if (py >= H || px0 + 4 > W) return;
+    const size_t st_off = (size_t)py * Wo + px0;
+    const v4f vv = {1.0f * id, 2.0f, 3.0f, (float)lane};
+    const int d0 = blockIdx.y * d_per_block, d1 = min(D, d0 + d_per_block);
+    for (int d = d0; d < d1; ++d) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = slab * 32 + 8 * i + g;
+            float* dst = var + (((size_t)n * C + c) * D + d) * HWo + st_off;
+            __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(dst));
+        }
+    }
+}
+
 }  // namespace mvsdet
 
 using namespace mvsdet;
 
-extern "C" int mvsdet_version(void) { return 3002; }
+extern "C" int mvsdet_version(void) { return 4001; }
+
+extern "C" int mvsdet_store_pattern_probe_f32(float* var, int N, int C, int D, int H, int W, int out_w_pitch, int tile_w,
+                                              int planes_per_block, mvsdet_stream_t stream) {
+    MVS_REQUIRE(var, "store_pattern_probe: NULL pointer");
+    MVS_REQUIRE(N > 0 && C > 0 && C % 32 == 0 && D > 0 && H > 0 && W > 0 && W % 4 == 0, "store_pattern_probe: C %% 32 == 0 and W %% 4 == 0 wanted (the sweep's FAST form)");
+    const int Wo = out_w_pitch > 0 ? out_w_pitch : W;
+    MVS_REQUIRE(Wo >= W && Wo % 4 == 0 && ((uintptr_t)var % 16 == 0), "store_pattern_probe: pitch / alignment");
+    MVS_REQUIRE(tile_w == 16 || tile_w == 32, "store_pattern_probe: tile width 16 or 32");
+    const int th = 128 / tile_w;
+    const int tiles_x = (W + tile_w - 1) / tile_w, tiles = tiles_x * ((H + th - 1) / th);
+    const long long blocks = (long long)N * tiles * (C / 32);
+    MVS_REQUIRE(blocks <= INT32_MAX, "store_pattern_probe: grid too large");
+    const int dpb = planes_per_block > 0 ? std::min(planes_per_block, D) : D;
+    dim3 grid((unsigned)blocks, (unsigned)((D + dpb - 1) / dpb));
+    if (tile_w == 16) hipLaunchKernelGGL(store_pattern_kernel<16>, grid, dim3(kThreads), 0, (hipStream_t)stream, var, C, D, H, W, Wo, tiles_x, tiles, dpb);
+    else hipLaunchKernelGGL(store_pattern_kernel<32>, grid, dim3(kThreads), 0, (hipStream_t)stream, var, C, D, H, W, Wo, tiles_x, tiles, dpb);
+    MVS_LAUNCH_CHECK("store_pattern_probe");
+    return MVSDET_OK;
+}
 
 extern "C" int mvsdet_set_option(const char* name, int value) {
     int* slot = option_slot(name);

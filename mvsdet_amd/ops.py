@@ -908,6 +908,16 @@ def device_copy(src: Tensor, dst: Tensor):
 
 
 # ------------------------------------------------------------------------------------------- cost network head (f-1)
+def store_pattern_probe(var: Tensor, W: int, tile_w: int, planes_per_block: int = 0) -> None:
+    """Overwrites `var` -- an (N,C,D,H,pitch) fp32 buffer -- with the sweep's store stream alone (bench.py: the ceiling of the
+    output layout on the box at hand)."""
+    _req(var, "var", dim=5)
+    N, C, D, H, pitch = var.shape
+    with torch.cuda.device(var.device):
+        _lib.check(_lib.load().mvsdet_store_pattern_probe_f32(_lib.ptr(var), N, C, D, H, int(W), int(pitch), int(tile_w),
+                                                              int(planes_per_block), _stream(var)), "store_pattern_probe")
+
+
 @torch.library.custom_op(f"{_NS}::conv3d_k3_cout2", mutates_args=(), device_types="cuda")
 def conv3d_k3_cout2(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     """Conv3d(Cin -> 2, kernel 3, stride 1, padding 1) of mvs_models/mvsnet.py:102 on (N,Cin,D,H,W) -> (N,2,D,H,W).

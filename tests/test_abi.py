@@ -49,7 +49,7 @@ def test_binding_table_matches_header():
 
 
 def test_host_only_entry_points(lib):
-    assert lib.mvsdet_version() == 3002
+    assert lib.mvsdet_version() == 4001
     # packed layout: ceil(C/32) slabs of 32 floats (128 B) per pixel
     assert lib.mvsdet_packed_bytes(40, 256, 60, 80) == 40 * 60 * 80 * 256 * 4
     assert lib.mvsdet_packed_bytes(3, 5, 4, 4) == 3 * 16 * 32 * 4
@@ -76,7 +76,7 @@ def test_argument_checks_do_not_launch(lib):
     # scratch: one 16-B box per (view, tile, plane, neighbour) + one flags word per (view, tile, plane) + proj / depth copies
     # + 7 plane-group boundaries (u16) per (view, tile)
     assert lib.mvsdet_plane_sweep_scratch_bytes(40, 2, 64, 120, 160) == \
-        40 * 150 * 64 * (2 * 16 + 4) + 40 * 2 * 64 + 40 * 64 * 4 + 40 * 150 * 7 * 2
+        16 + 40 * 150 * 64 * (2 * 16 + 4) + 40 * 2 * 64 + 40 * 64 * 4 + 40 * 150 * 7 * 2   # 16: the geometry header
     assert lib.mvsdet_plane_sweep_scratch_bytes(40, 0, 64, 120, 160) == 0
     assert lib.mvsdet_plane_sweep_workspace_bytes(40, 2, 256, 64, 120, 160) == \
         lib.mvsdet_packed_bytes(40, 256, 120, 160) + lib.mvsdet_plane_sweep_scratch_bytes(40, 2, 64, 120, 160)
