@@ -344,10 +344,13 @@ int mvsdet_backproject_weigh_mean_bwd_f32(const float* feat, const int64_t* feat
  * differ from an fp32 convolution by ~2^-16 of the products' size (logits of the network: 2e-6 .. 4e-6, bar 1e-4).
  *
  * "SCL" (split channel-last) activations: xs[piece 2][n][c8 = ceil(C/8)][Dp][Hp][Wp][8] bf16, piece = hi | mid,
- * (dp,hp,wp) = (d,h,w) + 1 inside a zero border; Dp/Hp/Wp and the size in bytes come from mvsdet_scl_bytes.
+ * (dp,hp,wp) = (d,h,w) + 1 inside a zero border; Dp/Hp/Wp (the border plus the largest tile overhang of any kernel that
+ * reads the form) and the size in bytes come from mvsdet_scl_bytes.
  * mvsdet_scl_pack_f32 cuts an (N,C,D,H,W) fp32 tensor (possibly row-pitched: mvsdet_plane_sweep_variance_tabled_pitched_f32; zero_border != 0: clear the buffer first; a buffer reused for the
  * same shape needs that once).  weight_split: [Cout/64][c8][14 tap pairs][2 groups of 32 outputs][2 pieces][64 lanes][8]
- * bf16, lane = 32 * (tap parity) + output % 32, tap 27 and channels >= Cin zero (mvsdet_amd.ops.split_conv_weight).
+ * bf16, lane = 32 * (tap parity) + MFMA row m, row m carrying output channel 8*((m>>4)*2 + ((m>>2)&1)) + (m&3) + 4*((m>>3)&1)
+ * of its group (so that a lane's accumulator registers 8q..8q+7 are eight consecutive channels = one SCL unit), tap 27 and
+ * channels >= Cin zero (mvsdet_amd.ops.split_conv_weight).
  * out (N,Cout,D,H,W) fp32 = [relu]([scale *] conv [+ shift] [+ residual]).  Stride 1, Cout % 64 == 0.
  * ------------------------------------------------------------------------------------------- */
 size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp /*HOST, may be NULL*/, int* Hp, int* Wp);
@@ -398,6 +401,34 @@ int mvsdet_conv3d_k3_s2_bf16x3_f32in_ws(const float* x, const int64_t* x_strides
 int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
                                 const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
                                 mvsdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layer-to-layer forms (round 4): a convolution can leave its result ALREADY CUT into bf16 pieces for the next one -- no fp32
+ * round trip through a packing pass, the consumer feeds its LDS by DMA, and the producer issues one 16-byte store per piece
+ * and 8 channels instead of eight 4-byte ones.  Chain of mvs_models/mvsnet.py:104-112:
+ *   conv0 -(out_f32: skip of conv11, out_pscl)-> conv1 -(out_scl)-> conv2 -(out_f32: skip of conv9, out_pscl)-> conv3
+ *   -(out_scl)-> conv4 -(out_scl)-> conv9 -(out_scl)-> conv11 -(out_f32)-> prob.
+ * "PSCL" (parity-split SCL) of an (N,C,D,H,W) tensor: [piece 2][class 8][n][c8][cDp][cHp][cWp][8] bf16, class = 4*(d&1) +
+ * 2*(h&1) + (w&1), voxel (d,h,w) at index (d/2+1, h/2+1, w/2+1) of its class, zero elsewhere: the eight stride-1 grids a
+ * stride-2 convolution reads (mvsdet_pscl_bytes).  Output buffers' borders must be zero before the call (cleared once per
+ * buffer: the kernels write interior voxels only); any of out_f32 / out_scl / out_pscl may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+size_t mvsdet_pscl_bytes(int N, int C, int D, int H, int W, int* cDp /*HOST, may be NULL*/, int* cHp, int* cWp);
+/* stride 1: input = xs (SCL) or x (fp32 + x_strides), exactly one of them; workspace as mvsdet_conv3d_k3_bf16x3_ws, used
+ * only when out_f32 is the sole output */
+int mvsdet_conv3d_k3_bf16x3_io(const void* xs, const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/,
+                               const void* weight_split, const float* scale, const float* shift, const float* residual,
+                               float* out_f32, void* out_scl, void* out_pscl, void* workspace, size_t workspace_bytes, int N,
+                               int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* stride 2: input = x (fp32 + x_strides) or x_pscl (the PSCL form of the (N,Cin,D,H,W) input), exactly one of them */
+int mvsdet_conv3d_k3_s2_bf16x3_io(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* x_pscl,
+                                  const void* weight_split, const float* scale, const float* shift, float* out_f32,
+                                  void* out_scl, void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int D, int H,
+                                  int W, int relu, mvsdet_stream_t stream);
+/* transposed: out_scl = SCL form of the (N,Cout,2D,2H,2W) result */
+int mvsdet_convT3d_k3_s2_bf16x3_io(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                   const float* residual, float* out_f32, void* out_scl, int N, int Cin, int Cout, int D, int H,
+                                   int W, int relu, mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement helper for bench.py: runs `fn`-independent HIP-event timing is done by the caller;

@@ -197,13 +197,74 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         self.matrix_precision = os.environ.get("MVSDET_COSTREG_PRECISION", "bf16x3")
         if self.matrix_precision not in ("bf16x3", "fp32"):
             raise ValueError(f"MVSDET_COSTREG_PRECISION must be 'bf16x3' or 'fp32', got {self.matrix_precision!r}")
-        # (shape, device, stream) -> SclTensor of the transposed layers' (coarse) inputs; their zero border is written once.
-        # Keyed by the stream as well: the buffer is refilled in place, outside the allocator's per-stream reuse tracking
+        # eval route on bf16x3: "scl" = every layer hands the next one its output already cut into bf16 pieces (SCL / PSCL
+        # forms: no fp32 round trip through a packing pass or a strided gather, inputs by LDS-DMA); "f32" = fp32 tensors
+        # between the layers (round 3).  Same values bit for bit.
+        self.layer_forms = "scl"
+        # (layer, kind, shape, device, stream) -> the SCL / PSCL buffer a layer writes; its zero border is written once.
+        # Keyed by the stream as well: the buffers are refilled in place, outside the allocator's per-stream reuse tracking
         self._scl = {}
+
+    def _chain_ok(self, x) -> bool:
+        """The eval route on which every layer hands the next one its output already cut into bf16 pieces."""
+        return (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not self.training
+                and self.matrix_precision == "bf16x3" and self.layer_forms == "scl"
+                and all(c.out_channels % 64 == 0 for c in (self.conv0.conv, self.conv1.conv, self.conv2.conv, self.conv3.conv,
+                                                           self.conv4.conv, self.conv9[0], self.conv11[0])))
+
+    def _buf(self, name, kind, shape, dev):
+        """The SCL / PSCL buffer a layer of the chain writes: allocated and zeroed once per (layer, shape, device, stream) -- the
+        kernels write interior voxels only, the zero border stays -- and refilled on every call (outside the allocator's
+        per-stream reuse tracking, hence the stream in the key)."""
+        from . import ops
+        key = (name, kind, tuple(shape), dev, torch.cuda.current_stream(dev).cuda_stream)
+        buf = self._scl.pop(key, None)
+        if buf is None:
+            while len(self._scl) >= 32:   # varying view counts: least recently used first
+                self._scl.pop(next(iter(self._scl)))
+            buf = (ops.scl_empty if kind == "scl" else ops.pscl_empty)(shape, dev)
+        self._scl[key] = buf
+        return buf
+
+    def _forward_chain(self, x):
+        """mvsnet.py:104-112 with the layer-to-layer forms of include/mvsdet_hip.h: conv0 -(fp32 skip, PSCL)-> conv1 -(SCL)->
+        conv2 -(fp32 skip, PSCL)-> conv3 -(SCL)-> conv4 -(SCL)-> conv9 -(SCL)-> conv11 -(fp32)-> prob.  Same values as the
+        fp32-handover route bit for bit (a producer cuts exactly the pieces the consumer would have cut)."""
+        from . import ops
+        n, _, d, h, w = x.shape
+        dev = x.device
+        b = self.conv0.conv.out_channels
+
+        def cbr(layer, inp, order, outputs, name, oshape):
+            sc, sh = _bn_affine(layer.bn)
+            wq = ops.split_conv_weight(layer.conv.weight, order)
+            kw = {}
+            if "scl" in outputs:
+                kw["scl_out"] = self._buf(name, "scl", oshape, dev)
+            if "pscl" in outputs:
+                kw["pscl_out"] = self._buf(name, "pscl", oshape, dev)
+            fn = ops.conv3d_k3_bf16x3 if order == 0 else ops.conv3d_k3_s2_bf16x3
+            return fn(inp, wq, sc, sh, True, outputs=outputs, **kw)
+
+        def up(seq, inp, skip, outputs, name, oshape):
+            sc, sh = _bn_affine(seq[1])
+            kw = {"scl_out": self._buf(name, "scl", oshape, dev)} if "scl" in outputs else {}
+            return ops.convT3d_k3_s2_bf16x3(inp, ops.split_conv_weight(seq[0].weight, 2), sc, sh, skip, True, outputs=outputs, **kw)
+
+        full, full_p = cbr(self.conv0, x, 0, ("f32", "pscl"), "conv0", (n, b, d, h, w))
+        h1 = cbr(self.conv1, full_p, 1, ("scl",), "conv1", (n, 2 * b, d // 2, h // 2, w // 2))
+        half, half_p = cbr(self.conv2, h1, 0, ("f32", "pscl"), "conv2", (n, 2 * b, d // 2, h // 2, w // 2))
+        q1 = cbr(self.conv3, half_p, 1, ("scl",), "conv3", (n, 4 * b, d // 4, h // 4, w // 4))
+        q2 = cbr(self.conv4, q1, 0, ("scl",), "conv4", (n, 4 * b, d // 4, h // 4, w // 4))
+        half2 = up(self.conv9, q2, half, ("scl",), "conv9", (n, 2 * b, d // 2, h // 2, w // 2))
+        full2 = up(self.conv11, half2, full, ("f32",), "conv11", (n, b, d, h, w))
+        return self._head(full2)
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
             raise ValueError(f"CostRegNet3DGS: D, H, W must be divisible by 4, got {tuple(x.shape[2:])}")
+        if self._chain_ok(x):
+            return self._forward_chain(x)
         full = self._cbr(self.conv0, x)                           # (N, 64, D, H, W)
         half = self._cbr(self.conv2, self._cbr(self.conv1, full))         # (N, 128, D/2, H/2, W/2)
         quarter = self._cbr(self.conv4, self._cbr(self.conv3, half))      # (N, 256, D/4, H/4, W/4)

@@ -23,7 +23,8 @@ static int env_int(const char* name, int dflt) {
 
 Options& options() {
     static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1),
-                        env_int("MVSDET_SWEEP_DSPLIT", 0), env_int("MVSDET_SWEEP_GROUPS", -1)};
+                        env_int("MVSDET_SWEEP_DSPLIT", 0), env_int("MVSDET_SWEEP_GROUPS", -1),
+                        env_int("MVSDET_CONV_SUBPAIRS", 0), env_int("MVSDET_CONV_NSPLIT", 0)};
     return o;
 }
 
@@ -35,6 +36,8 @@ static int* option_slot(const char* name) {
     if (!strcmp(name, "sweep_xcd")) return &o.sweep_xcd;
     if (!strcmp(name, "sweep_dsplit")) return &o.sweep_dsplit;
     if (!strcmp(name, "sweep_groups")) return &o.sweep_groups;
+    if (!strcmp(name, "conv_subpairs")) return &o.conv_subpairs;
+    if (!strcmp(name, "conv_nsplit")) return &o.conv_nsplit;
     return nullptr;
 }
 

@@ -21,6 +21,8 @@ struct Options {
     int sweep_dsplit;  // 0 = by the grid size; n > 0: every block sweeps ceil(D / n) consecutive planes
     int sweep_groups;  // -1 = by the plane count; 0 / 1 = off; g in [2, kSweepGroups]: a tile's planes are dealt to up to g blocks,
                        // cut where its footprint boxes are refilled (the near planes)
+    int conv_subpairs; // bf16x3 stride-1 convolution on 3x16x8 tiles: tap pairs per weight sub-stage; 0 = by the grid, 2 / 5 force
+    int conv_nsplit;   // bf16x3 convolutions: splits of the input channels; 0 = by the grid, n > 0 force (needs the workspace)
 };
 Options& options();
 

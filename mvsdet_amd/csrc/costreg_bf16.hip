@@ -38,14 +38,77 @@ typedef float f32x16b __attribute__((ext_vector_type(16)));
 
 constexpr int kBfW = 16;             // tile width (voxels along w): one MFMA column group = 2 h-rows of 16
 constexpr int kBfPairs = 14;         // tap pairs (27 taps + 1 empty)
-constexpr int kBfSubPairs = 5;       // tap pairs per weight sub-stage (5 + 5 + 4)
-constexpr int kBfWSlots = kBfSubPairs * 2 * 2 * 64;   // 16-byte slots of one weight buffer: [pair][row group][piece][lane]
+constexpr int kBfSubPairs = 5;       // tap pairs per weight sub-stage (5 + 5 + 4); the kernels take it as a template parameter:
+                                     // 2 (seven sub-stages) makes the LDS of a 3x16x8 tile 77 KiB, so that two blocks share a CU
+__host__ __device__ constexpr int bf_w_slots(int subp) { return subp * 2 * 2 * 64; }   // 16-byte slots of one weight buffer: [pair][row group][piece][lane]
 
 __host__ __device__ constexpr int bf_in_slots(int TD, int TH, int TW = kBfW) {   // 16-byte slots of one piece of one input buffer
     return ((TD + 2) * (TH + 2) * (TW + 2) + 63) / 64 * 64;
 }
-__host__ __device__ constexpr size_t bf_lds_bytes(int TD, int TH, int TW = kBfW) {
-    return (size_t)(2 * 2 * bf_in_slots(TD, TH, TW) + 2 * kBfWSlots) * 16;
+__host__ __device__ constexpr size_t bf_lds_bytes(int TD, int TH, int TW = kBfW, int subp = kBfSubPairs) {
+    return (size_t)(2 * 2 * bf_in_slots(TD, TH, TW) + 2 * bf_w_slots(subp)) * 16;
+}
+
+// Which output channel an accumulator register holds.  The 32x32 MFMA leaves row (r & 3) + 8 * (r >> 2) + 4 * hh of a row group in
+// register r of lane half hh = lane >> 5; the weights are laid out (split_conv_weight_kernel) so that row carries channel
+//     8 * (2 * (r >> 3) + hh) + (r & 7)
+// of the group: registers 8q .. 8q+7 of a lane are then EIGHT CONSECUTIVE channels = one 16-byte unit of the SCL form, and a
+// layer can hand its output to the next one already cut into bf16 pieces (one uint4 store per piece and unit instead of eight
+// 4-byte stores, no packing pass, and the consumer feeds its LDS by DMA).
+__host__ __device__ constexpr int bf_row_channel(int r, int hh) { return 8 * (2 * (r >> 3) + hh) + (r & 7); }
+__host__ __device__ constexpr int bf_mfma_row_channel(int m) {   // the same map from the MFMA row m = lane & 31 of an A fragment
+    return 8 * ((m >> 4) * 2 + ((m >> 2) & 1)) + (m & 3) + 4 * ((m >> 3) & 1);
+}
+
+// Where a convolution leaves its result: any combination of the fp32 (N,Cout,D,H,W) tensor, its SCL form and its
+// parity-split SCL form ("PSCL": the eight (d,h,w)-parity classes of the volume as eight compact SCL volumes, what a
+// stride-2 consumer reads tile by tile: conv3d_k3_s2_bf16x3_kernel).
+struct BfOut {
+    float* f32;            // or nullptr
+    uint4* scl;            // or nullptr; [piece][n][c8][Dp][Hp][Wp]
+    uint4* pscl;           // or nullptr; [piece][class 8][n][c8][cDp][cHp][cWp]
+    int N;                 // views (the class index of the PSCL form is outside the view index)
+    int Dp, Hp, Wp;        // padded extents of the SCL form
+    int cDp, cHp, cWp;     // padded extents of one parity class
+    size_t piece, cpiece;  // units per piece (SCL), per piece (PSCL: 8 classes)
+};
+
+// fp32 x 8 -> the two bf16 pieces (round to nearest even; the remainder is exact in fp32 and rounded once)
+__device__ __forceinline__ void bf_cut8(const float (&v)[8], uint4& hi, uint4& mid) {
+    unsigned h[4], m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned short hb[2], mb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const __bf16 a = (__bf16)v[2 * j + e];
+            const __bf16 b = (__bf16)(v[2 * j + e] - (float)a);
+            hb[e] = __builtin_bit_cast(unsigned short, a);
+            mb[e] = __builtin_bit_cast(unsigned short, b);
+        }
+        h[j] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+        m[j] = (unsigned)mb[0] | ((unsigned)mb[1] << 16);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    mid = make_uint4(m[0], m[1], m[2], m[3]);
+}
+
+// The 8 finished values (channels 8*c8 .. 8*c8+7 of view n at voxel (d,h,w)) into the SCL and / or PSCL form.
+__device__ __forceinline__ void bf_store_units(const BfOut& o, const float (&v)[8], int n, int C8o, int c8, int d, int h, int w) {
+    uint4 hi, mid;
+    bf_cut8(v, hi, mid);
+    if (o.scl) {
+        const size_t u = (((size_t)n * C8o + c8) * o.Dp + (d + 1)) * o.Hp * o.Wp + (size_t)(h + 1) * o.Wp + (w + 1);
+        o.scl[u] = hi;
+        o.scl[o.piece + u] = mid;
+    }
+    if (o.pscl) {
+        const int cls = ((d & 1) << 2) | ((h & 1) << 1) | (w & 1);
+        const size_t u = ((((size_t)cls * o.N + n) * C8o + c8) * o.cDp + ((d >> 1) + 1)) * o.cHp * o.cWp +
+                         (size_t)((h >> 1) + 1) * o.cWp + ((w >> 1) + 1);
+        o.pscl[u] = hi;
+        o.pscl[o.cpiece + u] = mid;
+    }
 }
 
 // fp32 NCDHW -> SCL (both pieces), interior voxels only: the border stays as the caller zeroed it.
@@ -83,7 +146,8 @@ __global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restr
     xs[piece_stride + o] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
 }
 
-// Conv3d weight (Cout,Cin,27) fp32 -> [Cout/64][c8][14][2 row groups][2 pieces][64 lanes][8] bf16 (see the entry point):
+// Conv3d weight (Cout,Cin,27) fp32 -> [Cout/64][c8][14][2 row groups][2 pieces][64 lanes][8] bf16 (see the entry point; lane =
+// 32 * (half of the pair) + MFMA row m, which carries output channel bf_mfma_row_channel(m) of its row group):
 // thread = one 16-byte unit.  A few hundred thousand elements: run on every call, so the kernel never multiplies a stale
 // copy of weights that were updated in place.
 struct TapTable { signed char t[2 * kBfPairs]; };   // the 3x3x3 tap (0..26) of every half of the 14 tap pairs; -1 = empty half
@@ -95,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void split_conv_weight_kernel(const float
     const int lane = (int)(u & 63), piece = (int)((u >> 6) & 1), a = (int)((u >> 7) & 1);
     const size_t r = u >> 8;
     const int p = (int)(r % kBfPairs), c8 = (int)((r / kBfPairs) % C8), ob = (int)(r / ((size_t)kBfPairs * C8));
-    const int o = ob * 64 + a * 32 + (lane & 31), t = taps.t[2 * p + (lane >> 5)];
+    const int o = ob * 64 + a * 32 + bf_mfma_row_channel(lane & 31), t = taps.t[2 * p + (lane >> 5)];
     unsigned short b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -125,13 +189,13 @@ __host__ __device__ constexpr int bf_tap_off(int t) {
 // TW: tile width.  16: an MFMA column group (32 voxels) = 2 h-rows of 16; 8 (fp32-input form only): 4 h-rows of 8 -- the tiles
 // 3 x 16 x 8 and 8 x 8 x 8 fit the half- and quarter-resolution volumes of the cost network (6 x 30 x 40, 3 x 15 x 20) and the
 // neck's 40 x 40 x 16 level, which 4 x 8 x 16 tiles pad 1.7x, 2.3x and 1.2x.
-template <int TD, int TH, bool F32IN, int TW = kBfW>
+template <int TD, int TH, bool F32IN, int TW = kBfW, int SUBP = kBfSubPairs>
 __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
     const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
+    const float* __restrict__ residual, BfOut dst, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
-    static_assert(TW == 16 || (TW == 8 && F32IN), "8-wide tiles: fp32-input form only");
+    float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                           // h-rows of one column group
     static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
     constexpr int NW = TD * TH * TW / 64;                 // waves
@@ -141,6 +205,9 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     constexpr int INS = bf_in_slots(TD, TH, TW);          // slots per piece
     constexpr int IN_DMA = INS / 64;                      // wave-instructions per piece and stage
     constexpr int IN_PER_WAVE = (2 * IN_DMA + NW - 1) / NW;
+    constexpr int NSUB = (kBfPairs + SUBP - 1) / SUBP;    // weight sub-stages per channel group
+    constexpr int kBfWSlots = bf_w_slots(SUBP);
+    static_assert(NSUB >= 2, "the fp32 fetch / cut needs two sub-stages");
     extern __shared__ uint4 s_bf[];   // [2 stages][2 pieces][INS] input, then [2 stages][kBfWSlots] weights
     uint4* s_in = s_bf;
     uint4* s_w = s_bf + 2 * 2 * INS;
@@ -242,8 +309,8 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     // Weights: wq[ob64][c8][pair 14][row group 2][piece 2][lane 64] in 16-byte units; sub-stage s = pairs 5s .. 5s+4
     const uint4* wn = wq + (size_t)ob64 * C8 * (kBfPairs * 4 * 64);
     auto dma_weights = [&](int c8, int s, int buf) {
-        const int ninstr = (s == 2 ? kBfPairs - 2 * kBfSubPairs : kBfSubPairs) * 4;
-        const uint4* src0 = wn + ((size_t)c8 * kBfPairs + s * kBfSubPairs) * (4 * 64) + lane;
+        const int ninstr = min(SUBP, kBfPairs - s * SUBP) * 4;
+        const uint4* src0 = wn + ((size_t)c8 * kBfPairs + s * SUBP) * (4 * 64) + lane;
         for (int i = wave; i < ninstr; i += NW) {
             uint4* dst = s_w + (size_t)buf * kBfWSlots + i * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 64),
@@ -274,12 +341,12 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
 
     auto compute = [&](auto sc, int ibuf, int wbuf) {
         constexpr int s = decltype(sc)::value;
-        constexpr int np = (s == 2 ? kBfPairs - 2 * kBfSubPairs : kBfSubPairs);
+        constexpr int np = (kBfPairs - s * SUBP < SUBP ? kBfPairs - s * SUBP : SUBP);
         const bf16x8* bin = s_in8 + (size_t)(ibuf * 2) * INS;
         const bf16x8* ain = s_w8 + (size_t)wbuf * kBfWSlots + lane;
 #pragma unroll
         for (int pl = 0; pl < np; ++pl) {
-            const int p = s * kBfSubPairs + pl;
+            const int p = s * SUBP + pl;
             const int toff = hh ? bf_tap_off<HH, HW>(2 * p + 1) : bf_tap_off<HH, HW>(2 * p);
             bf16x8 A[2][2], B[2][2];   // [row / column group][piece]
 #pragma unroll
@@ -312,17 +379,17 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
         }
         dma_weights(c8_begin, 0, 0);
     }
-    for (int c8 = c8_begin; c8 < c8_end; ++c8) {
-        const int ibuf = (c8 - c8_begin) & 1;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int wbuf = ((c8 - c8_begin) * 3 + s) & 1;
+    // one sub-stage: wait for the own transfers, barrier, start the next sub-stage's transfers, multiply
+    auto substage = [&](auto sc, int c8, int ibuf, int q) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s < NSUB) {
+            const int wbuf = q & 1;
             // this wave's DMAs (and, F32IN, register fetches) of the current stage have landed; after the barrier
             // everybody's have, and everybody is done reading the buffers the next stage's transfers (issued right below)
             // overwrite
             __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) only (expcnt 7, lgkmcnt 15 untouched)
             __builtin_amdgcn_s_barrier();
-            if (s < 2) {
+            if (s + 1 < NSUB) {
                 dma_weights(c8, s + 1, wbuf ^ 1);
             } else if (c8 + 1 < c8_end) {
                 dma_weights(c8 + 1, 0, wbuf ^ 1);
@@ -335,13 +402,22 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
             } else {
                 if (s == 0 && c8 + 1 < c8_end) dma_input(c8 + 1, ibuf ^ 1);
             }
-            if (s == 0) compute(std::integral_constant<int, 0>{}, ibuf, wbuf);
-            else if (s == 1) compute(std::integral_constant<int, 1>{}, ibuf, wbuf);
-            else compute(std::integral_constant<int, 2>{}, ibuf, wbuf);
+            compute(sc, ibuf, wbuf);
         }
+    };
+    for (int c8 = c8_begin; c8 < c8_end; ++c8) {
+        const int ibuf = (c8 - c8_begin) & 1;
+        const int q0 = (c8 - c8_begin) * NSUB;
+        substage(std::integral_constant<int, 0>{}, c8, ibuf, q0);
+        substage(std::integral_constant<int, 1>{}, c8, ibuf, q0 + 1);
+        substage(std::integral_constant<int, 2>{}, c8, ibuf, q0 + 2);
+        substage(std::integral_constant<int, 3>{}, c8, ibuf, q0 + 3);
+        substage(std::integral_constant<int, 4>{}, c8, ibuf, q0 + 4);
+        substage(std::integral_constant<int, 5>{}, c8, ibuf, q0 + 5);
+        substage(std::integral_constant<int, 6>{}, c8, ibuf, q0 + 6);
     }
 
-    // ---- epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (voxel), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    // ---- epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (voxel), register r of lane half hh = channel bf_row_channel(r, hh)
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -350,32 +426,35 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            // affine and residual of the 16 outputs are requested together, ahead of the stores: loads and stores share one
-            // in-order counter, so a load issued behind a store waits for the store's round trip as well (one element at a
-            // time this epilogue was a chain of 64 memory round trips per lane)
-            float sc[16], sh[16], rv[16];
+            // affine and residual of 8 outputs (registers 8q .. 8q+7 = eight consecutive channels) are requested together, ahead
+            // of the stores: loads and stores share one in-order counter, so a load issued behind a store waits for the store's
+            // round trip as well (one element at a time this epilogue was a chain of 64 memory round trips per lane)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
+            for (int q = 0; q < 2; ++q) {
+                float sc[8], sh[8], rv[8], v[8];
+                const int o0 = ob64 * 64 + a * 32 + bf_row_channel(8 * q, hh);   // channels o0 .. o0 + 7
+                const size_t idx0 = ((size_t)n * Cout + o0) * vol + (size_t)d * plane + (size_t)h * W + w;
                 const bool fin = nsplit == 1;
-                sc[r] = (fin && scale) ? scale[o] : 1.0f;
-                sh[r] = (fin && scale) ? shift[o] : 0.0f;
-                rv[r] = (fin && residual) ? residual[idx] : 0.0f;
-            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = acc[a][b][r];
-                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
-                if (nsplit > 1) {
-                    partial[(size_t)split * total + idx] = v;
-                    continue;
+                for (int j = 0; j < 8; ++j) {
+                    sc[j] = (fin && scale) ? scale[o0 + j] : 1.0f;
+                    sh[j] = (fin && scale) ? shift[o0 + j] : 0.0f;
+                    rv[j] = (fin && residual) ? residual[idx0 + (size_t)j * vol] : 0.0f;
                 }
-                if (scale) v = fmaf(v, sc[r], sh[r]);
-                if (residual) v = v + rv[r];
-                if (relu) v = fmaxf(v, 0.0f);
-                out[idx] = v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = acc[a][b][8 * q + j];
+                    if (nsplit > 1) {
+                        partial[(size_t)split * total + idx0 + (size_t)j * vol] = v[j];
+                        continue;
+                    }
+                    if (scale) v[j] = fmaf(v[j], sc[j], sh[j]);
+                    if (residual) v[j] = v[j] + rv[j];
+                    if (relu) v[j] = fmaxf(v[j], 0.0f);
+                    if (out) out[idx0 + (size_t)j * vol] = v[j];
+                }
+                // the same values cut into bf16 pieces: one 16-byte unit per piece
+                if (nsplit == 1 && (dst.scl || dst.pscl)) bf_store_units(dst, v, n, Cout / 8, ob64 * 8 + a * 4 + 2 * q + hh, d, h, w);
             }
         }
     }
@@ -414,11 +493,17 @@ __host__ __device__ constexpr int s2_tap_off(int pi, int j) {
 
 // Output tile TD x TH x TW: 4 x 8 x 16, or 3 x 16 x 8 (column group = 4 h-rows of 8) for the outputs 6 x 30 x 40 and 3 x 15 x 20 of
 // the cost network, which the former pads 1.7x and 2.3x.
-template <int TD, int TH, int TW>
+// PIN: the input is the parity-split SCL form of the tensor (what the producing layer's epilogue wrote: BfOut::pscl) -- a stage's
+// class tile then arrives by LDS-DMA like the stride-1 kernel's halo tile, and the fetch / cut / ds_write of the fp32 form
+// (every second element of a row: half of every fetched sector unused, ~100 vector instructions per thread and stage beside
+// 12 - 48 MFMAs) is gone.
+template <int TD, int TH, int TW, bool PIN = false>
 __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
-    const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
-    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out, int C8, int Cout, int Di, int Hi,
+    const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ xp,
+    int cDp, int cHp, int cWp, size_t cpiece, int Nviews, const uint4* __restrict__ wq,
+    const float* __restrict__ scale, const float* __restrict__ shift, BfOut dst, int C8, int Cout, int Di, int Hi,
     int Wi, int D, int H, int W, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
+    float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                // h-rows of one column group
     static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
     constexpr int NW = TD * TH * TW / 64, NT = 64 * NW;
@@ -438,7 +523,43 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
     const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
     const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
     const int col = lane & 31, hh = lane >> 5;
-    const float* xfn = xf + (size_t)n * sN;
+    const float* xfn = PIN ? nullptr : xf + (size_t)n * sN;
+
+    // ---- PIN: DMA plan of a class tile.  Class pi = (pd, ph, pw) keeps input voxel (2i - pd, ...)... stored at index i + 1 - ...:
+    // the PSCL form stores class coordinate c (input voxel 2c + parity) at index c + 1 (index 0 = the zero border the odd classes
+    // read for c = -1).  Tile slot (dz, hy, wx) of class pi is class coordinate (d0 + dz - pd, ...) = stored index d0 + dz + 1 - pd.
+    constexpr int IN_DMA = INS / 64;
+    constexpr int IN_PER_WAVE = (2 * IN_DMA + NW - 1) / NW;
+    const size_t c8_stride = (size_t)cDp * cHp * cWp, cls_stride = (size_t)Nviews * C8 * c8_stride;
+    const uint4* xn = PIN ? xp + ((size_t)n * C8) * c8_stride + ((size_t)d0 * cHp + h0) * cWp + w0 : nullptr;
+    unsigned in_src[IN_PER_WAVE];
+    if constexpr (PIN) {
+#pragma unroll
+        for (int k = 0; k < IN_PER_WAVE; ++k) {
+            const int i = wave + k * NW;
+            const int slot = (i % IN_DMA) * 64 + lane;
+            const int sv = slot < NVOX ? slot : 0;
+            const int dz = sv / (HH * HW), r = sv - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
+            in_src[k] = (unsigned)(((size_t)dz * cHp + hy) * cWp + wx);
+        }
+    }
+    auto dma_input = [&](int c8, int pi, int buf) {
+        if constexpr (PIN) {
+            const int pd = pi >> 2, ph = (pi >> 1) & 1, pw = pi & 1;
+            const uint4* base = xn + (size_t)pi * cls_stride + (size_t)c8 * c8_stride + ((size_t)(1 - pd) * cHp + (1 - ph)) * cWp + (1 - pw);
+#pragma unroll
+            for (int k = 0; k < IN_PER_WAVE; ++k) {
+                const int i = wave + k * NW;   // wave-uniform
+                if (i < 2 * IN_DMA) {
+                    const int piece = i / IN_DMA;
+                    const uint4* src = base + (size_t)piece * cpiece + in_src[k];
+                    uint4* dstl = s_in + (size_t)(buf * 2 + piece) * INS + (i % IN_DMA) * 64;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+                }
+            }
+        }
+    };
 
     // the thread's voxel slots of a class tile: tile index (dz, hy, wx) <-> input voxel 2*(d0 + dz) - pd, ... (class pi)
     int vz[NV], vy[NV], vx[NV];
@@ -562,22 +683,30 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
     const int nq = (c8_end - c8_begin) * 8;
     using S0 = std::integral_constant<int, 0>;
     if (nq > 0) {
-        fetch(S0{}, c8_begin, 0);
-        stage(S0{}, 0);
-        dma_weights(c8_begin, 0, 0);
-        fetch(S0{}, c8_begin, 1);
+        if constexpr (PIN) {
+            dma_input(c8_begin, 0, 0);
+            dma_weights(c8_begin, 0, 0);
+        } else {
+            fetch(S0{}, c8_begin, 0);
+            stage(S0{}, 0);
+            dma_weights(c8_begin, 0, 0);
+            fetch(S0{}, c8_begin, 1);
+        }
     }
     auto step = [&](auto pc, int c8) {
         constexpr int pi = decltype(pc)::value;
         constexpr int buf = pi & 1;
         const int q = (c8 - c8_begin) * 8 + pi;
-        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) and lgkmcnt(0): own fetches, DMAs and LDS writes are done
+        if constexpr (PIN) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMAs of the stage have landed
+        else __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) and lgkmcnt(0): own fetches, DMAs and LDS writes are done
         __builtin_amdgcn_s_barrier();
         if (q + 1 < nq) {
-            stage(S0{}, buf ^ 1);
+            if constexpr (PIN) dma_input(pi == 7 ? c8 + 1 : c8, (pi + 1) & 7, buf ^ 1);
+            else stage(S0{}, buf ^ 1);
             dma_weights(pi == 7 ? c8 + 1 : c8, (pi + 1) & 7, buf ^ 1);
         }
-        if (q + 2 < nq) fetch(S0{}, pi >= 6 ? c8 + 1 : c8, (pi + 2) & 7);
+        if constexpr (!PIN)
+            if (q + 2 < nq) fetch(S0{}, pi >= 6 ? c8 + 1 : c8, (pi + 2) & 7);
         compute(pc, buf);
     };
     for (int c8 = c8_begin; c8 < c8_end; ++c8) {
@@ -599,25 +728,28 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            float sc[16], sh[16];   // requested ahead of the stores (see conv3d_k3_bf16x3_kernel)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                sc[r] = (nsplit == 1 && scale) ? scale[o] : 1.0f;
-                sh[r] = (nsplit == 1 && scale) ? shift[o] : 0.0f;
-            }
+            for (int q = 0; q < 2; ++q) {
+                float sc[8], sh[8], v[8];   // requested ahead of the stores (see conv3d_k3_bf16x3_kernel)
+                const int o0 = ob64 * 64 + a * 32 + bf_row_channel(8 * q, hh);
+                const size_t idx0 = ((size_t)n * Cout + o0) * vol + (size_t)d * plane + (size_t)h * W + w;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = acc[a][b][r];
-                const size_t idx = ((size_t)n * Cout + o) * vol + (size_t)d * plane + (size_t)h * W + w;
-                if (nsplit > 1) {
-                    partial[(size_t)split * total + idx] = v;
-                    continue;
+                for (int j = 0; j < 8; ++j) {
+                    sc[j] = (nsplit == 1 && scale) ? scale[o0 + j] : 1.0f;
+                    sh[j] = (nsplit == 1 && scale) ? shift[o0 + j] : 0.0f;
                 }
-                if (scale) v = fmaf(v, sc[r], sh[r]);
-                if (relu) v = fmaxf(v, 0.0f);
-                out[idx] = v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = acc[a][b][8 * q + j];
+                    if (nsplit > 1) {
+                        partial[(size_t)split * total + idx0 + (size_t)j * vol] = v[j];
+                        continue;
+                    }
+                    if (scale) v[j] = fmaf(v[j], sc[j], sh[j]);
+                    if (relu) v[j] = fmaxf(v[j], 0.0f);
+                    if (out) out[idx0 + (size_t)j * vol] = v[j];
+                }
+                if (nsplit == 1 && (dst.scl || dst.pscl)) bf_store_units(dst, v, n, Cout / 8, ob64 * 8 + a * 4 + 2 * q + hh, d, h, w);
             }
         }
     }
@@ -660,8 +792,9 @@ __host__ __device__ constexpr int ct_tap_off(int pi, int j) {
 template <int PD, int PH, int TD, int TH, int TW>
 __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
+    const float* __restrict__ residual, const BfOut& dst, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu, int tile_xy) {
+    float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                           // h-rows of one column group
     static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
     constexpr int NW = TD * TH * TW / 64;
@@ -791,32 +924,74 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
             // the 16 skip values of this (row group, column group) are requested together, ahead of the stores: loads and
             // stores share one in-order counter, so a load issued behind a store waits for the store's round trip as well
             // -- one value at a time, the epilogue took half of the layer's time
-            float2 rv[16];
-            float sc[16], sh[16];   // (the affine too: a load between two stores waits for the first store)
+            if (!(dst.scl || dst.pscl)) {
+                // fp32 only: the 16 skip values of this (row group, column group) are requested together, ahead of the stores:
+                // loads and stores share one in-order counter, so a load issued behind a store waits for the store's round trip
+                // as well -- one value at a time, the epilogue took half of the layer's time (conv11: 1.2 GB of skip and output)
+                float2 rv[16];
+                float sc[16], sh[16];   // (the affine too: a load between two stores waits for the first store)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                rv[r] = residual ? *reinterpret_cast<const float2*>(residual + ((size_t)n * Cout + o) * ovol + pos) : make_float2(0.f, 0.f);
-                sc[r] = scale ? scale[o] : 1.0f;
-                sh[r] = scale ? shift[o] : 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ob64 * 64 + a * 32 + bf_row_channel(r, hh);
+                    rv[r] = residual ? *reinterpret_cast<const float2*>(residual + ((size_t)n * Cout + o) * ovol + pos) : make_float2(0.f, 0.f);
+                    sc[r] = scale ? scale[o] : 1.0f;
+                    sh[r] = scale ? shift[o] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ob64 * 64 + a * 32 + bf_row_channel(r, hh);
+                    float2 v = make_float2(acc[0][a][b][r], acc[1][a][b][r]);
+                    if (scale) {
+                        v.x = fmaf(v.x, sc[r], sh[r]);
+                        v.y = fmaf(v.y, sc[r], sh[r]);
+                    }
+                    if (relu) {
+                        v.x = fmaxf(v.x, 0.0f);
+                        v.y = fmaxf(v.y, 0.0f);
+                    }
+                    if (residual) {
+                        v.x = rv[r].x + v.x;
+                        v.y = rv[r].y + v.y;
+                    }
+                    *reinterpret_cast<float2*>(out + ((size_t)n * Cout + o) * ovol + pos) = v;
+                }
+                continue;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = ob64 * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float2 v = make_float2(acc[0][a][b][r], acc[1][a][b][r]);
-                if (scale) {
-                    v.x = fmaf(v.x, sc[r], sh[r]);
-                    v.y = fmaf(v.y, sc[r], sh[r]);
+            for (int q = 0; q < 2; ++q) {   // eight consecutive channels at a time: one unit per piece and w parity
+                float2 rv[8];
+                float sc[8], sh[8];
+                const int o0 = ob64 * 64 + a * 32 + bf_row_channel(8 * q, hh);
+                const size_t idx0 = ((size_t)n * Cout + o0) * ovol + pos;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    rv[j] = residual ? *reinterpret_cast<const float2*>(residual + idx0 + (size_t)j * ovol) : make_float2(0.f, 0.f);
+                    sc[j] = scale ? scale[o0 + j] : 1.0f;
+                    sh[j] = scale ? shift[o0 + j] : 0.0f;
                 }
-                if (relu) {
-                    v.x = fmaxf(v.x, 0.0f);
-                    v.y = fmaxf(v.y, 0.0f);
+                float v0[8], v1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float2 v = make_float2(acc[0][a][b][8 * q + j], acc[1][a][b][8 * q + j]);
+                    if (scale) {
+                        v.x = fmaf(v.x, sc[j], sh[j]);
+                        v.y = fmaf(v.y, sc[j], sh[j]);
+                    }
+                    if (relu) {
+                        v.x = fmaxf(v.x, 0.0f);
+                        v.y = fmaxf(v.y, 0.0f);
+                    }
+                    if (residual) {
+                        v.x = rv[j].x + v.x;
+                        v.y = rv[j].y + v.y;
+                    }
+                    v0[j] = v.x;
+                    v1[j] = v.y;
+                    if (out) *reinterpret_cast<float2*>(out + idx0 + (size_t)j * ovol) = v;
                 }
-                if (residual) {
-                    v.x = rv[r].x + v.x;
-                    v.y = rv[r].y + v.y;
-                }
-                *reinterpret_cast<float2*>(out + ((size_t)n * Cout + o) * ovol + pos) = v;
+                const int c8o = ob64 * 8 + a * 4 + 2 * q + hh;
+                bf_store_units(dst, v0, n, Cout / 8, c8o, 2 * di + PD, 2 * hi + PH, 2 * wi);
+                bf_store_units(dst, v1, n, Cout / 8, c8o, 2 * di + PD, 2 * hi + PH, 2 * wi + 1);
             }
         }
     }
@@ -827,7 +1002,7 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
 template <int TD, int TH, int TW>
 __global__ __launch_bounds__(TD * TH * TW) void convT3d_k3_s2_bf16x3_kernel(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ residual, float* __restrict__ out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
+    const float* __restrict__ residual, BfOut out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu) {
     const int cls = blockIdx.x & 3, tile_xy = blockIdx.x >> 2;
     if (cls == 0) convT3d_k3_s2_bf16x3_body<1, 1, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
@@ -844,7 +1019,25 @@ namespace {
 struct BfPlan {
     int td, th, tiles_d, tiles_h, tiles_w, Dp, Hp, Wp, tw = kBfW;
 };
-// tile = 4 x TH x 16 with TH = 8 or 12, whichever pads H less (60 rows: 12); padded extents = tiles + the one-voxel border
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// Padded extents of the SCL form of a (D,H,W) volume: the one-voxel zero border plus whatever the LARGEST tile overhang of
+// any kernel that reads the form needs -- tiles 4 x {8,12} x 16, {3,6} x 16 x 8 (stride 1) and 4 x 8 x 16, 3 x 16 x 8 (+ 1
+// halo voxel, transposed) -- so that a buffer does not depend on which tile shape a consumer picks.
+void scl_dims(int D, int H, int W, int& Dp, int& Hp, int& Wp) {
+    Dp = std::max(round_up(D, 3), std::max(round_up(D, 4), round_up(D, 6))) + 2;
+    Hp = std::max(round_up(H, 8), std::max(round_up(H, 12), round_up(H, 16))) + 2;
+    Wp = round_up(W, 16) + 2;
+}
+// One parity class of the PSCL form of a (D,H,W) volume: class coordinates 0 .. ceil(D/2)-1 stored at index + 1, read by the
+// stride-2 kernel's 4 x 8 x 16 or 3 x 16 x 8 output tiles (+ 1 slot)
+void pscl_dims(int D, int H, int W, int& cDp, int& cHp, int& cWp) {
+    const int Dc = (D + 1) / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+    cDp = std::max(round_up(Dc, 3), round_up(Dc, 4)) + 2;
+    cHp = std::max(round_up(Hc, 8), round_up(Hc, 16)) + 2;
+    cWp = round_up(Wc, 16) + 2;
+}
+// tile = 4 x TH x 16 with TH = 8 or 12, whichever pads H less (60 rows: 12): the tiling the number of input-channel splits
+// is derived from (for every input form and tile shape, so that all of them add up the same partial sums)
 BfPlan bf_plan(int D, int H, int W) {
     BfPlan p;
     p.td = 4;
@@ -853,19 +1046,18 @@ BfPlan bf_plan(int D, int H, int W) {
     p.tiles_d = (D + p.td - 1) / p.td;
     p.tiles_h = (H + p.th - 1) / p.th;
     p.tiles_w = (W + kBfW - 1) / kBfW;
-    p.Dp = p.tiles_d * p.td + 2;
-    p.Hp = std::max(pad8, pad12) + 2;   // covers the 4x8x16 tiles of the transposed convolution as well
-    p.Wp = p.tiles_w * kBfW + 2;
+    scl_dims(D, H, W, p.Dp, p.Hp, p.Wp);
     return p;
 }
-// The fp32-input form is free of the SCL layout: the tile of {4x12x16, 4x8x16, 3x16x8, 8x8x8} that pads (D, H, W) least
-// (first = preferred at equal padding: larger tiles, wider rows)
-BfPlan bf_plan_f32(int D, int H, int W) {
-    static const int cand[][3] = {{4, 12, 16}, {4, 8, 16}, {3, 16, 8}, {8, 8, 8}};
+// The tile that pads (D, H, W) least.  At equal padding the earlier candidate wins: 12- and 8-wave tiles before the 6-wave
+// one (its waves sit 2/2/1/1 on the four SIMDs).  8 x 8 x 8: fp32-input form only (the neck's levels).
+BfPlan bf_plan_tile(int D, int H, int W, bool f32in) {
+    static const int cand[][3] = {{4, 12, 16}, {4, 8, 16}, {6, 16, 8}, {3, 16, 8}, {8, 8, 8}};
     BfPlan best = bf_plan(D, H, W);
     long long best_vol = -1;
     for (const auto& c : cand) {
         const int td = c[0], th = c[1], tw = c[2];
+        if (td == 8 && !f32in) continue;
         const int nd = (D + td - 1) / td, nh = (H + th - 1) / th, nw = (W + tw - 1) / tw;
         const long long v = (long long)nd * td * nh * th * nw * tw;
         if (best_vol < 0 || v < best_vol) {
@@ -873,18 +1065,43 @@ BfPlan bf_plan_f32(int D, int H, int W) {
             best.td = td; best.th = th; best.tw = tw; best.tiles_d = nd; best.tiles_h = nh; best.tiles_w = nw;
         }
     }
-    return best;   // Dp, Hp, Wp: those of the SCL form, unused by the fp32-input kernels
+    return best;
+}
+BfOut make_out(float* f32, void* scl, void* pscl, int N, int Cout, int D, int H, int W) {
+    BfOut o;
+    o.f32 = f32;
+    o.scl = static_cast<uint4*>(scl);
+    o.pscl = static_cast<uint4*>(pscl);
+    o.N = N;
+    scl_dims(D, H, W, o.Dp, o.Hp, o.Wp);
+    pscl_dims(D, H, W, o.cDp, o.cHp, o.cWp);
+    o.piece = (size_t)N * (Cout / 8) * o.Dp * o.Hp * o.Wp;
+    o.cpiece = (size_t)8 * N * (Cout / 8) * o.cDp * o.cHp * o.cWp;
+    return o;
 }
 }  // namespace
 
 // Geometry of the split channel-last form of an (N,C,D,H,W) activation: padded extents and total bytes (both pieces).
 extern "C" size_t mvsdet_scl_bytes(int N, int C, int D, int H, int W, int* Dp, int* Hp, int* Wp) {
     if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    const BfPlan p = bf_plan(D, H, W);
-    if (Dp) *Dp = p.Dp;
-    if (Hp) *Hp = p.Hp;
-    if (Wp) *Wp = p.Wp;
-    return (size_t)2 * N * ((C + 7) / 8) * p.Dp * p.Hp * p.Wp * 16;
+    int dp, hp, wp;
+    scl_dims(D, H, W, dp, hp, wp);
+    if (Dp) *Dp = dp;
+    if (Hp) *Hp = hp;
+    if (Wp) *Wp = wp;
+    return (size_t)2 * N * ((C + 7) / 8) * dp * hp * wp * 16;
+}
+
+// Geometry of the parity-split SCL form: [piece 2][class 8][n][c8][cDp][cHp][cWp][8] bf16; class = 4*(d&1) + 2*(h&1) + (w&1),
+// voxel (d,h,w) at index (d/2 + 1, h/2 + 1, w/2 + 1) of its class, zero elsewhere.
+extern "C" size_t mvsdet_pscl_bytes(int N, int C, int D, int H, int W, int* cDp, int* cHp, int* cWp) {
+    if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    int dp, hp, wp;
+    pscl_dims(D, H, W, dp, hp, wp);
+    if (cDp) *cDp = dp;
+    if (cHp) *cHp = hp;
+    if (cWp) *cWp = wp;
+    return (size_t)2 * 8 * N * ((C + 7) / 8) * dp * hp * wp * 16;
 }
 
 // x (N,C,D,H,W) fp32, element strides xstr = {n, c, d, h} (w stride 1; NULL = contiguous) -> xs (SCL, mvsdet_scl_bytes).  The border of xs must be zero: `zero_border` != 0 clears the whole
@@ -973,6 +1190,8 @@ void launch_splitk_epilogue(const float* partial, int nsplit, size_t total, cons
 // splits of the channel groups for a grid of `blocks` blocks (one 8-12 wave block per CU): up to ~2 rounds of the chip, at
 // least 4 channel groups (12 weight sub-stages) per split
 static int bf_nsplit(long long blocks, int C8) {
+    const int forced = options().conv_nsplit;   // tuning knob: the size query and the launch both come through here
+    if (forced > 0) return (int)std::max(1, std::min(forced, C8 / 4));
     if (blocks >= 192) return 1;
     return (int)std::max(1LL, std::min<long long>((512 + blocks - 1) / blocks, C8 / 4));
 }
@@ -985,23 +1204,25 @@ extern "C" size_t mvsdet_conv3d_k3_bf16x3_workspace_bytes(int N, int Cin, int Co
 }
 
 static int launch_bf16x3(const char* name, const void* xs, const float* xf, const int64_t* xstr, const void* weight_split,
-                         const float* scale, const float* shift, const float* residual, float* out, int N, int Cin, int Cout,
-                         int D, int H, int W, int relu, mvsdet_stream_t stream, void* workspace = nullptr,
+                         const float* scale, const float* shift, const float* residual, float* out, void* out_scl, void* out_pscl,
+                         int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream, void* workspace = nullptr,
                          size_t workspace_bytes = 0) {
-    MVS_REQUIRE((xs || xf) && weight_split && out, "%s: NULL pointer", name);
+    MVS_REQUIRE((xs || xf) && weight_split && (out || out_scl || out_pscl), "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
-    MVS_REQUIRE((((uintptr_t)xs | (uintptr_t)weight_split) & 15u) == 0, "%s: xs and weights must be 16-byte aligned", name);
-    const BfPlan p = xf ? bf_plan_f32(D, H, W) : bf_plan(D, H, W);
+    MVS_REQUIRE((((uintptr_t)xs | (uintptr_t)weight_split | (uintptr_t)out_scl | (uintptr_t)out_pscl) & 15u) == 0,
+                "%s: SCL buffers and weights must be 16-byte aligned", name);
+    const BfPlan p = bf_plan_tile(D, H, W, xf != nullptr);
     const int C8 = (Cin + 7) / 8;
     MVS_REQUIRE((size_t)p.Dp * p.Hp * p.Wp < ((size_t)1 << 31), "%s: one padded channel-group volume exceeds 2^31 voxels", name);
     const size_t vol = (size_t)D * H * W, total = (size_t)N * Cout * vol;
     // without (enough) workspace the convolution runs unsplit.  The number of splits follows from the 4 x TH x 16 tiling for
-    // BOTH input forms (the fp32-input form may tile differently), so that the two forms add up the same partial sums
+    // EVERY input form and tile shape, so that all of them add up the same partial sums.  The split form writes fp32 only.
     const BfPlan ps = bf_plan(D, H, W);
     int nsplit = bf_nsplit((long long)ps.tiles_w * ps.tiles_h * ps.tiles_d * N * (Cout / 64), C8);
-    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float)) nsplit = 1;
+    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float) || out_scl || out_pscl) nsplit = 1;
+    MVS_REQUIRE(nsplit == 1 || out, "%s: the split form needs the fp32 output", name);
     MVS_REQUIRE((long long)N * (Cout / 64) * nsplit <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     const long long sN = xstr ? xstr[0] : (long long)Cin * vol, sC = xstr ? xstr[1] : (long long)vol;
     const long long sD = xstr ? xstr[2] : (long long)H * W, sH = xstr ? xstr[3] : (long long)W;
@@ -1010,29 +1231,37 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
         MVS_REQUIRE((long long)(D - 1) * sD + (long long)(H - 1) * sH + W < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
     }
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
+    const BfOut dst = make_out(out, out_scl, out_pscl, N, Cout, D, H, W);
     dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
     hipStream_t st = (hipStream_t)stream;
-#define MVS_BF_CASE(TD_, TH_, F32_, ...)                                                                                    \
+#define MVS_BF_CASE(TD_, TH_, F32_, TW_, SUBP_)                                                                             \
     {                                                                                                                       \
-        constexpr int TW_ = (0, ##__VA_ARGS__) ? (0, ##__VA_ARGS__) : kBfW;                                                 \
-        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_, TW_>;                                                             \
-        const size_t lds = bf_lds_bytes(TD_, TH_, TW_);                                                                     \
+        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_, TW_, SUBP_>;                                                      \
+        const size_t lds = bf_lds_bytes(TD_, TH_, TW_, SUBP_);                                                              \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
             hipSuccess) {                                                                                                   \
             set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                  \
             return MVSDET_ERR_HIP;                                                                                          \
         }                                                                                                                   \
         hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH,      \
-                           Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W,    \
+                           Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W,    \
                            p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total);        \
     }
+    // option "conv_subpairs" = 2: weight sub-stages of 2 tap pairs (instead of 5) bring the 3 x 16 x 8 tile's LDS to 77 KiB, two
+    // 6-wave blocks per CU.  Measured at the cost network's 6 x 30 x 40 layer: 1.00 against 0.97 ms -- seven barriers per
+    // channel group cost what the second block wins; kept as a knob, off by default.
+    const bool sub2 = options().conv_subpairs == 2;
     if (xf) {
-        if (p.tw == 8 && p.td == 3) MVS_BF_CASE(3, 16, true, 8)
-        else if (p.tw == 8) MVS_BF_CASE(8, 8, true, 8)
-        else if (p.th == 12) MVS_BF_CASE(4, 12, true)
-        else MVS_BF_CASE(4, 8, true)
+        if (p.tw == 8 && p.td == 3) { if (sub2) MVS_BF_CASE(3, 16, true, 8, 2) else MVS_BF_CASE(3, 16, true, 8, 5) }
+        else if (p.tw == 8 && p.td == 6) MVS_BF_CASE(6, 16, true, 8, 5)
+        else if (p.tw == 8) MVS_BF_CASE(8, 8, true, 8, 5)
+        else if (p.th == 12) MVS_BF_CASE(4, 12, true, kBfW, 5)
+        else MVS_BF_CASE(4, 8, true, kBfW, 5)
     } else {
-        if (p.th == 12) MVS_BF_CASE(4, 12, false) else MVS_BF_CASE(4, 8, false)
+        if (p.tw == 8 && p.td == 3) MVS_BF_CASE(3, 16, false, 8, 5)
+        else if (p.tw == 8) MVS_BF_CASE(6, 16, false, 8, 5)
+        else if (p.th == 12) MVS_BF_CASE(4, 12, false, kBfW, 5)
+        else MVS_BF_CASE(4, 8, false, kBfW, 5)
     }
 #undef MVS_BF_CASE
     MVS_LAUNCH_CHECK(name);
@@ -1044,39 +1273,49 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
 }
 
 // Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ per-channel affine] [+ residual] [+ ReLU] on the
-// bf16 matrix cores, three-term split (file header).  xs: SCL input (mvsdet_scl_pack_f32); weight_split: the weights cut
-// and permuted (mvsdet_split_conv_weight) to [Cout/64][Cin8][14 tap pairs][2 row groups][2 pieces][64 lanes][8] bf16 (lane =
-// 32*(tap parity) + output channel % 32; tap 27 zero; channels beyond Cin zero); out: (N,Cout,D,H,W) fp32.
+// bf16 matrix cores, three-term split (file header).  Input: xs = SCL form (mvsdet_scl_pack_f32 or a producing layer's
+// out_scl), or x = the fp32 tensor itself (x_strides = element strides of n, c, d, h; w stride 1; NULL = contiguous), cut
+// inside the kernel -- same results bit for bit.  weight_split: mvsdet_split_conv_weight.  Outputs, any combination (NULL =
+// not wanted): out_f32 (N,Cout,D,H,W); out_scl = its SCL form; out_pscl = its parity-split SCL form (their buffers'
+// borders must be zero: the kernel writes interior voxels only).  workspace (mvsdet_conv3d_k3_bf16x3_workspace_bytes; NULL
+// or too small: unsplit) is only used when out_f32 is the sole output.
+extern "C" int mvsdet_conv3d_k3_bf16x3_io(const void* xs, const float* x, const int64_t* x_strides, const void* weight_split,
+                                          const float* scale, const float* shift, const float* residual, float* out_f32,
+                                          void* out_scl, void* out_pscl, void* workspace, size_t workspace_bytes, int N, int Cin,
+                                          int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
+    MVS_REQUIRE((xs == nullptr) != (x == nullptr), "conv3d_k3_bf16x3_io: exactly one of xs (SCL) and x (fp32)");
+    return launch_bf16x3("conv3d_k3_bf16x3_io", xs, x, x_strides, weight_split, scale, shift, residual, out_f32, out_scl, out_pscl, N,
+                         Cin, Cout, D, H, W, relu, stream, workspace, workspace_bytes);
+}
+
 extern "C" int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
                                        const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W, int relu,
                                        mvsdet_stream_t stream) {
-    return launch_bf16x3("conv3d_k3_bf16x3", xs, nullptr, nullptr, weight_split, scale, shift, residual, out, N, Cin, Cout, D, H, W,
-                         relu, stream);
+    return launch_bf16x3("conv3d_k3_bf16x3", xs, nullptr, nullptr, weight_split, scale, shift, residual, out, nullptr, nullptr, N, Cin,
+                         Cout, D, H, W, relu, stream);
 }
 
-// The same convolution reading the fp32 tensor x (N,Cin,D,H,W) directly (x_strides = element strides of n, c, d, h; w
-// stride 1; NULL = contiguous): the operands are cut into their bf16 pieces inside the kernel -- same results bit for bit.
 extern "C" int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_strides, const void* weight_split,
                                              const float* scale, const float* shift, const float* residual, float* out, int N,
                                              int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
-    return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, N, Cin, Cout, D,
-                         H, W, relu, stream);
+    return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, nullptr, nullptr,
+                         N, Cin, Cout, D, H, W, relu, stream);
 }
 
 // The two forms with a workspace (mvsdet_conv3d_k3_bf16x3_workspace_bytes; NULL or too small: unsplit) for small volumes.
 extern "C" int mvsdet_conv3d_k3_bf16x3_ws(const void* xs, const void* weight_split, const float* scale, const float* shift,
                                           const float* residual, float* out, void* workspace, size_t workspace_bytes, int N, int Cin,
                                           int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
-    return launch_bf16x3("conv3d_k3_bf16x3", xs, nullptr, nullptr, weight_split, scale, shift, residual, out, N, Cin, Cout, D, H, W,
-                         relu, stream, workspace, workspace_bytes);
+    return launch_bf16x3("conv3d_k3_bf16x3", xs, nullptr, nullptr, weight_split, scale, shift, residual, out, nullptr, nullptr, N, Cin,
+                         Cout, D, H, W, relu, stream, workspace, workspace_bytes);
 }
 
 extern "C" int mvsdet_conv3d_k3_bf16x3_f32in_ws(const float* x, const int64_t* x_strides, const void* weight_split,
                                                 const float* scale, const float* shift, const float* residual, float* out,
                                                 void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int D, int H,
                                                 int W, int relu, mvsdet_stream_t stream) {
-    return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, N, Cin, Cout, D,
-                         H, W, relu, stream, workspace, workspace_bytes);
+    return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, nullptr, nullptr,
+                         N, Cin, Cout, D, H, W, relu, stream, workspace, workspace_bytes);
 }
 
 // Conv3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] of mvsnet.py:77,79 on the bf16 matrix
@@ -1090,21 +1329,24 @@ extern "C" size_t mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes(int N, int Cin, int
     return ns > 1 ? (size_t)ns * N * Cout * D * H * W * sizeof(float) : 0;
 }
 
-static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void* weight_split, const float* scale,
-                            const float* shift, float* out, void* workspace, size_t workspace_bytes, int N, int Cin, int Cout,
-                            int Di, int Hi, int Wi, int relu, mvsdet_stream_t stream) {
-    const char* name = "conv3d_k3_s2_bf16x3_f32in";
-    MVS_REQUIRE(x && weight_split && out, "%s: NULL pointer", name);
+static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void* x_pscl, const void* weight_split, const float* scale,
+                            const float* shift, float* out, void* out_scl, void* workspace, size_t workspace_bytes, int N, int Cin,
+                            int Cout, int Di, int Hi, int Wi, int relu, mvsdet_stream_t stream) {
+    const char* name = x_pscl ? "conv3d_k3_s2_bf16x3 (PSCL input)" : "conv3d_k3_s2_bf16x3_f32in";
+    MVS_REQUIRE((x == nullptr) != (x_pscl == nullptr), "conv3d_k3_s2_bf16x3: exactly one of x (fp32) and x_pscl");
+    MVS_REQUIRE(weight_split && (out || out_scl), "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && Di > 0 && Hi > 0 && Wi > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, Di, Hi, Wi);
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
-    MVS_REQUIRE(((uintptr_t)weight_split & 15u) == 0, "%s: weights must be 16-byte aligned", name);
+    MVS_REQUIRE((((uintptr_t)weight_split | (uintptr_t)x_pscl | (uintptr_t)out_scl) & 15u) == 0, "%s: SCL buffers and weights must be 16-byte aligned", name);
     const int D = (Di - 1) / 2 + 1, H = (Hi - 1) / 2 + 1, W = (Wi - 1) / 2 + 1;
     const size_t ivol = (size_t)Di * Hi * Wi;
     const long long sN = x_strides ? x_strides[0] : (long long)Cin * ivol, sC = x_strides ? x_strides[1] : (long long)ivol;
     const long long sD = x_strides ? x_strides[2] : (long long)Hi * Wi, sH = x_strides ? x_strides[3] : (long long)Wi;
-    MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= Wi, "%s: bad strides", name);
-    MVS_REQUIRE((long long)(Di - 1) * sD + (long long)(Hi - 1) * sH + Wi < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
+    if (x) {
+        MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= Wi, "%s: bad strides", name);
+        MVS_REQUIRE((long long)(Di - 1) * sD + (long long)(Hi - 1) * sH + Wi < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
+    }
     // output tile 4 x 8 x 16 or 3 x 16 x 8, whichever pads (D, H, W) less; the number of splits follows from the former
     const long long tiles416 = (long long)((W + kBfW - 1) / kBfW) * ((H + kS2TH - 1) / kS2TH) * ((D + kS2TD - 1) / kS2TD);
     const long long pad416 = tiles416 * (kS2TD * kS2TH * kBfW);
@@ -1114,12 +1356,20 @@ static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void
     const int tiles_w = (W + ttw - 1) / ttw, tiles_h = (H + tth - 1) / tth, tiles_d = (D + ttd - 1) / ttd;
     const size_t total = (size_t)N * Cout * D * H * W;
     int nsplit = bf_nsplit(tiles416 * N * (Cout / 64), (Cin + 7) / 8);
-    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float)) nsplit = 1;   // unsplit without (enough) workspace
+    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float) || out_scl) nsplit = 1;   // unsplit without (enough) workspace
+    MVS_REQUIRE(nsplit == 1 || out, "%s: the split form needs the fp32 output", name);
     MVS_REQUIRE((long long)N * (Cout / 64) * nsplit <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    int cDp = 0, cHp = 0, cWp = 0;
+    pscl_dims(Di, Hi, Wi, cDp, cHp, cWp);
+    MVS_REQUIRE(!x_pscl || (tiles_d * ttd + 2 <= cDp && tiles_h * tth + 2 <= cHp && tiles_w * ttw + 2 <= cWp),
+                "%s: the PSCL padding does not cover the tiles", name);
+    const int C8 = (Cin + 7) / 8;
+    const size_t cpiece = (size_t)8 * N * C8 * cDp * cHp * cWp;
+    const BfOut dst = make_out(out, out_scl, nullptr, N, Cout, D, H, W);
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
-#define MVS_S2_CASE(TD_, TH_, TW_)                                                                                           \
+#define MVS_S2_CASE(TD_, TH_, TW_, PIN_)                                                                                     \
     {                                                                                                                        \
-        auto* k = conv3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_>;                                                                 \
+        auto* k = conv3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_, PIN_>;                                                           \
         const size_t lds = s2_lds_bytes(TD_, TH_, TW_);                                                                      \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
             hipSuccess) {                                                                                                    \
@@ -1127,10 +1377,12 @@ static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void
             return MVSDET_ERR_HIP;                                                                                           \
         }                                                                                                                    \
         hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,                 \
-                           static_cast<const uint4*>(weight_split), scale, shift, out, (Cin + 7) / 8, Cout, Di, Hi, Wi, D, H, W, \
+                           static_cast<const uint4*>(x_pscl), cDp, cHp, cWp, cpiece, N,                                      \
+                           static_cast<const uint4*>(weight_split), scale, shift, dst, C8, Cout, Di, Hi, Wi, D, H, W,        \
                            tiles_w, relu, nsplit, static_cast<float*>(workspace), total);                                    \
     }
-    if (t38) MVS_S2_CASE(3, 16, 8) else MVS_S2_CASE(kS2TD, kS2TH, kBfW)
+    if (x_pscl) { if (t38) MVS_S2_CASE(3, 16, 8, true) else MVS_S2_CASE(kS2TD, kS2TH, kBfW, true) }
+    else { if (t38) MVS_S2_CASE(3, 16, 8, false) else MVS_S2_CASE(kS2TD, kS2TH, kBfW, false) }
 #undef MVS_S2_CASE
     MVS_LAUNCH_CHECK(name);
     if (nsplit > 1) {
@@ -1144,7 +1396,8 @@ static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void
 extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in(const float* x, const int64_t* x_strides, const void* weight_split,
                                                 const float* scale, const float* shift, float* out, int N, int Cin, int Cout,
                                                 int Di, int Hi, int Wi, int relu, mvsdet_stream_t stream) {
-    return launch_s2_bf16x3(x, x_strides, weight_split, scale, shift, out, nullptr, 0, N, Cin, Cout, Di, Hi, Wi, relu, stream);
+    return launch_s2_bf16x3(x, x_strides, nullptr, weight_split, scale, shift, out, nullptr, nullptr, 0, N, Cin, Cout, Di, Hi, Wi, relu,
+                            stream);
 }
 
 // with a workspace (mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes; NULL or too small: unsplit) for small volumes
@@ -1152,31 +1405,40 @@ extern "C" int mvsdet_conv3d_k3_s2_bf16x3_f32in_ws(const float* x, const int64_t
                                                    const float* scale, const float* shift, float* out, void* workspace,
                                                    size_t workspace_bytes, int N, int Cin, int Cout, int Di, int Hi, int Wi, int relu,
                                                    mvsdet_stream_t stream) {
-    return launch_s2_bf16x3(x, x_strides, weight_split, scale, shift, out, workspace, workspace_bytes, N, Cin, Cout, Di, Hi, Wi, relu,
-                            stream);
+    return launch_s2_bf16x3(x, x_strides, nullptr, weight_split, scale, shift, out, nullptr, workspace, workspace_bytes, N, Cin, Cout, Di,
+                            Hi, Wi, relu, stream);
+}
+
+// The general form: input = the fp32 tensor x (x_strides) or its parity-split SCL form x_pscl (a producing layer's out_pscl:
+// the class tiles then arrive by LDS-DMA); outputs out_f32 and / or out_scl (SCL form of the (N,Cout,D,H,W) result, zero border).
+extern "C" int mvsdet_conv3d_k3_s2_bf16x3_io(const float* x, const int64_t* x_strides, const void* x_pscl, const void* weight_split,
+                                             const float* scale, const float* shift, float* out_f32, void* out_scl, void* workspace,
+                                             size_t workspace_bytes, int N, int Cin, int Cout, int Di, int Hi, int Wi, int relu,
+                                             mvsdet_stream_t stream) {
+    return launch_s2_bf16x3(x, x_strides, x_pscl, weight_split, scale, shift, out_f32, out_scl, workspace, workspace_bytes, N, Cin, Cout,
+                            Di, Hi, Wi, relu, stream);
 }
 
 // ConvTranspose3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine] [+ ReLU] [+ residual,
 // added last] of mvsnet.py:92-100,110-111 on the bf16 matrix cores, three-term split.  xs: SCL form of the input (N,Cin,D,H,W)
-// (mvsdet_scl_pack_f32); weight_split: mvsdet_split_conv_weight_ordered(order = 2) of the (Cin,Cout,3,3,3) weight;
-// out / residual (N,Cout,2D,2H,2W) fp32, 8-byte aligned.
-extern "C" int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
-                                           const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W,
-                                           int relu, mvsdet_stream_t stream) {
+// (mvsdet_scl_pack_f32 or a producing layer's out_scl); weight_split: mvsdet_split_conv_weight_ordered(order = 2) of the
+// (Cin,Cout,3,3,3) weight; out_f32 / residual (N,Cout,2D,2H,2W) fp32, 8-byte aligned; out_scl: the SCL form of the result.
+static int launch_convT(const void* xs, const void* weight_split, const float* scale, const float* shift, const float* residual,
+                        float* out, void* out_scl, int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
     const char* name = "convT3d_k3_s2_bf16x3";
-    MVS_REQUIRE(xs && weight_split && out, "%s: NULL pointer", name);
+    MVS_REQUIRE(xs && weight_split && (out || out_scl), "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
-    MVS_REQUIRE((((uintptr_t)xs | (uintptr_t)weight_split) & 15u) == 0, "%s: xs and weights must be 16-byte aligned", name);
+    MVS_REQUIRE((((uintptr_t)xs | (uintptr_t)weight_split | (uintptr_t)out_scl) & 15u) == 0, "%s: SCL buffers and weights must be 16-byte aligned", name);
     MVS_REQUIRE(((uintptr_t)out & 7u) == 0 && (residual == nullptr || ((uintptr_t)residual & 7u) == 0),
                 "%s: out and residual must be 8-byte aligned", name);
-    const BfPlan p = bf_plan(D, H, W);   // the padded extents of the SCL input (its tile height may be 12: the extents only grow)
+    const BfPlan p = bf_plan(D, H, W);   // the padded extents of the SCL input
     const int C8 = (Cin + 7) / 8;
-    // input tile 4 x 8 x 16, or 3 x 16 x 8 where that pads (D, H, W) less and the SCL padding covers it
+    // input tile 4 x 8 x 16, or 3 x 16 x 8 where that pads (D, H, W) less
     const long long pad416 = (long long)((W + kBfW - 1) / kBfW) * kBfW * ((H + kS2TH - 1) / kS2TH) * kS2TH * ((D + kS2TD - 1) / kS2TD) * kS2TD;
     const long long pad38 = (long long)((W + 7) / 8) * 8 * ((H + 15) / 16) * 16 * ((D + 2) / 3) * 3;
-    const bool t38 = pad38 < pad416 && (D + 2) / 3 * 3 + 2 <= p.Dp && (H + 15) / 16 * 16 + 2 <= p.Hp && (W + 7) / 8 * 8 + 2 <= p.Wp;
+    const bool t38 = pad38 < pad416;
     const int ttd = t38 ? 3 : kS2TD, tth = t38 ? 16 : kS2TH, ttw = t38 ? 8 : kBfW;
     const int tiles_w = (W + ttw - 1) / ttw, tiles_h = (H + tth - 1) / tth, tiles_d = (D + ttd - 1) / ttd;
     // the halo tile reaches one voxel past the last tile: padded index tiles*T + 1 must exist
@@ -1184,6 +1446,7 @@ extern "C" int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_sp
                 "%s: the SCL padding does not cover the tiles", name);
     MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
+    const BfOut dst = make_out(out, out_scl, nullptr, N, Cout, 2 * D, 2 * H, 2 * W);
     dim3 grid((unsigned)(tiles_w * tiles_h * 4), (unsigned)tiles_d, (unsigned)(N * (Cout / 64)));
     hipStream_t st = (hipStream_t)stream;
 #define MVS_CT_CASE(TD_, TH_, TW_)                                                                                           \
@@ -1196,11 +1459,23 @@ extern "C" int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_sp
             return MVSDET_ERR_HIP;                                                                                           \
         }                                                                                                                    \
         hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, st, static_cast<const uint4*>(xs),                           \
-                           static_cast<const uint4*>(weight_split), scale, shift, residual, out, C8, Cout, D, H, W, p.Dp, p.Hp, \
+                           static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, \
                            p.Wp, piece, tiles_w, relu);                                                                      \
     }
     if (t38) MVS_CT_CASE(3, 16, 8) else MVS_CT_CASE(kS2TD, kS2TH, kBfW)
 #undef MVS_CT_CASE
     MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
+}
+
+extern "C" int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                           const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W,
+                                           int relu, mvsdet_stream_t stream) {
+    return launch_convT(xs, weight_split, scale, shift, residual, out, nullptr, N, Cin, Cout, D, H, W, relu, stream);
+}
+
+extern "C" int mvsdet_convT3d_k3_s2_bf16x3_io(const void* xs, const void* weight_split, const float* scale, const float* shift,
+                                              const float* residual, float* out_f32, void* out_scl, int N, int Cin, int Cout, int D,
+                                              int H, int W, int relu, mvsdet_stream_t stream) {
+    return launch_convT(xs, weight_split, scale, shift, residual, out_f32, out_scl, N, Cin, Cout, D, H, W, relu, stream);
 }

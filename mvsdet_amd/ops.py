@@ -703,10 +703,16 @@ def _tap_table(order: int):
     return t
 
 
+# MFMA row m of a row group carries output channel ROW_CHANNEL[m] (csrc/costreg_bf16.hip: bf_mfma_row_channel): a lane's
+# accumulator registers 8q..8q+7 are then eight consecutive channels, i.e. one 16-byte unit of the SCL form
+ROW_CHANNEL = [8 * ((m >> 4) * 2 + ((m >> 2) & 1)) + (m & 3) + 4 * ((m >> 3) & 1) for m in range(32)]
+
+
 def split_conv_weight(weight: Tensor, order: int = 0) -> Tensor:
     """Conv3d weight (Cout = 64*m, Cin, 3,3,3) fp32 -> the layout the bf16x3 kernels stream into LDS (include/mvsdet_hip.h):
     [Cout/64][ceil(Cin/8)][14 tap pairs][2 row groups][2 pieces][64 lanes][8 channels] bf16, lane = 32*(half of the pair) +
-    output % 32; empty halves and the channels beyond Cin are zero.  order 0: stride-1 convolution (pair p = taps 2p, 2p+1);
+    MFMA row m (which carries output ROW_CHANNEL[m] of its group of 32); empty halves and the channels beyond Cin are zero.
+    order 0: stride-1 convolution (pair p = taps 2p, 2p+1);
     1: stride-2 convolution (pairs grouped by the parity class of the input voxel); 2: `weight` is a ConvTranspose3d weight
     (Cin, Cout = 64*m, 3,3,3), pairs grouped by the parity class of the output voxel.  On a ROCm device this is ONE small
     kernel (run per call: in-place weight updates are always seen); on the CPU the same layout from torch ops (tests)."""
@@ -730,8 +736,8 @@ def split_conv_weight(weight: Tensor, order: int = 0) -> Tensor:
     w = torch.where(taps.view(1, 1, 28) >= 0, w[:, :, taps.clamp(min=0)], torch.zeros(()))   # (Cout, Cin, 28) in pair order
     w = torch.nn.functional.pad(w, (0, 0, 0, c8 * 8 - cin))                                  # channels -> 8*c8
     pieces = torch.stack(split_bf16(w), 0)                                                  # (piece, Cout, C, 28)
-    # (piece, ob, a, r, c8, j, p, h) -> (ob, c8, p, a, piece, h, r, j)
-    pieces = pieces.reshape(2, cout // 64, 2, 32, c8, 8, 14, 2).permute(1, 4, 6, 2, 0, 7, 3, 5)
+    # (piece, ob, a, m, c8, j, p, h) with row m <- channel ROW_CHANNEL[m]  -> (ob, c8, p, a, piece, h, m, j)
+    pieces = pieces.reshape(2, cout // 64, 2, 32, c8, 8, 14, 2)[:, :, :, torch.tensor(ROW_CHANNEL)].permute(1, 4, 6, 2, 0, 7, 3, 5)
     return pieces.contiguous().reshape(cout // 64, c8, 14, 2, 2, 64, 8)
 
 
@@ -751,6 +757,38 @@ class SclTensor:
         v = v.permute(0, 1, 2, 6, 3, 4, 5).reshape(2, n, c8 * 8, d, h, w)
         return v[0], v[1]
 
+    def border_is_zero(self) -> bool:
+        """Everything outside the interior voxels (tests: a producing kernel must not write there)."""
+        n, c, d, h, w = self.shape
+        dp, hp, wp = self.padded
+        v = self.data.view(2, n, (c + 7) // 8, dp, hp, wp, 8).clone()
+        v[:, :, :, 1:d + 1, 1:h + 1, 1:w + 1] = 0
+        return not bool(v.view(torch.int16).any())
+
+
+class PsclTensor:
+    """The parity-split SCL form (include/mvsdet_hip.h): flat bfloat16 buffer [2][8 classes][N][ceil(C/8)][cDp][cHp][cWp][8];
+    class = 4*(d&1) + 2*(h&1) + (w&1), voxel (d,h,w) at index (d//2 + 1, h//2 + 1, w//2 + 1) of its class."""
+
+    def __init__(self, data: Tensor, shape, padded):
+        self.data, self.shape, self.padded = data, tuple(int(v) for v in shape), tuple(int(v) for v in padded)
+
+    def pieces(self):
+        """(hi, mid) as (N, C8*8, D, H, W) bfloat16 tensors, and whether everything else in the buffer is zero -- for tests."""
+        n, c, d, h, w = self.shape
+        c8 = (c + 7) // 8
+        dp, hp, wp = self.padded
+        v = self.data.view(2, 8, n, c8, dp, hp, wp, 8)
+        out = torch.zeros((2, n, c8, d, h, w, 8), dtype=torch.bfloat16, device=self.data.device)
+        rest = v.clone()
+        for cls in range(8):
+            pd, ph, pw = cls >> 2, (cls >> 1) & 1, cls & 1
+            nd, nh, nw = (d - pd + 1) // 2, (h - ph + 1) // 2, (w - pw + 1) // 2
+            out[:, :, :, pd::2, ph::2, pw::2] = v[:, cls, :, :, 1:nd + 1, 1:nh + 1, 1:nw + 1]
+            rest[:, cls, :, :, 1:nd + 1, 1:nh + 1, 1:nw + 1] = 0
+        out = out.permute(0, 1, 2, 6, 3, 4, 5).reshape(2, n, c8 * 8, d, h, w)
+        return out[0], out[1], not bool(rest.view(torch.int16).any())
+
 
 def scl_geometry(N: int, C: int, D: int, H: int, W: int):
     """(bytes, (Dp, Hp, Wp)) of the SCL form of an (N,C,D,H,W) activation."""
@@ -758,6 +796,43 @@ def scl_geometry(N: int, C: int, D: int, H: int, W: int):
     dp, hp, wp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     nbytes = _lib.load().mvsdet_scl_bytes(N, C, D, H, W, ctypes.byref(dp), ctypes.byref(hp), ctypes.byref(wp))
     return int(nbytes), (dp.value, hp.value, wp.value)
+
+
+def pscl_geometry(N: int, C: int, D: int, H: int, W: int):
+    """(bytes, (cDp, cHp, cWp)) of the parity-split SCL form of an (N,C,D,H,W) activation."""
+    import ctypes
+    dp, hp, wp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    nbytes = _lib.load().mvsdet_pscl_bytes(N, C, D, H, W, ctypes.byref(dp), ctypes.byref(hp), ctypes.byref(wp))
+    return int(nbytes), (dp.value, hp.value, wp.value)
+
+
+def scl_empty(shape, device) -> SclTensor:
+    """A zeroed SCL buffer for an (N,C,D,H,W) result: a producing convolution fills the interior, the border stays zero."""
+    nbytes, padded = scl_geometry(*[int(v) for v in shape])
+    return SclTensor(torch.zeros((nbytes // 2,), dtype=torch.bfloat16, device=device), shape, padded)
+
+
+def pscl_empty(shape, device) -> PsclTensor:
+    nbytes, padded = pscl_geometry(*[int(v) for v in shape])
+    return PsclTensor(torch.zeros((nbytes // 2,), dtype=torch.bfloat16, device=device), shape, padded)
+
+
+def pscl_from_tensor(x: Tensor) -> PsclTensor:
+    """(N,C,D,H,W) fp32 -> PsclTensor with torch operators (tests and tools: in the product the form is written by the
+    producing convolution's epilogue)."""
+    n, c, d, h, w = x.shape
+    c8 = (c + 7) // 8
+    out = pscl_empty(x.shape, x.device)
+    dp, hp, wp = out.padded
+    v = out.data.view(2, 8, n, c8, dp, hp, wp, 8)
+    xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, 0, c8 * 8 - c))
+    for piece, t in enumerate(split_bf16(xp)):
+        t = t.view(n, c8, 8, d, h, w).permute(0, 1, 3, 4, 5, 2)           # (n, c8, d, h, w, 8)
+        for cls in range(8):
+            pd, ph, pw = cls >> 2, (cls >> 1) & 1, cls & 1
+            sub = t[:, :, pd::2, ph::2, pw::2]
+            v[piece, cls, :, :, 1:sub.shape[2] + 1, 1:sub.shape[3] + 1, 1:sub.shape[4] + 1] = sub
+    return out
 
 
 def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
@@ -779,12 +854,52 @@ def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
     return out
 
 
+def _check_affine(name, scale, shift, Cout):
+    if (scale is None) != (shift is None):
+        raise ValueError(f"{name}: scale and shift come together")
+    if scale is not None:
+        _req(scale, "scale", dim=1)
+        _req(shift, "shift", dim=1)
+        if scale.numel() != Cout or shift.numel() != Cout:
+            raise ValueError(f"{name}: scale / shift must have {Cout} elements")
+        return scale.contiguous(), shift.contiguous()
+    return None, None
+
+
+def _conv_outputs(name, outputs, shape, dev, scl_out, pscl_out, allow_pscl=True):
+    """The output buffers a convolution was asked for: `outputs` is a sequence out of "f32", "scl", "pscl" (order = order of
+    the returned values); `scl_out` / `pscl_out` are buffers of the same shape to refill (their borders are already zero)."""
+    if isinstance(outputs, str):
+        outputs = (outputs,)
+    bad = [o for o in outputs if o not in ("f32", "scl") + (("pscl",) if allow_pscl else ())]
+    if bad or not outputs:
+        raise ValueError(f"{name}: outputs {outputs!r}")
+    res = {}
+    if "f32" in outputs:
+        res["f32"] = torch.empty(shape, dtype=torch.float32, device=dev)
+    if "scl" in outputs:
+        ok = scl_out is not None and scl_out.shape == tuple(shape) and scl_out.data.device == dev
+        res["scl"] = scl_out if ok else scl_empty(shape, dev)
+    if "pscl" in outputs:
+        ok = pscl_out is not None and pscl_out.shape == tuple(shape) and pscl_out.data.device == dev
+        res["pscl"] = pscl_out if ok else pscl_empty(shape, dev)
+    return outputs, res
+
+
+def _ret(outputs, res):
+    vals = tuple(res[o] for o in outputs)
+    return vals[0] if len(vals) == 1 else vals
+
+
 def conv3d_k3_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
-                     residual: Optional[Tensor] = None) -> Tensor:
+                     residual: Optional[Tensor] = None, outputs=("f32",), scl_out: Optional[SclTensor] = None,
+                     pscl_out: Optional[PsclTensor] = None):
     """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 1, padding 1, no bias) [+ affine] [+ residual] [+ ReLU] on the bf16
-    matrix cores with three-term split operands (csrc/costreg_bf16.hip) -> (N,Cout,D,H,W) fp32.
+    matrix cores with three-term split operands (csrc/costreg_bf16.hip).
     x: the fp32 (N,Cin,D,H,W) tensor itself (any view with w stride 1: cut into pieces inside the kernel, no extra pass) or
-    its SclTensor form (scl_pack) -- identical results."""
+    its SclTensor form (scl_pack, or a producing layer's "scl" output) -- identical results.
+    outputs: any of "f32" (the (N,Cout,D,H,W) tensor), "scl" (SclTensor: already cut for a stride-1 / transposed consumer),
+    "pscl" (PsclTensor: for a stride-2 consumer); one value or a tuple in that order is returned."""
     import ctypes
     scl = isinstance(x, SclTensor)
     if scl:
@@ -799,102 +914,90 @@ def conv3d_k3_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Op
     if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
         raise ValueError(f"conv3d_k3_bf16x3: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
     Cout = weight_split.shape[0] * 64
-    if (scale is None) != (shift is None):
-        raise ValueError("conv3d_k3_bf16x3: scale and shift come together")
-    if scale is not None:
-        _req(scale, "scale", dim=1)
-        _req(shift, "shift", dim=1)
-        if scale.numel() != Cout or shift.numel() != Cout:
-            raise ValueError(f"conv3d_k3_bf16x3: scale / shift must have {Cout} elements")
-        scale, shift = scale.contiguous(), shift.contiguous()
-    out = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=dev)
+    scale, shift = _check_affine("conv3d_k3_bf16x3", scale, shift, Cout)
+    outputs, res = _conv_outputs("conv3d_k3_bf16x3", outputs, (N, Cout, D, H, W), dev, scl_out, pscl_out)
     if residual is not None:
         _req(residual, "residual", dim=5)
-        if tuple(residual.shape) != tuple(out.shape):
-            raise ValueError(f"conv3d_k3_bf16x3: residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+        if tuple(residual.shape) != (N, Cout, D, H, W):
+            raise ValueError(f"conv3d_k3_bf16x3: residual {tuple(residual.shape)} != output {(N, Cout, D, H, W)}")
         residual = residual.contiguous()
     weight_split = weight_split.contiguous()
     lib = _lib.load()
-    # small volumes: partial sums of the input-channel splits (0 bytes: the grid fills the chip unsplit)
-    wbytes = lib.mvsdet_conv3d_k3_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W)
+    # small volumes: partial sums of the input-channel splits (0 bytes: the grid fills the chip unsplit); fp32 output only
+    wbytes = lib.mvsdet_conv3d_k3_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W) if tuple(outputs) == ("f32",) else 0
     ws = torch.empty((wbytes // 4,), dtype=torch.float32, device=dev) if wbytes else None
+    xstr = None if scl else (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
     with torch.cuda.device(dev):
-        if scl:
-            _lib.check(lib.mvsdet_conv3d_k3_bf16x3_ws(_lib.ptr(x.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
-                                                      _lib.ptr(residual), _lib.ptr(out), _lib.ptr(ws), wbytes, N, Cin, Cout, D, H, W,
-                                                      int(relu), _stream(out)), "conv3d_k3_bf16x3")
-        else:
-            xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
-            _lib.check(lib.mvsdet_conv3d_k3_bf16x3_f32in_ws(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale),
-                                                            _lib.ptr(shift), _lib.ptr(residual), _lib.ptr(out), _lib.ptr(ws), wbytes,
-                                                            N, Cin, Cout, D, H, W, int(relu), _stream(out)), "conv3d_k3_bf16x3_f32in")
-    return out
+        _lib.check(lib.mvsdet_conv3d_k3_bf16x3_io(_lib.ptr(x.data) if scl else None, None if scl else _lib.ptr(x), xstr,
+                                                  _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual),
+                                                  _lib.ptr(res.get("f32")), _lib.ptr(res["scl"].data) if "scl" in res else None,
+                                                  _lib.ptr(res["pscl"].data) if "pscl" in res else None, _lib.ptr(ws), wbytes,
+                                                  N, Cin, Cout, D, H, W, int(relu), _lib.current_stream(dev)), "conv3d_k3_bf16x3")
+    return _ret(outputs, res)
 
 
-def conv3d_k3_s2_bf16x3(x: Tensor, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool) -> Tensor:
+def conv3d_k3_s2_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
+                        outputs=("f32",), scl_out: Optional[SclTensor] = None):
     """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] (mvsnet.py:77,79) on the bf16
-    matrix cores, three-term split: x (N,Cin,D,H,W) fp32 (w stride 1) -> (N,Cout,(D-1)//2+1,(H-1)//2+1,(W-1)//2+1);
+    matrix cores, three-term split: x (N,Cin,D,H,W) fp32 (w stride 1) or its PsclTensor form (a producing layer's "pscl"
+    output: the class tiles then arrive by LDS-DMA) -> (N,Cout,(D-1)//2+1,(H-1)//2+1,(W-1)//2+1) as "f32" and / or "scl";
     weight_split = split_conv_weight(weight, order=1)."""
     import ctypes
-    _req(x, "x", dim=5)
-    if x.stride(4) != 1 or min(x.stride()) < 0:
-        x = x.contiguous()
-    N, Cin, D, H, W = x.shape
+    pin = isinstance(x, PsclTensor)
+    if pin:
+        N, Cin, D, H, W = x.shape
+        dev = x.data.device
+    else:
+        _req(x, "x", dim=5)
+        if x.stride(4) != 1 or min(x.stride()) < 0:
+            x = x.contiguous()
+        N, Cin, D, H, W = x.shape
+        dev = x.device
     if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
         raise ValueError(f"conv3d_k3_s2_bf16x3: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
     Cout = weight_split.shape[0] * 64
-    if (scale is None) != (shift is None):
-        raise ValueError("conv3d_k3_s2_bf16x3: scale and shift come together")
-    if scale is not None:
-        _req(scale, "scale", dim=1)
-        _req(shift, "shift", dim=1)
-        if scale.numel() != Cout or shift.numel() != Cout:
-            raise ValueError(f"conv3d_k3_s2_bf16x3: scale / shift must have {Cout} elements")
-        scale, shift = scale.contiguous(), shift.contiguous()
-    out = torch.empty((N, Cout, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    scale, shift = _check_affine("conv3d_k3_s2_bf16x3", scale, shift, Cout)
+    oshape = (N, Cout, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    outputs, res = _conv_outputs("conv3d_k3_s2_bf16x3", outputs, oshape, dev, scl_out, None, allow_pscl=False)
     weight_split = weight_split.contiguous()
-    xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
+    xstr = None if pin else (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
     lib = _lib.load()
-    wbytes = lib.mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W)   # small volumes: input-channel splits
-    ws = torch.empty((wbytes // 4,), dtype=torch.float32, device=x.device) if wbytes else None
-    with torch.cuda.device(x.device):
-        _lib.check(lib.mvsdet_conv3d_k3_s2_bf16x3_f32in_ws(_lib.ptr(x), xstr, _lib.ptr(weight_split), _lib.ptr(scale),
-                                                           _lib.ptr(shift), _lib.ptr(out), _lib.ptr(ws), wbytes, N, Cin, Cout, D, H, W,
-                                                           int(relu), _stream(x)), "conv3d_k3_s2_bf16x3")
-    return out
+    wbytes = lib.mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W) if tuple(outputs) == ("f32",) else 0   # small volumes
+    ws = torch.empty((wbytes // 4,), dtype=torch.float32, device=dev) if wbytes else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.mvsdet_conv3d_k3_s2_bf16x3_io(None if pin else _lib.ptr(x), xstr, _lib.ptr(x.data) if pin else None,
+                                                     _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res.get("f32")),
+                                                     _lib.ptr(res["scl"].data) if "scl" in res else None, _lib.ptr(ws), wbytes, N, Cin,
+                                                     Cout, D, H, W, int(relu), _lib.current_stream(dev)), "conv3d_k3_s2_bf16x3")
+    return _ret(outputs, res)
 
 
 def convT3d_k3_s2_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor],
-                         residual: Optional[Tensor], relu: bool) -> Tensor:
+                         residual: Optional[Tensor], relu: bool, outputs=("f32",), scl_out: Optional[SclTensor] = None):
     """ConvTranspose3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, output_padding 1, no bias) [+ affine] [+ ReLU]
     [+ residual, added last] (mvsnet.py:92-100,110-111) on the bf16 matrix cores, three-term split: x (N,Cin,D,H,W) fp32 (or
-    its SclTensor) -> (N,Cout,2D,2H,2W); weight_split = split_conv_weight(weight (Cin,Cout,3,3,3), order=2)."""
+    its SclTensor) -> (N,Cout,2D,2H,2W) as "f32" and / or "scl"; weight_split = split_conv_weight(weight (Cin,Cout,3,3,3), order=2)."""
     xs = x if isinstance(x, SclTensor) else scl_pack(x)
     N, Cin, D, H, W = xs.shape
     if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
         raise ValueError(f"convT3d_k3_s2_bf16x3: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
     Cout = weight_split.shape[0] * 64
-    if (scale is None) != (shift is None):
-        raise ValueError("convT3d_k3_s2_bf16x3: scale and shift come together")
     dev = xs.data.device
-    if scale is not None:
-        _req(scale, "scale", dim=1)
-        _req(shift, "shift", dim=1)
-        if scale.numel() != Cout or shift.numel() != Cout:
-            raise ValueError(f"convT3d_k3_s2_bf16x3: scale / shift must have {Cout} elements")
-        scale, shift = scale.contiguous(), shift.contiguous()
-    out = torch.empty((N, Cout, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=dev)
+    scale, shift = _check_affine("convT3d_k3_s2_bf16x3", scale, shift, Cout)
+    oshape = (N, Cout, 2 * D, 2 * H, 2 * W)
+    outputs, res = _conv_outputs("convT3d_k3_s2_bf16x3", outputs, oshape, dev, scl_out, None, allow_pscl=False)
     if residual is not None:
         _req(residual, "residual", dim=5)
-        if tuple(residual.shape) != tuple(out.shape):
-            raise ValueError(f"convT3d_k3_s2_bf16x3: residual {tuple(residual.shape)} != output {tuple(out.shape)}")
+        if tuple(residual.shape) != oshape:
+            raise ValueError(f"convT3d_k3_s2_bf16x3: residual {tuple(residual.shape)} != output {oshape}")
         residual = residual.contiguous()
     weight_split = weight_split.contiguous()
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().mvsdet_convT3d_k3_s2_bf16x3(_lib.ptr(xs.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
-                                                           _lib.ptr(residual), _lib.ptr(out), N, Cin, Cout, D, H, W, int(relu),
-                                                           _stream(out)), "convT3d_k3_s2_bf16x3")
-    return out
+        _lib.check(_lib.load().mvsdet_convT3d_k3_s2_bf16x3_io(_lib.ptr(xs.data), _lib.ptr(weight_split), _lib.ptr(scale), _lib.ptr(shift),
+                                                              _lib.ptr(residual), _lib.ptr(res.get("f32")),
+                                                              _lib.ptr(res["scl"].data) if "scl" in res else None, N, Cin, Cout, D, H, W,
+                                                              int(relu), _lib.current_stream(dev)), "convT3d_k3_s2_bf16x3")
+    return _ret(outputs, res)
 
 
 # ------------------------------------------------------------------------------------------- misc

@@ -461,14 +461,14 @@ def g11_heads():
 
 def g12_cost_regularisation_grads():
     """mvs_models/mvsnet.py:73-113 CostRegNet_3DGS in TRAIN mode (BatchNorm on batch statistics) under autograd: LCG weights,
-    LCG input (2,256,4,8,16), loss = sum(logits * R) with LCG R.  Stored: the logits, the gradient of the input (sample) and of
+    LCG input (2,256,8,8,16), loss = sum(logits * R) with LCG R.  Stored: the logits, the gradient of the input (sample) and of
     EVERY parameter -- small tensors whole, large ones as every `stride`-th element of the flattened tensor plus their float64
     sum of squares -- and the BatchNorm running statistics after the step."""
     from lcg import lcg_fill_state, lcg_uniform
     mvsnet = sys.modules["refpkg.mvs_models.mvsnet"]
     torch.manual_seed(0)
     net = mvsnet.CostRegNet_3DGS().train()
-    shape = (2, 256, 4, 8, 16)
+    shape = (2, 256, 8, 8, 16)
     with torch.no_grad():
         lcg_fill_state(net, 12)
     x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), 120)).reshape(shape).abs().requires_grad_(True)
@@ -480,6 +480,8 @@ def g12_cost_regularisation_grads():
     for k, p in sorted(net.named_parameters()):
         g = p.grad.reshape(-1)
         stride = max(1, g.numel() // 8192)
+        while stride > 1 and (stride % 2 == 0 or stride % 3 == 0):   # coprime with the 27 taps and the channel counts: a stride
+            stride += 1                                               # of 108 would only ever sample tap (0,0,0)
         keys.append(k)
         out["g:" + k] = g[::stride].clone()
         out["n:" + k] = np.float64((g.double() ** 2).sum())

@@ -74,6 +74,28 @@ def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
     assert torch.equal(ops.conv3d_k3_bf16x3(pitched[..., :W], wq, scale.to(gpu), shift.to(gpu), True, res.to(gpu)).cpu(), full)
     wantf = torch.relu(torch.addcmul(shift.view(1, -1, 1, 1, 1), raw, scale.view(1, -1, 1, 1, 1)) + res)
     np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
+    # the layer-to-layer forms: the same values, already cut into the pieces a consumer would cut (bit for bit), nothing
+    # written outside the interior of the SCL / PSCL buffers -- from either input form, alone or together with the fp32 tensor
+    # (a small grid's fp32-only call is split over the input channels -- other partial sums -- the multi-output call never is)
+    from mvsdet_amd import _lib
+    was_split = _lib.load().mvsdet_conv3d_k3_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W) > 0
+    for inp in (xs, x.to(gpu)):
+        f32, scl, pscl = ops.conv3d_k3_bf16x3(inp, wq, scale.to(gpu), shift.to(gpu), True, res.to(gpu), outputs=("f32", "scl", "pscl"))
+        if was_split:
+            np.testing.assert_allclose(f32.cpu().numpy(), full.numpy(), rtol=0, atol=4e-7 * mag * float(scale.max()))
+        else:
+            assert torch.equal(f32.cpu(), full)
+        eh, em = ops.split_bf16(f32.cpu())
+        hi, mid = scl.pieces()
+        assert torch.equal(hi.cpu(), eh) and torch.equal(mid.cpu(), em) and scl.border_is_zero()
+        hi, mid, clean = pscl.pieces()
+        assert torch.equal(hi.cpu(), eh) and torch.equal(mid.cpu(), em) and clean
+    only = ops.conv3d_k3_bf16x3(xs, wq, scale.to(gpu), shift.to(gpu), True, res.to(gpu), outputs="scl", scl_out=scl)
+    assert only is scl and torch.equal(scl.pieces()[0].cpu(), eh) and scl.border_is_zero()
+    # ... and a stride-1 consumer of the SCL output sees what it would have cut from the fp32 tensor
+    if Cout == 64 and Cin <= 64:
+        w2 = ops.split_conv_weight((torch.randn(64, 64, 3, 3, 3, generator=g) / 40).to(gpu))
+        assert torch.equal(ops.conv3d_k3_bf16x3(scl, w2, None, None, False), ops.conv3d_k3_bf16x3(f32, w2, None, None, False))
 
 
 def test_scl_pack_reads_a_pitched_volume_in_place(gpu):
@@ -107,6 +129,26 @@ def test_conv3d_k3_s2_bf16x3(gpu, N, Cin, Cout, Di, Hi, Wi):
     full = ops.conv3d_k3_s2_bf16x3(x.to(gpu), wq, scale.to(gpu), shift.to(gpu), True).cpu()
     wantf = torch.relu(torch.addcmul(shift.view(1, -1, 1, 1, 1), raw, scale.view(1, -1, 1, 1, 1)))
     np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
+    # the parity-split SCL input (class tiles by LDS-DMA): the same MFMAs on the same pieces.  The fp32 form may have been split
+    # over the input channels (small volumes); the unsplit sums are compared at the accumulation-order tolerance then.
+    xp = ops.pscl_from_tensor(x.to(gpu))
+    hi, mid, clean = xp.pieces()
+    assert clean and torch.equal(hi[:, :Cin].cpu(), ops.split_bf16(x)[0])
+    f32, scl = ops.conv3d_k3_s2_bf16x3(xp, wq, scale.to(gpu), shift.to(gpu), True, outputs=("f32", "scl"))
+    from mvsdet_amd import _lib
+    if _lib.load().mvsdet_conv3d_k3_s2_bf16x3_workspace_bytes(N, Cin, Cout, Di, Hi, Wi) == 0:
+        assert torch.equal(f32.cpu(), full)
+    else:
+        np.testing.assert_allclose(f32.cpu().numpy(), full.numpy(), rtol=0, atol=4e-7 * mag)
+    eh, em = ops.split_bf16(f32.cpu())
+    hi, mid = scl.pieces()
+    assert torch.equal(hi.cpu(), eh) and torch.equal(mid.cpu(), em) and scl.border_is_zero()
+    # a producing stride-1 layer's PSCL output feeds this layer like the fp32 tensor does
+    if Cin % 64 == 0 and Cin <= 128:
+        wp = ops.split_conv_weight((torch.randn(Cin, 8, 3, 3, 3, generator=g) / 15).to(gpu))
+        pf, pp = ops.conv3d_k3_bf16x3(x[:, :8].contiguous().to(gpu), wp, None, None, True, outputs=("f32", "pscl"))
+        assert torch.equal(ops.conv3d_k3_s2_bf16x3(pp, wq, None, None, False, outputs=("f32", "scl"))[0],
+                           ops.conv3d_k3_s2_bf16x3(pf, wq, None, None, False, outputs=("f32", "scl"))[0])   # both unsplit
 
 
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 16, 64, 4, 8, 16), (2, 24, 64, 3, 7, 11), (1, 256, 128, 3, 15, 20),
@@ -135,6 +177,41 @@ def test_convT3d_k3_s2_bf16x3(gpu, N, Cin, Cout, D, H, W):
     full = ops.convT3d_k3_s2_bf16x3(x.to(gpu), wq, scale.to(gpu), shift.to(gpu), res.to(gpu), True).cpu()
     wantf = res + torch.relu(torch.addcmul(shift.view(1, -1, 1, 1, 1), raw, scale.view(1, -1, 1, 1, 1)))
     np.testing.assert_allclose(full.numpy(), wantf.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wantf.abs().max())))
+    f32, scl = ops.convT3d_k3_s2_bf16x3(x.to(gpu), wq, scale.to(gpu), shift.to(gpu), res.to(gpu), True, outputs=("f32", "scl"))
+    assert torch.equal(f32.cpu(), full)
+    eh, em = ops.split_bf16(full)
+    hi, mid = scl.pieces()
+    assert torch.equal(hi.cpu(), eh) and torch.equal(mid.cpu(), em) and scl.border_is_zero()
+
+
+def test_cost_network_layer_forms_agree_bit_for_bit(gpu):
+    """CostRegNet3DGS in eval mode: every layer handing the next one its output already cut into bf16 pieces (SCL / PSCL, the
+    default) against fp32 tensors between the layers: the same logits bit for bit, twice in a row (the buffers are reused)."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    torch.manual_seed(3)
+    net = CostRegNet3DGS(256).to(gpu).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    from mvsdet_amd import _lib
+    lib = _lib.load()
+    # these small grids would be split over the input channels on the fp32 route (other partial sums); the 40-view volumes
+    # of the shipped configuration never are: the knob keeps both routes unsplit here
+    _lib.check(lib.mvsdet_set_option(b"conv_nsplit", 1), "set_option")
+    try:
+        for shape in ((2, 256, 12, 20, 40), (3, 256, 4, 12, 16), (2, 256, 12, 20, 40)):
+            x = torch.rand(shape, device=gpu)
+            with torch.no_grad():
+                net.layer_forms = "f32"
+                ref = net(x)
+                net.layer_forms = "scl"
+                a = net(x)
+                b = net(x * 0.5 + 0.1)
+                c = net(x)
+            assert torch.equal(a, ref) and torch.equal(c, ref) and not torch.equal(b, ref)
+    finally:
+        _lib.check(lib.mvsdet_set_option(b"conv_nsplit", 0), "set_option")
 
 
 def test_conv3d_k3_bf16x3_argument_checks(gpu):
