@@ -283,6 +283,11 @@ int mvsdet_bn3d_relu_bwd_f32(const float* x, const float* grad_out, const float*
                              mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N, int Cin,
                                int D, int H, int W, mvsdet_stream_t stream);
+/* The same layer on the SUM of two tensors, x + x2 (x2 NULL: x alone), formed while the halo tiles are staged: mvsnet.py:111-112
+ * `x = conv0 + self.conv11(x); x = self.prob(x)` without the skip addition in the transposed layer's epilogue (which then is a
+ * pure store stream).  A second input needs W % 4 == 0 and 16-byte aligned tensors. */
+int mvsdet_conv3d_k3_cout2_sum_f32(const float* x, const float* x2, const float* weight, const float* bias, float* out, int N,
+                                   int Cin, int D, int H, int W, mvsdet_stream_t stream);
 
 /* Backward of the head (training): grad_x (N,Cin,D,H,W) from grad_out (N,2,D,H,W) and weight (2,Cin,3,3,3); and the
  * weight gradient as partial (nsplit,2,Cin,27) sums (one per voxel split, added up by the caller). */
@@ -361,6 +366,10 @@ int mvsdet_split_conv_weight(const float* weight, void* weight_split, int Cout, 
  * input voxel); 2 = for the transposed convolution: `weight` is a ConvTranspose3d weight (Cin,Cout,3,3,3), pairs grouped by the
  * parity class of the output voxel. */
 int mvsdet_split_conv_weight_ordered(const float* weight, void* weight_split, int Cout, int Cin, int order, mvsdet_stream_t stream);
+/* up to 8 weight tensors in ONE launch (a network's layers: run per forward call, so in-place weight updates are always seen);
+ * weights / weight_splits: HOST arrays of `count` device pointers; Cout / Cin / orders: HOST arrays */
+int mvsdet_split_conv_weights_batched(const float* const* weights, void* const* weight_splits, const int* Cout, const int* Cin,
+                                      const int* orders, int count, mvsdet_stream_t stream);
 int mvsdet_scl_pack_f32(const float* x, const int64_t* x_strides /*HOST[4] = element strides of n, c, d, h; w stride 1; NULL = contiguous*/,
                         void* xs, int N, int C, int D, int H, int W, int zero_border, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_bf16x3(const void* xs, const void* weight_split, const float* scale, const float* shift,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_cout2_dx_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_dw_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_conv3d_k3_cout2_sum_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_backproject_weigh_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_backproject_weigh_mean_packed_f32": [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp,
@@ -83,6 +84,7 @@ SIGNATURES = {
     "mvsdet_split_conv_weight_bytes": [_i, _i],
     "mvsdet_split_conv_weight": [_vp, _vp, _i, _i, _vp],
     "mvsdet_split_conv_weight_ordered": [_vp, _vp, _i, _i, _i, _vp],
+    "mvsdet_split_conv_weights_batched": [_vp, _vp, _vp, _vp, _vp, _i, _vp],
     "mvsdet_convT3d_k3_s2_bf16x3": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_s2_bf16x3_f32in": [_vp, _i64p, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_scl_pack_f32": [_vp, _i64p, _vp, _i, _i, _i, _i, _i, _i, _vp],

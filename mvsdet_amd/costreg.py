@@ -228,16 +228,21 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
 
     def _forward_chain(self, x):
         """mvsnet.py:104-112 with the layer-to-layer forms of include/mvsdet_hip.h: conv0 -(fp32 skip, PSCL)-> conv1 -(SCL)->
-        conv2 -(fp32 skip, PSCL)-> conv3 -(SCL)-> conv4 -(SCL)-> conv9 -(SCL)-> conv11 -(fp32)-> prob.  Same values as the
+        conv2 -(fp32 skip, PSCL)-> conv3 -(SCL)-> conv4 -(SCL)-> conv9 -(SCL)-> conv11 -(fp32)-> [+ conv0] prob.  Same values as the
         fp32-handover route bit for bit (a producer cuts exactly the pieces the consumer would have cut)."""
         from . import ops
         n, _, d, h, w = x.shape
         dev = x.device
         b = self.conv0.conv.out_channels
 
+        # all seven weight tensors cut into their bf16 pieces by ONE launch, on every call: an in-place update is always seen
+        layers = [(self.conv0.conv, 0), (self.conv1.conv, 1), (self.conv2.conv, 0), (self.conv3.conv, 1), (self.conv4.conv, 0),
+                  (self.conv9[0], 2), (self.conv11[0], 2)]
+        wsplit = dict(zip((id(m) for m, _ in layers), ops.split_conv_weights([(m.weight, o) for m, o in layers])))
+
         def cbr(layer, inp, order, outputs, name, oshape):
             sc, sh = _bn_affine(layer.bn)
-            wq = ops.split_conv_weight(layer.conv.weight, order)
+            wq = wsplit[id(layer.conv)]
             kw = {}
             if "scl" in outputs:
                 kw["scl_out"] = self._buf(name, "scl", oshape, dev)
@@ -249,7 +254,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         def up(seq, inp, skip, outputs, name, oshape):
             sc, sh = _bn_affine(seq[1])
             kw = {"scl_out": self._buf(name, "scl", oshape, dev)} if "scl" in outputs else {}
-            return ops.convT3d_k3_s2_bf16x3(inp, ops.split_conv_weight(seq[0].weight, 2), sc, sh, skip, True, outputs=outputs, **kw)
+            return ops.convT3d_k3_s2_bf16x3(inp, wsplit[id(seq[0])], sc, sh, skip, True, outputs=outputs, **kw)
 
         full, full_p = cbr(self.conv0, x, 0, ("f32", "pscl"), "conv0", (n, b, d, h, w))
         h1 = cbr(self.conv1, full_p, 1, ("scl",), "conv1", (n, 2 * b, d // 2, h // 2, w // 2))
@@ -257,8 +262,10 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         q1 = cbr(self.conv3, half_p, 1, ("scl",), "conv3", (n, 4 * b, d // 4, h // 4, w // 4))
         q2 = cbr(self.conv4, q1, 0, ("scl",), "conv4", (n, 4 * b, d // 4, h // 4, w // 4))
         half2 = up(self.conv9, q2, half, ("scl",), "conv9", (n, 2 * b, d // 2, h // 2, w // 2))
-        full2 = up(self.conv11, half2, full, ("f32",), "conv11", (n, b, d, h, w))
-        return self._head(full2)
+        # mvsnet.py:111-112: x = conv0 + conv11(x); prob(x).  The addition is formed by the head while it stages its input, so
+        # conv11's epilogue is a pure store stream instead of load - wait - store round trips over 1.2 GB
+        up11 = up(self.conv11, half2, None, ("f32",), "conv11", (n, b, d, h, w))
+        return ops.conv3d_k3_cout2_sum(full, up11, self.prob.weight.detach(), self.prob.bias.detach())
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):

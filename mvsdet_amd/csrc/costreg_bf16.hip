@@ -174,6 +174,45 @@ __global__ __launch_bounds__(kThreads) void split_conv_weight_kernel(const float
                         (unsigned)b[4] | ((unsigned)b[5] << 16), (unsigned)b[6] | ((unsigned)b[7] << 16));
 }
 
+// All weight tensors of a network in ONE launch (the cost network has seven: a launch each was 0.07 ms of kernels and twice that
+// of launch gaps per scene, and caching the pieces instead would miss an in-place update through `.data`).
+constexpr int kSplitBatchMax = 8;
+struct SplitBatch {
+    const float* w[kSplitBatchMax];
+    uint4* out[kSplitBatchMax];
+    unsigned long long first[kSplitBatchMax + 1];   // first unit of tensor i in the launch's flat unit index
+    int Cin[kSplitBatchMax], order[kSplitBatchMax], Cout[kSplitBatchMax];
+    TapTable taps[3];
+    int n;
+};
+__global__ __launch_bounds__(kThreads) void split_conv_weight_batched_kernel(SplitBatch b) {
+    const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (g >= b.first[b.n]) return;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kSplitBatchMax; ++k)
+        if (k < b.n && g >= b.first[k]) i = k;
+    const size_t u = g - b.first[i];
+    const int Cin = b.Cin[i], C8 = (Cin + 7) / 8, order = b.order[i];
+    const long long so = order == 2 ? 27 : (long long)Cin * 27, sc = order == 2 ? (long long)b.Cout[i] * 27 : 27;
+    const int lane = (int)(u & 63), piece = (int)((u >> 6) & 1), a = (int)((u >> 7) & 1);
+    const size_t r = u >> 8;
+    const int p = (int)(r % kBfPairs), c8 = (int)((r / kBfPairs) % C8), ob = (int)(r / ((size_t)kBfPairs * C8));
+    const int o = ob * 64 + a * 32 + bf_mfma_row_channel(lane & 31), t = b.taps[order].t[2 * p + (lane >> 5)];
+    const float* w = b.w[i];
+    unsigned short bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c8 * 8 + j;
+        const float f = (t >= 0 && c < Cin) ? w[(size_t)o * so + (size_t)c * sc + t] : 0.0f;
+        const __bf16 hi = (__bf16)f;
+        const __bf16 v = piece ? (__bf16)(f - (float)hi) : hi;
+        bb[j] = __builtin_bit_cast(unsigned short, v);
+    }
+    b.out[i][u] = make_uint4((unsigned)bb[0] | ((unsigned)bb[1] << 16), (unsigned)bb[2] | ((unsigned)bb[3] << 16),
+                             (unsigned)bb[4] | ((unsigned)bb[5] << 16), (unsigned)bb[6] | ((unsigned)bb[7] << 16));
+}
+
 // tap t of the 3x3x3 kernel as an offset in halo voxels; tap 27 (the empty half of pair 13) aliases tap 26
 template <int HH, int HW = kBfW + 2>
 __host__ __device__ constexpr int bf_tap_off(int t) {
@@ -1175,6 +1214,39 @@ extern "C" int mvsdet_split_conv_weight_ordered(const float* weight, void* weigh
                        (hipStream_t)stream, weight, static_cast<uint4*>(weight_split), Cin, (Cin + 7) / 8, units, tap_table(order),
                        so, sc);
     MVS_LAUNCH_CHECK("split_conv_weight");
+    return MVSDET_OK;
+}
+
+// Up to 8 weight tensors in one launch: weights[i] (Cout[i] = 64*m, Cin[i], 3,3,3) (order 2: (Cin,Cout,3,3,3)) -> splits[i]
+// (mvsdet_split_conv_weight_bytes(Cout[i], Cin[i]) bytes each), tap order orders[i] as for mvsdet_split_conv_weight_ordered.
+// The pointer arrays are HOST arrays of device pointers.
+extern "C" int mvsdet_split_conv_weights_batched(const float* const* weights, void* const* splits, const int* Cout, const int* Cin,
+                                                 const int* orders, int count, mvsdet_stream_t stream) {
+    MVS_REQUIRE(weights && splits && Cout && Cin && orders, "split_conv_weights_batched: NULL pointer");
+    MVS_REQUIRE(count > 0 && count <= kSplitBatchMax, "split_conv_weights_batched: 1..%d tensors per call", kSplitBatchMax);
+    SplitBatch b;
+    b.n = count;
+    b.first[0] = 0;
+    for (int k = 0; k < 3; ++k) b.taps[k] = tap_table(k);
+    for (int i = 0; i < kSplitBatchMax; ++i) {
+        const bool live = i < count;
+        if (live) {
+            MVS_REQUIRE(weights[i] && splits[i], "split_conv_weights_batched: NULL tensor %d", i);
+            MVS_REQUIRE(Cout[i] > 0 && Cout[i] % 64 == 0 && Cin[i] > 0 && orders[i] >= 0 && orders[i] <= 2,
+                        "split_conv_weights_batched: tensor %d: Cout=%d (multiple of 64), Cin=%d, order=%d", i, Cout[i], Cin[i], orders[i]);
+            MVS_REQUIRE(((uintptr_t)splits[i] & 15u) == 0, "split_conv_weights_batched: outputs must be 16-byte aligned");
+        }
+        b.w[i] = live ? weights[i] : nullptr;
+        b.out[i] = live ? static_cast<uint4*>(splits[i]) : nullptr;
+        b.Cin[i] = live ? Cin[i] : 1;
+        b.Cout[i] = live ? Cout[i] : 64;
+        b.order[i] = live ? orders[i] : 0;
+        b.first[i + 1] = b.first[i] + (live ? mvsdet_split_conv_weight_bytes(Cout[i], Cin[i]) / 16 : 0);
+    }
+    const size_t units = b.first[count];
+    hipLaunchKernelGGL(split_conv_weight_batched_kernel, dim3((unsigned)((units + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, b);
+    MVS_LAUNCH_CHECK("split_conv_weights_batched");
     return MVSDET_OK;
 }
 

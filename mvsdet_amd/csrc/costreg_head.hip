@@ -113,23 +113,163 @@ __global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_kernel(const float* 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4 form of the forward kernel.  The round-1 kernel above read one LDS dword per 4 FMAs (the LDS, not the vector
+// pipe, set its time: 0.41 ms = 1.4 TB/s of input) and staged its halo with scalar loads in chunks of four channels.
+//   thread = 4 (d) x 2 (w) output voxels x 2 outputs = 16 sums: per (channel, kh) it reads the 6 x 6 halo values it needs as
+//            18 ds_read_b64 and feeds 3 kw x 3 kd x 8 voxels x 2 outputs = 144 FMAs (8 FMAs per LDS instruction);
+//   block  = 4 x 12 x 40 output voxels (240 of 256 threads compute: 60 x 80 maps tile without padding), halo rows of 48 floats
+//            = 12 aligned float4 (w0 - 4 .. w0 + 43), staged one channel at a time through registers (4 float4 per thread and
+//            input, fetched while the previous channel is multiplied);
+//   x2     = optional second input ADDED to x while staging: mvsnet.py:111-112 `x = conv0 + self.conv11(x); x = self.prob(x)` --
+//            the transposed layer then leaves out the skip addition (its epilogue becomes a pure store stream instead of
+//            load - wait - store round trips: csrc/costreg_bf16.hip) and the sum is formed here, in the same fp32 addition.
+// W % 4 == 0 and 16-byte aligned tensors (whole float4 either inside or outside the volume); other shapes take the kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kV2TD = 4, kV2TH = 12, kV2WP = 20, kV2TW = 2 * kV2WP;
+constexpr int kV2HD = kV2TD + 2, kV2HH = kV2TH + 2, kV2Pitch = 48, kV2Q = kV2Pitch / 4;
+constexpr int kV2Halo4 = kV2HD * kV2HH * kV2Q;                          // 1008 float4 per channel
+constexpr int kV2Stage = (kV2Halo4 + kThreads - 1) / kThreads;          // 4 per thread
+
+__global__ __launch_bounds__(kThreads, 4) void conv3d_k3_cout2_v2_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                                          const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                                          float* __restrict__ out, int Cin, int D, int H, int W,
+                                                                          int tiles_w, int tiles_h) {
+    __shared__ float4 s_in[2][kV2Halo4];   // two channels in flight: one being multiplied, one being written
+    const int tid = threadIdx.x;
+    const int wp = tid % kV2WP, th = tid / kV2WP;            // th 0..12 (12: the 16 threads that only stage)
+    const bool worker = th < kV2TH;
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int w0 = bw * kV2TW, h0 = bh * kV2TH, d0 = blockIdx.y * kV2TD, n = blockIdx.z;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    const float* xn = x + (size_t)n * Cin * vol;
+    const float* x2n = x2 ? x2 + (size_t)n * Cin * vol : nullptr;
+
+    float acc[2][kV2TD][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < kV2TD; ++t) acc[o][t][0] = acc[o][t][1] = bias ? bias[o] : 0.0f;
+
+    // staging plan, the same for every channel: float4 f = tid + 256*k of the halo tile -> offset inside a channel volume,
+    // or -1 (outside the volume: zeros)
+    int s_off[kV2Stage];
+#pragma unroll
+    for (int k = 0; k < kV2Stage; ++k) {
+        const int f = tid + k * kThreads;
+        const int dz = f / (kV2HH * kV2Q), r2 = f - dz * (kV2HH * kV2Q);
+        const int hy = r2 / kV2Q, q = r2 - hy * kV2Q;
+        const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 - 4 + 4 * q;
+        const bool ok = f < kV2Halo4 && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w + 3 < W;
+        s_off[k] = ok ? (int)((size_t)d * plane + (size_t)h * W + w) : -1;
+    }
+    float4 nxt[kV2Stage];
+    auto fetch = [&](int c) {
+        const float* xc = xn + (size_t)c * vol;
+        const float* yc = x2n ? x2n + (size_t)c * vol : nullptr;
+#pragma unroll
+        for (int k = 0; k < kV2Stage; ++k) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s_off[k] >= 0) {
+                a = *reinterpret_cast<const float4*>(xc + s_off[k]);
+                if (yc) {
+                    const float4 b = *reinterpret_cast<const float4*>(yc + s_off[k]);
+                    a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+                }
+            }
+            nxt[k] = a;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < kV2Stage; ++k) {
+            const int f = tid + k * kThreads;
+            if (f < kV2Halo4) s_in[buf][f] = nxt[k];
+        }
+    };
+    fetch(0);
+    stage(0);
+    if (Cin > 1) fetch(1);
+    for (int c = 0; c < Cin; ++c) {
+        const int buf = c & 1;
+        __syncthreads();   // channel c is in s_in[buf]; everybody is done with s_in[buf ^ 1] (channel c - 1)
+        if (c + 1 < Cin) stage(buf ^ 1);
+        if (c + 2 < Cin) fetch(c + 2);
+        if (worker) {
+            const float* w0p = wgt + (size_t)c * 27;                   // weight[0][c][kd][kh][kw] (wave-uniform: scalar loads)
+            const float* w1p = wgt + ((size_t)Cin + c) * 27;           // weight[1][c][...]
+            const float* tile = reinterpret_cast<const float*>(s_in[buf]);
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh) {   // not unrolled: three rows' worth of halo values in flight spill
+                // halo floats 2*wp + 3 .. 2*wp + 6 of the row (index 4 = w0): read as three aligned pairs from 2*wp + 2
+                float v[kV2HD][4];
+#pragma unroll
+                for (int dz = 0; dz < kV2HD; ++dz) {
+                    const float2* rowp = reinterpret_cast<const float2*>(tile + ((size_t)dz * kV2HH + th + kh) * kV2Pitch + 2 * wp + 2);
+                    const float2 p0 = rowp[0], p1 = rowp[1], p2 = rowp[2];
+                    v[dz][0] = p0.y; v[dz][1] = p1.x; v[dz][2] = p1.y; v[dz][3] = p2.x;
+                }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd) {
+                        const float a = w0p[(kd * 3 + kh) * 3 + kw], b = w1p[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+                        for (int t = 0; t < kV2TD; ++t)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                acc[0][t][e] = fmaf(v[t + kd][e + kw], a, acc[0][t][e]);
+                                acc[1][t][e] = fmaf(v[t + kd][e + kw], b, acc[1][t][e]);
+                            }
+                    }
+            }
+        }
+    }
+    const int h = h0 + th, w = w0 + 2 * wp;
+    if (worker && h < H && w < W) {   // W % 4 == 0 and w even: both voxels of the pair are inside
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int t = 0; t < kV2TD; ++t)
+                if (d0 + t < D)
+                    *reinterpret_cast<float2*>(out + ((size_t)n * 2 + o) * vol + (size_t)(d0 + t) * plane + (size_t)h * W + w) =
+                        make_float2(acc[o][t][0], acc[o][t][1]);
+    }
+}
 }  // namespace mvsdet
 
 using namespace mvsdet;
 
-extern "C" int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N,
-                                          int Cin, int D, int H, int W, mvsdet_stream_t stream) {
+// out (N,2,D,H,W) = conv3d(x [+ x2], weight (2,Cin,3,3,3), bias); x2 (same shape as x, or NULL) is added while staging.
+extern "C" int mvsdet_conv3d_k3_cout2_sum_f32(const float* x, const float* x2, const float* weight, const float* bias, float* out,
+                                              int N, int Cin, int D, int H, int W, mvsdet_stream_t stream) {
     MVS_REQUIRE(x && weight && out, "conv3d_k3_cout2: NULL pointer");
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_cout2: bad shape N=%d Cin=%d D=%d H=%d W=%d", N, Cin, D,
                 H, W);
-    const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH, tiles_d = (D + kTD - 1) / kTD;
-    MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_cout2: N or D too large");
     MVS_REQUIRE((size_t)D * H * W < (size_t)INT32_MAX, "conv3d_k3_cout2: one channel volume exceeds 2^31 elements");
-    dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
-    hipLaunchKernelGGL(conv3d_k3_cout2_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, weight, bias, out, Cin, D, H,
-                       W, tiles_w, tiles_h);
+    const bool v2 = W % 4 == 0 && (((uintptr_t)x | (uintptr_t)x2) & 15u) == 0 && ((uintptr_t)out & 7u) == 0;
+    MVS_REQUIRE(v2 || !x2, "conv3d_k3_cout2: a second input needs W %% 4 == 0 and 16-byte aligned tensors");
+    if (v2) {
+        const int tiles_w = (W + kV2TW - 1) / kV2TW, tiles_h = (H + kV2TH - 1) / kV2TH, tiles_d = (D + kV2TD - 1) / kV2TD;
+        MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_cout2: N or D too large");
+        dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
+        hipLaunchKernelGGL(conv3d_k3_cout2_v2_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, x2, weight, bias, out, Cin, D,
+                           H, W, tiles_w, tiles_h);
+    } else {
+        const int tiles_w = (W + kTW - 1) / kTW, tiles_h = (H + kTH - 1) / kTH, tiles_d = (D + kTD - 1) / kTD;
+        MVS_REQUIRE(N <= 65535 && tiles_d <= 65535, "conv3d_k3_cout2: N or D too large");
+        dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)N);
+        hipLaunchKernelGGL(conv3d_k3_cout2_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, weight, bias, out, Cin, D, H,
+                           W, tiles_w, tiles_h);
+    }
     MVS_LAUNCH_CHECK("conv3d_k3_cout2");
     return MVSDET_OK;
+}
+
+extern "C" int mvsdet_conv3d_k3_cout2_f32(const float* x, const float* weight, const float* bias, float* out, int N,
+                                          int Cin, int D, int H, int W, mvsdet_stream_t stream) {
+    return mvsdet_conv3d_k3_cout2_sum_f32(x, nullptr, weight, bias, out, N, Cin, D, H, W, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -93,15 +93,18 @@ BF16X3_MIN_VOXELS = 256
 S2_BF16X3 = True
 
 
-def _split_weight(conv: nn.Conv3d) -> Tensor:
-    """The weight cut into bf16 pieces in the bf16x3 kernel's layout (tap order of the layer's stride), kept on the module
-    (the neck's weights are 300 MB: not re-split per call) until the weight tensor changes or `drop_derived_tensors` runs."""
+def _split_weight(conv: nn.Module, order: int | None = None) -> Tensor:
+    """The weight cut into bf16 pieces in the bf16x3 kernel's layout (tap order of the layer's stride; `order` 2 = a
+    ConvTranspose3d weight), kept on the module (the neck's weights are 300 MB: not re-split per call) until the weight tensor
+    changes or `drop_derived_tensors` runs."""
     from . import ops
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.device)
+    if order is None:
+        order = 1 if conv.stride[0] == 2 else 0
+    key = (w.data_ptr(), w._version, w.device, order)
     cached = conv.__dict__.get("_mvs_wsplit")
     if cached is None or cached[0] != key:
-        cached = (key, ops.split_conv_weight(w, order=1 if conv.stride[0] == 2 else 0))
+        cached = (key, ops.split_conv_weight(w, order=order))
         conv.__dict__["_mvs_wsplit"] = cached
     return cached[1]
 

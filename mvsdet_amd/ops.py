@@ -741,6 +741,34 @@ def split_conv_weight(weight: Tensor, order: int = 0) -> Tensor:
     return pieces.contiguous().reshape(cout // 64, c8, 14, 2, 2, 64, 8)
 
 
+def split_conv_weights(items) -> list:
+    """`split_conv_weight` of several (weight, order) pairs in ONE launch (up to 8 per launch): a network's layers, cut anew on
+    every forward call so that an in-place weight update -- also one through `.data`, which bumps no version counter -- is seen."""
+    import ctypes
+    items = list(items)
+    outs = []
+    lib = _lib.load()
+    for lo in range(0, len(items), 8):
+        chunk = items[lo:lo + 8]
+        ws, cins, couts, orders, res = [], [], [], [], []
+        for weight, order in chunk:
+            cin, cout = (weight.shape[:2] if order == 2 else weight.shape[1::-1])
+            if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3) or order not in (0, 1, 2) or not weight.is_cuda:
+                raise ValueError(f"split_conv_weights: weight {tuple(weight.shape)} (order {order})")
+            ws.append(weight.detach().to(torch.float32).contiguous())
+            res.append(torch.empty((cout // 64, (cin + 7) // 8, 14, 2, 2, 64, 8), dtype=torch.bfloat16, device=weight.device))
+            cins.append(int(cin)); couts.append(int(cout)); orders.append(int(order))
+        n = len(chunk)
+        wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+        op = (ctypes.c_void_p * n)(*[r.data_ptr() for r in res])
+        ia = lambda v: (ctypes.c_int * n)(*v)   # noqa: E731
+        with torch.cuda.device(ws[0].device):
+            _lib.check(lib.mvsdet_split_conv_weights_batched(wp, op, ia(couts), ia(cins), ia(orders), n, _stream(ws[0])),
+                       "split_conv_weights_batched")
+        outs.extend(res)
+    return outs
+
+
 class SclTensor:
     """An activation in the split channel-last form the bf16x3 convolutions read (include/mvsdet_hip.h): `data` is the
     flat bfloat16 buffer [2][N][ceil(C/8)][Dp][Hp][Wp][8] with a zero border; `shape` the logical (N,C,D,H,W)."""
@@ -1019,6 +1047,32 @@ def store_pattern_probe(var: Tensor, W: int, tile_w: int, planes_per_block: int 
     with torch.cuda.device(var.device):
         _lib.check(_lib.load().mvsdet_store_pattern_probe_f32(_lib.ptr(var), N, C, D, H, int(W), int(pitch), int(tile_w),
                                                               int(planes_per_block), _stream(var)), "store_pattern_probe")
+
+
+def conv3d_k3_cout2_sum(x: Tensor, x2: Optional[Tensor], weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """Conv3d(Cin -> 2, kernel 3, padding 1, bias) of mvs_models/mvsnet.py:102,112 on x + x2 (N,Cin,D,H,W) -> (N,2,D,H,W): the
+    skip addition of mvsnet.py:111 formed while the head stages its input (forward only; x2 None: x alone)."""
+    _req(x, "x", dim=5)
+    _req(weight, "weight", dim=5)
+    N, Cin, D, H, W = x.shape
+    if tuple(weight.shape) != (2, Cin, 3, 3, 3):
+        raise ValueError(f"conv3d_k3_cout2_sum: weight {tuple(weight.shape)} != (2,{Cin},3,3,3)")
+    if x2 is not None:
+        _req(x2, "x2", dim=5)
+        if x2.shape != x.shape:
+            raise ValueError(f"conv3d_k3_cout2_sum: x2 {tuple(x2.shape)} != x {tuple(x.shape)}")
+        if W % 4:
+            return conv3d_k3_cout2(x + x2, weight, bias)
+        x2 = x2.contiguous()
+    if bias is not None:
+        _req(bias, "bias", dim=1)
+        bias = bias.contiguous()
+    x, weight = x.contiguous(), weight.contiguous()
+    out = torch.empty((N, 2, D, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_conv3d_k3_cout2_sum_f32(_lib.ptr(x), _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out),
+                                                              N, Cin, D, H, W, _stream(x)), "conv3d_k3_cout2_sum")
+    return out
 
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_cout2", mutates_args=(), device_types="cuda")

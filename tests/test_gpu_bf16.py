@@ -184,6 +184,21 @@ def test_convT3d_k3_s2_bf16x3(gpu, N, Cin, Cout, D, H, W):
     assert torch.equal(hi.cpu(), eh) and torch.equal(mid.cpu(), em) and scl.border_is_zero()
 
 
+@pytest.mark.parametrize("N,Cin,D,H,W", [(2, 64, 12, 60, 80), (1, 5, 3, 7, 12), (1, 64, 4, 12, 40), (2, 3, 9, 25, 44)])
+def test_head_on_the_sum_of_two_inputs(gpu, N, Cin, D, H, W):
+    """mvsnet.py:111-112: the 64 -> 2 head on conv0 + conv11(x) with the addition formed while the halo tiles are staged: the
+    same bits as the head on the precomputed sum, and ATen's convolution within fp32 accumulation order."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(Cin + W)
+    x, y = torch.randn(N, Cin, D, H, W, generator=g), torch.randn(N, Cin, D, H, W, generator=g)
+    wgt, bias = torch.randn(2, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5, torch.randn(2, generator=g)
+    got = ops.conv3d_k3_cout2_sum(x.to(gpu), y.to(gpu), wgt.to(gpu), bias.to(gpu))
+    one = ops.conv3d_k3_cout2_sum((x + y).to(gpu), None, wgt.to(gpu), bias.to(gpu))
+    assert torch.equal(got, one) and torch.equal(one, ops.conv3d_k3_cout2((x + y).to(gpu), wgt.to(gpu), bias.to(gpu)))
+    ref = F.conv3d((x + y).double(), wgt.double(), bias.double(), padding=1)
+    np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-5 * max(1.0, float(ref.abs().max())))
+
+
 def test_cost_network_layer_forms_agree_bit_for_bit(gpu):
     """CostRegNet3DGS in eval mode: every layer handing the next one its output already cut into bf16 pieces (SCL / PSCL, the
     default) against fp32 tensors between the layers: the same logits bit for bit, twice in a row (the buffers are reused)."""

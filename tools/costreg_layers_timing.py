@@ -15,7 +15,7 @@ import torch  # noqa: E402
 from mvsdet_amd import _lib, ops  # noqa: E402
 from mvsdet_amd.costreg import CostRegNet3DGS  # noqa: E402
 
-NAMES = ["conv3d_k3_bf16x3", "conv3d_k3_s2_bf16x3", "convT3d_k3_s2_bf16x3", "conv3d_k3_cout2", "scl_pack", "split_conv_weight"]
+NAMES = ["conv3d_k3_bf16x3", "conv3d_k3_s2_bf16x3", "convT3d_k3_s2_bf16x3", "conv3d_k3_cout2", "conv3d_k3_cout2_sum", "scl_pack", "split_conv_weight"]
 
 
 def main():
@@ -61,7 +61,7 @@ def main():
     labels = iter(["conv0", "conv1", "conv2", "conv3", "conv4", "conv9", "conv11"])
     tot = 0.0
     for name, med, mn in rows:
-        lab = next(labels) if name in NAMES[:3] else ("head" if name == "conv3d_k3_cout2" else "")
+        lab = next(labels) if name in NAMES[:3] else ("head" if name.startswith("conv3d_k3_cout2") else "")
         if name != "split_conv_weight":
             print(f"{lab:7s} {name:24s} median {med:7.3f} ms   min {mn:7.3f} ms")
         tot += med
