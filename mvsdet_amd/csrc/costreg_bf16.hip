@@ -152,14 +152,28 @@ __global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restr
 // copy of weights that were updated in place.
 struct TapTable { signed char t[2 * kBfPairs]; };   // the 3x3x3 tap (0..26) of every half of the 14 tap pairs; -1 = empty half
 
+// 16x16x32 layout (order 3): [Cout/64][c8][k-step 7][row group 4][piece 2][64 lanes][8]: lane = 16 * (tap of the k-step) + row m,
+// row m of row group rg = channel 32*(rg >> 1) + 8*(m >> 2) + 4*(rg & 1) + (m & 3), tap = 4*ks + (lane >> 4) (27: empty)
+__device__ __forceinline__ void bf_m16_unit(size_t u, int C8, int& o, int& t, int& c8) {
+    const int lane = (int)(u & 63), rg = (int)((u >> 7) & 3), m = lane & 15;
+    const size_t r = u >> 9;
+    const int ks = (int)(r % 7), ob = (int)(r / ((size_t)7 * C8));
+    c8 = (int)((r / 7) % C8);
+    o = ob * 64 + 32 * (rg >> 1) + 8 * (m >> 2) + 4 * (rg & 1) + (m & 3);
+    t = 4 * ks + (lane >> 4);
+    if (t > 26) t = -1;
+}
+
 __global__ __launch_bounds__(kThreads) void split_conv_weight_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin,
-                                                                     int C8, size_t units, TapTable taps, long long so, long long sc) {
+                                                                     int C8, size_t units, TapTable taps, long long so, long long sc,
+                                                                     int m16) {
     const size_t u = (size_t)blockIdx.x * kThreads + threadIdx.x;
     if (u >= units) return;
-    const int lane = (int)(u & 63), piece = (int)((u >> 6) & 1), a = (int)((u >> 7) & 1);
+    int lane = (int)(u & 63), piece = (int)((u >> 6) & 1), a = (int)((u >> 7) & 1);
     const size_t r = u >> 8;
-    const int p = (int)(r % kBfPairs), c8 = (int)((r / kBfPairs) % C8), ob = (int)(r / ((size_t)kBfPairs * C8));
-    const int o = ob * 64 + a * 32 + bf_mfma_row_channel(lane & 31), t = taps.t[2 * p + (lane >> 5)];
+    int p = (int)(r % kBfPairs), c8 = (int)((r / kBfPairs) % C8), ob = (int)(r / ((size_t)kBfPairs * C8));
+    int o = ob * 64 + a * 32 + bf_mfma_row_channel(lane & 31), t = taps.t[2 * p + (lane >> 5)];
+    if (m16) bf_m16_unit(u, C8, o, t, c8);
     unsigned short b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -197,8 +211,10 @@ __global__ __launch_bounds__(kThreads) void split_conv_weight_batched_kernel(Spl
     const long long so = order == 2 ? 27 : (long long)Cin * 27, sc = order == 2 ? (long long)b.Cout[i] * 27 : 27;
     const int lane = (int)(u & 63), piece = (int)((u >> 6) & 1), a = (int)((u >> 7) & 1);
     const size_t r = u >> 8;
-    const int p = (int)(r % kBfPairs), c8 = (int)((r / kBfPairs) % C8), ob = (int)(r / ((size_t)kBfPairs * C8));
-    const int o = ob * 64 + a * 32 + bf_mfma_row_channel(lane & 31), t = b.taps[order].t[2 * p + (lane >> 5)];
+    const int p = (int)(r % kBfPairs), ob = (int)(r / ((size_t)kBfPairs * C8));
+    int c8 = (int)((r / kBfPairs) % C8);
+    int o = ob * 64 + a * 32 + bf_mfma_row_channel(lane & 31), t = b.taps[order == 3 ? 0 : order].t[2 * p + (lane >> 5)];
+    if (order == 3) bf_m16_unit(u, C8, o, t, c8);
     const float* w = b.w[i];
     unsigned short bb[8];
 #pragma unroll
@@ -228,7 +244,13 @@ __host__ __device__ constexpr int bf_tap_off(int t) {
 // TW: tile width.  16: an MFMA column group (32 voxels) = 2 h-rows of 16; 8 (fp32-input form only): 4 h-rows of 8 -- the tiles
 // 3 x 16 x 8 and 8 x 8 x 8 fit the half- and quarter-resolution volumes of the cost network (6 x 30 x 40, 3 x 15 x 20) and the
 // neck's 40 x 40 x 16 level, which 4 x 8 x 16 tiles pad 1.7x, 2.3x and 1.2x.
-template <int TD, int TH, bool F32IN, int TW = kBfW, int SUBP = kBfSubPairs>
+// M16: v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  The 32 k of one instruction are FOUR taps of 8 channels
+// (lane group lane >> 4 = tap 4*ks + group of k-step ks; 27 taps = 7 k-steps, one slot empty), a wave's 64 voxels x 64 channels
+// are 4 x 4 accumulators of 16 x 16, per k-step 8 A + 8 B fragments feed 48 instructions: the same LDS reads, matrix cycles and
+// sums per output as the 32 x 32 form, but MFMA-dense loops hold a higher clock on this shape (MI355X_MICROARCH.md, DVFS
+// give-back item 7: ~1.12 - 1.15 x the FLOP/s at equal cycles per FLOP).  Weights: split order 3 (k-step-major, SUBP = 6 "pairs"
+// = 3 k-steps per sub-stage: 3 + 3 + 1).
+template <int TD, int TH, bool F32IN, int TW = kBfW, int SUBP = kBfSubPairs, bool M16 = false>
 __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
     const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -247,6 +269,7 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     constexpr int NSUB = (kBfPairs + SUBP - 1) / SUBP;    // weight sub-stages per channel group
     constexpr int kBfWSlots = bf_w_slots(SUBP);
     static_assert(NSUB >= 2, "the fp32 fetch / cut needs two sub-stages");
+    static_assert(!M16 || SUBP % 2 == 0, "16x16x32: a k-step is two pair slots of weights");
     extern __shared__ uint4 s_bf[];   // [2 stages][2 pieces][INS] input, then [2 stages][kBfWSlots] weights
     uint4* s_in = s_bf;
     uint4* s_w = s_bf + 2 * 2 * INS;
@@ -366,14 +389,36 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
         const int dz = g / (TH / RG), hy = RG * (g % (TH / RG)) + col / TW;
         vb[b] = (dz * HH + hy) * HW + col % TW;
     }
+    // M16: four column groups of 16 voxels, g16 = 4*wave + cg: RG16 = 16 / TW h-rows each; lane = (voxel lane & 15, tap group lane >> 4)
+    constexpr int RG16 = 16 / TW > 0 ? 16 / TW : 1;
+    const int col16 = lane & 15, kg = lane >> 4;
+    int vb16[4], toffs[7];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+        const int g = 4 * wave + cg;
+        const int dz = g / (TH / RG16), hy = RG16 * (g % (TH / RG16)) + col16 / TW;
+        vb16[cg] = (dz * HH + hy) * HW + col16 % TW;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks)
+        toffs[ks] = kg == 0 ? bf_tap_off<HH, HW>(4 * ks) : kg == 1 ? bf_tap_off<HH, HW>(4 * ks + 1)
+                  : kg == 2 ? bf_tap_off<HH, HW>(4 * ks + 2) : bf_tap_off<HH, HW>(4 * ks + 3);
 
     f32x16b acc[2][2];   // [row group (32 output channels)][column group]
+    typedef float f32x4b __attribute__((ext_vector_type(4)));
+    f32x4b acc16[4][4];  // M16: [row group (16 output channels)][column group (16 voxels)]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.0f;
 
     const bf16x8* s_in8 = reinterpret_cast<const bf16x8*>(s_in);
     const bf16x8* s_w8 = reinterpret_cast<const bf16x8*>(s_w);
@@ -383,27 +428,51 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
         constexpr int np = (kBfPairs - s * SUBP < SUBP ? kBfPairs - s * SUBP : SUBP);
         const bf16x8* bin = s_in8 + (size_t)(ibuf * 2) * INS;
         const bf16x8* ain = s_w8 + (size_t)wbuf * kBfWSlots + lane;
+        if constexpr (M16) {
 #pragma unroll
-        for (int pl = 0; pl < np; ++pl) {
-            const int p = s * SUBP + pl;
-            const int toff = hh ? bf_tap_off<HH, HW>(2 * p + 1) : bf_tap_off<HH, HW>(2 * p);
-            bf16x8 A[2][2], B[2][2];   // [row / column group][piece]
+            for (int kl = 0; kl < np / 2; ++kl) {
+                const int toff = toffs[s * (SUBP / 2) + kl];
+                bf16x8 A[4][2], B[4][2];   // [row / column group][piece]
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) A[a][q] = ain[((pl * 2 + a) * 2 + q) * 64];
+                    for (int q = 0; q < 2; ++q) A[a][q] = ain[((kl * 4 + a) * 2 + q) * 64];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb[b] + toff];
+                    for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb16[b] + toff];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], acc[a][b], 0, 0, 0);   // w_mid * x_hi
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], acc[a][b], 0, 0, 0);   // w_hi * x_mid
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], acc[a][b], 0, 0, 0);   // w_hi * x_hi
-                }
+                    for (int b = 0; b < 4; ++b) {
+                        acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[a][1], B[b][0], acc16[a][b], 0, 0, 0);   // w_mid * x_hi
+                        acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[a][0], B[b][1], acc16[a][b], 0, 0, 0);   // w_hi * x_mid
+                        acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[a][0], B[b][0], acc16[a][b], 0, 0, 0);   // w_hi * x_hi
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < np; ++pl) {
+                const int p = s * SUBP + pl;
+                const int toff = hh ? bf_tap_off<HH, HW>(2 * p + 1) : bf_tap_off<HH, HW>(2 * p);
+                bf16x8 A[2][2], B[2][2];   // [row / column group][piece]
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) A[a][q] = ain[((pl * 2 + a) * 2 + q) * 64];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb[b] + toff];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], acc[a][b], 0, 0, 0);   // w_mid * x_hi
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], acc[a][b], 0, 0, 0);   // w_hi * x_mid
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], acc[a][b], 0, 0, 0);   // w_hi * x_hi
+                    }
+            }
         }
     };
 
@@ -458,6 +527,44 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
 
     // ---- epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (voxel), register r of lane half hh = channel bf_row_channel(r, hh)
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    if constexpr (M16) {
+        // 16x16: column = lane & 15 (voxel), register r of lane group kg = row 4*kg + r of the row group; the weights are laid out
+        // so that row m of row group rg carries channel 32*(rg >> 1) + 8*(m >> 2) + 4*(rg & 1) + (m & 3): row groups 2q and 2q+1
+        // together give a lane the eight consecutive channels 32q + 8kg .. + 7
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            const int g = 4 * wave + cg;
+            const int d = d0 + g / (TH / RG16), h = h0 + RG16 * (g % (TH / RG16)) + col16 / TW, w = w0 + col16 % TW;
+            if (d >= D || h >= H || w >= W) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float sc[8], sh[8], rv[8], v[8];
+                const int o0 = ob64 * 64 + 32 * q + 8 * kg;
+                const size_t idx0 = ((size_t)n * Cout + o0) * vol + (size_t)d * plane + (size_t)h * W + w;
+                const bool fin = nsplit == 1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sc[j] = (fin && scale) ? scale[o0 + j] : 1.0f;
+                    sh[j] = (fin && scale) ? shift[o0 + j] : 0.0f;
+                    rv[j] = (fin && residual) ? residual[idx0 + (size_t)j * vol] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = j < 4 ? acc16[2 * q][cg][j & 3] : acc16[2 * q + 1][cg][j & 3];
+                    if (nsplit > 1) {
+                        partial[(size_t)split * total + idx0 + (size_t)j * vol] = v[j];
+                        continue;
+                    }
+                    if (scale) v[j] = fmaf(v[j], sc[j], sh[j]);
+                    if (residual) v[j] = v[j] + rv[j];
+                    if (relu) v[j] = fmaxf(v[j], 0.0f);
+                    if (out) out[idx0 + (size_t)j * vol] = v[j];
+                }
+                if (nsplit == 1 && (dst.scl || dst.pscl)) bf_store_units(dst, v, n, Cout / 8, ob64 * 8 + 4 * q + kg, d, h, w);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int g = 2 * wave + b;
@@ -1206,13 +1313,14 @@ extern "C" int mvsdet_split_conv_weight_ordered(const float* weight, void* weigh
                                                 mvsdet_stream_t stream) {
     MVS_REQUIRE(weight && weight_split, "split_conv_weight: NULL pointer");
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0 && Cin > 0, "split_conv_weight: Cout=%d must be a positive multiple of 64, Cin=%d > 0", Cout, Cin);
-    MVS_REQUIRE(order >= 0 && order <= 2, "split_conv_weight: order %d not in {0,1,2}", order);
+    MVS_REQUIRE(order >= 0 && order <= 3, "split_conv_weight: order %d not in {0,1,2,3}", order);
+    if (order == 0 && options().conv_mfma16) order = 3;   // the stride-1 kernels then run their 16x16x32 form: its layout
     MVS_REQUIRE(((uintptr_t)weight_split & 15u) == 0, "split_conv_weight: output must be 16-byte aligned");
     const size_t units = mvsdet_split_conv_weight_bytes(Cout, Cin) / 16;
     const long long so = order == 2 ? 27 : (long long)Cin * 27, sc = order == 2 ? (long long)Cout * 27 : 27;
     hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((units + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       (hipStream_t)stream, weight, static_cast<uint4*>(weight_split), Cin, (Cin + 7) / 8, units, tap_table(order),
-                       so, sc);
+                       (hipStream_t)stream, weight, static_cast<uint4*>(weight_split), Cin, (Cin + 7) / 8, units,
+                       tap_table(order == 3 ? 0 : order), so, sc, order == 3 ? 1 : 0);
     MVS_LAUNCH_CHECK("split_conv_weight");
     return MVSDET_OK;
 }
@@ -1232,7 +1340,7 @@ extern "C" int mvsdet_split_conv_weights_batched(const float* const* weights, vo
         const bool live = i < count;
         if (live) {
             MVS_REQUIRE(weights[i] && splits[i], "split_conv_weights_batched: NULL tensor %d", i);
-            MVS_REQUIRE(Cout[i] > 0 && Cout[i] % 64 == 0 && Cin[i] > 0 && orders[i] >= 0 && orders[i] <= 2,
+            MVS_REQUIRE(Cout[i] > 0 && Cout[i] % 64 == 0 && Cin[i] > 0 && orders[i] >= 0 && orders[i] <= 3,
                         "split_conv_weights_batched: tensor %d: Cout=%d (multiple of 64), Cin=%d, order=%d", i, Cout[i], Cin[i], orders[i]);
             MVS_REQUIRE(((uintptr_t)splits[i] & 15u) == 0, "split_conv_weights_batched: outputs must be 16-byte aligned");
         }
@@ -1240,7 +1348,7 @@ extern "C" int mvsdet_split_conv_weights_batched(const float* const* weights, vo
         b.out[i] = live ? static_cast<uint4*>(splits[i]) : nullptr;
         b.Cin[i] = live ? Cin[i] : 1;
         b.Cout[i] = live ? Cout[i] : 64;
-        b.order[i] = live ? orders[i] : 0;
+        b.order[i] = live ? ((orders[i] == 0 && options().conv_mfma16) ? 3 : orders[i]) : 0;
         b.first[i + 1] = b.first[i] + (live ? mvsdet_split_conv_weight_bytes(Cout[i], Cin[i]) / 16 : 0);
     }
     const size_t units = b.first[count];
@@ -1306,9 +1414,9 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     const BfOut dst = make_out(out, out_scl, out_pscl, N, Cout, D, H, W);
     dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
     hipStream_t st = (hipStream_t)stream;
-#define MVS_BF_CASE(TD_, TH_, F32_, TW_, SUBP_)                                                                             \
+#define MVS_BF_CASE(TD_, TH_, F32_, TW_, SUBP_, M16_)                                                                       \
     {                                                                                                                       \
-        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_, TW_, SUBP_>;                                                      \
+        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_, TW_, SUBP_, M16_>;                                                \
         const size_t lds = bf_lds_bytes(TD_, TH_, TW_, SUBP_);                                                              \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
             hipSuccess) {                                                                                                   \
@@ -1319,22 +1427,25 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
                            Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W,    \
                            p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total);        \
     }
+#define MVS_BF_TILE(TD_, TH_, F32_, TW_) { if (m16) MVS_BF_CASE(TD_, TH_, F32_, TW_, 6, true) else MVS_BF_CASE(TD_, TH_, F32_, TW_, 5, false) }
     // option "conv_subpairs" = 2: weight sub-stages of 2 tap pairs (instead of 5) bring the 3 x 16 x 8 tile's LDS to 77 KiB, two
     // 6-wave blocks per CU.  Measured at the cost network's 6 x 30 x 40 layer: 1.00 against 0.97 ms -- seven barriers per
     // channel group cost what the second block wins; kept as a knob, off by default.
-    const bool sub2 = options().conv_subpairs == 2;
+    // option "conv_mfma16": the 16x16x32 form of the kernel (the weights must have been split while the option was set).
+    const bool sub2 = options().conv_subpairs == 2, m16 = options().conv_mfma16 != 0;
     if (xf) {
-        if (p.tw == 8 && p.td == 3) { if (sub2) MVS_BF_CASE(3, 16, true, 8, 2) else MVS_BF_CASE(3, 16, true, 8, 5) }
-        else if (p.tw == 8 && p.td == 6) MVS_BF_CASE(6, 16, true, 8, 5)
-        else if (p.tw == 8) MVS_BF_CASE(8, 8, true, 8, 5)
-        else if (p.th == 12) MVS_BF_CASE(4, 12, true, kBfW, 5)
-        else MVS_BF_CASE(4, 8, true, kBfW, 5)
+        if (p.tw == 8 && p.td == 3) { if (sub2 && !m16) MVS_BF_CASE(3, 16, true, 8, 2, false) else MVS_BF_TILE(3, 16, true, 8) }
+        else if (p.tw == 8 && p.td == 6) MVS_BF_TILE(6, 16, true, 8)
+        else if (p.tw == 8) MVS_BF_TILE(8, 8, true, 8)
+        else if (p.th == 12) MVS_BF_TILE(4, 12, true, kBfW)
+        else MVS_BF_TILE(4, 8, true, kBfW)
     } else {
-        if (p.tw == 8 && p.td == 3) MVS_BF_CASE(3, 16, false, 8, 5)
-        else if (p.tw == 8) MVS_BF_CASE(6, 16, false, 8, 5)
-        else if (p.th == 12) MVS_BF_CASE(4, 12, false, kBfW, 5)
-        else MVS_BF_CASE(4, 8, false, kBfW, 5)
+        if (p.tw == 8 && p.td == 3) MVS_BF_TILE(3, 16, false, 8)
+        else if (p.tw == 8) MVS_BF_TILE(6, 16, false, 8)
+        else if (p.th == 12) MVS_BF_TILE(4, 12, false, kBfW)
+        else MVS_BF_TILE(4, 8, false, kBfW)
     }
+#undef MVS_BF_TILE
 #undef MVS_BF_CASE
     MVS_LAUNCH_CHECK(name);
     if (nsplit > 1) {

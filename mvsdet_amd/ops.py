@@ -708,6 +708,14 @@ def _tap_table(order: int):
 ROW_CHANNEL = [8 * ((m >> 4) * 2 + ((m >> 2) & 1)) + (m & 3) + 4 * ((m >> 3) & 1) for m in range(32)]
 
 
+def get_option(name: str) -> int:
+    """A tuning option of the library (mvsdet_get_option)."""
+    import ctypes
+    v = ctypes.c_int(0)
+    _lib.check(_lib.load().mvsdet_get_option(name.encode(), ctypes.byref(v)), "get_option")
+    return int(v.value)
+
+
 def split_conv_weight(weight: Tensor, order: int = 0) -> Tensor:
     """Conv3d weight (Cout = 64*m, Cin, 3,3,3) fp32 -> the layout the bf16x3 kernels stream into LDS (include/mvsdet_hip.h):
     [Cout/64][ceil(Cin/8)][14 tap pairs][2 row groups][2 pieces][64 lanes][8 channels] bf16, lane = 32*(half of the pair) +
@@ -720,7 +728,7 @@ def split_conv_weight(weight: Tensor, order: int = 0) -> Tensor:
         cin, cout = weight.shape[:2]
     else:
         cout, cin = weight.shape[:2]
-    if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3) or order not in (0, 1, 2):
+    if cout % 64 or tuple(weight.shape[2:]) != (3, 3, 3) or order not in (0, 1, 2, 3):
         raise ValueError(f"split_conv_weight: weight {tuple(weight.shape)} (order {order}) has no 64*m output channels / 3x3x3 taps")
     c8 = (cin + 7) // 8
     if weight.is_cuda:
@@ -732,10 +740,15 @@ def split_conv_weight(weight: Tensor, order: int = 0) -> Tensor:
         return out
     w = weight.detach().to(torch.float32)
     w = (w.transpose(0, 1) if order == 2 else w).reshape(cout, cin, 27)
-    taps = torch.tensor(_tap_table(order))
+    taps = torch.tensor(_tap_table(0 if order == 3 else order))
     w = torch.where(taps.view(1, 1, 28) >= 0, w[:, :, taps.clamp(min=0)], torch.zeros(()))   # (Cout, Cin, 28) in pair order
     w = torch.nn.functional.pad(w, (0, 0, 0, c8 * 8 - cin))                                  # channels -> 8*c8
     pieces = torch.stack(split_bf16(w), 0)                                                  # (piece, Cout, C, 28)
+    if order == 3 or (order == 0 and get_option("conv_mfma16")):
+        # the 16x16x32 form: channel = ob*64 + 32q + 8mh + 4b + ml (row group rg = 2q + b, row m = 4mh + ml), tap = 4ks + kg
+        # (piece, ob, q, mh, b, ml, c8, j, ks, kg) -> (ob, c8, ks, q, b, piece, kg, mh, ml, j)
+        pieces = pieces.reshape(2, cout // 64, 2, 4, 2, 4, c8, 8, 7, 4).permute(1, 6, 8, 2, 4, 0, 9, 3, 5, 7)
+        return pieces.contiguous().reshape(cout // 64, c8, 14, 2, 2, 64, 8)
     # (piece, ob, a, m, c8, j, p, h) with row m <- channel ROW_CHANNEL[m]  -> (ob, c8, p, a, piece, h, m, j)
     pieces = pieces.reshape(2, cout // 64, 2, 32, c8, 8, 14, 2)[:, :, :, torch.tensor(ROW_CHANNEL)].permute(1, 4, 6, 2, 0, 7, 3, 5)
     return pieces.contiguous().reshape(cout // 64, c8, 14, 2, 2, 64, 8)
