@@ -1437,7 +1437,9 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
         if (p.tw == 8 && p.td == 3) { if (sub2 && !m16) MVS_BF_CASE(3, 16, true, 8, 2, false) else MVS_BF_TILE(3, 16, true, 8) }
         else if (p.tw == 8 && p.td == 6) MVS_BF_TILE(6, 16, true, 8)
         else if (p.tw == 8) MVS_BF_TILE(8, 8, true, 8)
-        else if (p.th == 12) MVS_BF_TILE(4, 12, true, kBfW)
+        // (the cost network's first layer: two weight sub-stages of 4 + 3 k-steps instead of 3 + 3 + 1 -- one barrier less per
+        // channel group, all 160 KiB of LDS; "conv_subpairs" = 6 keeps three)
+        else if (p.th == 12) { if (m16 && options().conv_subpairs != 6) MVS_BF_CASE(4, 12, true, kBfW, 8, true) else MVS_BF_TILE(4, 12, true, kBfW) }
         else MVS_BF_TILE(4, 8, true, kBfW)
     } else {
         if (p.tw == 8 && p.td == 3) MVS_BF_TILE(3, 16, false, 8)
