@@ -250,8 +250,10 @@ __host__ __device__ constexpr int bf_tap_off(int t) {
 // sums per output as the 32 x 32 form, but MFMA-dense loops hold a higher clock on this shape (MI355X_MICROARCH.md, DVFS
 // give-back item 7: ~1.12 - 1.15 x the FLOP/s at equal cycles per FLOP).  Weights: split order 3 (k-step-major, SUBP = 6 "pairs"
 // = 3 k-steps per sub-stage: 3 + 3 + 1).
-template <int TD, int TH, bool F32IN, int TW = kBfW, int SUBP = kBfSubPairs, bool M16 = false>
-__global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
+// CGN (16x16x32 form): column groups of 16 voxels per wave.  4: a wave = 64 voxels; 2: 32 voxels, twice the waves -- the
+// 3 x 16 x 8 tile then runs on 12 waves (three on every SIMD) instead of 6 (2/2/1/1 on the one block a CU holds).
+template <int TD, int TH, bool F32IN, int TW = kBfW, int SUBP = kBfSubPairs, bool M16 = false, int CGN = 4>
+__global__ __launch_bounds__(TD * TH * TW * 4 / CGN) void conv3d_k3_bf16x3_kernel(
     const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
     const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, BfOut dst, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                           // h-rows of one column group
     static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
-    constexpr int NW = TD * TH * TW / 64;                 // waves
+    static_assert(CGN == 4 || (M16 && CGN == 2), "half-size waves: 16x16x32 form only");
+    constexpr int NW = TD * TH * TW / (16 * CGN);         // waves
     constexpr int NT = 64 * NW;                           // threads
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     constexpr int NVOX = HD * HH * HW;
@@ -392,10 +395,10 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
     // M16: four column groups of 16 voxels, g16 = 4*wave + cg: RG16 = 16 / TW h-rows each; lane = (voxel lane & 15, tap group lane >> 4)
     constexpr int RG16 = 16 / TW > 0 ? 16 / TW : 1;
     const int col16 = lane & 15, kg = lane >> 4;
-    int vb16[4], toffs[7];
+    int vb16[CGN], toffs[7];
 #pragma unroll
-    for (int cg = 0; cg < 4; ++cg) {
-        const int g = 4 * wave + cg;
+    for (int cg = 0; cg < CGN; ++cg) {
+        const int g = CGN * wave + cg;
         const int dz = g / (TH / RG16), hy = RG16 * (g % (TH / RG16)) + col16 / TW;
         vb16[cg] = (dz * HH + hy) * HW + col16 % TW;
     }
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
 
     f32x16b acc[2][2];   // [row group (32 output channels)][column group]
     typedef float f32x4b __attribute__((ext_vector_type(4)));
-    f32x4b acc16[4][4];  // M16: [row group (16 output channels)][column group (16 voxels)]
+    f32x4b acc16[4][CGN];  // M16: [row group (16 output channels)][column group (16 voxels)]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < CGN; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc16[a][b][r] = 0.0f;
 
@@ -432,19 +435,19 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
 #pragma unroll
             for (int kl = 0; kl < np / 2; ++kl) {
                 const int toff = toffs[s * (SUBP / 2) + kl];
-                bf16x8 A[4][2], B[4][2];   // [row / column group][piece]
+                bf16x8 A[4][2], B[CGN][2];   // [row / column group][piece]
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) A[a][q] = ain[((kl * 4 + a) * 2 + q) * 64];
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < CGN; ++b)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb16[b] + toff];
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
+                    for (int b = 0; b < CGN; ++b) {
                         acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[a][1], B[b][0], acc16[a][b], 0, 0, 0);   // w_mid * x_hi
                         acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[a][0], B[b][1], acc16[a][b], 0, 0, 0);   // w_hi * x_mid
                         acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[a][0], B[b][0], acc16[a][b], 0, 0, 0);   // w_hi * x_hi
@@ -532,8 +535,8 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_bf16x3_kernel(
         // so that row m of row group rg carries channel 32*(rg >> 1) + 8*(m >> 2) + 4*(rg & 1) + (m & 3): row groups 2q and 2q+1
         // together give a lane the eight consecutive channels 32q + 8kg .. + 7
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int g = 4 * wave + cg;
+        for (int cg = 0; cg < CGN; ++cg) {
+            const int g = CGN * wave + cg;
             const int d = d0 + g / (TH / RG16), h = h0 + RG16 * (g % (TH / RG16)) + col16 / TW, w = w0 + col16 % TW;
             if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
@@ -914,13 +917,13 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
 __host__ __device__ constexpr int ct_pairs(int pd, int ph) { return s2_pairs(pd * 4 + ph * 2) + s2_pairs(pd * 4 + ph * 2 + 1); }
 constexpr int kCtWSlots = 6 * 2 * 2 * 64;   // up to 6 tap pairs per stage
 // slots of one piece of one input stage: the halo tile, rounded up until the 2 * INS / 64 DMAs of a stage divide evenly over the waves
-__host__ __device__ constexpr int ct_ins(int TD, int TH, int TW) {
+__host__ __device__ constexpr int ct_ins(int TD, int TH, int TW, int CG = 2) {
     int ins = ((TD + 1) * (TH + 1) * (TW + 1) + 63) / 64 * 64;
-    while ((2 * ins / 64) % (TD * TH * TW / 64)) ins += 64;
+    while ((2 * ins / 64) % (TD * TH * TW / (32 * CG))) ins += 64;
     return ins;
 }
-__host__ __device__ constexpr size_t ct_lds_bytes(int TD = kS2TD, int TH = kS2TH, int TW = kBfW) {
-    return (size_t)(3 * 2 * ct_ins(TD, TH, TW) + 3 * kCtWSlots) * 16;
+__host__ __device__ constexpr size_t ct_lds_bytes(int TD = kS2TD, int TH = kS2TH, int TW = kBfW, int CG = 2) {
+    return (size_t)(3 * 2 * ct_ins(TD, TH, TW, CG) + 3 * kCtWSlots) * 16;
 }
 // tap j of output class pi as an offset in the halo tile (origin = the tile's first input voxel): per odd dimension bit 0 ->
 // k = 0 reads input i + 1, bit 1 -> k = 2 reads input i
@@ -935,18 +938,21 @@ __host__ __device__ constexpr int ct_tap_off(int pi, int j) {
     return (od * HH + oh) * HW + ow;
 }
 
-template <int PD, int PH, int TD, int TH, int TW>
+// CG: column groups (32 coarse voxels each) per wave.  2: a wave = 64 voxels x 64 channels x 2 w parities = 8 accumulators, the
+// 3 x 16 x 8 tile = 6 waves, which sit 2/2/1/1 on the four SIMDs of the one block a CU holds; 1: 4 accumulators, 12 waves, three
+// on every SIMD (each A fragment then feeds half the MFMAs: 6 LDS reads per 6 instead of 8 per 12).
+template <int PD, int PH, int TD, int TH, int TW, int CG>
 __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, const BfOut& dst, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu, int tile_xy) {
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                           // h-rows of one column group
-    static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
-    constexpr int NW = TD * TH * TW / 64;
-    constexpr int HH = TH + 1, HW = TW + 1, NVOX = (TD + 1) * HH * HW, INS = ct_ins(TD, TH, TW);
+    static_assert(TH % RG == 0 && (TD * TH * TW) % (32 * CG) == 0, "whole column groups, CG per wave");
+    constexpr int NW = TD * TH * TW / (32 * CG);
+    constexpr int HH = TH + 1, HW = TW + 1, NVOX = (TD + 1) * HH * HW, INS = ct_ins(TD, TH, TW, CG);
     constexpr int IN_DMA = INS / 64;                      // 12 wave-instructions per piece
-    constexpr int IN_PER_WAVE = 2 * IN_DMA / NW;          // 3 (8 waves) or 4 (6 waves)
+    constexpr int IN_PER_WAVE = 2 * IN_DMA / NW;          // 3 (8 waves), 4 (6 waves) or 2 (12 waves)
     constexpr int PI0 = PD * 4 + PH * 2, NP0 = s2_pairs(PI0), NP1 = s2_pairs(PI0 + 1), NP = NP0 + NP1;
     constexpr int W_PER_WAVE = (NP * 4 + NW - 1) / NW;    // weight DMAs per wave and stage (the tail repeats earlier pieces)
     constexpr int DMA_PER_STAGE = IN_PER_WAVE + W_PER_WAVE;
@@ -995,20 +1001,20 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
         }
     };
 
-    int vb[2];
+    int vb[CG];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int g = 2 * wave + b;
+    for (int b = 0; b < CG; ++b) {
+        const int g = CG * wave + b;
         const int dz = g / (TH / RG), hy = RG * (g % (TH / RG)) + col / TW;
         vb[b] = (dz * HH + hy) * HW + col % TW;
     }
-    f32x16b acc[2][2][2];   // [w parity][row group][column group]
+    f32x16b acc[2][2][CG];   // [w parity][row group][column group]
 #pragma unroll
     for (int pw = 0; pw < 2; ++pw)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < CG; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pw][a][b][r] = 0.0f;
     const bf16x8* s_in8 = reinterpret_cast<const bf16x8*>(s_in);
@@ -1022,19 +1028,19 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
             const int pw = pl < NP0 ? 0 : 1;
             const int pi = PI0 + pw, pj = pw ? pl - NP0 : pl;
             const int toff = hh ? ct_tap_off<HH, HW>(pi, 2 * pj + 1) : ct_tap_off<HH, HW>(pi, 2 * pj);
-            bf16x8 A[2][2], B[2][2];
+            bf16x8 A[2][2], B[CG][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) A[a][q] = ain[((pl * 2 + a) * 2 + q) * 64];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < CG; ++b)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb[b] + toff];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < CG; ++b) {
                     acc[pw][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], acc[pw][a][b], 0, 0, 0);
                     acc[pw][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], acc[pw][a][b], 0, 0, 0);
                     acc[pw][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], acc[pw][a][b], 0, 0, 0);
@@ -1060,8 +1066,8 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
     const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
     const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int g = 2 * wave + b;
+    for (int b = 0; b < CG; ++b) {
+        const int g = CG * wave + b;
         const int di = d0 + g / (TH / RG), hi = h0 + RG * (g % (TH / RG)) + col / TW, wi = w0 + col % TW;
         if (di >= Di || hi >= Hi || wi >= Wi) continue;
         const size_t pos = (size_t)(2 * di + PD) * oplane + (size_t)(2 * hi + PH) * Wo + 2 * wi;
@@ -1070,7 +1076,7 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
             // the 16 skip values of this (row group, column group) are requested together, ahead of the stores: loads and
             // stores share one in-order counter, so a load issued behind a store waits for the store's round trip as well
             // -- one value at a time, the epilogue took half of the layer's time
-            if (!(dst.scl || dst.pscl)) {
+            if (CG == 2 && !(dst.scl || dst.pscl)) {   // (12-wave form: 168 registers per lane do not hold 16 at a time)
                 // fp32 only: the 16 skip values of this (row group, column group) are requested together, ahead of the stores:
                 // loads and stores share one in-order counter, so a load issued behind a store waits for the store's round trip
                 // as well -- one value at a time, the epilogue took half of the layer's time (conv11: 1.2 GB of skip and output)
@@ -1145,16 +1151,16 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
 
 // ONE launch for the four (PD, PH) classes: class = blockIdx.x & 3, so the four blocks that read the same input tile are
 // dispatched together (the tile's second to fourth reads hit L2) and the grid has one tail instead of four.
-template <int TD, int TH, int TW>
-__global__ __launch_bounds__(TD * TH * TW) void convT3d_k3_s2_bf16x3_kernel(
+template <int TD, int TH, int TW, int CG>
+__global__ __launch_bounds__(TD * TH * TW * 2 / CG) void convT3d_k3_s2_bf16x3_kernel(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, BfOut out, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
     size_t piece_stride, int tiles_w, int relu) {
     const int cls = blockIdx.x & 3, tile_xy = blockIdx.x >> 2;
-    if (cls == 0) convT3d_k3_s2_bf16x3_body<1, 1, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
-    else if (cls == 1) convT3d_k3_s2_bf16x3_body<1, 0, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
-    else if (cls == 2) convT3d_k3_s2_bf16x3_body<0, 1, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
-    else convT3d_k3_s2_bf16x3_body<0, 0, TD, TH, TW>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    if (cls == 0) convT3d_k3_s2_bf16x3_body<1, 1, TD, TH, TW, CG>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else if (cls == 1) convT3d_k3_s2_bf16x3_body<1, 0, TD, TH, TW, CG>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else if (cls == 2) convT3d_k3_s2_bf16x3_body<0, 1, TD, TH, TW, CG>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
+    else convT3d_k3_s2_bf16x3_body<0, 0, TD, TH, TW, CG>(xs, wq, scale, shift, residual, out, C8, Cout, Di, Hi, Wi, Dp, Hp, Wp, piece_stride, tiles_w, relu, tile_xy);
 }
 
 }  // namespace mvsdet
@@ -1414,16 +1420,17 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     const BfOut dst = make_out(out, out_scl, out_pscl, N, Cout, D, H, W);
     dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
     hipStream_t st = (hipStream_t)stream;
-#define MVS_BF_CASE(TD_, TH_, F32_, TW_, SUBP_, M16_)                                                                       \
+#define MVS_BF_CASE(TD_, TH_, F32_, TW_, SUBP_, M16_, ...)                                                                  \
     {                                                                                                                       \
-        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_, TW_, SUBP_, M16_>;                                                \
+        constexpr int CGN_ = (0, ##__VA_ARGS__) ? (0, ##__VA_ARGS__) : 4;                                                   \
+        auto* k = conv3d_k3_bf16x3_kernel<TD_, TH_, F32_, TW_, SUBP_, M16_, CGN_>;                                          \
         const size_t lds = bf_lds_bytes(TD_, TH_, TW_, SUBP_);                                                              \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
             hipSuccess) {                                                                                                   \
             set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                  \
             return MVSDET_ERR_HIP;                                                                                          \
         }                                                                                                                   \
-        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH,      \
+        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_ * 4 / CGN_), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH, \
                            Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W,    \
                            p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total);        \
     }
@@ -1434,7 +1441,8 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     // option "conv_mfma16": the 16x16x32 form of the kernel (the weights must have been split while the option was set).
     const bool sub2 = options().conv_subpairs == 2, m16 = options().conv_mfma16 != 0;
     if (xf) {
-        if (p.tw == 8 && p.td == 3) { if (sub2 && !m16) MVS_BF_CASE(3, 16, true, 8, 2, false) else MVS_BF_TILE(3, 16, true, 8) }
+        // the 3 x 16 x 8 tile on 12 waves of 32 voxels (16x16x32 form; option "conv_cgn" = 4: 6 waves of 64)
+        if (p.tw == 8 && p.td == 3) { if (sub2 && !m16) MVS_BF_CASE(3, 16, true, 8, 2, false) else if (m16 && options().conv_cgn != 4) MVS_BF_CASE(3, 16, true, 8, 6, true, 2) else MVS_BF_TILE(3, 16, true, 8) }
         else if (p.tw == 8 && p.td == 6) MVS_BF_TILE(6, 16, true, 8)
         else if (p.tw == 8) MVS_BF_TILE(8, 8, true, 8)
         // (the cost network's first layer: two weight sub-stages of 4 + 3 k-steps instead of 3 + 3 + 1 -- one barrier less per
@@ -1442,7 +1450,7 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
         else if (p.th == 12) { if (m16 && options().conv_subpairs != 6) MVS_BF_CASE(4, 12, true, kBfW, 8, true) else MVS_BF_TILE(4, 12, true, kBfW) }
         else MVS_BF_TILE(4, 8, true, kBfW)
     } else {
-        if (p.tw == 8 && p.td == 3) MVS_BF_TILE(3, 16, false, 8)
+        if (p.tw == 8 && p.td == 3) { if (m16 && options().conv_cgn != 4) MVS_BF_CASE(3, 16, false, 8, 6, true, 2) else MVS_BF_TILE(3, 16, false, 8) }
         else if (p.tw == 8) MVS_BF_TILE(6, 16, false, 8)
         else if (p.th == 12) MVS_BF_TILE(4, 12, false, kBfW)
         else MVS_BF_TILE(4, 8, false, kBfW)
@@ -1634,20 +1642,22 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
     const BfOut dst = make_out(out, out_scl, nullptr, N, Cout, 2 * D, 2 * H, 2 * W);
     dim3 grid((unsigned)(tiles_w * tiles_h * 4), (unsigned)tiles_d, (unsigned)(N * (Cout / 64)));
     hipStream_t st = (hipStream_t)stream;
-#define MVS_CT_CASE(TD_, TH_, TW_)                                                                                           \
+#define MVS_CT_CASE(TD_, TH_, TW_, CG_)                                                                                      \
     {                                                                                                                        \
-        const size_t lds = ct_lds_bytes(TD_, TH_, TW_);                                                                      \
-        auto* k = convT3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_>;                                                                \
+        const size_t lds = ct_lds_bytes(TD_, TH_, TW_, CG_);                                                                 \
+        auto* k = convT3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_, CG_>;                                                           \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
             hipSuccess) {                                                                                                    \
             set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                   \
             return MVSDET_ERR_HIP;                                                                                           \
         }                                                                                                                    \
-        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, st, static_cast<const uint4*>(xs),                           \
+        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_ * 2 / CG_), lds, st, static_cast<const uint4*>(xs),                 \
                            static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, \
                            p.Wp, piece, tiles_w, relu);                                                                      \
     }
-    if (t38) MVS_CT_CASE(3, 16, 8) else MVS_CT_CASE(kS2TD, kS2TH, kBfW)
+    // the 3 x 16 x 8 tile on 12 waves of one column group each (option "convT_cg" = 2: the 6-wave form)
+    if (t38) { if (options().convT_cg == 2) MVS_CT_CASE(3, 16, 8, 2) else MVS_CT_CASE(3, 16, 8, 1) }
+    else MVS_CT_CASE(kS2TD, kS2TH, kBfW, 2)
 #undef MVS_CT_CASE
     MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;
