@@ -24,7 +24,7 @@ static int env_int(const char* name, int dflt) {
 Options& options() {
     static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1),
                         env_int("MVSDET_SWEEP_DSPLIT", 0), env_int("MVSDET_SWEEP_GROUPS", -1),
-                        env_int("MVSDET_CONV_SUBPAIRS", 0), env_int("MVSDET_CONV_NSPLIT", 0), env_int("MVSDET_CONV_CGN", 0), env_int("MVSDET_CONVT_CG", 0),
+                        env_int("MVSDET_CONV_SUBPAIRS", 0), env_int("MVSDET_CONV_NSPLIT", 0), env_int("MVSDET_CONV_CGN", 0), env_int("MVSDET_CONV_S2_CG", 0), env_int("MVSDET_CONV_S2_OB", 0), env_int("MVSDET_CONVT_CG", 0),
                         env_int("MVSDET_CONV_MFMA16", 1)};
     return o;
 }
@@ -42,6 +42,8 @@ static int* option_slot(const char* name) {
     if (!strcmp(name, "conv_mfma16")) return &o.conv_mfma16;
     if (!strcmp(name, "convT_cg")) return &o.convT_cg;
     if (!strcmp(name, "conv_cgn")) return &o.conv_cgn;
+    if (!strcmp(name, "conv_s2_cg")) return &o.conv_s2_cg;
+    if (!strcmp(name, "conv_s2_ob")) return &o.conv_s2_ob;
     return nullptr;
 }
 

@@ -24,6 +24,8 @@ struct Options {
     int conv_subpairs; // bf16x3 stride-1 convolution on 3x16x8 tiles: tap pairs per weight sub-stage; 0 = by the grid, 2 / 5 force
     int conv_nsplit;   // bf16x3 convolutions: splits of the input channels; 0 = by the grid, n > 0 force (needs the workspace)
     int conv_cgn;      // stride-1 bf16x3 convolution (16x16x32 form) on 3x16x8 tiles: 0 / 2 = 12 waves of 32 voxels, 4 = 6 waves of 64
+    int conv_s2_cg;    // stride-2 bf16x3 convolution fed by PSCL on 3x16x8 tiles: 0 / 1 = 12 waves of one column group, 2 = 6 of two
+    int conv_s2_ob;    // stride-2 bf16x3 convolution fed by PSCL: 1 = 64 output channels per block, else 128 where Cout allows
     int convT_cg;      // transposed bf16x3 convolution on 3x16x8 tiles: column groups per wave; 0 / 1 = 12 waves of one, 2 = 6 waves of two
     int conv_mfma16;   // 1 (default): the bf16x3 stride-1 convolution on v_mfma_f32_16x16x32_bf16 (conv0 of the cost network 5.37 -> 4.91 ms:
                        // the chip holds a higher clock on this shape); 0: 32x32x16.  Weights must be split under the same setting.

@@ -623,8 +623,8 @@ constexpr int kS2TD = 4, kS2TH = 8;
 constexpr int kS2HH = kS2TH + 1, kS2HW = kBfW + 1;
 constexpr int kS2WSlots = 4 * 2 * 2 * 64;                    // up to 4 tap pairs per stage
 __host__ __device__ constexpr int s2_ins(int TD, int TH, int TW) { return ((TD + 1) * (TH + 1) * (TW + 1) + 63) / 64 * 64; }
-__host__ __device__ constexpr size_t s2_lds_bytes(int TD = kS2TD, int TH = kS2TH, int TW = kBfW) {
-    return (size_t)(2 * 2 * s2_ins(TD, TH, TW) + 2 * kS2WSlots) * 16;
+__host__ __device__ constexpr size_t s2_lds_bytes(int TD = kS2TD, int TH = kS2TH, int TW = kBfW, int OB = 1) {
+    return (size_t)(2 * 2 * s2_ins(TD, TH, TW) + 2 * OB * kS2WSlots) * 16;
 }
 __host__ __device__ constexpr int s2_pairs(int pi) { return (1 << ((pi >> 2) + ((pi >> 1) & 1) + (pi & 1))) / 2 == 0 ? 1 : (1 << ((pi >> 2) + ((pi >> 1) & 1) + (pi & 1))) / 2; }
 __host__ __device__ constexpr int s2_first_pair(int pi) { int n = 0; for (int q = 0; q < pi; ++q) n += s2_pairs(q); return n; }
@@ -646,29 +646,33 @@ __host__ __device__ constexpr int s2_tap_off(int pi, int j) {
 // class tile then arrives by LDS-DMA like the stride-1 kernel's halo tile, and the fetch / cut / ds_write of the fp32 form
 // (every second element of a row: half of every fetched sector unused, ~100 vector instructions per thread and stage beside
 // 12 - 48 MFMAs) is gone.
-template <int TD, int TH, int TW, bool PIN = false>
-__global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
+// CG: column groups (32 output voxels) per wave: 2 = 64 voxels x 64 channels per wave; 1 = twice the waves of half the voxels
+// (the 3 x 16 x 8 tile: 12 waves, three on every SIMD, instead of 6).
+// OB: groups of 64 output channels per block.  2: a block's staged class tile feeds twice the MFMAs (this layer reads 8 x the
+// voxels it writes: its input DMAs, not its matrix work, set its time) and a wave's B fragment serves 4 row groups.
+template <int TD, int TH, int TW, bool PIN = false, int CG = 2, int OB = 1>
+__global__ __launch_bounds__(TD * TH * TW * 2 / CG) void conv3d_k3_s2_bf16x3_kernel(
     const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ xp,
     int cDp, int cHp, int cWp, size_t cpiece, int Nviews, const uint4* __restrict__ wq,
     const float* __restrict__ scale, const float* __restrict__ shift, BfOut dst, int C8, int Cout, int Di, int Hi,
     int Wi, int D, int H, int W, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                // h-rows of one column group
-    static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
-    constexpr int NW = TD * TH * TW / 64, NT = 64 * NW;
+    static_assert(TH % RG == 0 && (TD * TH * TW) % (32 * CG) == 0, "whole column groups, CG per wave");
+    constexpr int NW = TD * TH * TW / (32 * CG), NT = 64 * NW;
     constexpr int HH = TH + 1, HW = TW + 1, NVOX = (TD + 1) * HH * HW, INS = s2_ins(TD, TH, TW);
     constexpr int NV = (NVOX + NT - 1) / NT;   // 2 voxel slots per thread and stage
-    extern __shared__ uint4 s_bf[];            // [2 stages][2 pieces][INS] input, then [2 stages][kS2WSlots] weights
+    extern __shared__ uint4 s_bf[];            // [2 stages][2 pieces][INS] input, then [2 stages][OB][kS2WSlots] weights
     uint4* s_in = s_bf;
     uint4* s_w = s_bf + 2 * 2 * INS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
-    const int nob = Cout / 64;
-    // blockIdx.z = (view, block of 64 output channels, split of the channel groups): see conv3d_k3_bf16x3_kernel
+    const int nob = Cout / (64 * OB);
+    // blockIdx.z = (view, block of 64 * OB output channels, split of the channel groups): see conv3d_k3_bf16x3_kernel
     const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
-    const int n = zo / nob, ob64 = zo % nob;
+    const int n = zo / nob, ob64 = (zo % nob) * OB;   // first group of 64 channels of the block
     const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
     const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
     const int col = lane & 31, hh = lane >> 5;
@@ -774,25 +778,26 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
         for (int q = 0; q < 8; ++q)
             if (q == pi) { first = s2_first_pair(q); np = s2_pairs(q); }
         const uint4* src0 = wn + ((size_t)c8 * kBfPairs + first) * (4 * 64) + lane;
-        for (int i = wave; i < np * 4; i += NW) {
-            uint4* dst = s_w + (size_t)buf * kS2WSlots + i * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 64),
+        for (int i = wave; i < OB * np * 4; i += NW) {
+            const int o = i / (np * 4), r = i - o * (np * 4);   // group of 64 channels, 64-unit chunk of the class's pairs
+            uint4* dst = s_w + (size_t)(buf * OB + o) * kS2WSlots + r * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + (size_t)o * C8 * (kBfPairs * 4 * 64) + r * 64),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
-    int vb[2];
+    int vb[CG];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int g = 2 * wave + b;
+    for (int b = 0; b < CG; ++b) {
+        const int g = CG * wave + b;
         const int dz = g / (TH / RG), hy = RG * (g % (TH / RG)) + col / TW;
         vb[b] = (dz * HH + hy) * HW + col % TW;
     }
-    f32x16b acc[2][2];
+    f32x16b acc[2 * OB][CG];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2 * OB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < CG; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     const bf16x8* s_in8 = reinterpret_cast<const bf16x8*>(s_in);
@@ -802,23 +807,23 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
         constexpr int pi = decltype(pc)::value;
         constexpr int np = s2_pairs(pi);
         const bf16x8* bin = s_in8 + (size_t)(buf * 2) * INS;
-        const bf16x8* ain = s_w8 + (size_t)buf * kS2WSlots + lane;
+        const bf16x8* ain = s_w8 + (size_t)buf * OB * kS2WSlots + lane;
 #pragma unroll
         for (int pl = 0; pl < np; ++pl) {
             const int toff = hh ? s2_tap_off<HH, HW>(pi, 2 * pl + 1) : s2_tap_off<HH, HW>(pi, 2 * pl);
-            bf16x8 A[2][2], B[2][2];
+            bf16x8 A[2 * OB][2], B[CG][2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2 * OB; ++a)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) A[a][q] = ain[((pl * 2 + a) * 2 + q) * 64];
+                for (int q = 0; q < 2; ++q) A[a][q] = ain[(size_t)(a >> 1) * kS2WSlots + ((pl * 2 + (a & 1)) * 2 + q) * 64];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < CG; ++b)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) B[b][q] = bin[(size_t)q * INS + vb[b] + toff];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2 * OB; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < CG; ++b) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], acc[a][b], 0, 0, 0);
@@ -871,12 +876,12 @@ __global__ __launch_bounds__(TD * TH * TW) void conv3d_k3_s2_bf16x3_kernel(
 
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int g = 2 * wave + b;
+    for (int b = 0; b < CG; ++b) {
+        const int g = CG * wave + b;
         const int d = d0 + g / (TH / RG), h = h0 + RG * (g % (TH / RG)) + col / TW, w = w0 + col % TW;
         if (d >= D || h >= H || w >= W) continue;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < 2 * OB; ++a) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float sc[8], sh[8], v[8];   // requested ahead of the stores (see conv3d_k3_bf16x3_kernel)
@@ -1560,22 +1565,33 @@ static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void
     const size_t cpiece = (size_t)8 * N * C8 * cDp * cHp * cWp;
     const BfOut dst = make_out(out, out_scl, nullptr, N, Cout, D, H, W);
     dim3 grid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
-#define MVS_S2_CASE(TD_, TH_, TW_, PIN_)                                                                                     \
+#define MVS_S2_CASE(TD_, TH_, TW_, PIN_, CG_, ...)                                                                           \
     {                                                                                                                        \
-        auto* k = conv3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_, PIN_>;                                                           \
-        const size_t lds = s2_lds_bytes(TD_, TH_, TW_);                                                                      \
+        constexpr int OB_ = (0, ##__VA_ARGS__) ? (0, ##__VA_ARGS__) : 1;                                                     \
+        auto* k = conv3d_k3_s2_bf16x3_kernel<TD_, TH_, TW_, PIN_, CG_, OB_>;                                                 \
+        const size_t lds = s2_lds_bytes(TD_, TH_, TW_, OB_);                                                                 \
+        grid.z = (unsigned)(N * (Cout / (64 * OB_)) * nsplit);                                                               \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
             hipSuccess) {                                                                                                    \
             set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                   \
             return MVSDET_ERR_HIP;                                                                                           \
         }                                                                                                                    \
-        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,                 \
+        hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_ * 2 / CG_), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,       \
                            static_cast<const uint4*>(x_pscl), cDp, cHp, cWp, cpiece, N,                                      \
                            static_cast<const uint4*>(weight_split), scale, shift, dst, C8, Cout, Di, Hi, Wi, D, H, W,        \
                            tiles_w, relu, nsplit, static_cast<float*>(workspace), total);                                    \
     }
-    if (x_pscl) { if (t38) MVS_S2_CASE(3, 16, 8, true) else MVS_S2_CASE(kS2TD, kS2TH, kBfW, true) }
-    else { if (t38) MVS_S2_CASE(3, 16, 8, false) else MVS_S2_CASE(kS2TD, kS2TH, kBfW, false) }
+    // the PSCL-fed 3 x 16 x 8 tile on 12 waves of one column group (conv1 0.573 -> 0.563, conv3 0.304 -> 0.291 ms: two 6-wave
+    // blocks already share a CU here; option "conv_s2_cg" = 2: the 6-wave form)
+    // ("conv_s2_ob" = 1: 64 output channels per block; default: 128 where the layer has them)
+    if (x_pscl) {
+        if (t38) {
+            if (options().conv_s2_cg == 2) MVS_S2_CASE(3, 16, 8, true, 2)
+            else if (Cout % 128 == 0 && nsplit == 1 && options().conv_s2_ob != 1) MVS_S2_CASE(3, 16, 8, true, 1, 2)
+            else MVS_S2_CASE(3, 16, 8, true, 1)
+        } else MVS_S2_CASE(kS2TD, kS2TH, kBfW, true, 2)
+    }
+    else { if (t38) MVS_S2_CASE(3, 16, 8, false, 2) else MVS_S2_CASE(kS2TD, kS2TH, kBfW, false, 2) }
 #undef MVS_S2_CASE
     MVS_LAUNCH_CHECK(name);
     if (nsplit > 1) {
