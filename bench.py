@@ -448,9 +448,9 @@ def full_chain_rate(device, steps=10):
     c0_tfl = 2.0 * 27 * wr["C"] * 64 * wr["N"] * wr["D"] * wr["H"] * wr["W"] / 1e12
     roof = {"bound": "mfma", "achieved": round(3 * c0_tfl / c0_ms * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s",
             "frac": round(3 * c0_tfl / c0_ms * 1e3 / 2500.0, 4),
-            "kernel": "conv3d_k3_bf16x3_kernel (conv0 256->64: 61 % of the network; bf16 MFMA, 3 terms per product)",
-            "note": "peak = dense bf16 at 2.4 GHz; by SQ_BUSY_CYCLES the kernel sustains ~1.65 GHz with the matrix pipes ~70 % busy "
-                    "(profiles/r03_costreg_pmc.txt, DESIGN 4.3)",
+            "kernel": "conv3d_k3_bf16x3_kernel (conv0 256->64: 55 % of the network; bf16 MFMA, 3 terms per product)",
+            "note": "peak = dense bf16 at 2.4 GHz; by SQ_BUSY_CYCLES the kernel (16x16x32 MFMA) sustains ~1.87 GHz with the matrix pipes "
+                    "~69 % busy (profiles/r04_costreg_pmc.txt, DESIGN 4.3)",
             "kernel_ms": round(c0_ms, 3), "useful_TFLOPs": round(c0_tfl / c0_ms * 1e3, 1),
             "network_ms": round(net_ms, 3), "network_useful_TFLOPs": round(tfl / net_ms * 1e3, 1),
             "network_vs_fp32_mfma_peak": round(tfl / net_ms * 1e3 / 157.3, 3), "matrix_precision": net.matrix_precision}
