@@ -265,6 +265,12 @@ int mvsdet_conv3d_k3_dw_bf16x3(const float* x, const float* grad_out, float* par
  * as a transposed-convolution weight, dX of a transposed layer = mvsdet_conv3d_k3_s2_mfma_f32 likewise. */
 int mvsdet_conv3d_k3_s2_dw_mfma_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
                                     int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
+/* The same sum (either orientation) on the bf16 matrix cores with three-term split operands (csrc/costreg_dw_s2_bf16.hip:
+ * blocks of 64 coarse x 16 fine channels on v_mfma_f32_16x16x32_bf16; the fine rows are de-interleaved along w while they
+ * are cut into bf16 pieces, so that every tap's fragment is one aligned LDS read).  Same arguments and partial layout;
+ * W a multiple of 8 (the rows of both tensors are read as float4), D and H even. */
+int mvsdet_conv3d_k3_s2_dw_bf16x3(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
+                                  int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
 /* Training-mode BatchNorm3d [+ ReLU] of the network's ConvBnReLU3D / Sequential(ConvTranspose3d, BatchNorm3d, ReLU) blocks
  * (mvs_models/module.py:26-37, mvsnet.py:92-100): batch statistics over (N, D, H, W) per channel (biased variance),
  * running statistics updated in place with `momentum` (unbiased variance, as torch.nn.BatchNorm3d; NULL = not tracked),

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_dw_mfma_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_dw_bf16x3": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_s2_dw_mfma_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_conv3d_k3_s2_dw_bf16x3": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_dx_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_dw_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -84,7 +84,7 @@ class _ConvK3S2(torch.autograd.Function):
             else:
                 gx = ops.convT3d_k3_s2_mfma(gy, ops.permute_convT_weight(weight.detach()), None, None, None, False)
         if ctx.needs_input_grad[1]:
-            gw = ops.conv3d_k3_dw(x, gy, 0, 2)
+            gw = ops.conv3d_k3_dw(x, gy, 0, 2, ctx.bf16x3 and x.shape[-1] % 8 == 0)
         return gx, gw, None
 
 
@@ -115,7 +115,7 @@ class _ConvT3S2(torch.autograd.Function):
             else:
                 gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(weight.detach()), None, None, False, 2)
         if ctx.needs_input_grad[1]:
-            gw = ops.conv3d_k3_dw(gy, x, 0, 2)
+            gw = ops.conv3d_k3_dw(gy, x, 0, 2, ctx.bf16x3 and gy.shape[-1] % 8 == 0)
         return gx, gw, None
 
 

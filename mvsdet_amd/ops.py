@@ -1231,15 +1231,14 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1, 
     (0 = automatic: up to 128 splits, fewer when Cin*Cout is large so that the partial sums stay below 256 MB).
     With stride 2 and the tensors exchanged (x = grad of the output, grad_out = the input) this is the weight gradient of
     ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1) in its own (Cin,Cout,3,3,3) layout.
-    bf16x3 (stride 1 only): the sum runs on the bf16 matrix cores with three-term split operands (csrc/costreg_dw_bf16.hip)."""
+    bf16x3: the sum runs on the bf16 matrix cores with three-term split operands (csrc/costreg_dw_bf16.hip; stride 2:
+    csrc/costreg_dw_s2_bf16.hip, blocks of 64 grad_out x 16 x channels); rows are read as float4: W a multiple of 4 (stride 2: 8)."""
     _req(x, "x", dim=5)
     _req(grad_out, "grad_out", dim=5)
     if stride not in (1, 2):
         raise ValueError(f"conv3d_k3_dw: stride {stride} not in (1, 2)")
-    if bf16x3 and stride != 1:
-        raise ValueError("conv3d_k3_dw: the bf16x3 kernel covers stride 1")
-    if bf16x3 and x.shape[-1] % 4:
-        raise ValueError(f"conv3d_k3_dw: the bf16x3 kernel reads rows as float4, W={x.shape[-1]} is not a multiple of 4")
+    if bf16x3 and x.shape[-1] % (4 * stride):
+        raise ValueError(f"conv3d_k3_dw: the bf16x3 kernel reads rows as float4, W={x.shape[-1]} is not a multiple of {4 * stride}")
     N, Cin, D, H, W = x.shape
     Cout = grad_out.shape[1]
     if any(v % stride for v in (D, H, W)) or tuple(grad_out.shape) != (N, Cout, D // stride, H // stride, W // stride):
@@ -1248,15 +1247,17 @@ def conv3d_k3_dw(x: Tensor, grad_out: Tensor, nsplit: int = 0, stride: int = 1, 
     lib = _lib.load()
     if nsplit <= 0:
         nsplit = max(8, min(128, (256 << 20) // (Cout * Cin * 108)))
-        if bf16x3:   # one block of 9 waves per CU: 256 / (channel blocks) splits, a multiple of 8 (one split = one XCD)
-            nsplit = max(8, min(64, (256 // (((Cin + 31) // 32) * ((Cout + 31) // 32))) // 8 * 8))
-    if bf16x3:       # the kernel keeps the columns of a split in a 4096-entry table
-        nsplit = max(nsplit, -(-(N * ((H + 3) // 4) * ((W + 15) // 16)) // 4096))
+        if bf16x3:   # one block of 12 waves per CU: 256 / (channel blocks) splits, a multiple of 8 (one split = one XCD)
+            cblocks = ((Cin + 31) // 32) * ((Cout + 31) // 32) if stride == 1 else ((Cin + 15) // 16) * ((Cout + 63) // 64)
+            nsplit = max(8, min(64, (256 // cblocks) // 8 * 8))
+    if bf16x3:       # the kernels keep the columns of a split in a 4096-entry table
+        cols = N * ((H + 3) // 4) * ((W + 15) // 16) if stride == 1 else N * ((H // 2 + 3) // 4) * ((W // 2 + 7) // 8)
+        nsplit = max(nsplit, -(-cols // 4096))
     pbytes = lib.mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)
     partial = torch.empty((nsplit, Cout, Cin, 27), dtype=torch.float32, device=x.device)
     fn = lib.mvsdet_conv3d_k3_dw_mfma_f32 if stride == 1 else lib.mvsdet_conv3d_k3_s2_dw_mfma_f32
     if bf16x3:
-        fn = lib.mvsdet_conv3d_k3_dw_bf16x3
+        fn = lib.mvsdet_conv3d_k3_dw_bf16x3 if stride == 1 else lib.mvsdet_conv3d_k3_s2_dw_bf16x3
     with torch.cuda.device(x.device):
         _lib.check(fn(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), pbytes, nsplit, N, Cin, Cout, D, H, W, _stream(x)),
                    "conv3d_k3_dw")

@@ -268,6 +268,47 @@ def test_conv3d_k3_dw_bf16x3(gpu, N, Cin, Cout, D, H, W, nsplit):
     assert float((got - fp32).abs().max()) <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,nsplit", [(2, 16, 64, 4, 8, 16, 4), (1, 40, 70, 2, 6, 24, 3), (2, 5, 3, 2, 2, 8, 2),
+                                                     (1, 64, 128, 6, 10, 40, 200), (2, 64, 128, 12, 60, 80, 0),
+                                                     (1, 33, 31, 6, 14, 24, 7), (3, 8, 130, 2, 4, 16, 1),
+                                                     (2, 128, 64, 4, 12, 40, 0)])
+def test_conv3d_k3_s2_dw_bf16x3(gpu, N, Cin, Cout, D, H, W, nsplit):
+    """Weight gradient of the stride-2 layers (conv1, conv3) and -- the same call with the fine tensor first -- of the transposed
+    ones (conv9, conv11) on the bf16 matrix cores (csrc/costreg_dw_s2_bf16.hip): against the float64 sum of the same three
+    piece products, against ATen's conv3d_weight in float64 within the scheme's truncation, against the fp32-MFMA kernel,
+    and against autograd of conv_transpose3d for the exchanged orientation."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + Cin)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    gy = torch.randn(N, Cout, D // 2, H // 2, W // 2, generator=g)
+    shape = (Cout, Cin, 3, 3, 3)
+    xh, xm = (t.double() for t in ops.split_bf16(x))
+    yh, ym = (t.double() for t in ops.split_bf16(gy))
+    cw = lambda a, b: torch.nn.grad.conv3d_weight(a, shape, b, stride=2, padding=1)
+    want = cw(xh, yh) + cw(xh, ym) + cw(xm, yh)
+    got = ops.conv3d_k3_dw(x.to(gpu), gy.to(gpu), nsplit, 2, True).cpu()
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    nv = N * D * H * W / 8
+    np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=0, atol=2e-6 * scale * max(1.0, nv ** 0.5 / 8))
+    full = cw(x.double(), gy.double())
+    assert float((got.double() - full).abs().max()) <= 1e-4 * scale
+    fp32 = ops.conv3d_k3_dw(x.to(gpu), gy.to(gpu), nsplit, 2).cpu()
+    assert float((got - fp32).abs().max()) <= 1e-4 * scale
+    # the transposed layer (Cout -> Cin, input gy-shaped, output x-shaped): its (Cout,Cin,3,3,3) weight gradient is the same sum
+    xt = gy.double().requires_grad_(True)
+    wt = torch.zeros(shape, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv_transpose3d(xt, wt, stride=2, padding=1, output_padding=1).backward(x.double())
+    assert float((got.double() - wt.grad).abs().max()) <= 1e-4 * scale
+
+
+def test_conv3d_k3_s2_dw_bf16x3_needs_rows_of_whole_float4(gpu):
+    from mvsdet_amd import ops
+    x = torch.zeros(1, 8, 2, 4, 12, device=gpu)
+    with pytest.raises(ValueError, match="multiple of 8"):
+        ops.conv3d_k3_dw(x, torch.zeros(1, 8, 1, 2, 6, device=gpu), 0, 2, True)
+
+
 def test_conv3d_k3_dw_bf16x3_needs_rows_of_whole_float4(gpu):
     from mvsdet_amd import ops
     x = torch.randn(1, 8, 2, 4, 18, device=gpu)
