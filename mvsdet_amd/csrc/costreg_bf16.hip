@@ -1591,7 +1591,11 @@ static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void
             else MVS_S2_CASE(3, 16, 8, true, 1)
         } else MVS_S2_CASE(kS2TD, kS2TH, kBfW, true, 2)
     }
-    else { if (t38) MVS_S2_CASE(3, 16, 8, false, 2) else MVS_S2_CASE(kS2TD, kS2TH, kBfW, false, 2) }
+    else if (t38) {   // fp32 input (the training route, the neck): the same 12 waves of one column group
+        if (options().conv_s2_cg == 2) MVS_S2_CASE(3, 16, 8, false, 2)
+        else if (Cout % 128 == 0 && nsplit == 1 && options().conv_s2_ob != 1) MVS_S2_CASE(3, 16, 8, false, 1, 2)
+        else MVS_S2_CASE(3, 16, 8, false, 1)
+    } else MVS_S2_CASE(kS2TD, kS2TH, kBfW, false, 2)
 #undef MVS_S2_CASE
     MVS_LAUNCH_CHECK(name);
     if (nsplit > 1) {
