@@ -410,7 +410,10 @@ class MVSDetHotPath:
         h, w = geo.height, geo.width
         out = dict(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
                    est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
-                   depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo)
+                   depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo,
+                   # mvsdet.py:582 `opacity = torch.max(prob_volume, dim=1)[0]`: the first of the sorted top-k values IS that
+                   # maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume, cropped at :583
+                   opacity=est_dens[:, 0])
         if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU)
             out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
             if self.bbox_head is not None:

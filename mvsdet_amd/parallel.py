@@ -179,7 +179,8 @@ def forward_scene_view_sharded(hp, feature: torch.Tensor, img_meta: dict, cost_l
         buf[C] = cnt.to(buf.dtype)                          # exact: counts are far below 2^24
         h, w = geo.height, geo.width
         out.update(variance=variance, prob_volume=prob, off_pred=off, est_depth=est_depth[:, :, :h, :w],
-                   est_densities=est_dens[:, :, :h, :w], depth_coding=avg_depth[:, :h, :w].unsqueeze(1))
+                   est_densities=est_dens[:, :, :h, :w], depth_coding=avg_depth[:, :h, :w].unsqueeze(1),
+                   opacity=est_dens[:, 0])
     if sharded:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     cnt = buf[C]

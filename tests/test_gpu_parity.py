@@ -287,6 +287,8 @@ def test_end_to_end_scene_vs_reference_chain(gpu, oracle):
     np.testing.assert_allclose(out["prob_volume"].cpu().numpy(), g["prob"], rtol=0, atol=TOL)
     np.testing.assert_allclose(out["est_densities"].cpu().numpy(), g["est_dens"], rtol=0, atol=TOL)
     np.testing.assert_allclose(out["depth_coding"].cpu().numpy(), g["depth_coding"], rtol=0, atol=TOL)
+    # NVS branch: mvsdet.py:582 `opacity = torch.max(prob_volume, dim=1)[0]` -- the kernel's first top-k value, the same bits
+    assert torch.equal(out["opacity"], out["prob_volume"].max(dim=1)[0])
     # est_depth / voxel volume depend on discrete choices (plane ranking, depth-window tests) that flip when a
     # probability gap or a window margin is below the fp32 noise of the chain: compare where they are decided
     srt = np.sort(g["prob"], axis=1)[:, ::-1]
