@@ -532,14 +532,15 @@ def store_pattern_ceiling(w, device, reps=5):
     tile width and planes per block, non-temporal 16-byte stores, no taps, no arithmetic: mvsdet_store_pattern_probe_f32)
     timed on a volume of the workload's size.  A device-to-device copy (5 TB/s) is no ceiling of a write-only stream; this is."""
     from mvsdet_amd import _lib, ops
-    if w["C"] % 32 or w["W"] % 4 or w.get("half"):
+    if w["C"] % 32 or w["W"] % 4:
         return None
+    dt, eb = (torch.float16, 2) if w.get("half") else (torch.float32, 4)
     tw, th, _ = _lib.sweep_tile_shape(2, w["D"], w["H"], w["W"])
     n = min(w["N"], w.get("chunk") or w["N"])
     dpb = 0
     if w["D"] <= 16 and tw == 16:
         dpb = (w["D"] + (w["D"] + 3) // 4 - 1) // ((w["D"] + 3) // 4)   # the sweep's "about four planes per block" (planesweep.hip)
-    var = torch.empty((n, w["C"], w["D"], w["H"], w["W"]), dtype=torch.float32, device=device)
+    var = torch.empty((n, w["C"], w["D"], w["H"], w["W"]), dtype=dt, device=device)
     ops.store_pattern_probe(var, w["W"], tw, dpb)
     ts = []
     for _ in range(reps):
@@ -549,7 +550,7 @@ def store_pattern_ceiling(w, device, reps=5):
         e1.record()
         torch.cuda.synchronize(device)
         ts.append(e0.elapsed_time(e1))
-    nbytes = var.numel() * 4
+    nbytes = var.numel() * eb
     del var
     torch.cuda.empty_cache()
     return {"GBps": round(nbytes / (float(np.median(ts)) * 1e-3) / 1e9, 1), "ms": round(float(np.median(ts)), 4), "tile": [tw, th],
@@ -689,6 +690,10 @@ def side_workload(name, device, steps=3, warmup=1):
     if w.get("chunk"):
         out["views_per_launch"] = w["chunk"]
         out["note"] = "one launch = table + slab kernel of one view chunk"
+    sp = store_pattern_ceiling(w, device, reps=3)
+    if sp:   # the kernel's store stream alone, same tiles / element size / planes per block
+        out["store_pattern_ceiling"] = sp
+        out["frac_of_store_pattern_ceiling"] = round(sp["ms"] / slab_ms, 4)
     return out
 
 

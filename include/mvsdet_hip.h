@@ -49,6 +49,8 @@ const char* mvsdet_last_error(void);
  *   "sweep_boxcap"  texels of one LDS footprint box (default: what fits, 312 / 200 by the tile shape; 0 = gather every tap
  *                   from global memory)
  *   "sweep_xcd"     0 | 1   XCD-aware block map for fewer than 8 channel slabs
+ *   "sweep_dsplit", "sweep_groups", "conv_*", "convT_cg"   schedules of the sweep's plane split and of the bf16x3
+ *                   convolutions (csrc/common.h: struct Options); "probe_f16_pair" shapes mvsdet_store_pattern_probe_f16 only
  * "sweep_tw" decides the layout of the sweep geometry: consume one (mvsdet_plane_sweep_variance_tabled_f32) under the
  * "sweep_tw" it was built with (mvsdet_plane_sweep_table_f32).  "sweep_boxcap" is baked into the geometry (union boxes,
  * staged / refill flags); the consuming call sizes its LDS slots for the largest capacity a geometry of that tile shape
@@ -457,6 +459,11 @@ int mvsdet_copy_f32(const float* src, float* dst, size_t n_floats, mvsdet_stream
  * non-temporal 16-byte stores and nothing else.  bench.py times it to report what the output LAYOUT allows on the box at hand
  * (`frac_of_store_pattern_ceiling`); `var` is overwritten with arbitrary values. */
 int mvsdet_store_pattern_probe_f32(float* var, int N, int C, int D, int H, int W, int out_w_pitch, int tile_w,
+                                   int planes_per_block, mvsdet_stream_t stream);
+/* The same for fp16 storage (BASELINE configs[4]): a lane's four pixels are 8 bytes, a wave-instruction writes 8 channel rows of
+ * 64 bytes -- half a 128-byte line per row.  Option "probe_f16_pair" = 1: lanes of adjacent pixel quads store 16 bytes of two
+ * channel rows instead (an experiment; the sweep's own flush is the unpaired pattern). */
+int mvsdet_store_pattern_probe_f16(void* var, int N, int C, int D, int H, int W, int out_w_pitch, int tile_w,
                                    int planes_per_block, mvsdet_stream_t stream);
 
 #ifdef __cplusplus

@@ -77,6 +77,7 @@ SIGNATURES = {
                                               _i, _i, _i, _i, _i, _i, _f, _vp],
     "mvsdet_copy_f32": [_vp, _vp, _sz, _vp],
     "mvsdet_store_pattern_probe_f32": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_store_pattern_probe_f16": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_scl_bytes": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mvsdet_pscl_bytes": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mvsdet_conv3d_k3_bf16x3_io": [_vp, _vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],

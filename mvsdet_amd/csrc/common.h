@@ -27,6 +27,9 @@ struct Options {
     int conv_s2_cg;    // stride-2 bf16x3 convolution fed by PSCL on 3x16x8 tiles: 0 / 1 = 12 waves of one column group, 2 = 6 of two
     int conv_s2_ob;    // stride-2 bf16x3 convolution fed by PSCL: 1 = 64 output channels per block, else 128 where Cout allows
     int convT_cg;      // transposed bf16x3 convolution on 3x16x8 tiles: column groups per wave; 0 / 1 = 12 waves of one, 2 = 6 waves of two
+    int probe_f16_pair; // mvsdet_store_pattern_probe_f16 only: 1 = lanes of adjacent pixel quads own the octet between them and store
+                       // 16 bytes of two channel rows instead of 8 of four (what a paired flush of the fp16 sweep WOULD reach: +12 %,
+                       // not built -- the fp16 sweep is bound by its vector work); 0 (default) = the kernel's own pattern
     int conv_mfma16;   // 1 (default): the bf16x3 stride-1 convolution on v_mfma_f32_16x16x32_bf16 (conv0 of the cost network 5.37 -> 4.91 ms:
                        // the chip holds a higher clock on this shape); 0: 32x32x16.  Weights must be split under the same setting.
 };

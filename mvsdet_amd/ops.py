@@ -1053,13 +1053,16 @@ def device_copy(src: Tensor, dst: Tensor):
 
 # ------------------------------------------------------------------------------------------- cost network head (f-1)
 def store_pattern_probe(var: Tensor, W: int, tile_w: int, planes_per_block: int = 0) -> None:
-    """Overwrites `var` -- an (N,C,D,H,pitch) fp32 buffer -- with the sweep's store stream alone (bench.py: the ceiling of the
-    output layout on the box at hand)."""
-    _req(var, "var", dim=5)
+    """Overwrites `var` -- an (N,C,D,H,pitch) fp32 or fp16 buffer -- with the sweep's store stream alone (bench.py: the ceiling
+    of the output layout on the box at hand)."""
+    if var.dtype not in (torch.float32, torch.float16) or not var.is_cuda or not var.is_contiguous() or var.dim() != 5:
+        raise ValueError("store_pattern_probe: var must be a contiguous 5-D fp32 or fp16 CUDA tensor")
     N, C, D, H, pitch = var.shape
+    lib = _lib.load()
+    fn = lib.mvsdet_store_pattern_probe_f32 if var.dtype == torch.float32 else lib.mvsdet_store_pattern_probe_f16
     with torch.cuda.device(var.device):
-        _lib.check(_lib.load().mvsdet_store_pattern_probe_f32(_lib.ptr(var), N, C, D, H, int(W), int(pitch), int(tile_w),
-                                                              int(planes_per_block), _stream(var)), "store_pattern_probe")
+        _lib.check(fn(_lib.ptr(var), N, C, D, H, int(W), int(pitch), int(tile_w), int(planes_per_block), _stream(var)),
+                   "store_pattern_probe")
 
 
 def conv3d_k3_cout2_sum(x: Tensor, x2: Optional[Tensor], weight: Tensor, bias: Optional[Tensor]) -> Tensor:
