@@ -343,6 +343,29 @@ template <int S>
 __device__ __forceinline__ int quad_bcast(int v) {
     return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xf, 0xf, true);
 }
+// quad_bcast<S>(v) + add as ONE instruction.  The operand v must have been written at least two wait states earlier (a DPP
+// operand fresh from the vector pipe is a hazard hipcc cannot see inside inline assembly): dpp_sources_settled() below.
+// All of these statements are volatile: they keep their program order among themselves.
+template <int S>
+__device__ __forceinline__ int quad_bcast_add(int v, int add) {
+    int r;
+    if constexpr (S == 0) asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
+    else if constexpr (S == 1) asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
+    else if constexpr (S == 2) asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
+    else asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
+    return r;
+}
+// Two wait states between the instructions that wrote the four values (its inputs: they come first) and every
+// quad_bcast_add after it (volatile like it: they come later).
+__device__ __forceinline__ void dpp_sources_settled(int a, int b, int c, int d) {
+    asm volatile("s_nop 1" : : "v"(a), "v"(b), "v"(c), "v"(d));
+}
+// 16 bytes at an LDS ADDRESS (not an index into a __shared__ array: the address arrives ready-made from quad_bcast_add)
+__device__ __forceinline__ float4 lds_f4_at(int addr) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 t = *(const __attribute__((address_space(3))) v4*)(size_t)(unsigned)addr;
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 template <int Q>
 __device__ __forceinline__ int from_quad(int v) {
     return Q == 0 ? __builtin_amdgcn_update_dpp(v, v, 0x114 /* row_shr:4 */, 0xf, 0xA, false)
@@ -433,6 +456,8 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
     }
     const float rcp = 1.0f / (float)(K + 1);
     const int slot_f4 = (box_cap + kBoxPad) * 8;  // float4 per LDS slot
+    const int g16 = g * 16;                       // the lane's 16 bytes of a texel
+    const int g16_lds = g16 + (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)s_box;   // ... as an LDS address
 
     // the lane's 4 consecutive pixels: tile-local p0 .. p0+3 (4 | TW, so they share a row)
     const int p0 = 32 * sub + 4 * ps;
@@ -607,9 +632,9 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
             S_[s][0] = f[s][0]; S_[s][1] = f[s][1];
             Q_[s][0] = f[s][0] * f[s][0]; Q_[s][1] = f[s][1] * f[s][1];   // loop invariant: hoisted (16 VGPRs)
         }
-#define MVS_TAP_STEP(SS, LOADER)                                                                                      \
+#define MVS_TAP_STEP(SS, LOADER, OFF)                                                                                 \
         {                                                                                                             \
-            const int o0 = quad_bcast<SS>(ro0), o1 = quad_bcast<SS>(ro1), o2 = quad_bcast<SS>(ro2), o3 = quad_bcast<SS>(ro3); \
+            const int o0 = OFF(SS, ro0), o1 = OFF(SS, ro1), o2 = OFF(SS, ro2), o3 = OFF(SS, ro3);                     \
             const f2 w0 = splat(__int_as_float(quad_bcast<SS>(rw0))), w1 = splat(__int_as_float(quad_bcast<SS>(rw1)));  \
             const f2 w2 = splat(__int_as_float(quad_bcast<SS>(rw2))), w3 = splat(__int_as_float(quad_bcast<SS>(rw3)));  \
             const float4 t0 = LOADER(o0), t1 = LOADER(o1), t2 = LOADER(o2), t3 = LOADER(o3);                          \
@@ -620,8 +645,13 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
             S_[SS][0] = S_[SS][0] + va; S_[SS][1] = S_[SS][1] + vb;                                                   \
             Q_[SS][0] = pk_fma(va, va, Q_[SS][0]); Q_[SS][1] = pk_fma(vb, vb, Q_[SS][1]);                             \
         }
-#define MVS_LDS_TAP(O) s_box[(O) + g]
-#define MVS_GLB_TAP(O) nb_img[j][(O) + g]
+        // Tap offsets travel in BYTES, so that the quad broadcast and the addition of the lane's own 16 bytes of the texel are ONE
+        // v_add_u32_dpp (an index needs a v_mov_b32_dpp and a v_lshl_add_u32 -- a VOP3, which takes no DPP operand).  hipcc folds
+        // only half of them by itself: the LDS path spells the instruction out (quad_bcast_add).
+#define MVS_LDS_TAP(O) lds_f4_at(O)   /* O holds the LDS address itself */
+#define MVS_GLB_TAP(O) (*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nb_img[j]) + (O)))
+#define MVS_LDS_OFF(SS, R) quad_bcast_add<SS>(R, g16_lds)
+#define MVS_GLB_OFF(SS, R) (quad_bcast<SS>(R) + g16)
 #define MVS_TAPS_OF(QQ)                                                                                               \
         {                                                                                                             \
             if constexpr (2 * p + QQ < K) {                                                                           \
@@ -634,11 +664,12 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
                     const int rw0 = from_quad<QQ>(__float_as_int(dw.x)), rw1 = from_quad<QQ>(__float_as_int(dw.y));   \
                     const int rw2 = from_quad<QQ>(__float_as_int(dw.z)), rw3 = from_quad<QQ>(__float_as_int(dw.w));   \
                     if (fj & kFlagStaged) {                                                                           \
-                        MVS_TAP_STEP(0, MVS_LDS_TAP) MVS_TAP_STEP(1, MVS_LDS_TAP)                                     \
-                        MVS_TAP_STEP(2, MVS_LDS_TAP) MVS_TAP_STEP(3, MVS_LDS_TAP)                                     \
+                        dpp_sources_settled(ro0, ro1, ro2, ro3);                                                      \
+                        MVS_TAP_STEP(0, MVS_LDS_TAP, MVS_LDS_OFF) MVS_TAP_STEP(1, MVS_LDS_TAP, MVS_LDS_OFF)           \
+                        MVS_TAP_STEP(2, MVS_LDS_TAP, MVS_LDS_OFF) MVS_TAP_STEP(3, MVS_LDS_TAP, MVS_LDS_OFF)           \
                     } else {                                                                                          \
-                        MVS_TAP_STEP(0, MVS_GLB_TAP) MVS_TAP_STEP(1, MVS_GLB_TAP)                                     \
-                        MVS_TAP_STEP(2, MVS_GLB_TAP) MVS_TAP_STEP(3, MVS_GLB_TAP)                                     \
+                        MVS_TAP_STEP(0, MVS_GLB_TAP, MVS_GLB_OFF) MVS_TAP_STEP(1, MVS_GLB_TAP, MVS_GLB_OFF)           \
+                        MVS_TAP_STEP(2, MVS_GLB_TAP, MVS_GLB_OFF) MVS_TAP_STEP(3, MVS_GLB_TAP, MVS_GLB_OFF)           \
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
@@ -661,11 +692,11 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
             const int pitch = hix - lox + 1;
             const int xa = clampi(tp.x0, lox, hix) - lox, xb = clampi(tp.x0 + 1, lox, hix) - lox;
             const int ya = (clampi(tp.y0, loy, hiy) - loy) * pitch, yb = (clampi(tp.y0 + 1, loy, hiy) - loy) * pitch;
-            const int sbase = min(2 * p + qd, K - 1) * slot_f4;
-            const int do0 = l_staged ? box_slot(ya + xa) * 8 + sbase : (ya + xa) * 8;
-            const int do1 = l_staged ? box_slot(ya + xb) * 8 + sbase : (ya + xb) * 8;
-            const int do2 = l_staged ? box_slot(yb + xa) * 8 + sbase : (yb + xa) * 8;
-            const int do3 = l_staged ? box_slot(yb + xb) * 8 + sbase : (yb + xb) * 8;
+            const int sbase = min(2 * p + qd, K - 1) * slot_f4 * 16;
+            const int do0 = l_staged ? box_slot(ya + xa) * 128 + sbase : (ya + xa) * 128;   // bytes: a texel of a slab is 128
+            const int do1 = l_staged ? box_slot(ya + xb) * 128 + sbase : (ya + xb) * 128;
+            const int do2 = l_staged ? box_slot(yb + xa) * 128 + sbase : (yb + xa) * 128;
+            const int do3 = l_staged ? box_slot(yb + xb) * 128 + sbase : (yb + xb) * 128;
             MVS_TAPS_OF(0)
             MVS_TAPS_OF(1)
         };
@@ -675,6 +706,8 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
 #undef MVS_TAP_STEP
 #undef MVS_LDS_TAP
 #undef MVS_GLB_TAP
+#undef MVS_LDS_OFF
+#undef MVS_GLB_OFF
         // ---- variance (channel 8*i + g, the lane's 4 consecutive pixels): kept in registers, stored at the top of the
         //      next iteration (after a possible box refill)
 #pragma unroll
