@@ -470,6 +470,9 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
         f[s][0] = (f2){v.x, v.y};
         f[s][1] = (f2){v.z, v.w};
     }
+    f2 fsq[4][2];  // their squares: the reference view's term of the sum of squares
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { fsq[s][0] = f[s][0] * f[s][0]; fsq[s][1] = f[s][1] * f[s][1]; }
     // stores: uniform base of (channel 8*i of the slab, plane d) + one 32-bit lane offset (channel g, the pixels)
     // (bytes; the entry point checks that 8 channel rows of the volume stay below 4 GiB)
     const unsigned st_off = ((unsigned)g * (unsigned)D * (unsigned)HWo + (unsigned)(py * Wo + px0)) * (unsigned)sizeof(OutT);
@@ -626,11 +629,16 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
         }
         if (d_pending >= 0) flush(d_pending);
 
+        // sum and sum of squares over the views, starting from the reference view's own term.  Where neighbour 0 is visible (the
+        // usual plane) its tap steps write f + v and f*f + v*v directly -- the same additions, without 16 register copies a plane
         f2 S_[4][2], Q_[4][2];
+        const bool first_live = K > 0 && (fl & kFlagLive);   // scalar
+        if (!first_live) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            S_[s][0] = f[s][0]; S_[s][1] = f[s][1];
-            Q_[s][0] = f[s][0] * f[s][0]; Q_[s][1] = f[s][1] * f[s][1];   // loop invariant: hoisted (16 VGPRs)
+            for (int s = 0; s < 4; ++s) {
+                S_[s][0] = f[s][0]; S_[s][1] = f[s][1];
+                Q_[s][0] = fsq[s][0]; Q_[s][1] = fsq[s][1];
+            }
         }
 #define MVS_TAP_STEP(SS, LOADER, OFF)                                                                                 \
         {                                                                                                             \
@@ -642,8 +650,9 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
             va = pk_fma((f2){t1.x, t1.y}, w1, va); vb = pk_fma((f2){t1.z, t1.w}, w1, vb);                             \
             va = pk_fma((f2){t2.x, t2.y}, w2, va); vb = pk_fma((f2){t2.z, t2.w}, w2, vb);                             \
             va = pk_fma((f2){t3.x, t3.y}, w3, va); vb = pk_fma((f2){t3.z, t3.w}, w3, vb);                             \
-            S_[SS][0] = S_[SS][0] + va; S_[SS][1] = S_[SS][1] + vb;                                                   \
-            Q_[SS][0] = pk_fma(va, va, Q_[SS][0]); Q_[SS][1] = pk_fma(vb, vb, Q_[SS][1]);                             \
+            S_[SS][0] = (j == 0 ? f[SS][0] : S_[SS][0]) + va; S_[SS][1] = (j == 0 ? f[SS][1] : S_[SS][1]) + vb;       \
+            Q_[SS][0] = pk_fma(va, va, j == 0 ? fsq[SS][0] : Q_[SS][0]);                                               \
+            Q_[SS][1] = pk_fma(vb, vb, j == 0 ? fsq[SS][1] : Q_[SS][1]);                                               \
         }
         // Tap offsets travel in BYTES, so that the quad broadcast and the addition of the lane's own 16 bytes of the texel are ONE
         // v_add_u32_dpp (an index needs a v_mov_b32_dpp and a v_lshl_add_u32 -- a VOP3, which takes no DPP operand).  hipcc folds
