@@ -360,6 +360,22 @@ __device__ __forceinline__ int quad_bcast_add(int v, int add) {
 __device__ __forceinline__ void dpp_sources_settled(int a, int b, int c, int d) {
     asm volatile("s_nop 1" : : "v"(a), "v"(b), "v"(c), "v"(d));
 }
+// fmaf(-m, m, q) as the one IEEE instruction it is, spelled out so that hipcc does not pair two of them into a v_pk_fma_f32
+// (whose results then need register copies to reach their places in the store vectors)
+__device__ __forceinline__ float fma_neg_sq(float m, float q) {
+    float r;
+    asm("v_fma_f32 %0, -%1, %1, %2" : "=v"(r) : "v"(m), "v"(q));
+    return r;
+}
+// variance of channels (2h, 2h+1)'s pixel s from the sum and the sum of squares over the views: the two products packed over
+// the channel pair, the final fused multiply-add per value, written straight into its place in the lane's store vectors
+typedef float sweep_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void variance_of(float (&vout)[4][4], int s, int h, sweep_f2 sum, sweep_f2 sq, float rcp) {
+    const sweep_f2 r2 = {rcp, rcp};
+    const sweep_f2 m = sum * r2, q = sq * r2;
+    vout[2 * h][s] = fma_neg_sq(m.x, q.x);
+    vout[2 * h + 1][s] = fma_neg_sq(m.y, q.y);
+}
 // 16 bytes at an LDS ADDRESS (not an index into a __shared__ array: the address arrives ready-made from quad_bcast_add)
 __device__ __forceinline__ float4 lds_f4_at(int addr) {
     typedef float v4 __attribute__((ext_vector_type(4)));
@@ -389,7 +405,8 @@ __host__ __device__ constexpr size_t sweep_lds_bytes(int K, int box_cap) { retur
 // FAST: every channel row of the slab exists (C % 32 == 0) and every lane's 4 pixels are all inside or all outside the
 // image with 16-byte aligned rows (W % 4 == 0): the stores are four unconditional vector stores under one lane predicate.
 template <int K, int TW, bool FAST, typename OutT = float>
-__global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
+__global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_sweep_variance_kernel(   // 16x8 tiles: three 52-KiB blocks per CU (planesweep.hip: max_box_cap)
+    
     const float* __restrict__ packed, const float* __restrict__ ref_packed, const int64_t* __restrict__ nbr,
     const int4* __restrict__ header, const float* __restrict__ proj, const float* __restrict__ depth, const int4* __restrict__ boxes,
     const unsigned* __restrict__ flags, const unsigned short* __restrict__ groups, OutT* __restrict__ var, int N, int C, int S,
@@ -650,9 +667,15 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
             va = pk_fma((f2){t1.x, t1.y}, w1, va); vb = pk_fma((f2){t1.z, t1.w}, w1, vb);                             \
             va = pk_fma((f2){t2.x, t2.y}, w2, va); vb = pk_fma((f2){t2.z, t2.w}, w2, vb);                             \
             va = pk_fma((f2){t3.x, t3.y}, w3, va); vb = pk_fma((f2){t3.z, t3.w}, w3, vb);                             \
-            S_[SS][0] = (j == 0 ? f[SS][0] : S_[SS][0]) + va; S_[SS][1] = (j == 0 ? f[SS][1] : S_[SS][1]) + vb;       \
-            Q_[SS][0] = pk_fma(va, va, j == 0 ? fsq[SS][0] : Q_[SS][0]);                                               \
-            Q_[SS][1] = pk_fma(vb, vb, j == 0 ? fsq[SS][1] : Q_[SS][1]);                                               \
+            const f2 sa = (j == 0 ? f[SS][0] : S_[SS][0]) + va, sb = (j == 0 ? f[SS][1] : S_[SS][1]) + vb;             \
+            const f2 qa = pk_fma(va, va, j == 0 ? fsq[SS][0] : Q_[SS][0]);                                             \
+            const f2 qb = pk_fma(vb, vb, j == 0 ? fsq[SS][1] : Q_[SS][1]);                                             \
+            if constexpr (j == K - 1) {   /* the last neighbour: its sums are complete -- straight on to the variance */ \
+                variance_of(vout, SS, 0, sa, qa, rcp);                                                                \
+                variance_of(vout, SS, 1, sb, qb, rcp);                                                                \
+            } else {                                                                                                  \
+                S_[SS][0] = sa; S_[SS][1] = sb; Q_[SS][0] = qa; Q_[SS][1] = qb;                                       \
+            }                                                                                                         \
         }
         // Tap offsets travel in BYTES, so that the quad broadcast and the addition of the lane's own 16 bytes of the texel are ONE
         // v_add_u32_dpp (an index needs a v_mov_b32_dpp and a v_lshl_add_u32 -- a VOP3, which takes no DPP operand).  hipcc folds
@@ -719,14 +742,12 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_kernel(
 #undef MVS_GLB_OFF
         // ---- variance (channel 8*i + g, the lane's 4 consecutive pixels): kept in registers, stored at the top of the
         //      next iteration (after a possible box refill)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        // where the last neighbour was visible its tap steps have done it already (the usual plane: no merge of register sets)
+        if (!(K > 0 && ((fl >> (4 * (KK - 1))) & kFlagLive))) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float sv = (i & 1) ? S_[s][i >> 1].y : S_[s][i >> 1].x;
-                const float qv = (i & 1) ? Q_[s][i >> 1].y : Q_[s][i >> 1].x;
-                const float m = sv * rcp;
-                vout[i][s] = fmaf(-m, m, qv * rcp);
+                variance_of(vout, s, 0, S_[s][0], Q_[s][0], rcp);
+                variance_of(vout, s, 1, S_[s][1], Q_[s][1], rcp);
             }
         }
         d_pending = d;
