@@ -16,6 +16,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_neck -o neck -- 
 find $out/kt_neck -name "*kernel_stats.csv" -exec cp {} $out/neck_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_train -o train -- python3 tools/costreg_train_profile.py > $out/kt_train.log 2>&1
 find $out/kt_train -name "*kernel_stats.csv" -exec cp {} $out/costreg_train_kernel_stats.csv \;
+# matrix-core counters of the training step's kernels (forward, dX, the stride-1 and stride-2 / transposed weight gradients)
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc_train -o pmc -- python3 tools/costreg_train_profile.py > $out/pmc_train.log 2>&1
+python3 tools/pmc_summary.py $out/pmc_train > $out/pmc_train_summary.txt 2>&1
 find $out -name "*_kernel_trace.csv" -delete
 python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt 2>&1
 python3 tools/pmc_summary.py $out/pmc2 >> $out/pmc_summary.txt 2>&1
