@@ -346,11 +346,10 @@ __global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dw_kernel(const floa
     const int tw = tid % kTW, th = tid / kTW;
     const int c = blockIdx.x, split = blockIdx.y;
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
-    float acc[2][27];
+    typedef float hf2 __attribute__((ext_vector_type(2)));   // the two output channels of a tap as one packed pair (v_pk_fma_f32)
+    hf2 acc[27];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int k = 0; k < 27; ++k) acc[o][k] = 0.0f;
+    for (int k = 0; k < 27; ++k) acc[k] = hf2{0.0f, 0.0f};
     const int tiles_per_view = tiles_d * tiles_h * tiles_w;
     const int ntiles = N * tiles_per_view;
     for (int tile = split; tile < ntiles; tile += nsplit) {
@@ -368,12 +367,13 @@ __global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dw_kernel(const floa
         }
         __syncthreads();
         const int h = h0 + th, w = w0 + tw;
-        float g[2][kTD];
+        hf2 g[kTD];
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int t = 0; t < kTD; ++t)
-                g[o][t] = (h < H && w < W && d0 + t < D) ? gy[((size_t)n * 2 + o) * vol + (size_t)(d0 + t) * plane + (size_t)h * W + w] : 0.0f;
+        for (int t = 0; t < kTD; ++t) {
+            const bool in = h < H && w < W && d0 + t < D;
+            const size_t at = (size_t)(d0 + t) * plane + (size_t)h * W + w;
+            g[t] = hf2{in ? gy[((size_t)n * 2 + 0) * vol + at] : 0.0f, in ? gy[((size_t)n * 2 + 1) * vol + at] : 0.0f};
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -385,10 +385,8 @@ __global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dw_kernel(const floa
 #pragma unroll
                 for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-                    for (int t = 0; t < kTD; ++t) {
-                        acc[0][(kd * 3 + kh) * 3 + kw] = fmaf(g[0][t], v[t + kd], acc[0][(kd * 3 + kh) * 3 + kw]);
-                        acc[1][(kd * 3 + kh) * 3 + kw] = fmaf(g[1][t], v[t + kd], acc[1][(kd * 3 + kh) * 3 + kw]);
-                    }
+                    for (int t = 0; t < kTD; ++t)
+                        acc[(kd * 3 + kh) * 3 + kw] = __builtin_elementwise_fma(g[t], hf2{v[t + kd], v[t + kd]}, acc[(kd * 3 + kh) * 3 + kw]);
             }
     }
     // block reduction of the 54 sums: butterfly inside each wave, then the four waves through LDS
@@ -396,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dw_kernel(const floa
     for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
-            float v = acc[o][k];
+            float v = o ? acc[k].y : acc[k].x;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
             if (lane == 0) s_red[wave][o * 27 + k] = v;
