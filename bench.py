@@ -303,6 +303,21 @@ def backward_rooflines(w, device, reps=5):
                                     "kernel_ms": round(dw_ms, 4), "min_ms": round(dw_min, 4), "useful_TFLOPs": round(fl / (dw_ms * 1e-3) / 1e12, 1)}
     del gvar, gy, x
     torch.cuda.empty_cache()
+    # the stride-2 / transposed layers' weight gradient (mvsnet.py:77,92-100) at conv1's shape: fine 64 channels at full
+    # resolution, coarse 128 channels at half of it (conv11 is the same call with the tensors exchanged)
+    if D % 2 == 0 and H % 2 == 0 and W % 8 == 0:
+        xf = torch.randn((N, 64, D, H, W), device=device)
+        gc = torch.randn((N, 128, D // 2, H // 2, W // 2), device=device)
+        s2_ms, s2_min = timed(lambda: ops.conv3d_k3_dw(xf, gc, 0, 2, True))
+        fl2 = 2.0 * 27 * 64 * 128 * N * (D // 2) * (H // 2) * (W // 2)
+        out["weight_gradient_stride2"] = {"bound": "mfma", "achieved": round(3 * fl2 / (s2_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
+                                          "unit": "TFLOP/s", "frac": round(3 * fl2 / (s2_ms * 1e-3) / 1e12 / 2500.0, 4),
+                                          "kernel": "conv3d_k3_s2_dw_bf16x3_kernel (conv1 64 -> 128 / conv11 128 -> 64; 64 coarse x 16 fine "
+                                                    "channels per block on v_mfma_f32_16x16x32_bf16)",
+                                          "kernel_ms": round(s2_ms, 4), "min_ms": round(s2_min, 4),
+                                          "useful_TFLOPs": round(fl2 / (s2_ms * 1e-3) / 1e12, 1)}
+        del xf, gc
+        torch.cuda.empty_cache()
     return out
 
 
