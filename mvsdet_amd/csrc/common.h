@@ -26,7 +26,8 @@ struct Options {
     int conv_cgn;      // stride-1 bf16x3 convolution (16x16x32 form) on 3x16x8 tiles: 0 / 2 = 12 waves of 32 voxels, 4 = 6 waves of 64
     int conv_s2_cg;    // stride-2 bf16x3 convolution fed by PSCL on 3x16x8 tiles: 0 / 1 = 12 waves of one column group, 2 = 6 of two
     int conv_s2_ob;    // stride-2 bf16x3 convolution fed by PSCL: 1 = 64 output channels per block, else 128 where Cout allows
-    int convT_cg;      // transposed bf16x3 convolution on 3x16x8 tiles: column groups per wave; 0 / 1 = 12 waves of one, 2 = 6 waves of two
+    int convT_cg;      // transposed bf16x3 convolution on 3x16x8 tiles: 0 / 3 = all eight output parity classes in one block of 32 output
+                       // channels (12 waves); 1 = one block per (PD, PH), 12 waves of one column group; 2 = 6 waves of two
     int probe_f16_pair; // mvsdet_store_pattern_probe_f16 only: 1 = lanes of adjacent pixel quads own the octet between them and store
                        // 16 bytes of two channel rows instead of 8 of four (what a paired flush of the fp16 sweep WOULD reach: +12 %,
                        // not built -- the fp16 sweep is bound by its vector work); 0 (default) = the kernel's own pattern

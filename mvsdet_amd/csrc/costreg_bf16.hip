@@ -1154,6 +1154,167 @@ __device__ __forceinline__ void convT3d_k3_s2_bf16x3_body(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The transposed layer with ALL EIGHT output parity classes in one block (option "convT_fused"): block = (coarse tile of
+// 3 x 16 x 8 input voxels, 32 output channels), 12 waves of one column group; a wave holds 8 accumulators = the 8 outputs
+// 2i + (pd, ph, pw) of its 32 coarse voxels x 32 channels.  Against one block per (PD, PH): the halo tile of a stage is staged
+// once for all classes (Cout / 32 times per tile instead of 4 x Cout / 64), and a stage is the 14 tap pairs of all classes =
+// 42 MFMAs per wave behind one barrier instead of 6 - 18.  Every accumulator still sums the same (channel group, tap pair)
+// sequence as in the per-class kernel: bit-identical.  LDS: 3 x (2 pieces x 768 slots input + 28 x 64 slots weights) = 159.8 KB.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCtfWSlots = kBfPairs * 2 * 64;   // 14 pairs x 2 pieces x one row group of 32 channels
+__host__ __device__ constexpr size_t ctf_lds_bytes(int TD, int TH, int TW) {
+    return (size_t)(3 * 2 * ct_ins(TD, TH, TW, 1) + 3 * kCtfWSlots) * 16;
+}
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_kernel(
+    const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ residual, BfOut dst, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
+    size_t piece_stride, int tiles_w, int relu) {
+    float* __restrict__ out = dst.f32;
+    constexpr int RG = 32 / TW;
+    static_assert(TH % RG == 0 && (TD * TH * TW) % 32 == 0, "whole column groups");
+    constexpr int NW = TD * TH * TW / 32;
+    constexpr int HH = TH + 1, HW = TW + 1, NVOX = (TD + 1) * HH * HW, INS = ct_ins(TD, TH, TW, 1);
+    constexpr int IN_DMA = INS / 64, IN_PER_WAVE = 2 * IN_DMA / NW;
+    constexpr int W_CHUNKS = kBfPairs * 2;                               // (pair, piece) chunks of 64 units
+    constexpr int W_PER_WAVE = (W_CHUNKS + NW - 1) / NW;                  // the tail repeats earlier chunks
+    constexpr int DMA_PER_STAGE = IN_PER_WAVE + W_PER_WAVE;
+    static_assert(2 * IN_DMA % NW == 0, "input DMAs must divide evenly over the waves");
+    extern __shared__ uint4 s_bf[];   // [3 stages][2 pieces][INS] input, then [3 stages][kCtfWSlots] weights
+    uint4* s_in = s_bf;
+    uint4* s_w = s_bf + 3 * 2 * INS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    const int nob = Cout / 32;
+    const int n = blockIdx.z / nob, ob32 = blockIdx.z % nob, ob64 = ob32 >> 1, rg = ob32 & 1;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int col = lane & 31, hh = lane >> 5;
+
+    const size_t c8_stride = (size_t)Dp * Hp * Wp;
+    const uint4* xn = xs + ((size_t)n * C8) * c8_stride + ((size_t)(d0 + 1) * Hp + (h0 + 1)) * Wp + (w0 + 1);
+    unsigned in_src[IN_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < IN_PER_WAVE; ++k) {
+        const int i = wave + k * NW;
+        const int slot = (i % IN_DMA) * 64 + lane;
+        const int sv = slot < NVOX ? slot : 0;
+        const int dz = sv / (HH * HW), r = sv - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
+        in_src[k] = (unsigned)(((size_t)dz * Hp + hy) * Wp + wx);
+    }
+    // weights: wq[ob64][c8][pair 14][row group 2][piece 2][lane 64]; this block's row group only, as [pair][piece][lane]
+    const uint4* wn = wq + (size_t)ob64 * C8 * (kBfPairs * 4 * 64) + (size_t)rg * (2 * 64) + lane;
+    auto dma_stage = [&](int c8, int buf) {
+#pragma unroll
+        for (int k = 0; k < IN_PER_WAVE; ++k) {
+            const int i = wave + k * NW;
+            const int piece = i / IN_DMA;
+            const uint4* src = xn + (size_t)piece * piece_stride + (size_t)c8 * c8_stride + in_src[k];
+            uint4* dstl = s_in + (size_t)(buf * 2 + piece) * INS + (i % IN_DMA) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < W_PER_WAVE; ++k) {
+            const int i = (wave + k * NW) % W_CHUNKS;   // chunk = (pair i >> 1, piece i & 1)
+            uint4* dstl = s_w + (size_t)buf * kCtfWSlots + i * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wn + (size_t)c8 * (kBfPairs * 4 * 64) + (size_t)((i >> 1) * 4 + (i & 1)) * 64),
+                                             (__attribute__((address_space(3))) void*)dstl, 16, 0, 0);
+        }
+    };
+
+    const int g = wave;
+    const int vb = ((g / (TH / RG)) * HH + RG * (g % (TH / RG)) + col / TW) * HW + col % TW;
+    f32x16b acc[8];   // output parity class pi = 4 * pd + 2 * ph + pw
+#pragma unroll
+    for (int pi = 0; pi < 8; ++pi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pi][r] = 0.0f;
+    const bf16x8* s_in8 = reinterpret_cast<const bf16x8*>(s_in);
+    const bf16x8* s_w8 = reinterpret_cast<const bf16x8*>(s_w);
+
+    auto compute = [&](int buf) {
+        const bf16x8* bin = s_in8 + (size_t)(buf * 2) * INS + vb;
+        const bf16x8* ain = s_w8 + (size_t)buf * kCtfWSlots + lane;
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) {
+#pragma unroll
+            for (int pj = 0; pj < s2_pairs(pi); ++pj) {
+                const int pl = s2_first_pair(pi) + pj;
+                const int toff = hh ? ct_tap_off<HH, HW>(pi, 2 * pj + 1) : ct_tap_off<HH, HW>(pi, 2 * pj);
+                const bf16x8 a0 = ain[(pl * 2 + 0) * 64], a1 = ain[(pl * 2 + 1) * 64];
+                const bf16x8 b0 = bin[toff], b1 = bin[(size_t)INS + toff];
+                acc[pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[pi], 0, 0, 0);
+                acc[pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[pi], 0, 0, 0);
+                acc[pi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[pi], 0, 0, 0);
+            }
+        }
+    };
+
+    dma_stage(0, 0);
+    if (C8 > 1) dma_stage(1, 1);
+    int buf = 0;
+    for (int c8 = 0; c8 < C8; ++c8) {
+        if (c8 + 1 < C8) __builtin_amdgcn_s_waitcnt(0x0f70 | (DMA_PER_STAGE & 15) | ((DMA_PER_STAGE >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+        if (c8 + 2 < C8) dma_stage(c8 + 2, buf == 0 ? 2 : buf - 1);
+        compute(buf);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // epilogue: lane = coarse voxel; per (pd, ph) the two w parities are neighbouring outputs -> one float2; eight channels at a time
+    const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+    const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
+    const int di = d0 + g / (TH / RG), hi = h0 + RG * (g % (TH / RG)) + col / TW, wi = w0 + col % TW;
+    if (di >= Di || hi >= Hi || wi >= Wi) return;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+        const int pd = cls >> 1, ph = cls & 1;
+        const size_t pos = (size_t)(2 * di + pd) * oplane + (size_t)(2 * hi + ph) * Wo + 2 * wi;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float2 rv[8];
+            float sc[8], sh[8];
+            const int o0 = ob64 * 64 + rg * 32 + bf_row_channel(8 * q, hh);
+            const size_t idx0 = ((size_t)n * Cout + o0) * ovol + pos;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rv[j] = residual ? *reinterpret_cast<const float2*>(residual + idx0 + (size_t)j * ovol) : make_float2(0.f, 0.f);
+                sc[j] = scale ? scale[o0 + j] : 1.0f;
+                sh[j] = scale ? shift[o0 + j] : 0.0f;
+            }
+            float v0[8], v1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float2 v = make_float2(acc[2 * cls][8 * q + j], acc[2 * cls + 1][8 * q + j]);
+                if (scale) {
+                    v.x = fmaf(v.x, sc[j], sh[j]);
+                    v.y = fmaf(v.y, sc[j], sh[j]);
+                }
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.0f);
+                    v.y = fmaxf(v.y, 0.0f);
+                }
+                if (residual) {
+                    v.x = rv[j].x + v.x;
+                    v.y = rv[j].y + v.y;
+                }
+                v0[j] = v.x;
+                v1[j] = v.y;
+                if (out) *reinterpret_cast<float2*>(out + idx0 + (size_t)j * ovol) = v;
+            }
+            if (dst.scl || dst.pscl) {
+                const int c8o = ob64 * 8 + rg * 4 + 2 * q + hh;
+                bf_store_units(dst, v0, n, Cout / 8, c8o, 2 * di + pd, 2 * hi + ph, 2 * wi);
+                bf_store_units(dst, v1, n, Cout / 8, c8o, 2 * di + pd, 2 * hi + ph, 2 * wi + 1);
+            }
+        }
+    }
+}
+
 // ONE launch for the four (PD, PH) classes: class = blockIdx.x & 3, so the four blocks that read the same input tile are
 // dispatched together (the tile's second to fourth reads hit L2) and the grid has one tail instead of four.
 template <int TD, int TH, int TW, int CG>
@@ -1675,7 +1836,20 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
                            static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, \
                            p.Wp, piece, tiles_w, relu);                                                                      \
     }
-    // the 3 x 16 x 8 tile on 12 waves of one column group each (option "convT_cg" = 2: the 6-wave form)
+    // the 3 x 16 x 8 tile: all eight output parity classes in one block of 32 output channels (conv9 0.40 -> 0.30, conv11 0.66 ->
+    // 0.48 ms, the same bits); option "convT_cg" = 1: one block per (PD, PH) on 12 waves of one column group, 2: on 6 waves of two
+    if (t38 && options().convT_cg != 1 && options().convT_cg != 2) {
+        const size_t lds = ctf_lds_bytes(3, 16, 8);
+        auto* k = convT3d_k3_s2_bf16x3_fused_kernel<3, 16, 8>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
+            return MVSDET_ERR_HIP;
+        }
+        MVS_REQUIRE((long long)N * (Cout / 32) <= 65535, "%s: N*Cout/32 too large", name);
+        dim3 fgrid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 32)));
+        hipLaunchKernelGGL(k, fgrid, dim3(3 * 16 * 8 * 2), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split),
+                           scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, relu);
+    } else
     if (t38) { if (options().convT_cg == 2) MVS_CT_CASE(3, 16, 8, 2) else MVS_CT_CASE(3, 16, 8, 1) }
     else MVS_CT_CASE(kS2TD, kS2TH, kBfW, 2)
 #undef MVS_CT_CASE

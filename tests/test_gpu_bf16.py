@@ -184,6 +184,31 @@ def test_convT3d_k3_s2_bf16x3(gpu, N, Cin, Cout, D, H, W):
     assert torch.equal(hi.cpu(), eh) and torch.equal(mid.cpu(), em) and scl.border_is_zero()
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(2, 128, 64, 6, 30, 40), (1, 24, 128, 3, 15, 20), (1, 8, 64, 5, 17, 9)])
+def test_convT3d_block_shapes_agree_bit_for_bit(gpu, N, Cin, Cout, D, H, W):
+    """The transposed layer with all eight output parity classes in one block of 32 output channels (the default on 3 x 16 x 8
+    tiles) against one block per (PD, PH) on 12 waves and on 6: every output sums the same (channel group, tap pair) sequence --
+    equal bits, in the fp32 output and in the split channel-last form handed to the next layer."""
+    from mvsdet_amd import _lib, ops
+    g = torch.Generator().manual_seed(Cin + W)
+    x = (torch.randn(N, Cin, D, H, W, generator=g)).to(gpu)
+    wq = ops.split_conv_weight((torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (27 * Cin / 8) ** 0.5).to(gpu), 2)
+    scale, shift = (torch.rand(Cout, generator=g) + 0.5).to(gpu), (torch.randn(Cout, generator=g) * 0.1).to(gpu)
+    res = torch.randn(N, Cout, 2 * D, 2 * H, 2 * W, generator=g).to(gpu)
+    outs = []
+    try:
+        for cg in (0, 1, 2):
+            _lib.set_option("convT_cg", cg)
+            f32, scl = ops.convT3d_k3_s2_bf16x3(x, wq, scale, shift, res, True, outputs=("f32", "scl"))
+            hi, mid = scl.pieces()
+            outs.append((f32.clone(), hi.clone(), mid.clone()))
+    finally:
+        _lib.set_option("convT_cg", 0)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("N,Cin,D,H,W", [(2, 64, 12, 60, 80), (1, 5, 3, 7, 12), (1, 64, 4, 12, 40), (2, 3, 9, 25, 44)])
 def test_head_on_the_sum_of_two_inputs(gpu, N, Cin, D, H, W):
     """mvsnet.py:111-112: the 64 -> 2 head on conv0 + conv11(x) with the addition formed while the halo tiles are staged: the
