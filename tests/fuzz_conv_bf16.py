@@ -5,8 +5,8 @@ Random shapes (ragged tiles in d, h and w, channel counts that are no multiple o
 output channels), the three layer kinds (stride 1 on the SCL form, on the fp32 tensor and on a row-pitched view of it; stride 2;
 transposed), with and without affine / ReLU / residual -- each against a float64 evaluation of the SAME three products
 (x_hi*w_hi + x_hi*w_mid + x_mid*w_hi): what remains is fp32 accumulation order, bounded by 4e-7 of the summed products.
-Every fourth case is the stride-1 WEIGHT GRADIENT (csrc/costreg_dw_bf16.hip): W a multiple of 4, any channel counts, any
-number of splits; and every eighth forward case has 256-1024 input channels on a small volume, so that the kernels split
+Every fourth case is a WEIGHT GRADIENT (stride 1: csrc/costreg_dw_bf16.hip, W a multiple of 4; half of them stride 2 / transposed:
+csrc/costreg_dw_s2_bf16.hip, even D and H, W a multiple of 8), any channel counts, any number of splits; and every eighth forward case has 256-1024 input channels on a small volume, so that the kernels split
 the input channels over blocks (partial sums + epilogue kernel)."""
 import os
 import sys
@@ -41,29 +41,34 @@ def main():
         if kind != "dw" and seed % 8 >= 4:   # few tiles, many input channels: the split form
             N, Cin = 1, int(rng.choice([256, 384, 512, 1024]))
             D, H, W = int(rng.integers(1, 5)), int(rng.integers(1, 13)), int(rng.integers(1, 17))
+        dw_stride = 1
         if kind == "dw":
             W = 4 * int(rng.integers(1, 12))
             Cout = int(rng.choice([1, 2, 31, 32, 33, 64, 70]))
+            if seed % 8 >= 4:   # the stride-2 / transposed weight gradient (csrc/costreg_dw_s2_bf16.hip): even D, H, W a multiple of 8
+                dw_stride, D, H, W = 2, 2 * int(rng.integers(1, 6)), 2 * int(rng.integers(1, 15)), 8 * int(rng.integers(1, 7))
+                Cout = int(rng.choice([1, 3, 63, 64, 65, 128, 130]))
         x = torch.randn(N, Cin, D, H, W, generator=g) * float(rng.uniform(0.1, 4.0))
         affine, relu, resid = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         scale = (torch.rand(Cout, generator=g) + 0.5) if affine else None
         shift = (torch.randn(Cout, generator=g) * 0.1) if affine else None
         dv = lambda t: None if t is None else t.to(dev)   # noqa: E731
         if kind == "dw":
-            gy = torch.randn(N, Cout, D, H, W, generator=g) * float(rng.uniform(0.1, 4.0))
+            st = dw_stride
+            gy = torch.randn(N, Cout, D // st, H // st, W // st, generator=g) * float(rng.uniform(0.1, 4.0))
             shape = (Cout, Cin, 3, 3, 3)
-            cw = lambda a, b: torch.nn.grad.conv3d_weight(a, shape, b, padding=1)   # noqa: E731
+            cw = lambda a, b: torch.nn.grad.conv3d_weight(a, shape, b, stride=st, padding=1)   # noqa: E731
             xh, xm = (t.double() for t in ops.split_bf16(x))
             yh, ym = (t.double() for t in ops.split_bf16(gy))
             ref = cw(xh, yh) + cw(xh, ym) + cw(xm, yh)
             mag = float(cw(x.abs().double(), gy.abs().double()).max())
             nsplit = int(rng.choice([0, 1, 2, 5, 8, 16, 40]))
-            got = ops.conv3d_k3_dw(x.to(dev), gy.to(dev), nsplit, 1, True)
+            got = ops.conv3d_k3_dw(x.to(dev), gy.to(dev), nsplit, st, True)
             err = float((got.cpu().double() - ref).abs().max())
             tol = 4e-7 * mag + 1e-30
             if not (got.shape == ref.shape and err <= tol):
                 bad += 1
-                print(f"seed {seed} dw N={N} Cin={Cin} Cout={Cout} {D}x{H}x{W} nsplit={nsplit}: err {err:.3e} tol {tol:.3e}", flush=True)
+                print(f"seed {seed} dw stride {st} N={N} Cin={Cin} Cout={Cout} {D}x{H}x{W} nsplit={nsplit}: err {err:.3e} tol {tol:.3e}", flush=True)
             continue
         if kind == "s1":
             w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
