@@ -57,6 +57,41 @@ static __global__ __launch_bounds__(kThreads) void pack_features_kernel(const In
     }
 }
 
+// The same for dense fp32 maps (pixel stride 1, row stride W, H*W and the view / channel strides multiples of 4, 16-byte aligned):
+// one block = 128 pixels x one slab, a thread loads FOUR float4 (4 pixels of 4 channel rows: 512 B per channel row and
+// wave-instruction instead of 256), LDS rows 136 floats apart: the float4 writes are aligned and the transposing reads
+// (lane = (pixel, g): rows g, 8+g, 16+g, 24+g of one pixel) fall on bank 8*g + pixel -- all 64 banks, no conflict.
+static __global__ __launch_bounds__(kThreads) void pack_features_dense_kernel(const float* __restrict__ feat, int64_t s0, int64_t s1,
+                                                                               float* __restrict__ packed, int C, int S, int HW) {
+    constexpr int kPix = 128, kPitch = 136;
+    __shared__ float tile[kSlab * kPitch];
+    const int pix0 = blockIdx.x * kPix, s = blockIdx.y, n = blockIdx.z;
+    const int q = threadIdx.x & 31, r0 = threadIdx.x >> 5;   // pixel quad, first of the thread's four channel rows
+    {
+        const int pix = pix0 + 4 * q;
+        const float* src = feat + (int64_t)n * s0 + pix;
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = s * kSlab + r0 + 8 * k;
+            v[k] = (pix < HW && c < C) ? *reinterpret_cast<const float4*>(src + (int64_t)c * s1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(&tile[(r0 + 8 * k) * kPitch + 4 * q]) = v[k];
+    }
+    __syncthreads();
+    const int g = threadIdx.x & 7;
+#pragma unroll
+    for (int p = threadIdx.x >> 3; p < kPix; p += 32) {
+        const int pix = pix0 + p;
+        if (pix < HW) {
+            const float4 v = make_float4(tile[g * kPitch + p], tile[(8 + g) * kPitch + p], tile[(16 + g) * kPitch + p],
+                                         tile[(24 + g) * kPitch + p]);
+            *reinterpret_cast<float4*>(packed + (((size_t)n * S + s) * HW + pix) * kSlab + 4 * g) = v;
+        }
+    }
+}
+
 // unpack: feat[n][c][pix] = packed[n][s][pix][4g+i]  (dense NCHW output; used by the backward pass)
 static __global__ __launch_bounds__(kThreads) void unpack_features_kernel(const float* __restrict__ packed,
                                                                            float* __restrict__ feat, int C, int S, int H,

@@ -76,6 +76,16 @@ static int pack_entry(const char* name, const InT* feat, const int64_t* fs, floa
     MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "%s: one slab image exceeds 2^31 elements", name);
     MVS_REQUIRE(N <= 65535 && num_slabs(C) <= 65535, "%s: N or C too large", name);
     const int S = num_slabs(C);
+    if constexpr (sizeof(InT) == 4) {
+        // dense maps (the usual case: the 2-D backbone's output; a cropped view takes the general kernel): float4 loads
+        if (fs[3] == 1 && fs[2] == W && (H * W) % 4 == 0 && fs[1] % 4 == 0 && fs[0] % 4 == 0 && (uintptr_t)feat % 16 == 0) {
+            dim3 dgrid((H * W + 127) / 128, S, N);
+            hipLaunchKernelGGL(pack_features_dense_kernel, dgrid, dim3(kThreads), 0, (hipStream_t)stream, (const float*)feat, fs[0],
+                               fs[1], packed, C, S, H * W);
+            MVS_LAUNCH_CHECK(name);
+            return MVSDET_OK;
+        }
+    }
     dim3 grid((H * W + 63) / 64, S, N);
     hipLaunchKernelGGL(pack_features_kernel<InT>, grid, dim3(kThreads), 0, (hipStream_t)stream, feat, fs[0], fs[1], fs[2],
                        fs[3], packed, C, S, H, W);

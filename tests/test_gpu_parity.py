@@ -84,6 +84,24 @@ def test_plane_sweep_variance_shapes(gpu, oracle, N, K, C, D, H, W):
         assert np.abs(var).max() < 1e-6
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 12, 16), (1, 33, 7, 20), (3, 5, 3, 4), (2, 32, 9, 13), (1, 256, 60, 80)])
+def test_pack_features_layout(gpu, N, C, H, W):
+    """packed[n][s][y][x][4g+i] = feat[n][32s + 8i + g][y][x] (include/mvsdet_hip.h), zero where the channel does not exist -- for dense
+    maps (the float4 kernel where H*W is a multiple of 4), for a cropped view of a larger tensor and for a channel slice (the
+    general kernel): all the same bits."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(C + W)
+    big = torch.randn(N, C + 3, H + 2, W + 5, generator=g).to(gpu)
+    feat = big[:, 1:C + 1, :H, :W].contiguous()
+    S = (C + 31) // 32
+    want = torch.zeros(N, S * 32, H, W, device=gpu)
+    want[:, :C] = feat
+    want = want.view(N, S, 4, 8, H, W).permute(0, 1, 4, 5, 3, 2).reshape(N, S, H, W, 32)   # [n][s][y][x][g][i] -> q = 4g + i
+    got = ops.pack_features(feat)
+    assert torch.equal(got.view(N, S, H, W, 32), want)
+    assert torch.equal(ops.pack_features(big[:, 1:C + 1, :H, :W]), got)          # a strided view: the general kernel
+
+
 def test_plane_sweep_both_tile_sizes_and_packed_entry(gpu, oracle, monkeypatch):
     """packed entry point == dense entry point; pack handles a non-contiguous crop view."""
     from mvsdet_amd import ops
