@@ -1,3 +1,4 @@
+"""pack_features at the headline and the reference-true shape (GPU box)."""
 import torch
 from mvsdet_amd import ops
 dev = torch.device("cuda:0")
