@@ -186,6 +186,9 @@ class MVSDetHotPath:
         # width is a multiple of 16 but not of 32 swept with the 32x4 tiles (48 planes or more): 6.1 against 6.5 ms at 50 views x
         # 96 planes x 60x80.  The cost network and the depth distribution read such views in place.  False: always contiguous.
         self.pitched_variance = "auto"
+        # True: neck_3d / bbox_head of a scene run on a side stream (forward_scene returns out["detector_ready"], a CUDA event)
+        self.overlap_detector = False
+        self._detector_streams: dict = {}
 
     # ---- reference-named methods (mvsdet.py:249, 266, 298) -------------------------------------------
     def collect_proj(self, w2c, intr, neighbor_ids):
@@ -415,6 +418,28 @@ class MVSDetHotPath:
                    # maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume, cropped at :583
                    opacity=est_dens[:, 0])
         if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU)
+            if self.overlap_detector and volume_mean.is_cuda:
+                # The neck works on ONE 40 x 40 x 16 volume: 200 blocks for 256 CUs at its largest level, a few dozen small kernels
+                # at the others.  On a stream of its own it runs beside the NEXT scene's packing, sweep and first convolution
+                # instead of in front of them.  The caller makes its stream wait for out["detector_ready"] before it touches
+                # out["neck"] / out["head"] (their memory belongs to that stream's pool).
+                dev = volume_mean.device
+                cur = torch.cuda.current_stream(dev)
+                side = self._detector_streams.get(str(dev))
+                if side is None:
+                    side = self._detector_streams[str(dev)] = torch.cuda.Stream(device=dev)
+                ready = torch.cuda.Event()
+                ready.record(cur)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
+                    if self.bbox_head is not None:
+                        out["head"] = self.bbox_head(out["neck"])
+                    done = torch.cuda.Event()
+                    done.record(side)
+                volume_mean.record_stream(side)
+                out["detector_ready"] = done
+                return out
             out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
             if self.bbox_head is not None:
                 out["head"] = self.bbox_head(out["neck"])   # (centerness, bbox, cls) lists over the levels

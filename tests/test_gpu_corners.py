@@ -412,3 +412,34 @@ def test_geometry_of_another_tile_shape_is_refused(gpu, oracle):
     t_big = torch.zeros_like(t_plain)
     t_big[:t_d.numel()] = t_d
     assert torch.isnan(ops.plane_sweep_variance_tabled(packed, nb, t_big, C, D, H, W)).all()
+
+
+def test_detector_on_a_side_stream_gives_the_same_outputs(gpu):
+    """`MVSDetHotPath.overlap_detector`: neck and head convolutions of a scene on a stream of their own, three scenes back to back
+    without a synchronisation in between: after waiting for out["detector_ready"] the same bits as the one-stream route."""
+    from mvsdet_amd import synthetic
+    from mvsdet_amd.head import NerfDetHeadConvs
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    from mvsdet_amd.neck import IndoorImVoxelNeck
+    torch.manual_seed(3)
+    N, C, D, hw = 5, 32, 8, (24, 32)
+    neck = IndoorImVoxelNeck(C, 64, [1, 1, 1]).to(gpu).eval()
+    head = NerfDetHeadConvs(18, 3, 64, 6).to(gpu).eval()
+    hp = MVSDetHotPath([16, 16, 8], [0.4, 0.4, 0.4], [0.2, 5.0], D, topk=3, neck_3d=neck, bbox_head=head)
+    scenes = [(synthetic.make_features(N, C, hw, seed=s).to(gpu), synthetic.make_cost_logits(N, D, hw, seed=s).to(gpu),
+               synthetic.make_img_meta(N, hw, seed=s)) for s in (1, 2, 3)]
+    with torch.no_grad():
+        serial = [hp.forward_scene(f, m, cost_logits=c) for f, c, m in scenes]
+        torch.cuda.synchronize(gpu)
+        hp.overlap_detector = True
+        over = [hp.forward_scene(f, m, cost_logits=c) for f, c, m in scenes]     # no synchronisation between the scenes
+        for o in over:
+            torch.cuda.current_stream(gpu).wait_event(o["detector_ready"])
+        torch.cuda.synchronize(gpu)
+    for a, b in zip(serial, over):
+        assert torch.equal(a["volume"], b["volume"])
+        for x, y in zip(a["neck"], b["neck"]):
+            assert torch.equal(x, y)
+        for la, lb in zip(a["head"], b["head"]):
+            for x, y in zip(la, lb):
+                assert torch.equal(x, y)
