@@ -504,7 +504,7 @@ def full_chain_rate(device, steps=10):
             "scenes_per_sec": round(steps / el, 3), "cost_network_roofline": roof, "neck_roofline": neck_roof,
             "ms_per_scene": round(el / steps * 1e3, 3),
             "detector_on_side_stream": {"scenes_per_sec": round(steps / el_overlap, 3), "ms_per_scene": round(el_overlap / steps * 1e3, 3),
-                                        "note": "neck + head of scene i on their own stream beside scene i+1's packing, sweep and conv0 "
+                                        "note": "depth distribution, lifting, neck and head of scene i on their own stream beside scene i+1's packing, sweep and conv0 "
                                                 "(MVSDetHotPath.overlap_detector); the device is synchronised once, after the last scene; "
                                                 "whole scenes alternating between two streams on top of it gain nothing (94.8 against 96.5)"},
             "cost_network_tflop": round(CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12, 3),

@@ -186,7 +186,8 @@ class MVSDetHotPath:
         # width is a multiple of 16 but not of 32 swept with the 32x4 tiles (48 planes or more): 6.1 against 6.5 ms at 50 views x
         # 96 planes x 60x80.  The cost network and the depth distribution read such views in place.  False: always contiguous.
         self.pitched_variance = "auto"
-        # True: neck_3d / bbox_head of a scene run on a side stream (forward_scene returns out["detector_ready"], a CUDA event)
+        # True: what follows the cost network (depth distribution, lifting, neck_3d / bbox_head) runs on a side stream; forward_scene
+        # returns out["ready"] (= out["detector_ready"]), a CUDA event the consumer's stream waits for
         self.overlap_detector = False
         self._detector_streams: dict = {}
 
@@ -408,39 +409,45 @@ class MVSDetHotPath:
             cost_logits = self.cost_regularization(variance)
         elif cost_logits is None:
             raise ValueError("forward_scene needs `cost_logits` when no cost_regularization module is set")
-        prob, off, est_depth, est_dens, est_idx, avg_depth = self.depth_distribution(cost_logits)
-        volume_mean, valid = self.lift(feature, packed, geo, est_depth, est_dens)
-        h, w = geo.height, geo.width
-        out = dict(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
-                   est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
-                   depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo,
-                   # mvsdet.py:582 `opacity = torch.max(prob_volume, dim=1)[0]`: the first of the sorted top-k values IS that
-                   # maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume, cropped at :583
-                   opacity=est_dens[:, 0])
-        if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU)
-            if self.overlap_detector and volume_mean.is_cuda:
-                # The neck works on ONE 40 x 40 x 16 volume: 200 blocks for 256 CUs at its largest level, a few dozen small kernels
-                # at the others.  On a stream of its own it runs beside the NEXT scene's packing, sweep and first convolution
-                # instead of in front of them.  The caller makes its stream wait for out["detector_ready"] before it touches
-                # out["neck"] / out["head"] (their memory belongs to that stream's pool).
-                dev = volume_mean.device
-                cur = torch.cuda.current_stream(dev)
-                side = self._detector_streams.get(str(dev))
-                if side is None:
-                    side = self._detector_streams[str(dev)] = torch.cuda.Stream(device=dev)
-                ready = torch.cuda.Event()
-                ready.record(cur)
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
-                    if self.bbox_head is not None:
-                        out["head"] = self.bbox_head(out["neck"])
-                    done = torch.cuda.Event()
-                    done.record(side)
-                volume_mean.record_stream(side)
-                out["detector_ready"] = done
-                return out
-            out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
-            if self.bbox_head is not None:
-                out["head"] = self.bbox_head(out["neck"])   # (centerness, bbox, cls) lists over the levels
+
+        def tail():
+            prob, off, est_depth, est_dens, est_idx, avg_depth = self.depth_distribution(cost_logits)
+            volume_mean, valid = self.lift(feature, packed, geo, est_depth, est_dens)
+            h, w = geo.height, geo.width
+            out = dict(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
+                       est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
+                       depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo,
+                       # mvsdet.py:582 `opacity = torch.max(prob_volume, dim=1)[0]`: the first of the sorted top-k values IS that
+                       # maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume, cropped at :583
+                       opacity=est_dens[:, 0])
+            if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU)
+                out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
+                if self.bbox_head is not None:
+                    out["head"] = self.bbox_head(out["neck"])   # (centerness, bbox, cls) lists over the levels
+            return out
+
+        if not (self.overlap_detector and variance.is_cuda):
+            return tail()
+        # Everything behind the cost network -- depth distribution, lifting, and the neck and head when they are attached -- on a
+        # stream of its own: small kernels that do not fill the chip (one thread per pixel; ONE 40 x 40 x 16 volume: 200 blocks for
+        # 256 CUs at the neck's largest level) run beside the NEXT scene's packing, sweep and first convolution instead of in
+        # front of them.  The caller makes its stream wait for out["ready"] before it touches any output but `variance` (their
+        # memory belongs to the side stream's pool).
+        dev = variance.device
+        cur = torch.cuda.current_stream(dev)
+        side = self._detector_streams.get(str(dev))
+        if side is None:
+            side = self._detector_streams[str(dev)] = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            out = tail()
+            done = torch.cuda.Event()
+            done.record(side)
+        # inputs of the tail that live in another stream's pool must not be recycled while the side stream reads them
+        for t in (cost_logits, packed, feature, geo.neighbor_ids, geo.points):
+            if isinstance(t, Tensor) and t.is_cuda:
+                t.record_stream(side)
+        out["ready"] = out["detector_ready"] = done
         return out
