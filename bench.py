@@ -456,6 +456,8 @@ def full_chain_rate(device, steps=10):
     from mvsdet_amd import ops
     with torch.no_grad():
         var = out["variance"]
+        net(var)   # untimed: the loops above left the allocator's pools in another state (the side stream's), the first call re-grows them
+        torch.cuda.synchronize(device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
