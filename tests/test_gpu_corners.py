@@ -414,18 +414,22 @@ def test_geometry_of_another_tile_shape_is_refused(gpu, oracle):
     assert torch.isnan(ops.plane_sweep_variance_tabled(packed, nb, t_big, C, D, H, W)).all()
 
 
-def test_detector_on_a_side_stream_gives_the_same_outputs(gpu):
-    """`MVSDetHotPath.overlap_detector`: neck and head convolutions of a scene on a stream of their own, three scenes back to back
-    without a synchronisation in between: after waiting for out["detector_ready"] the same bits as the one-stream route."""
+@pytest.mark.parametrize("with_network", [False, True])
+def test_detector_on_a_side_stream_gives_the_same_outputs(gpu, with_network):
+    """`MVSDetHotPath.overlap_detector`: what follows the cost network -- depth distribution, lifting, neck and head convolutions --
+    on a stream of its own, three scenes back to back without a synchronisation in between: after waiting for out["ready"] the same
+    bits as the one-stream route (with stand-in logits, and with the cost network on our kernels in front of the tail)."""
     from mvsdet_amd import synthetic
+    from mvsdet_amd.costreg import CostRegNet3DGS
     from mvsdet_amd.head import NerfDetHeadConvs
     from mvsdet_amd.hotpath import MVSDetHotPath
     from mvsdet_amd.neck import IndoorImVoxelNeck
     torch.manual_seed(3)
-    N, C, D, hw = 5, 32, 8, (24, 32)
+    N, C, D, hw = 5, 64 if with_network else 32, 8, (24, 32)
     neck = IndoorImVoxelNeck(C, 64, [1, 1, 1]).to(gpu).eval()
     head = NerfDetHeadConvs(18, 3, 64, 6).to(gpu).eval()
-    hp = MVSDetHotPath([16, 16, 8], [0.4, 0.4, 0.4], [0.2, 5.0], D, topk=3, neck_3d=neck, bbox_head=head)
+    net = CostRegNet3DGS(C).to(gpu).eval() if with_network else None
+    hp = MVSDetHotPath([16, 16, 8], [0.4, 0.4, 0.4], [0.2, 5.0], D, topk=3, neck_3d=neck, bbox_head=head, cost_regularization=net)
     scenes = [(synthetic.make_features(N, C, hw, seed=s).to(gpu), synthetic.make_cost_logits(N, D, hw, seed=s).to(gpu),
                synthetic.make_img_meta(N, hw, seed=s)) for s in (1, 2, 3)]
     with torch.no_grad():
@@ -434,10 +438,11 @@ def test_detector_on_a_side_stream_gives_the_same_outputs(gpu):
         hp.overlap_detector = True
         over = [hp.forward_scene(f, m, cost_logits=c) for f, c, m in scenes]     # no synchronisation between the scenes
         for o in over:
-            torch.cuda.current_stream(gpu).wait_event(o["detector_ready"])
+            torch.cuda.current_stream(gpu).wait_event(o["ready"])
         torch.cuda.synchronize(gpu)
     for a, b in zip(serial, over):
-        assert torch.equal(a["volume"], b["volume"])
+        assert torch.equal(a["volume"], b["volume"]) and torch.equal(a["prob_volume"], b["prob_volume"])
+        assert torch.equal(a["est_depth"], b["est_depth"]) and torch.equal(a["depth_coding"], b["depth_coding"])
         for x, y in zip(a["neck"], b["neck"]):
             assert torch.equal(x, y)
         for la, lb in zip(a["head"], b["head"]):
