@@ -118,4 +118,33 @@ static __global__ __launch_bounds__(kThreads) void unpack_features_kernel(const 
     }
 }
 
+// The same for H*W a multiple of 4 and a 16-byte aligned output: 128 pixels per block, float4 stores (the mirror image of
+// pack_features_dense_kernel: LDS rows 136 floats apart, lane (pixel, g) writes rows g, 8+g, 16+g, 24+g on bank 8*g + pixel).
+static __global__ __launch_bounds__(kThreads) void unpack_features_dense_kernel(const float* __restrict__ packed, float* __restrict__ feat,
+                                                                                 int C, int S, int HW) {
+    constexpr int kPix = 128, kPitch = 136;
+    __shared__ float tile[kSlab * kPitch];
+    const int pix0 = blockIdx.x * kPix, s = blockIdx.y, n = blockIdx.z;
+    const int g = threadIdx.x & 7;
+#pragma unroll
+    for (int p = threadIdx.x >> 3; p < kPix; p += 32) {
+        const int pix = pix0 + p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pix < HW) v = *reinterpret_cast<const float4*>(packed + (((size_t)n * S + s) * HW + pix) * kSlab + 4 * g);
+        tile[g * kPitch + p] = v.x;
+        tile[(8 + g) * kPitch + p] = v.y;
+        tile[(16 + g) * kPitch + p] = v.z;
+        tile[(24 + g) * kPitch + p] = v.w;
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    const int pix = pix0 + 4 * q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = s * kSlab + r0 + 8 * k;
+        if (pix < HW && c < C)
+            *reinterpret_cast<float4*>(feat + ((size_t)n * C + c) * HW + pix) = *reinterpret_cast<const float4*>(&tile[(r0 + 8 * k) * kPitch + 4 * q]);
+    }
+}
+
 }  // namespace mvsdet

@@ -431,8 +431,13 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
 #undef MVS_BWD_LAUNCH
 #undef MVS_BWD_LAUNCH1
     MVS_LAUNCH_CHECK("plane_sweep_variance_bwd");
-    dim3 ugrid((HW + 63) / 64, S, N);
-    hipLaunchKernelGGL(unpack_features_kernel, ugrid, dim3(kThreads), 0, stream, gpacked, gfeat, C, S, H, W);
+    if (HW % 4 == 0 && (uintptr_t)gfeat % 16 == 0) {
+        dim3 dgrid((HW + 127) / 128, S, N);
+        hipLaunchKernelGGL(unpack_features_dense_kernel, dgrid, dim3(kThreads), 0, stream, gpacked, gfeat, C, S, HW);
+    } else {
+        dim3 ugrid((HW + 63) / 64, S, N);
+        hipLaunchKernelGGL(unpack_features_kernel, ugrid, dim3(kThreads), 0, stream, gpacked, gfeat, C, S, H, W);
+    }
     MVS_LAUNCH_CHECK("unpack_features");
     return MVSDET_OK;
 }
