@@ -200,6 +200,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # eval route on bf16x3: "scl" = every layer hands the next one its output already cut into bf16 pieces (SCL / PSCL
         # forms: no fp32 round trip through a packing pass or a strided gather, inputs by LDS-DMA); "f32" = fp32 tensors
         # between the layers (round 3).  Same values bit for bit.
+        self.skip_in_head = False   # True: conv0 + conv11(x) formed by the head while it stages its input (round 4's first form)
         self.layer_forms = "scl"
         # (layer, kind, shape, device, stream) -> the SCL / PSCL buffer a layer writes; its zero border is written once.
         # Keyed by the stream as well: the buffers are refilled in place, outside the allocator's per-stream reuse tracking
@@ -262,10 +263,15 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         q1 = cbr(self.conv3, half_p, 1, ("scl",), "conv3", (n, 4 * b, d // 4, h // 4, w // 4))
         q2 = cbr(self.conv4, q1, 0, ("scl",), "conv4", (n, 4 * b, d // 4, h // 4, w // 4))
         half2 = up(self.conv9, q2, half, ("scl",), "conv9", (n, 2 * b, d // 2, h // 2, w // 2))
-        # mvsnet.py:111-112: x = conv0 + conv11(x); prob(x).  The addition is formed by the head while it stages its input, so
-        # conv11's epilogue is a pure store stream instead of load - wait - store round trips over 1.2 GB
-        up11 = up(self.conv11, half2, None, ("f32",), "conv11", (n, b, d, h, w))
-        return ops.conv3d_k3_cout2_sum(full, up11, self.prob.weight.detach(), self.prob.bias.detach())
+        # mvsnet.py:111-112: x = conv0 + conv11(x); prob(x).  With one block per (PD, PH) in the transposed kernel the addition was
+        # cheaper in the head's staging (conv11's epilogue then only stores); with all eight classes in one block the skip tensor read
+        # in conv11's epilogue costs less than a second input costs the head (0.65 + 0.31 against 0.48 + 0.53 ms): same bits either way
+        # (one fp32 addition of the same two values)
+        if self.skip_in_head:
+            up11 = up(self.conv11, half2, None, ("f32",), "conv11", (n, b, d, h, w))
+            return ops.conv3d_k3_cout2_sum(full, up11, self.prob.weight.detach(), self.prob.bias.detach())
+        up11 = up(self.conv11, half2, full, ("f32",), "conv11", (n, b, d, h, w))
+        return ops.conv3d_k3_cout2_sum(up11, None, self.prob.weight.detach(), self.prob.bias.detach())
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
