@@ -426,8 +426,8 @@ class MVSDetHotPath:
                     out["head"] = self.bbox_head(out["neck"])   # (centerness, bbox, cls) lists over the levels
             return out
 
-        if not (self.overlap_detector and variance.is_cuda):
-            return tail()
+        if not (self.overlap_detector and variance.is_cuda) or (torch.is_grad_enabled() and (feature.requires_grad or cost_logits.requires_grad)):
+            return tail()   # one stream under autograd: the backward's stream order is left to the ops' own streams
         # Everything behind the cost network -- depth distribution, lifting, and the neck and head when they are attached -- on a
         # stream of its own: small kernels that do not fill the chip (one thread per pixel; ONE 40 x 40 x 16 volume: 200 blocks for
         # 256 CUs at the neck's largest level) run beside the NEXT scene's packing, sweep and first convolution instead of in
