@@ -31,6 +31,8 @@ struct Options {
     int probe_f16_pair; // mvsdet_store_pattern_probe_f16 only: 1 = lanes of adjacent pixel quads own the octet between them and store
                        // 16 bytes of two channel rows instead of 8 of four (what a paired flush of the fp16 sweep WOULD reach: +12 %,
                        // not built -- the fp16 sweep is bound by its vector work); 0 (default) = the kernel's own pattern
+    int conv_xcd;      // stride-1 bf16x3 convolution: 1 (default) = an XCD takes a contiguous eighth of the grid (neighbouring tiles share
+                       // their halo voxels in one L2); 0 = blocks round-robin over the XCDs
     int conv_mfma16;   // 1 (default): the bf16x3 stride-1 convolution on v_mfma_f32_16x16x32_bf16 (conv0 of the cost network 5.37 -> 4.91 ms:
                        // the chip holds a higher clock on this shape); 0: 32x32x16.  Weights must be split under the same setting.
 };

@@ -73,6 +73,20 @@ struct BfOut {
     size_t piece, cpiece;  // units per piece (SCL), per piece (PSCL: 8 classes)
 };
 
+// Blocks are dealt to the 8 XCDs round-robin by their linear id.  With `xcd_map` XCD x takes the x-th EIGHTH of the grid in its
+// natural order instead of every eighth block: neighbouring tiles -- which share their halo voxels -- and the blocks of output
+// channels that read the same tile meet in one L2 (conv2 of the cost network 0.81 -> 0.74 ms).  Host: the grid is a multiple of 8.
+__device__ __forceinline__ void xcd_block_id(int xcd_map, unsigned& bx, unsigned& by, unsigned& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (xcd_map) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const unsigned moved = (lin & 7u) * (total >> 3) + (lin >> 3);
+        bx = moved % gridDim.x;
+        by = (moved / gridDim.x) % gridDim.y;
+        bz = moved / (gridDim.x * gridDim.y);
+    }
+}
 // fp32 x 8 -> the two bf16 pieces (round to nearest even; the remainder is exact in fp32 and rounded once)
 __device__ __forceinline__ void bf_cut8(const float (&v)[8], uint4& hi, uint4& mid) {
     unsigned h[4], m[4];
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(TD * TH * TW * 4 / CGN) void conv3d_k3_bf16x3_kerne
     const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
     const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, BfOut dst, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
-    size_t piece_stride, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
+    size_t piece_stride, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total, int xcd_map) {
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                           // h-rows of one column group
     static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
@@ -279,15 +293,17 @@ __global__ __launch_bounds__(TD * TH * TW * 4 / CGN) void conv3d_k3_bf16x3_kerne
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
-    // blockIdx.z = (view, block of 64 output channels, split of the channel groups): a small volume (the 3-D neck's 20x20x8 and
+    unsigned bx, by, bz;
+    xcd_block_id(xcd_map, bx, by, bz);
+    const int bw = bx % tiles_w, bh = bx / tiles_w;
+    // bz = (view, block of 64 output channels, split of the channel groups): a small volume (the 3-D neck's 20x20x8 and
     // 10x10x4 levels: 1-12 tiles) is split over the input channels so that the grid fills the chip; each split writes raw
     // partial sums that splitk_epilogue_kernel adds up (ascending split order) before the affine, residual and ReLU
     const int nob = Cout / 64;
-    const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
+    const int split = bz % nsplit, zo = bz / nsplit;
     const int n = zo / nob, ob64 = zo % nob;
     const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
-    const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = by * TD;
     const int col = lane & 31, hh = lane >> 5;
 
     // ---- DMA plans.  Input: wave-instruction i of a stage = (piece i / IN_DMA, slots 64*(i % IN_DMA) ..); the lane's slot
@@ -655,7 +671,7 @@ __global__ __launch_bounds__(TD * TH * TW * 2 / CG) void conv3d_k3_s2_bf16x3_ker
     const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ xp,
     int cDp, int cHp, int cWp, size_t cpiece, int Nviews, const uint4* __restrict__ wq,
     const float* __restrict__ scale, const float* __restrict__ shift, BfOut dst, int C8, int Cout, int Di, int Hi,
-    int Wi, int D, int H, int W, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total) {
+    int Wi, int D, int H, int W, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total, int xcd_map) {
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                // h-rows of one column group
     static_assert(TH % RG == 0 && (TD * TH * TW) % (32 * CG) == 0, "whole column groups, CG per wave");
@@ -668,13 +684,15 @@ __global__ __launch_bounds__(TD * TH * TW * 2 / CG) void conv3d_k3_s2_bf16x3_ker
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    unsigned bx, by, bz;
+    xcd_block_id(xcd_map, bx, by, bz);
+    const int bw = bx % tiles_w, bh = bx / tiles_w;
     const int nob = Cout / (64 * OB);
-    // blockIdx.z = (view, block of 64 * OB output channels, split of the channel groups): see conv3d_k3_bf16x3_kernel
-    const int split = blockIdx.z % nsplit, zo = blockIdx.z / nsplit;
+    // bz = (view, block of 64 * OB output channels, split of the channel groups): see conv3d_k3_bf16x3_kernel
+    const int split = bz % nsplit, zo = bz / nsplit;
     const int n = zo / nob, ob64 = (zo % nob) * OB;   // first group of 64 channels of the block
     const int c8_begin = (int)((long long)C8 * split / nsplit), c8_end = (int)((long long)C8 * (split + 1) / nsplit);
-    const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = by * TD;
     const int col = lane & 31, hh = lane >> 5;
     const float* xfn = PIN ? nullptr : xf + (size_t)n * sN;
 
@@ -1170,7 +1188,7 @@ template <int TD, int TH, int TW>
 __global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_kernel(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, BfOut dst, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
-    size_t piece_stride, int tiles_w, int relu) {
+    size_t piece_stride, int tiles_w, int relu, int xcd_map) {
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;
     static_assert(TH % RG == 0 && (TD * TH * TW) % 32 == 0, "whole column groups");
@@ -1187,10 +1205,12 @@ __global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_k
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bw = blockIdx.x % tiles_w, bh = blockIdx.x / tiles_w;
+    unsigned bx, by, bz;
+    xcd_block_id(xcd_map, bx, by, bz);
+    const int bw = bx % tiles_w, bh = bx / tiles_w;
     const int nob = Cout / 32;
-    const int n = blockIdx.z / nob, ob32 = blockIdx.z % nob, ob64 = ob32 >> 1, rg = ob32 & 1;
-    const int w0 = bw * TW, h0 = bh * TH, d0 = blockIdx.y * TD;
+    const int n = bz / nob, ob32 = bz % nob, ob64 = ob32 >> 1, rg = ob32 & 1;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = by * TD;
     const int col = lane & 31, hh = lane >> 5;
 
     const size_t c8_stride = (size_t)Dp * Hp * Wp;
@@ -1585,6 +1605,7 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
     const BfOut dst = make_out(out, out_scl, out_pscl, N, Cout, D, H, W);
     dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64) * nsplit));
+    const int xcd_map = options().conv_xcd != 0 && ((long long)grid.x * grid.y * grid.z) % 8 == 0 && (long long)grid.x * grid.y * grid.z >= 64;
     hipStream_t st = (hipStream_t)stream;
 #define MVS_BF_CASE(TD_, TH_, F32_, TW_, SUBP_, M16_, ...)                                                                  \
     {                                                                                                                       \
@@ -1598,7 +1619,7 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
         }                                                                                                                   \
         hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_ * 4 / CGN_), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH, \
                            Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W,    \
-                           p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total);        \
+                           p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total, xcd_map);        \
     }
 #define MVS_BF_TILE(TD_, TH_, F32_, TW_) { if (m16) MVS_BF_CASE(TD_, TH_, F32_, TW_, 6, true) else MVS_BF_CASE(TD_, TH_, F32_, TW_, 5, false) }
     // option "conv_subpairs" = 2: weight sub-stages of 2 tap pairs (instead of 5) bring the 3 x 16 x 8 tile's LDS to 77 KiB, two
@@ -1740,7 +1761,9 @@ static int launch_s2_bf16x3(const float* x, const int64_t* x_strides, const void
         hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_ * 2 / CG_), lds, (hipStream_t)stream, x, sN, sC, sD, sH, Cin,       \
                            static_cast<const uint4*>(x_pscl), cDp, cHp, cWp, cpiece, N,                                      \
                            static_cast<const uint4*>(weight_split), scale, shift, dst, C8, Cout, Di, Hi, Wi, D, H, W,        \
-                           tiles_w, relu, nsplit, static_cast<float*>(workspace), total);                                    \
+                           tiles_w, relu, nsplit, static_cast<float*>(workspace), total,                                     \
+                           (int)(options().conv_xcd != 0 && ((long long)grid.x * grid.y * grid.z) % 8 == 0 &&                \
+                                 (long long)grid.x * grid.y * grid.z >= 64));                                                \
     }
     // the PSCL-fed 3 x 16 x 8 tile on 12 waves of one column group (conv1 0.573 -> 0.563, conv3 0.304 -> 0.291 ms: two 6-wave
     // blocks already share a CU here; option "conv_s2_cg" = 2: the 6-wave form)
@@ -1848,7 +1871,9 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
         MVS_REQUIRE((long long)N * (Cout / 32) <= 65535, "%s: N*Cout/32 too large", name);
         dim3 fgrid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 32)));
         hipLaunchKernelGGL(k, fgrid, dim3(3 * 16 * 8 * 2), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split),
-                           scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, relu);
+                           scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, relu,
+                           (int)(options().conv_xcd != 0 && ((long long)fgrid.x * fgrid.y * fgrid.z) % 8 == 0 &&
+                                 (long long)fgrid.x * fgrid.y * fgrid.z >= 64));
     } else
     if (t38) { if (options().convT_cg == 2) MVS_CT_CASE(3, 16, 8, 2) else MVS_CT_CASE(3, 16, 8, 1) }
     else MVS_CT_CASE(kS2TD, kS2TH, kBfW, 2)
