@@ -21,6 +21,15 @@
 // atomics.  The sums are also more accurate than fp32 ones and lose nothing when a box collects thousands of taps.
 // A footprint larger than the box falls back to one global fp32 atomic per tap.  The packed gradient map is unpacked
 // to (N,C,H,W) afterwards.
+//
+// What bounds it (round 4, rocprofv3 --pmc at the reference-true shape, tools/pmc_bwd.sh): NOT the LDS atomics -- the same
+// kernel with the image in 64-bit fixed point (ds_add_u64 costs half a ds_add_f64: tools/micro/lds_atomic_mask.hip) waits a
+// quarter as long on the LDS (SQ_WAIT_INST_LDS 1.8e8 -> 4.5e7) and is 3 % faster, less than the pass over dL/dvar that finds
+// its scale costs.  With two waves per SIMD the waves spend 54 % of their cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) on
+// dL/dvar from HBM and the taps from L2 while the vector pipe is 63 % busy.  GROUPS = 2 (D >= 32) doubles the waves on the
+// same LDS: wave group q of a block takes the planes d with d % GROUPS == q, both add into the SAME gradient images (sums
+// commute) and meet at the refills: 55.3 -> 44.4 ms at 64 planes of 120 x 160; at 12 planes it loses (2.8 -> 3.1 ms: six
+// planes per group between a block's zeroing and flush), so short sweeps keep one group.
 #include "common.h"
 
 #include <algorithm>
@@ -38,8 +47,8 @@ __device__ __forceinline__ int grad_swizzle(int base) { return (base >> 6) & 1; 
 
 constexpr int kHalfSlab = kSlab / 2;  // packed floats of a texel one kernel instance owns
 
-template <int K, int TW, int HALF>
-__global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
+template <int K, int TW, int HALF, int GROUPS>
+__global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_variance_bwd_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
     const float* __restrict__ depth, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
     const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S, int D, int H, int W, int tiles_x,
@@ -62,7 +71,8 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     const int tile = bt % tiles, n = bt / tiles;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_of_block = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_of_block & 3, plane_group = wave_of_block >> 2;
     const int g = lane & 7, ps = lane >> 3;
     const size_t slab_stride = (size_t)HW * kSlab;
     // float2 views of the slab images, already at the lane's two floats: texel t is element 16 * t
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
     auto flush_box = [&](int j) {
         const int nc = rx1[j] - rx0[j] + 1, ntex = nc * (ry1[j] - ry0[j] + 1);
         const float inv_nc = 1.0f / (float)nc;
-        for (int t0 = wave * 4; t0 < ntex; t0 += 16) {
+        for (int t0 = wave_of_block * 4; t0 < ntex; t0 += 16 * GROUPS) {
             const int t = t0 + (lane >> 4), q = lane & 15;
             if (t < ntex) {
                 const int row = (int)(((float)t + 0.5f) * inv_nc), col = t - row * nc;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
         }
     };
 
-    for (int e = tid; e < K * slot_el / 2; e += kThreads) reinterpret_cast<double2*>(s_grad)[e] = make_double2(0.0, 0.0);
+    for (int e = tid; e < K * slot_el / 2; e += kThreads * GROUPS) reinterpret_cast<double2*>(s_grad)[e] = make_double2(0.0, 0.0);
     __syncthreads();
 
     const unsigned* fl_bt = flags + (size_t)bt * D;
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_kernel(
             }
             __syncthreads();  // slots zeroed again before anyone adds into them
         }
+        if (GROUPS > 1 && d % GROUPS != plane_group) continue;   // the refills above are everybody's, the plane is one group's
         // ---- dL/dvar of the lane's pixels and channels: 8 channel rows x 128 contiguous bytes per wave-instruction
         float go[4][2];
 #pragma unroll
@@ -394,26 +405,29 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     const int box_cap = sweep_box_cap(K, tw);
     const size_t lds = sweep_lds_bytes(K, box_cap);
     dim3 grid((unsigned)nblocks);
+    // plane groups of a block (header comment): option "bwd_groups" 0 = by the plane count, 1 / 2 force
+    const int groups = options().bwd_groups ? std::min(2, std::max(1, options().bwd_groups)) : (D >= 32 ? 2 : 1);
     // two instances: the lower and the upper 16 packed floats of every texel = channels 8i + {0..3} and 8i + {4..7} of the
     // slab (pack.h), so the upper one has nothing to do only when C <= 4
-#define MVS_BWD_LAUNCH1(KV, TWV, HV)                                                                                   \
+#define MVS_BWD_LAUNCH1(KV, TWV, HV, GV)                                                                                 \
     {                                                                                                                  \
-        auto* k = plane_sweep_variance_bwd_kernel<KV, TWV, HV>;                                                        \
+        auto* k = plane_sweep_variance_bwd_kernel<KV, TWV, HV, GV>;                                                    \
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                    80 * 1024) != hipSuccess) {                                         \
             set_error("plane_sweep_variance_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");             \
             return MVSDET_ERR_HIP;                                                                                     \
         }                                                                                                              \
-        hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
+        hipLaunchKernelGGL(k, grid, dim3(kThreads * GV), lds, stream, packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
                            gpacked, N, C, S, D, H, W, tiles_x, tiles, box_cap);                                        \
     }
 #define MVS_BWD_LAUNCH(KV, TWV)                        \
     {                                                  \
         if (C > 4) {                                   \
             grid = dim3((unsigned)((nblocks + 7) / 8 * 16)); \
-            MVS_BWD_LAUNCH1(KV, TWV, 2)                \
+            if (groups == 2) MVS_BWD_LAUNCH1(KV, TWV, 2, 2) \
+            else MVS_BWD_LAUNCH1(KV, TWV, 2, 1)        \
         } else                                         \
-            MVS_BWD_LAUNCH1(KV, TWV, 0)                \
+            MVS_BWD_LAUNCH1(KV, TWV, 0, 1)             \
     }
 #define MVS_BWD_CASE(KV)                     \
     case KV:                                 \

@@ -49,7 +49,7 @@ def make_case(seed):
             proj[n, j, :3, 3] = t
     depth = np.sort(rng.uniform(0.2, 5.0, (1, D)).astype(np.float32), axis=1).repeat(N, 0)
     opts = {"sweep_tw": int(rng.choice([0, 0, 16, 32])), "sweep_boxcap": int(rng.choice([512, 512, 0, 24, 100, 200])),
-            "sweep_xcd": int(rng.choice([0, 1]))}
+            "sweep_xcd": int(rng.choice([0, 1])), "bwd_groups": int(rng.choice([0, 1, 2]))}
     return (N, K, C, D, H, W), feat, nbr, proj, depth, opts
 
 
@@ -58,7 +58,7 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dev = torch.device("cuda:0")
     O.build()
-    saved = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap", "sweep_xcd")}
+    saved = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap", "sweep_xcd", "bwd_groups")}
     bad = 0
     for seed in range(first, first + cases):
         shape, feat, nbr, proj, depth, opts = make_case(seed)

@@ -61,6 +61,24 @@ def test_backward_stage1_multi_slab(gpu, oracle, N, K, C, D, H, W):
     _check_bwd(gpu, oracle, *_scene(oracle, N, K, C, D, H, W, seed=21))
 
 
+@pytest.mark.parametrize("N,K,C,D,H,W", [
+    (3, 2, 64, 5, 24, 32),     # odd plane count: one wave group takes three planes, the other two
+    (3, 2, 40, 4, 33, 47),     # ragged tiles
+    (3, 1, 64, 1, 12, 18),     # one plane: the second group only meets the first at the barriers
+    (2, 2, 32, 33, 20, 28),    # the plane count from which two groups are the default
+])
+def test_backward_stage1_two_plane_groups(gpu, oracle, N, K, C, D, H, W):
+    """Two wave groups of a block share its LDS gradient images and split its planes (option "bwd_groups",
+    csrc/planesweep_bwd.hip): same result as one group, which the oracle pins."""
+    from mvsdet_amd import _lib
+    saved = _lib.get_option("bwd_groups")
+    try:
+        _lib.set_option("bwd_groups", 2)
+        _check_bwd(gpu, oracle, *_scene(oracle, N, K, C, D, H, W, seed=23))
+    finally:
+        _lib.set_option("bwd_groups", saved)
+
+
 def test_backward_stage1_over_box_capacity(gpu, oracle):
     """Footprints larger than the LDS gradient box (3-6x scale: a 128-pixel tile covers > 256 source texels) take the
     per-tap global-atomic path; shrink maps pile many pixels onto one texel; both inside one launch with C = 96."""
