@@ -303,6 +303,12 @@ int mvsdet_conv3d_k3_cout2_dx_f32(const float* grad_out, const float* weight, fl
                                   int W, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_cout2_dw_f32(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
                                   int N, int Cin, int D, int H, int W, mvsdet_stream_t stream);
+/* The weight gradient on the bf16 matrix cores with three-term split operands (within ~1e-5 of the fp32 sums' scale): x streams
+ * from global memory straight into the MFMA fragments, grad_out's 3 x 3 neighbouring rows are staged per x row.  nsplit = blocks =
+ * rows of partial (nsplit,2,Cin,27); Cin in {16, 32, 64}, W % 4 == 0, 16-byte aligned tensors (else MVSDET_ERR_INVALID_ARG: use
+ * the fp32 call). */
+int mvsdet_conv3d_k3_cout2_dw_bf16x3(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
+                                     int N, int Cin, int D, int H, int W, mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a9  backproject_Weigh -- mvsdet.py:1372-1492 (gt_depth=None).

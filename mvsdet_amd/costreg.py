@@ -145,18 +145,19 @@ class _HeadConv(torch.autograd.Function):
     csrc/costreg_head.hip (MIOpen: 363 ms for one forward + backward at the reference-true shape; here about 2 ms)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bf16x3=False):
         from . import ops
         ctx.save_for_backward(x, weight)
+        ctx.bf16x3 = bool(bf16x3)   # the weight gradient on the bf16 matrix cores (three-term split operands)
         return ops.conv3d_k3_cout2(x, weight, bias)
 
     @staticmethod
     def backward(ctx, gy):
         from . import ops
         x, weight = ctx.saved_tensors
-        gx, gw = ops.conv3d_k3_cout2_backward(x, weight.detach(), gy.contiguous())
+        gx, gw = ops.conv3d_k3_cout2_backward(x, weight.detach(), gy.contiguous(), 32, ctx.bf16x3)
         gb = gy.sum(dim=(0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
-        return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), gb
+        return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), gb, None
 
 
 class _ConvBnReLU3d(nn.Module):
@@ -343,7 +344,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             from . import ops
             return ops.conv3d_k3_cout2(full, self.prob.weight.detach(), self.prob.bias.detach())
         if self.hip_backward and full.is_cuda and full.dtype == torch.float32 and torch.is_grad_enabled():
-            return _HeadConv.apply(full, self.prob.weight, self.prob.bias)
+            return _HeadConv.apply(full, self.prob.weight, self.prob.bias, self.matrix_precision == "bf16x3")
         return self.prob(full)
 
     @staticmethod

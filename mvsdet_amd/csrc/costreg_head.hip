@@ -407,6 +407,146 @@ __global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dw_kernel(const floa
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix cores with three-term split operands (the arithmetic of costreg_dw_bf16.hip):
+//
+//     dW[o][c][kd,kh,kw] = sum over views and voxels u of  x[n,c,u] * gy[n,o,u - (kd-1,kh-1,kw-1)]      (gy = 0 outside the volume)
+//
+// one GEMM with the voxels as the reduction: M = the input channels (MT tiles of 16), N = the 54 (o, tap) pairs padded to 64, on
+// v_mfma_f32_16x16x32_bf16.  The SMALL tensor is the shifted one: x (N,Cin,D,H,W -- 590 MB at the reference-true shape, the
+// only stream that matters) goes from global memory straight into the A fragments, 16 bytes per lane, never through the LDS;
+// gy (2 channels) is staged per x row as its 3 x 3 neighbouring rows of both channels with zero halos, and a lane reads its
+// (o, tap) column's 8 voxels from there at the tap's shift.
+//   wave  : walks x rows (n, d, h), all input channels of a row, 32 voxels per k-step.  The 32 k of an instruction are the voxels
+//           w0 + 4g + {0..3} and w0 + 16 + 4g + {0..3} of k-group g = lane >> 4: the four groups of a channel read 64
+//           contiguous bytes per load instruction
+//   block : 4 independent waves (their own gy rows in LDS, no barrier in the loop); the four accumulator sets are added
+//           through the LDS at the end: partial[block][o][c][27], the caller adds the blocks up
+// The fp32 kernel above: 1.0 ms at (40,64,12,60,80); this one is bound by the x stream.
+typedef short hd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hd_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHdwRows = 19;   // 2 output channels x 3 x 3 neighbouring rows of grad_out, and a row that stays zero
+constexpr int kHdwLead = 4;    // floats in front of a row's voxel 0 (the last of them is the left halo): the data is 16-byte aligned
+
+__host__ __device__ constexpr int hdw_pitch(int W) {
+    // voxels up to the k-step's end + the right halo, a multiple of 4 floats that is no multiple of 32 (rows on different banks)
+    const int p = kHdwLead + (W + 31) / 32 * 32 + 4;
+    return p % 32 == 0 ? p + 4 : p;
+}
+__host__ __device__ constexpr size_t hdw_lds_bytes(int Cin, int W) { return ((size_t)4 * kHdwRows * hdw_pitch(W) + (size_t)Cin * 64) * sizeof(float); }
+
+__device__ __forceinline__ unsigned hd_pack(__bf16 a, __bf16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// 8 floats -> their bf16 roundings (hi) and the roundings of the exact remainders (mid)
+__device__ __forceinline__ void hd_cut8(const float (&f)[8], hd_bf16x8& hi, hd_bf16x8& mid) {
+    hd_u32x4 h, m;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const __bf16 a0 = (__bf16)f[2 * p], a1 = (__bf16)f[2 * p + 1];
+        h[p] = hd_pack(a0, a1);
+        m[p] = hd_pack((__bf16)(f[2 * p] - (float)a0), (__bf16)(f[2 * p + 1] - (float)a1));
+    }
+    hi = __builtin_bit_cast(hd_bf16x8, h);
+    mid = __builtin_bit_cast(hd_bf16x8, m);
+}
+
+template <int MT>
+__global__ __launch_bounds__(kThreads) void conv3d_k3_cout2_dw_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                             float* __restrict__ partial, int N, int D, int H, int W) {
+    constexpr int Cin = 16 * MT;
+    extern __shared__ float s_hd[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r16 = lane & 15;
+    const int pitch = hdw_pitch(W);
+    float* const rows = s_hd + wave * kHdwRows * pitch;
+    float* const red = s_hd + 4 * kHdwRows * pitch;
+    for (int i = lane; i < kHdwRows * pitch; i += 64) rows[i] = 0.0f;   // halos, the columns behind W and the zero row stay so
+    // where the lane's (o, tap) column of each N tile starts reading: row (o, 1 - (kd-1), 1 - (kh-1)), column shifted by 1 - kw
+    int boff[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int j = 16 * nt + r16;
+        const int o = j / 27, tap = j - 27 * o, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        boff[nt] = (j < 54 ? (o * 9 + (2 - kd) * 3 + (2 - kh)) * pitch + 1 - kw : 18 * pitch) + kHdwLead + 4 * g;
+    }
+    const int HW = H * W, W4 = W >> 2;
+    const size_t vol = (size_t)D * HW;
+    const int nrows = N * D * H, ksteps = (W + 31) >> 5;
+    hd_f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+        const int n = row / (D * H), dh = row - n * (D * H), d = dh / H, h = dh - d * H;
+        // the 18 rows of grad_out around (d, h): zero where the volume ends
+        for (int q = lane; q < 18 * W4; q += 64) {
+            const int rr = q / W4, c4 = q - rr * W4;
+            const int o = rr / 9, zd = d + (rr % 9) / 3 - 1, zh = h + rr % 3 - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zd >= 0 && zd < D && zh >= 0 && zh < H)
+                v = *reinterpret_cast<const float4*>(gy + ((size_t)n * 2 + o) * vol + (size_t)zd * HW + (size_t)zh * W + 4 * c4);
+            *reinterpret_cast<float4*>(rows + rr * pitch + kHdwLead + 4 * c4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float* xr = x + ((size_t)n * Cin + r16) * vol + (size_t)d * HW + (size_t)h * W + 4 * g;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int w0 = 32 * ks + 4 * g;
+            hd_bf16x8 ahi[MT], amid[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float* p = xr + (size_t)(16 * mt) * vol + 32 * ks;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (w0 < W) v0 = *reinterpret_cast<const float4*>(p);
+                if (w0 + 16 < W) v1 = *reinterpret_cast<const float4*>(p + 16);
+                const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                hd_cut8(f, ahi[mt], amid[mt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float* b = rows + boff[nt] + 32 * ks;
+                const float f[8] = {b[0], b[1], b[2], b[3], b[16], b[17], b[18], b[19]};
+                hd_bf16x8 bhi, bmid;
+                hd_cut8(f, bhi, bmid);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amid[mt], bhi, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[mt], bmid, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[mt], bhi, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the row's reads are issued before the next row's stores (one wave: LDS in order)
+    }
+    // the four waves' sums, one after the other into the reduction area; row = channel 16 mt + 4 g + i, column = 16 nt + r16
+#pragma unroll 1
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* cell = red + (16 * mt + 4 * g + i) * 64 + 16 * nt + r16;
+                        *cell = (wv ? *cell : 0.0f) + acc[mt][nt][i];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < Cin * 54; e += kThreads) {
+        const int c = e / 54, j = e - 54 * c, o = j / 27, tap = j - 27 * o;
+        partial[(((size_t)blockIdx.x * 2 + o) * Cin + c) * 27 + tap] = red[c * 64 + j];
+    }
+}
+
 }  // namespace mvsdet
 
 extern "C" int mvsdet_conv3d_k3_cout2_dx_f32(const float* grad_out, const float* weight, float* grad_x, int N, int Cin, int D,
@@ -437,5 +577,40 @@ extern "C" int mvsdet_conv3d_k3_cout2_dw_f32(const float* x, const float* grad_o
     hipLaunchKernelGGL(conv3d_k3_cout2_dw_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, x, grad_out, partial, N, Cin, D,
                        H, W, tiles_w, tiles_h, tiles_d, nsplit);
     MVS_LAUNCH_CHECK("conv3d_k3_cout2_dw");
+    return MVSDET_OK;
+}
+
+// bf16x3 form of the weight gradient (see conv3d_k3_cout2_dw_bf16x3_kernel): Cin in {16, 32, 64}, W % 4 == 0, 16-byte aligned
+// tensors; nsplit = blocks = rows of `partial`.  Within ~1e-5 of the fp32 kernel's sums (three-term split operands).
+extern "C" int mvsdet_conv3d_k3_cout2_dw_bf16x3(const float* x, const float* grad_out, float* partial, size_t partial_bytes,
+                                                int nsplit, int N, int Cin, int D, int H, int W, mvsdet_stream_t stream) {
+    MVS_REQUIRE(x && grad_out && partial, "conv3d_k3_cout2_dw_bf16x3: NULL pointer");
+    MVS_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3d_k3_cout2_dw_bf16x3: bad shape");
+    MVS_REQUIRE(Cin == 16 || Cin == 32 || Cin == 64, "conv3d_k3_cout2_dw_bf16x3: Cin=%d is not 16, 32 or 64", Cin);
+    MVS_REQUIRE(W % 4 == 0 && W <= 4096, "conv3d_k3_cout2_dw_bf16x3: W=%d is no multiple of 4 (or > 4096)", W);
+    MVS_REQUIRE(((uintptr_t)x | (uintptr_t)grad_out) % 16 == 0, "conv3d_k3_cout2_dw_bf16x3: tensors must be 16-byte aligned");
+    MVS_REQUIRE(nsplit > 0 && nsplit <= 65535, "conv3d_k3_cout2_dw_bf16x3: nsplit=%d outside [1,65535]", nsplit);
+    MVS_REQUIRE((long long)N * D * H < INT32_MAX && (long long)D * H * W < INT32_MAX, "conv3d_k3_cout2_dw_bf16x3: volume too large");
+    if (partial_bytes < (size_t)nsplit * 2 * Cin * 27 * sizeof(float)) {
+        set_error("conv3d_k3_cout2_dw_bf16x3: partial buffer %zu B too small", partial_bytes);
+        return MVSDET_ERR_WORKSPACE;
+    }
+    const size_t lds = hdw_lds_bytes(Cin, W);
+    MVS_REQUIRE(lds <= 160 * 1024, "conv3d_k3_cout2_dw_bf16x3: W=%d needs %zu B of LDS", W, lds);
+#define MVS_HDW_LAUNCH(MTV)                                                                                              \
+    {                                                                                                                    \
+        auto* k = conv3d_k3_cout2_dw_bf16x3_kernel<MTV>;                                                                 \
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   160 * 1024) != hipSuccess) {                                          \
+            set_error("conv3d_k3_cout2_dw_bf16x3: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");              \
+            return MVSDET_ERR_HIP;                                                                                       \
+        }                                                                                                                \
+        hipLaunchKernelGGL(k, dim3((unsigned)nsplit), dim3(kThreads), lds, (hipStream_t)stream, x, grad_out, partial, N, D, H, W); \
+    }
+    if (Cin == 64) MVS_HDW_LAUNCH(4)
+    else if (Cin == 32) MVS_HDW_LAUNCH(2)
+    else MVS_HDW_LAUNCH(1)
+#undef MVS_HDW_LAUNCH
+    MVS_LAUNCH_CHECK("conv3d_k3_cout2_dw_bf16x3");
     return MVSDET_OK;
 }

@@ -1273,8 +1273,11 @@ def _(x, grad_out, nsplit=0, stride=1, bf16x3=False):
 
 
 @torch.library.custom_op(f"{_NS}::conv3d_k3_cout2_backward", mutates_args=(), device_types="cuda")
-def conv3d_k3_cout2_backward(x: Tensor, weight: Tensor, grad_out: Tensor, nsplit: int = 32) -> Tuple[Tensor, Tensor]:
-    """Gradients of conv3d_k3_cout2 w.r.t. x (N,Cin,D,H,W) and weight (2,Cin,3,3,3) from grad_out (N,2,D,H,W)."""
+def conv3d_k3_cout2_backward(x: Tensor, weight: Tensor, grad_out: Tensor, nsplit: int = 32,
+                             bf16x3: bool = False) -> Tuple[Tensor, Tensor]:
+    """Gradients of conv3d_k3_cout2 w.r.t. x (N,Cin,D,H,W) and weight (2,Cin,3,3,3) from grad_out (N,2,D,H,W).
+    bf16x3: the weight gradient on the bf16 matrix cores with three-term split operands where its kernel applies
+    (Cin in {16, 32, 64}, W % 4 == 0), three blocks per CU; otherwise (and by default) the fp32 kernel with `nsplit` voxel splits."""
     _req(x, "x", dim=5)
     _req(weight, "weight", dim=5)
     _req(grad_out, "grad_out", dim=5)
@@ -1284,17 +1287,21 @@ def conv3d_k3_cout2_backward(x: Tensor, weight: Tensor, grad_out: Tensor, nsplit
     x, weight, grad_out = x.contiguous(), weight.contiguous(), grad_out.contiguous()
     lib = _lib.load()
     gx = torch.empty_like(x)
+    on_mfma = bool(bf16x3) and Cin in (16, 32, 64) and W % 4 == 0 and x.data_ptr() % 16 == 0 and grad_out.data_ptr() % 16 == 0
+    if on_mfma:
+        nsplit = min(768, N * D * H)   # blocks of four waves, a wave takes whole x rows (n, d, h)
     partial = torch.empty((nsplit, 2, Cin, 27), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(lib.mvsdet_conv3d_k3_cout2_dx_f32(_lib.ptr(grad_out), _lib.ptr(weight), _lib.ptr(gx), N, Cin, D, H, W,
                                                      _stream(x)), "conv3d_k3_cout2_dx")
-        _lib.check(lib.mvsdet_conv3d_k3_cout2_dw_f32(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), partial.numel() * 4,
-                                                     nsplit, N, Cin, D, H, W, _stream(x)), "conv3d_k3_cout2_dw")
+        fn = lib.mvsdet_conv3d_k3_cout2_dw_bf16x3 if on_mfma else lib.mvsdet_conv3d_k3_cout2_dw_f32
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(partial), partial.numel() * 4, nsplit, N, Cin, D, H, W,
+                      _stream(x)), "conv3d_k3_cout2_dw")
     return gx, partial.sum(0).view(2, Cin, 3, 3, 3)
 
 
 @conv3d_k3_cout2_backward.register_fake
-def _(x, weight, grad_out, nsplit=32):
+def _(x, weight, grad_out, nsplit=32, bf16x3=False):
     return torch.empty_like(x), torch.empty_like(weight)
 
 

@@ -1277,6 +1277,31 @@ def test_cost_network_head_backward(gpu, N, Cin, D, H, W):
     torch.testing.assert_close(gw.cpu(), ref_w, rtol=0, atol=3e-6 * float(ref_w.abs().max()) * max(1.0, (N * D * H * W) ** 0.5 / 8))
 
 
+@pytest.mark.parametrize("N,Cin,D,H,W", [
+    (2, 64, 12, 20, 40),   # the shipped head: 64 channels; W = 40: a second k-step with 8 of its 32 voxels
+    (1, 64, 3, 5, 80),     # the reference-true row length (two and a half k-steps)
+    (3, 32, 2, 7, 4),      # two channel tiles, rows shorter than one k-step, more waves than rows in some blocks
+    (1, 16, 1, 1, 36),     # one channel tile, a single row: every neighbouring row is padding
+    (2, 64, 4, 9, 128),    # whole k-steps only
+])
+def test_cost_network_head_weight_gradient_bf16x3(gpu, N, Cin, D, H, W):
+    """The head's weight gradient on the bf16 matrix cores with three-term split operands (csrc/costreg_head.hip:
+    conv3d_k3_cout2_dw_bf16x3_kernel) against ATen-CPU's conv3d_weight in double, and the input gradient it travels with."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 10 + Cin + W)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    wgt = torch.randn(2, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    gy = torch.randn(N, 2, D, H, W, generator=g)
+    ref_w = torch.nn.grad.conv3d_weight(x.double(), wgt.shape, gy.double(), padding=1)
+    gx, gw = ops.conv3d_k3_cout2_backward(x.to(gpu), wgt.to(gpu), gy.to(gpu), 5, True)
+    gx0, gw0 = ops.conv3d_k3_cout2_backward(x.to(gpu), wgt.to(gpu), gy.to(gpu), 5, False)
+    assert torch.equal(gx, gx0)
+    scale = float(ref_w.abs().max())
+    # three-term split products: 2^-16 of |x||gy| per product, summed over N*D*H*W of them
+    assert float((gw.cpu().double() - ref_w).abs().max()) <= 1e-5 * scale * max(1.0, (N * D * H * W) ** 0.5 / 8)
+    assert float((gw - gw0).abs().max()) <= 2e-5 * scale * max(1.0, (N * D * H * W) ** 0.5 / 8)
+
+
 @pytest.mark.parametrize("N,C,D,H,W,relu", [(2, 8, 4, 6, 12, True), (3, 5, 3, 5, 7, True), (1, 64, 2, 4, 8, False), (2, 3, 1, 1, 1, True)])
 def test_batchnorm_relu_training_kernels(gpu, N, C, D, H, W, relu):
     """Training-mode BatchNorm3d [+ ReLU] (csrc/costreg_bn.hip) against ATen-CPU: output, batch statistics, and the gradients
