@@ -285,6 +285,13 @@ int mvsdet_bn3d_relu_train_fwd_f32(const float* x, const float* gamma, const flo
                                    float* running_var, float* out, float* save_mean, float* save_invstd, void* workspace,
                                    size_t workspace_bytes, int N, int C, long long vol, float momentum, float eps, int relu,
                                    mvsdet_stream_t stream);
+/* The same with a residual tensor (N, C, vol; NULL = none) added AFTER the activation: out = [relu](bn(x)) + residual, the
+ * `skip + Sequential(ConvTranspose3d, BatchNorm3d, ReLU)(x)` of mvsnet.py:109-111 without a pass of its own.  The backward is
+ * unchanged (the residual's gradient is grad_out itself). */
+int mvsdet_bn3d_relu_train_fwd_res_f32(const float* x, const float* gamma, const float* beta, const float* residual,
+                                       float* running_mean, float* running_var, float* out, float* save_mean, float* save_invstd,
+                                       void* workspace, size_t workspace_bytes, int N, int C, long long vol, float momentum, float eps,
+                                       int relu, mvsdet_stream_t stream);
 int mvsdet_bn3d_relu_bwd_f32(const float* x, const float* grad_out, const float* gamma, const float* beta,
                              const float* save_mean, const float* save_invstd, float* grad_x, float* grad_gamma,
                              float* grad_beta, void* workspace, size_t workspace_bytes, int N, int C, long long vol, int relu,

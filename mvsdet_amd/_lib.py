@@ -54,6 +54,7 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_mfma_workspace_bytes": [_i, _i, _i, _i, _i, _i, _i],
     "mvsdet_bn3d_workspace_bytes": [_i],
     "mvsdet_bn3d_relu_train_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, ctypes.c_longlong, _f, _f, _i, _vp],
+    "mvsdet_bn3d_relu_train_fwd_res_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, ctypes.c_longlong, _f, _f, _i, _vp],
     "mvsdet_bn3d_relu_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, ctypes.c_longlong, _i, _vp],
     "mvsdet_conv3d_k3_mfma_ws_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_dw_partial_bytes": [_i, _i, _i],

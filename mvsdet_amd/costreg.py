@@ -18,6 +18,7 @@ on the GPU it, not the plane sweep, is what a scene costs.
 from __future__ import annotations
 
 import os
+from typing import Optional
 
 import torch
 from torch import nn
@@ -64,28 +65,37 @@ class _ConvK3S2(torch.autograd.Function):
     `ops.conv3d_k3_dw(stride=2)`.  D, H, W even (the network asks for multiples of 4)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bf16x3=False):
+    def forward(ctx, x, weight, bf16x3=False, split_skip=False):
+        """split_skip: also return x itself as a second output, for the skip connection that reads it (mvsnet.py:109-111).  The
+        input then has this one consumer, both gradients arrive here together, and the skip's is added in the epilogue of the
+        input-gradient kernel instead of by a pass of autograd's own over the full-resolution tensor."""
         from . import ops
         ctx.save_for_backward(x, weight)
         ctx.bf16x3 = bool(bf16x3)
+        ctx.set_materialize_grads(False)
         if ctx.bf16x3:
-            return ops.conv3d_k3_s2_bf16x3(x, ops.split_conv_weight(weight, 1), None, None, False)
-        return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(weight), None, None, False, 2)
+            y = ops.conv3d_k3_s2_bf16x3(x, ops.split_conv_weight(weight, 1), None, None, False)
+        else:
+            y = ops.conv3d_k3_mfma(x, ops.permute_conv_weight(weight), None, None, False, 2)
+        return (y, x.view_as(x)) if split_skip else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         from . import ops
         x, weight = ctx.saved_tensors
-        gy = gy.contiguous()
         gx = gw = None
+        if gy is None:   # only the skip branch reached the loss
+            return gskip, None, None, None
+        gy = gy.contiguous()
         if ctx.needs_input_grad[0]:
+            res = None if gskip is None else gskip.contiguous()
             if ctx.bf16x3 and weight.shape[1] % 64 == 0:   # the (Cout,Cin,3,3,3) tensor read as a ConvTranspose3d weight
-                gx = ops.convT3d_k3_s2_bf16x3(gy, ops.split_conv_weight(weight.detach(), 2), None, None, None, False)
+                gx = ops.convT3d_k3_s2_bf16x3(gy, ops.split_conv_weight(weight.detach(), 2), None, None, res, False)
             else:
-                gx = ops.convT3d_k3_s2_mfma(gy, ops.permute_convT_weight(weight.detach()), None, None, None, False)
+                gx = ops.convT3d_k3_s2_mfma(gy, ops.permute_convT_weight(weight.detach()), None, None, res, False)
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_k3_dw(x, gy, 0, 2, ctx.bf16x3 and x.shape[-1] % 8 == 0)
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 class _ConvT3S2(torch.autograd.Function):
@@ -119,12 +129,12 @@ class _ConvT3S2(torch.autograd.Function):
         return gx, gw, None
 
 
-def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor) -> torch.Tensor:
+def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu(bn(x)) with batch statistics (module.py:26-37; mvsnet.py:92-100) on the streaming kernels of
     csrc/costreg_bn.hip -- two passes over x forward, ReLU in the second, the mask recomputed going backward -- and the
     running statistics updated the way torch.nn.BatchNorm3d does (momentum, unbiased variance, num_batches_tracked)."""
     from . import ops
-    out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True)
+    out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True, residual)   # residual: added after the ReLU
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             m = x.numel() // x.shape[1]
@@ -280,13 +290,17 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         if self._chain_ok(x):
             return self._forward_chain(x)
         full = self._cbr(self.conv0, x)                           # (N, 64, D, H, W)
-        half = self._cbr(self.conv2, self._cbr(self.conv1, full))         # (N, 128, D/2, H/2, W/2)
-        quarter = self._cbr(self.conv4, self._cbr(self.conv3, half))      # (N, 256, D/4, H/4, W/4)
+        # the stride-2 layers hand their input back as the skip tensor (`_ConvK3S2`: its gradient joins the input gradient in
+        # that layer's own kernel)
+        h1, full = self._cbr(self.conv1, full, split_skip=True)
+        half = self._cbr(self.conv2, h1)                          # (N, 128, D/2, H/2, W/2)
+        q1, half = self._cbr(self.conv3, half, split_skip=True)
+        quarter = self._cbr(self.conv4, q1)                       # (N, 256, D/4, H/4, W/4)
         half = self._up(self.conv9, quarter, half)        # half + relu(bn(deconv(quarter)))
         full = self._up(self.conv11, half, full)
         return self._head(full)                       # (N, 2, D, H, W)
 
-    def _cbr(self, layer, x):
+    def _cbr(self, layer, x, split_skip: bool = False):
         """A ConvBnReLU3D layer (mvsnet.py:76-82: conv0..conv4, stride 1 or 2).  Without autograd and in eval mode
         (BatchNorm = per-channel affine) the fp32-MFMA kernel of csrc/costreg_conv0.hip runs conv + BN + ReLU in one
         pass -- conv0 at the reference-true shape: 15.7 ms (130 TFLOP/s) instead of 33.6 + 0.5 ms for MIOpen, the same
@@ -300,17 +314,26 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
                 # the bf16 matrix cores with three-term split operands (csrc/costreg_bf16.hip): conv0 4.8 ms instead of 15.2
                 # on the fp32 MFMA; the stride-2 layers as sums over the 8 parity classes of their input
                 if conv.stride == (1, 1, 1):
-                    return ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(conv.weight), scale, shift, True)
-                return ops.conv3d_k3_s2_bf16x3(x, ops.split_conv_weight(conv.weight, 1), scale, shift, True)
+                    y = ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(conv.weight), scale, shift, True)
+                else:
+                    y = ops.conv3d_k3_s2_bf16x3(x, ops.split_conv_weight(conv.weight, 1), scale, shift, True)
+                return (y, x) if split_skip else y
             wperm = ops.permute_conv_weight(conv.weight)   # a few MB at most, negligible next to the convolution
-            return ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
+            y = ops.conv3d_k3_mfma(x, wperm, scale, shift, True, conv.stride[0])
+            return (y, x) if split_skip else y
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
             # autograd: convolution forward / backward on our kernels; BatchNorm + ReLU too when it uses batch statistics
-            fn = _ConvK3S1 if conv.stride == (1, 1, 1) else _ConvK3S2
-            y = fn.apply(x, conv.weight, self.matrix_precision == "bf16x3")
-            return _bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y))
-        return layer(x)
+            skip = x
+            if conv.stride == (1, 1, 1):
+                y = _ConvK3S1.apply(x, conv.weight, self.matrix_precision == "bf16x3")
+            elif split_skip:
+                y, skip = _ConvK3S2.apply(x, conv.weight, self.matrix_precision == "bf16x3", True)
+            else:
+                y = _ConvK3S2.apply(x, conv.weight, self.matrix_precision == "bf16x3")
+            y = _bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y))
+            return (y, skip) if split_skip else y
+        return (layer(x), x) if split_skip else layer(x)
 
     def _up(self, seq, x, skip):
         """mvsnet.py:110-111: skip + Sequential(ConvTranspose3d, BatchNorm3d, ReLU)(x); one fp32-MFMA kernel per output
@@ -334,7 +357,9 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and deconv.out_channels % 64 == 0 and deconv.in_channels % 64 == 0):
             y = _ConvT3S2.apply(x, deconv.weight, self.matrix_precision == "bf16x3")
-            return skip + (_bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y)))
+            if _bn_hip_ok(bn, y):
+                return _bn_relu_train(bn, y, skip)   # the skip addition in the BatchNorm's second pass
+            return skip + torch.relu_(bn(y))
         return skip + seq(x)
 
     def _head(self, full):

@@ -98,11 +98,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, size_t vol, cons
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(M > 1.0 ? var * M / (M - 1.0) : var);
 }
 
-// y = [relu](x * scale_c + shift_c); grid (chunks of a (view, channel) volume, C, N)
+// y = [relu](x * scale_c + shift_c) [+ residual]; grid (chunks of a (view, channel) volume, C, N)
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, float* __restrict__ y, int C, size_t vol,
-                                                           int relu) {
+                                                           const float* __restrict__ shift, const float* __restrict__ residual,
+                                                           float* __restrict__ y, int C, size_t vol, int relu) {
     const int c = blockIdx.y, n = blockIdx.z;
     const float sc = scale[c], sh = shift[c];
     const size_t base = ((size_t)n * C + c) * vol;
@@ -112,10 +112,15 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
             float4 v = *reinterpret_cast<const float4*>(x + base + 4 * i);
             v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (residual) {   // the skip tensor of mvsnet.py:109-111, added after the activation as `skip + relu(bn(.))` does
+                const float4 r = *reinterpret_cast<const float4*>(residual + base + 4 * i);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
             *reinterpret_cast<float4*>(y + base + 4 * i) = v;
         } else {
             float v = fmaf(x[base + i], sc, sh);
-            y[base + i] = relu ? fmaxf(v, 0.f) : v;
+            v = relu ? fmaxf(v, 0.f) : v;
+            y[base + i] = residual ? v + residual[base + i] : v;
         }
     }
 }
@@ -227,15 +232,15 @@ int bn_check(const char* name, int N, int C, long long vol, const void* workspac
 }
 }  // namespace
 
-extern "C" int mvsdet_bn3d_relu_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
-                                              float* running_var, float* out, float* save_mean, float* save_invstd,
-                                              void* workspace, size_t workspace_bytes, int N, int C, long long vol, float momentum,
-                                              float eps, int relu, mvsdet_stream_t stream_) {
+extern "C" int mvsdet_bn3d_relu_train_fwd_res_f32(const float* x, const float* gamma, const float* beta, const float* residual,
+                                                  float* running_mean, float* running_var, float* out, float* save_mean,
+                                                  float* save_invstd, void* workspace, size_t workspace_bytes, int N, int C,
+                                                  long long vol, float momentum, float eps, int relu, mvsdet_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     MVS_REQUIRE(x && out && save_mean && save_invstd, "bn3d_relu_train_fwd: NULL pointer");
     if (int rc = bn_check("bn3d_relu_train_fwd", N, C, vol, workspace, workspace_bytes)) return rc;
     const BnWs w = bn_ws(workspace, C);
-    const bool vec = (vol % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) & 15u) == 0;
+    const bool vec = (vol % 4 == 0) && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual) & 15u) == 0;
     dim3 rgrid((unsigned)C, kBnSplit);
     if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, rgrid, dim3(kThreads), 0, stream, x, w.partial, N, C, (size_t)vol);
     else hipLaunchKernelGGL(bn_stats_kernel<false>, rgrid, dim3(kThreads), 0, stream, x, w.partial, N, C, (size_t)vol);
@@ -243,10 +248,18 @@ extern "C" int mvsdet_bn3d_relu_train_fwd_f32(const float* x, const float* gamma
                        running_var, save_mean, save_invstd, w.scale, w.shift, C, (double)N * (double)vol, momentum, eps);
     const size_t cnt = (size_t)vol / (vec ? 4 : 1);
     dim3 agrid((unsigned)std::min<size_t>((cnt + kThreads - 1) / kThreads, 64), (unsigned)C, (unsigned)N);
-    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, out, C, (size_t)vol, relu);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, out, C, (size_t)vol, relu);
+    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, residual, out, C, (size_t)vol, relu);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, residual, out, C, (size_t)vol, relu);
     MVS_LAUNCH_CHECK("bn3d_relu_train_fwd");
     return MVSDET_OK;
+}
+
+extern "C" int mvsdet_bn3d_relu_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                              float* running_var, float* out, float* save_mean, float* save_invstd,
+                                              void* workspace, size_t workspace_bytes, int N, int C, long long vol, float momentum,
+                                              float eps, int relu, mvsdet_stream_t stream) {
+    return mvsdet_bn3d_relu_train_fwd_res_f32(x, gamma, beta, nullptr, running_mean, running_var, out, save_mean, save_invstd, workspace,
+                                              workspace_bytes, N, C, vol, momentum, eps, relu, stream);
 }
 
 extern "C" int mvsdet_bn3d_relu_bwd_f32(const float* x, const float* grad_out, const float* gamma, const float* beta,

@@ -1307,11 +1307,17 @@ def _(x, weight, grad_out, nsplit=32, bf16x3=False):
 
 @torch.library.custom_op(f"{_NS}::bn3d_relu_train", mutates_args=(), device_types="cuda")
 def bn3d_relu_train(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float,
-                    relu: bool) -> Tuple[Tensor, Tensor, Tensor]:
+                    relu: bool, residual: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """Training-mode BatchNorm3d [+ ReLU] (mvs_models/module.py:26-37) on the batch statistics of x (N,C,D,H,W) fp32 ->
     (out, batch mean, 1/sqrt(biased batch variance + eps)).  The running statistics are the caller's to update (a custom
-    operator with an autograd formula must not mutate its inputs): mvsdet_amd.costreg does it from the returned vectors."""
+    operator with an autograd formula must not mutate its inputs): mvsdet_amd.costreg does it from the returned vectors.
+    residual (same shape as x): out = [relu](bn(x)) + residual in the same pass (mvsnet.py:109-111, the skip additions)."""
     _req(x, "x", dim=5)
+    if residual is not None:
+        _req(residual, "residual", dim=5)
+        if residual.shape != x.shape:
+            raise ValueError(f"bn3d_relu_train: residual {tuple(residual.shape)} != x {tuple(x.shape)}")
+        residual = residual.contiguous()
     N, C = x.shape[:2]
     vol = x[0, 0].numel()
     for t, name in ((weight, "weight"), (bias, "bias")):
@@ -1329,14 +1335,14 @@ def bn3d_relu_train(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor],
     wb = lib.mvsdet_bn3d_workspace_bytes(C)
     ws = torch.empty(wb // 8, dtype=torch.float64, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.mvsdet_bn3d_relu_train_fwd_f32(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), None, None, _lib.ptr(out),
-                                                      _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(ws), wb, N, C, vol, 0.0,
-                                                      float(eps), int(relu), _stream(x)), "bn3d_relu_train")
+        _lib.check(lib.mvsdet_bn3d_relu_train_fwd_res_f32(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(residual), None, None,
+                                                          _lib.ptr(out), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(ws), wb, N, C, vol,
+                                                          0.0, float(eps), int(relu), _stream(x)), "bn3d_relu_train")
     return out, mean, invstd
 
 
 @bn3d_relu_train.register_fake
-def _(x, weight, bias, eps, relu):
+def _(x, weight, bias, eps, relu, residual=None):
     return torch.empty_like(x), x.new_empty(x.shape[1]), x.new_empty(x.shape[1])
 
 
@@ -1372,15 +1378,17 @@ def _(x, grad_out, weight, bias, save_mean, save_invstd, relu):
 
 
 def _bn_setup(ctx, inputs, output):
-    x, weight, bias, _, relu = inputs
+    x, weight, bias, _, relu, residual = inputs
     ctx.save_for_backward(x, weight, bias, output[1], output[2])
     ctx.relu = relu
+    ctx.has_residual = residual is not None
 
 
 def _bn_bwd(ctx, g_out, g_mean, g_invstd):
     x, weight, bias, mean, invstd = ctx.saved_tensors
     gx, gw, gb = bn3d_relu_backward(x, g_out.contiguous(), weight, bias, mean, invstd, ctx.relu)
-    return gx, (gw if weight is not None else None), (gb if bias is not None else None), None, None
+    # the residual is added after the activation: its gradient is grad_out itself
+    return gx, (gw if weight is not None else None), (gb if bias is not None else None), None, None, (g_out if ctx.has_residual else None)
 
 
 bn3d_relu_train.register_autograd(_bn_bwd, setup_context=_bn_setup)

@@ -1277,6 +1277,25 @@ def test_cost_network_head_backward(gpu, N, Cin, D, H, W):
     torch.testing.assert_close(gw.cpu(), ref_w, rtol=0, atol=3e-6 * float(ref_w.abs().max()) * max(1.0, (N * D * H * W) ** 0.5 / 8))
 
 
+@pytest.mark.parametrize("N,C,D,H,W", [(2, 8, 4, 6, 12), (3, 5, 3, 5, 7)])
+def test_batchnorm_relu_with_residual(gpu, N, C, D, H, W):
+    """`skip + relu(bn(x))` (mvsnet.py:109-111) in the BatchNorm's second pass: the output is the two-pass result plus the skip
+    tensor bit for bit, the skip's gradient is grad_out, the others are those of the call without a residual."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(C * 7 + N)
+    x, skip, gy = (torch.randn(N, C, D, H, W, generator=g).to(gpu) for _ in range(3))
+    wgt, b = (torch.rand(C, generator=g) + 0.5).to(gpu), torch.randn(C, generator=g).to(gpu)
+    leaves = lambda: [t.clone().requires_grad_(True) for t in (x, wgt, b, skip)]   # noqa: E731
+    x1, w1, b1, s1 = leaves()
+    out1, mean1, inv1 = ops.bn3d_relu_train(x1, w1, b1, 1e-5, True, s1)
+    out1.backward(gy)
+    x0, w0, b0, s0 = leaves()
+    out0, mean0, inv0 = ops.bn3d_relu_train(x0, w0, b0, 1e-5, True)
+    (out0 + s0).backward(gy)
+    assert torch.equal(out1, out0 + s0) and torch.equal(mean1, mean0) and torch.equal(inv1, inv0)
+    assert torch.equal(s1.grad, gy) and torch.equal(x1.grad, x0.grad) and torch.equal(w1.grad, w0.grad) and torch.equal(b1.grad, b0.grad)
+
+
 @pytest.mark.parametrize("N,Cin,D,H,W", [
     (2, 64, 12, 20, 40),   # the shipped head: 64 channels; W = 40: a second k-step with 8 of its 32 voxels
     (1, 64, 3, 5, 80),     # the reference-true row length (two and a half k-steps)
