@@ -35,7 +35,7 @@ class _ConvModule(nn.Module):
         return F.relu(x, inplace=True) if self.with_act else x
 
 
-_DERIVED = ("_mvs_affine", "_fused", "_mvs_wsplit")   # tensors computed from parameters and kept on a module
+_DERIVED = ("_mvs_affine", "_fused", "_mvs_wsplit", "_mvs_wmat")   # tensors computed from parameters and kept on a module
 
 
 def drop_derived_tensors(root: nn.Module) -> None:
@@ -109,6 +109,28 @@ def _split_weight(conv: nn.Module, order: int | None = None) -> Tensor:
     return cached[1]
 
 
+def _gemm_weight(conv: nn.Module, bn: nn.BatchNorm3d):
+    """The 1x1x1 convolution (Cout x Cin) or the ConvTranspose3d(k=2, s=2) (8*Cout x Cin, rows ordered (p, q, r, o)) as ONE matrix
+    with the eval-mode BatchNorm's scale folded in, and the matching bias column; kept on the module like the split weights
+    (three tiny kernels per layer and call otherwise)."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device) + tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    cached = conv.__dict__.get("_mvs_wmat")
+    if cached is None or cached[0] != key:
+        scale, shift = _bn_affine(bn)
+        with torch.no_grad():
+            if isinstance(conv, nn.ConvTranspose3d):
+                cout = conv.out_channels
+                wmat = (w.detach() * scale.view(1, -1, 1, 1, 1)).permute(2, 3, 4, 1, 0).reshape(8 * cout, w.shape[0]).contiguous()
+                bias = shift.repeat(8).view(1, -1, 1).contiguous()
+            else:
+                wmat = (w.detach().reshape(conv.out_channels, -1) * scale[:, None]).contiguous()
+                bias = shift.view(1, -1, 1).contiguous()
+        cached = (key, wmat, bias)
+        conv.__dict__["_mvs_wmat"] = cached
+    return cached[1], cached[2]
+
+
 def _conv_k3(x: Tensor, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool, residual: Tensor | None = None) -> Tensor:
     """Conv3d(k=3, p=1, stride 1|2) + BN(eval) [+ residual] [+ ReLU] in one MFMA kernel."""
     from . import ops
@@ -138,9 +160,8 @@ class ResModule(nn.Module):
                 ds = self.downsample
                 xs = x[:, :, ::self.stride, ::self.stride, ::self.stride]
                 n, c, d, h, w = xs.shape
-                scale, shift = _bn_affine(ds.bn)
-                wmat = ds.conv.weight.detach().reshape(ds.conv.out_channels, c) * scale[:, None]
-                identity = torch.baddbmm(shift.view(1, -1, 1), wmat.unsqueeze(0).expand(n, -1, -1), xs.reshape(n, c, -1))
+                wmat, bias = _gemm_weight(ds.conv, ds.bn)
+                identity = torch.baddbmm(bias, wmat.unsqueeze(0).expand(n, -1, -1), xs.reshape(n, c, -1))
                 identity = identity.view(n, -1, d, h, w)
             h0 = _conv_k3(x, self.conv0.conv, self.conv0.bn, True)
             return _conv_k3(h0, self.conv1.conv, self.conv1.bn, True, identity)   # relu(bn(conv1) + identity)
@@ -163,13 +184,13 @@ class _UpBlock(nn.Sequential):
             deconv, bn = self[0], self[1]
             n, cin, d, h, w = x.shape
             cout = deconv.out_channels
-            scale, shift = _bn_affine(bn)
-            # out[:, o, 2i+p, 2j+q, 2k+r] = sum_c x[:, c, i, j, k] * W[c, o, p, q, r]: one (8*Cout x Cin) GEMM
-            wmat = (deconv.weight.detach() * scale.view(1, -1, 1, 1, 1)).permute(2, 3, 4, 1, 0).reshape(8 * cout, cin)
-            y = torch.matmul(wmat.unsqueeze(0), x.reshape(n, cin, -1)).view(n, 2, 2, 2, cout, d, h, w)
-            y = y.permute(0, 4, 5, 1, 6, 2, 7, 3).reshape(n, cout, 2 * d, 2 * h, 2 * w)
-            y = F.relu_(y + shift.view(1, -1, 1, 1, 1))
-            return _conv_k3(y, self[3], self[4], True)
+            # out[:, o, 2i+p, 2j+q, 2k+r] = sum_c x[:, c, i, j, k] * W[c, o, p, q, r]: one (8*Cout x Cin) GEMM with the BatchNorm's
+            # shift as its bias; the ReLU writes the interleaved (N, Cout, 2D, 2H, 2W) tensor directly (one pass, no copy)
+            wmat, bias = _gemm_weight(deconv, bn)
+            y = torch.baddbmm(bias, wmat.unsqueeze(0).expand(n, -1, -1), x.reshape(n, cin, -1)).view(n, 2, 2, 2, cout, d, h, w)
+            out = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+            torch.clamp_min(y.permute(0, 4, 5, 1, 6, 2, 7, 3), 0.0, out=out.view(n, cout, d, 2, h, 2, w, 2))
+            return _conv_k3(out, self[3], self[4], True)
         return super().forward(x)
 
 
