@@ -159,9 +159,13 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
 
     const unsigned* fl_bt = flags + (size_t)bt * D;
     const float* depth_n = depth + (size_t)n * D;
+    // flags and depth of a plane are requested a plane ahead (scalars: two SGPRs), as in the forward kernel
+    unsigned fl_next = K > 0 ? fl_bt[0] : 0u;
+    float dv_next = K > 0 ? depth_n[0] : 0.0f;
     for (int d = 0; d < D; ++d) {
-        const unsigned fl = K > 0 ? fl_bt[d] : 0u;
-        const float dval = K > 0 ? depth_n[d] : 0.0f;
+        const unsigned fl = __builtin_amdgcn_readfirstlane(fl_next);
+        const float dval = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dv_next)));
+        if (K > 0 && d + 1 < D) { fl_next = fl_bt[d + 1]; dv_next = depth_n[d + 1]; }
         bool refill = false;
 #pragma unroll
         for (int j = 0; j < K; ++j)
