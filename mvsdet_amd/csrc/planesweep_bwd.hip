@@ -159,6 +159,27 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
 
     const unsigned* fl_bt = flags + (size_t)bt * D;
     const float* depth_n = depth + (size_t)n * D;
+    // dL/dvar of one plane, the lane's 4 pixels of its 2 channels
+    float4 gnext[2];
+    auto load_go = [&](int d) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_ok[i]) {
+                const float* src = gvar + g_off[i] + (size_t)d * HW;
+                if (st_vec) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (st_n > 1) v.y = src[1];
+                    if (st_n > 2) v.z = src[2];
+                    if (st_n > 3) v.w = src[3];
+                }
+            }
+            gnext[i] = v;
+        }
+    };
+    if constexpr (GROUPS == 1) load_go(0);   // the first plane
     // flags and depth of a plane are requested a plane ahead (scalars: two SGPRs), as in the forward kernel
     unsigned fl_next = K > 0 ? fl_bt[0] : 0u;
     float dv_next = K > 0 ? depth_n[0] : 0.0f;
@@ -189,24 +210,16 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
             __syncthreads();  // slots zeroed again before anyone adds into them
         }
         if (GROUPS > 1 && d % GROUPS != plane_group) continue;   // the refills above are everybody's, the plane is one group's
-        // ---- dL/dvar of the lane's pixels and channels: 8 channel rows x 128 contiguous bytes per wave-instruction
+        // ---- dL/dvar of the lane's pixels and channels (8 channel rows x 128 contiguous bytes per wave-instruction): this
+        //      plane's was requested while the group's previous plane was computed; the next one's is requested now
+        //      (one group: 160 VGPRs, still three blocks per CU, 2.75 -> 2.64 ms at 12 planes; two groups have 128 and spill
+        //      with it: they request their plane here)
         float go[4][2];
+        if constexpr (GROUPS > 1) load_go(d);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g_ok[i]) {
-                const float* src = gvar + g_off[i] + (size_t)d * HW;
-                if (st_vec) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    v.x = src[0];
-                    if (st_n > 1) v.y = src[1];
-                    if (st_n > 2) v.z = src[2];
-                    if (st_n > 3) v.w = src[3];
-                }
-            }
-            go[0][i] = v.x; go[1][i] = v.y; go[2][i] = v.z; go[3][i] = v.w;
-        }
+        for (int i = 0; i < 2; ++i) { go[0][i] = gnext[i].x; go[1][i] = gnext[i].y; go[2][i] = gnext[i].z; go[3][i] = gnext[i].w; }
+        if constexpr (GROUPS == 1)
+            if (d + 1 < D) load_go(d + 1);
         // ---- pass 1 over the neighbours: warped values (taps gathered from the slab images), S.  The lane keeps what it
         //      decoded (tap offsets in the gradient slot / gradient image, weights) for pass 2, which fetches it again
         //      by DPP instead of holding the broadcast copies of every neighbour.
