@@ -6,7 +6,7 @@ output channels), the three layer kinds (stride 1 on the SCL form, on the fp32 t
 transposed), with and without affine / ReLU / residual -- each against a float64 evaluation of the SAME three products
 (x_hi*w_hi + x_hi*w_mid + x_mid*w_hi): what remains is fp32 accumulation order, bounded by 4e-7 of the summed products.
 Every fourth case is a WEIGHT GRADIENT (stride 1: csrc/costreg_dw_bf16.hip, W a multiple of 4; half of them stride 2 / transposed:
-csrc/costreg_dw_s2_bf16.hip, even D and H, W a multiple of 8), any channel counts, any number of splits; and every eighth forward case has 256-1024 input channels on a small volume, so that the kernels split
+csrc/costreg_dw_s2_bf16.hip, even D and H, W a multiple of 8; one in four of the stride-1 ones the 64 -> 2 head's), any channel counts, any number of splits; and every eighth forward case has 256-1024 input channels on a small volume, so that the kernels split
 the input channels over blocks (partial sums + epilogue kernel)."""
 import os
 import sys
@@ -42,9 +42,12 @@ def main():
             N, Cin = 1, int(rng.choice([256, 384, 512, 1024]))
             D, H, W = int(rng.integers(1, 5)), int(rng.integers(1, 13)), int(rng.integers(1, 17))
         dw_stride = 1
+        head = kind == "dw" and seed % 16 == 3
         if kind == "dw":
             W = 4 * int(rng.integers(1, 12))
             Cout = int(rng.choice([1, 2, 31, 32, 33, 64, 70]))
+            if head:
+                Cin, Cout, W = int(rng.choice([16, 32, 64])), 2, 4 * int(rng.integers(1, 30))
             if seed % 8 >= 4:   # the stride-2 / transposed weight gradient (csrc/costreg_dw_s2_bf16.hip): even D, H, W a multiple of 8
                 dw_stride, D, H, W = 2, 2 * int(rng.integers(1, 6)), 2 * int(rng.integers(1, 15)), 8 * int(rng.integers(1, 7))
                 Cout = int(rng.choice([1, 3, 63, 64, 65, 128, 130]))
@@ -63,12 +66,16 @@ def main():
             ref = cw(xh, yh) + cw(xh, ym) + cw(xm, yh)
             mag = float(cw(x.abs().double(), gy.abs().double()).max())
             nsplit = int(rng.choice([0, 1, 2, 5, 8, 16, 40]))
-            got = ops.conv3d_k3_dw(x.to(dev), gy.to(dev), nsplit, st, True)
+            if head:   # the 64 -> 2 head's weight gradient (csrc/costreg_head.hip: conv3d_k3_cout2_dw_bf16x3_kernel)
+                wz = torch.zeros(2, Cin, 3, 3, 3, device=dev)
+                got = ops.conv3d_k3_cout2_backward(x.to(dev), wz, gy.to(dev), 5, True)[1]
+            else:
+                got = ops.conv3d_k3_dw(x.to(dev), gy.to(dev), nsplit, st, True)
             err = float((got.cpu().double() - ref).abs().max())
             tol = 4e-7 * mag + 1e-30
             if not (got.shape == ref.shape and err <= tol):
                 bad += 1
-                print(f"seed {seed} dw stride {st} N={N} Cin={Cin} Cout={Cout} {D}x{H}x{W} nsplit={nsplit}: err {err:.3e} tol {tol:.3e}", flush=True)
+                print(f"seed {seed} {'head ' if head else ''}dw stride {st} N={N} Cin={Cin} Cout={Cout} {D}x{H}x{W} nsplit={nsplit}: err {err:.3e} tol {tol:.3e}", flush=True)
             continue
         if kind == "s1":
             w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
