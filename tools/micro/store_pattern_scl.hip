@@ -25,12 +25,14 @@ __global__ __launch_bounds__(256) void k(void* out, int tiles_x, int tiles) {
     const v4f vv = {1.0f * id, 2.0f, 3.0f, (float)lane};
     const v4u uu = {(unsigned)id, (unsigned)lane, 3u, 4u};
     for (int d = d0; d < d1; ++d) {
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 6) {
             float* var = (float*)out;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = slab * 32 + 8 * i + g;
-                __builtin_nontemporal_store(vv, reinterpret_cast<v4f*>(var + (((size_t)n * C + c) * D + d) * (H * W) + (size_t)py * W + px0));
+                v4f* dst = reinterpret_cast<v4f*>(var + (((size_t)n * C + c) * D + d) * (H * W) + (size_t)py * W + px0);
+                if (MODE == 6) *dst = vv;   // plain stores: may the L2 merge the two tiles' halves of a 128-byte line?
+                else __builtin_nontemporal_store(vv, dst);
             }
         } else {
             v4u* scl = (v4u*)out;
@@ -89,6 +91,7 @@ int main() {
     hipMemset(buf, 0, bytes);
     for (int r = 0; r < 2; ++r) {
         run<0>("fp32 NCDHW (64-byte runs)", buf);
+        run<6>("fp32 NCDHW, plain stores", buf);
         run<1>("SCL, an instruction = every second pixel pair", buf);
         run<2>("SCL, a lane's two pixels adjacent", buf);
         run<3>("SCL, adjacent pixels, plain stores", buf);
