@@ -1559,13 +1559,16 @@ void launch_splitk_epilogue(const float* partial, int nsplit, size_t total, cons
                             const float* residual, float* out, int Cout, size_t vol, int relu, hipStream_t st);   // costreg_conv0.hip
 }
 
-// splits of the channel groups for a grid of `blocks` blocks (one 8-12 wave block per CU): up to ~2 rounds of the chip, at
+// splits of the channel groups for a grid of `blocks` blocks (one 8-12 wave block per CU): up to ~3 rounds of the chip, at
 // least 4 channel groups (12 weight sub-stages) per split
 static int bf_nsplit(long long blocks, int C8) {
     const int forced = options().conv_nsplit;   // tuning knob: the size query and the launch both come through here
     if (forced > 0) return (int)std::max(1, std::min(forced, C8 / 4));
     if (blocks >= 192) return 1;
-    return (int)std::max(1LL, std::min<long long>((512 + blocks - 1) / blocks, C8 / 4));
+    // three rounds of the chip (option "conv_split_blocks", default 768): the 3-D neck of one scene 2.54 -> 2.32 ms against two
+    // rounds (512); four (1024) 2.43 -- shorter chains of stages per block against more partial sums to write and add
+    const int target = std::max(1, options().conv_split_blocks);
+    return (int)std::max(1LL, std::min<long long>((target + blocks - 1) / blocks, C8 / 4));
 }
 
 extern "C" size_t mvsdet_conv3d_k3_bf16x3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
