@@ -35,6 +35,7 @@ struct Options {
                        // their halo voxels in one L2); 0 = blocks round-robin over the XCDs
     int conv_split_blocks; // bf16x3 convolutions on small grids: the input channels are split until about this many blocks run (768 =
                        // three rounds of 256 CUs)
+    int conv_split_min_groups; // ... and a split keeps at least this many groups of 8 input channels (default 2: neck + head 2.39 -> 2.35 ms against 4)
     int bwd_groups;    // backward sweep: wave groups of a block that share its gradient images and split its planes; 0 = by the plane
                        // count (2 from 32 planes), 1 / 2 force
     int conv_mfma16;   // 1 (default): the bf16x3 stride-1 convolution on v_mfma_f32_16x16x32_bf16 (conv0 of the cost network 5.37 -> 4.91 ms:

@@ -1560,7 +1560,7 @@ void launch_splitk_epilogue(const float* partial, int nsplit, size_t total, cons
 }
 
 // splits of the channel groups for a grid of `blocks` blocks (one 8-12 wave block per CU): up to ~3 rounds of the chip, at
-// least 4 channel groups (12 weight sub-stages) per split
+// least 2 channel groups per split (options "conv_split_blocks", "conv_split_min_groups")
 static int bf_nsplit(long long blocks, int C8) {
     const int forced = options().conv_nsplit;   // tuning knob: the size query and the launch both come through here
     if (forced > 0) return (int)std::max(1, std::min(forced, C8 / 4));
@@ -1568,7 +1568,8 @@ static int bf_nsplit(long long blocks, int C8) {
     // three rounds of the chip (option "conv_split_blocks", default 768): the 3-D neck of one scene 2.54 -> 2.32 ms against two
     // rounds (512); four (1024) 2.43 -- shorter chains of stages per block against more partial sums to write and add
     const int target = std::max(1, options().conv_split_blocks);
-    return (int)std::max(1LL, std::min<long long>((target + blocks - 1) / blocks, C8 / 4));
+    const int ming = std::max(1, options().conv_split_min_groups);
+    return (int)std::max(1LL, std::min<long long>((target + blocks - 1) / blocks, C8 / ming));
 }
 
 extern "C" size_t mvsdet_conv3d_k3_bf16x3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
