@@ -150,6 +150,9 @@ def _bn_hip_ok(bn: nn.BatchNorm3d, x: torch.Tensor) -> bool:
     return bn.training and x.is_cuda and x.dtype == torch.float32 and bn.affine
 
 
+_SIDE_STREAMS: dict = {}   # device -> the stream the second half of the views runs on (CostRegNet3DGS.view_streams)
+
+
 class _HeadConv(torch.autograd.Function):
     """The head Conv3d(64 -> 2, k=3, p=1, bias) with forward and both gradients on the streaming kernels of
     csrc/costreg_head.hip (MIOpen: 363 ms for one forward + backward at the reference-true shape; here about 2 ms)."""
@@ -213,6 +216,11 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # between the layers (round 3).  Same values bit for bit.
         self.skip_in_head = False   # True: conv0 + conv11(x) formed by the head while it stages its input (round 4's first form)
         self.layer_forms = "scl"
+        # The eval chain on TWO halves of the views, the second on a stream of its own (views are independent: BatchNorm is an
+        # affine): several of its kernels have grids of 3.1 rounds of the chip (800 blocks on 256 CUs at 40 views), and the tail of
+        # one half's kernel fills with the other half's blocks -- 7.6 -> 7.35 ms, the same bits (three pieces 7.6, four 7.8:
+        # tools/study/two_stream_network.py).  1 = one batch on the caller's stream.
+        self.view_streams = int(os.environ.get("MVSDET_COSTREG_STREAMS", "2"))
         # (layer, kind, shape, device, stream) -> the SCL / PSCL buffer a layer writes; its zero border is written once.
         # Keyed by the stream as well: the buffers are refilled in place, outside the allocator's per-stream reuse tracking
         self._scl = {}
@@ -232,7 +240,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         key = (name, kind, tuple(shape), dev, torch.cuda.current_stream(dev).cuda_stream)
         buf = self._scl.pop(key, None)
         if buf is None:
-            while len(self._scl) >= 32:   # varying view counts: least recently used first
+            while len(self._scl) >= 64:   # varying view counts, two streams: least recently used first
                 self._scl.pop(next(iter(self._scl)))
             buf = (ops.scl_empty if kind == "scl" else ops.pscl_empty)(shape, dev)
         self._scl[key] = buf
@@ -288,7 +296,22 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         if any(s % 4 for s in x.shape[2:]):
             raise ValueError(f"CostRegNet3DGS: D, H, W must be divisible by 4, got {tuple(x.shape[2:])}")
         if self._chain_ok(x):
-            return self._forward_chain(x)
+            n = x.shape[0]
+            if self.view_streams < 2 or n < 8:
+                return self._forward_chain(x)
+            dev = x.device
+            cur = torch.cuda.current_stream(dev)
+            side = _SIDE_STREAMS.get(str(dev))   # module-level: a stream does not pickle with a model
+            if side is None:
+                side = _SIDE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+            cut = (n + 1) // 2
+            side.wait_stream(cur)          # x is ready; the caller keeps it alive until this call returns
+            with torch.cuda.stream(side):
+                second = self._forward_chain(x[cut:])
+            first = self._forward_chain(x[:cut])
+            cur.wait_stream(side)
+            second.record_stream(cur)      # allocated under the side stream, read by the concatenation on this one
+            return torch.cat((first, second), 0)
         full = self._cbr(self.conv0, x)                           # (N, 64, D, H, W)
         # the stride-2 layers hand their input back as the skip tensor (`_ConvK3S2`: its gradient joins the input gradient in
         # that layer's own kernel)

@@ -406,7 +406,19 @@ class MVSDetHotPath:
             packed = ops.pack_features(feature.detach())
             variance = self.cost_volume(feature, geo, packed)
         if self.cost_regularization is not None:
-            cost_logits = self.cost_regularization(variance)
+            net = self.cost_regularization
+            halves = getattr(net, "view_streams", 1)
+            if self.overlap_detector and halves > 1 and not torch.is_grad_enabled():
+                # the previous scene's neck and head are running beside this network on their own stream: a second stream
+                # INSIDE the network (CostRegNet3DGS.view_streams: 89.5 -> 90.4 scenes/s alone) then takes from them what it
+                # gives (pipelined 97 against 99-103 scenes/s on one box)
+                net.view_streams = 1
+                try:
+                    cost_logits = net(variance)
+                finally:
+                    net.view_streams = halves
+            else:
+                cost_logits = net(variance)
         elif cost_logits is None:
             raise ValueError("forward_scene needs `cost_logits` when no cost_regularization module is set")
 
