@@ -224,6 +224,29 @@ def test_head_on_the_sum_of_two_inputs(gpu, N, Cin, D, H, W):
     np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), rtol=0, atol=1e-5 * max(1.0, float(ref.abs().max())))
 
 
+def test_cost_network_on_two_halves_of_the_views_agrees_bit_for_bit(gpu):
+    """`CostRegNet3DGS.view_streams = 2` (eval chain, 8 views or more): the second half of the views on a stream of its own -- the
+    same logits as one batch on the caller's stream, for an even and an odd number of views, back to back without a
+    synchronisation in between (the halves' buffers are keyed by the stream)."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    torch.manual_seed(5)
+    net = CostRegNet3DGS(64).to(gpu).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    assert net.view_streams == 2
+    xs = [torch.rand(shape, device=gpu) for shape in ((8, 64, 4, 12, 16), (11, 64, 8, 8, 24), (8, 64, 4, 12, 16))]
+    with torch.no_grad():
+        two = [net(x) for x in xs]
+        net.view_streams = 1
+        one = [net(x) for x in xs]
+        net.view_streams = 2
+    torch.cuda.synchronize(gpu)
+    for a, b in zip(one, two):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
 def test_cost_network_layer_forms_agree_bit_for_bit(gpu):
     """CostRegNet3DGS in eval mode: every layer handing the next one its output already cut into bf16 pieces (SCL / PSCL, the
     default) against fp32 tensors between the layers: the same logits bit for bit, twice in a row (the buffers are reused)."""
