@@ -484,7 +484,8 @@ def full_chain_rate(device, steps=10):
                     "~69 % busy (profiles/r04_costreg_pmc.txt, DESIGN 4.3)",
             "kernel_ms": round(c0_ms, 3), "useful_TFLOPs": round(c0_tfl / c0_ms * 1e3, 1),
             "network_ms": round(net_ms, 3), "network_useful_TFLOPs": round(tfl / net_ms * 1e3, 1),
-            "network_vs_fp32_mfma_peak": round(tfl / net_ms * 1e3 / 157.3, 3), "matrix_precision": net.matrix_precision}
+            "network_vs_fp32_mfma_peak": round(tfl / net_ms * 1e3 / 157.3, 3), "matrix_precision": net.matrix_precision,
+            "view_streams": int(net.view_streams)}   # 2: the second half of the views on a stream of its own (CostRegNet3DGS.view_streams)
     with torch.no_grad():
         vol = out["volume"].unsqueeze(0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
