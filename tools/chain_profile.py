@@ -30,6 +30,7 @@ dev = torch.device("cuda:0")
 wr = bench.WORKLOADS["scannet_ref_40v_12d_60x80"]
 torch.manual_seed(0)
 net = CostRegNet3DGS(wr["C"]).to(dev).eval()
+net.view_streams = 1   # per-kernel times: one batch on one stream (two halves on two streams overlap their kernels)
 neck = IndoorImVoxelNeck(wr["C"], 128, [1, 1, 1]).to(dev).eval()
 head = NerfDetHeadConvs(18, 3, 128, 6).to(dev).eval()
 hp = MVSDetHotPath(bench.N_VOXELS, bench.VOXEL_SIZE, list(wr["near_far"]), wr["D"], topk=3, cost_regularization=net, neck_3d=neck,

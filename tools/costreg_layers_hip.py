@@ -16,6 +16,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = CostRegNet3DGS(w["C"]).to(dev).eval()
+net.view_streams = 1   # per-kernel times: one batch on one stream (two halves on two streams overlap their kernels)
 x = torch.rand(w["N"], w["C"], w["D"], w["H"], w["W"], device=dev)
 with torch.no_grad():
     net(x)

@@ -27,6 +27,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = CostRegNet3DGS(256).to(dev).eval()
+    net.view_streams = 1   # per-kernel times: one batch on one stream (two halves on two streams overlap their kernels)
     x = torch.rand(40, 256, 12, 60, 80, device=dev)
     log = []
     real = {n: getattr(ops, n) for n in NAMES}
