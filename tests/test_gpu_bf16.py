@@ -237,6 +237,7 @@ def test_cost_network_on_two_halves_of_the_views_agrees_bit_for_bit(gpu):
             m.running_var.uniform_(0.5, 1.5)
     assert net.view_streams == 2
     xs = [torch.rand(shape, device=gpu) for shape in ((8, 64, 4, 12, 16), (11, 64, 8, 8, 24), (8, 64, 4, 12, 16))]
+    xs.append(torch.rand((9, 64, 4, 12, 48), device=gpu)[..., :16])   # a row-pitched volume (forward_scene's pitched variance): halves of a strided view
     with torch.no_grad():
         two = [net(x) for x in xs]
         net.view_streams = 1
@@ -245,6 +246,8 @@ def test_cost_network_on_two_halves_of_the_views_agrees_bit_for_bit(gpu):
     torch.cuda.synchronize(gpu)
     for a, b in zip(one, two):
         assert a.shape == b.shape and torch.equal(a, b)
+    with torch.no_grad():
+        assert torch.equal(two[-1], net(xs[-1].contiguous()))
 
 
 def test_cost_network_layer_forms_agree_bit_for_bit(gpu):
