@@ -18,6 +18,7 @@ on the GPU it, not the plane sweep, is what a scene costs.
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -150,7 +151,9 @@ def _bn_hip_ok(bn: nn.BatchNorm3d, x: torch.Tensor) -> bool:
     return bn.training and x.is_cuda and x.dtype == torch.float32 and bn.affine
 
 
-_SIDE_STREAMS: dict = {}   # device -> the stream the second half of the views runs on (CostRegNet3DGS.view_streams)
+# module -> {device: the stream the second half of its views runs on} (CostRegNet3DGS.view_streams); outside the modules because a
+# stream does not pickle, per module because the layers' SCL buffers are keyed by the stream
+_SIDE_STREAMS = weakref.WeakKeyDictionary()
 
 
 class _HeadConv(torch.autograd.Function):
@@ -301,9 +304,10 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
                 return self._forward_chain(x)
             dev = x.device
             cur = torch.cuda.current_stream(dev)
-            side = _SIDE_STREAMS.get(str(dev))   # module-level: a stream does not pickle with a model
+            mine = _SIDE_STREAMS.setdefault(self, {})
+            side = mine.get(str(dev))
             if side is None:
-                side = _SIDE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+                side = mine[str(dev)] = torch.cuda.Stream(device=dev)
             cut = (n + 1) // 2
             side.wait_stream(cur)          # x is ready; the caller keeps it alive until this call returns
             with torch.cuda.stream(side):
