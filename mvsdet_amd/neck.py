@@ -13,6 +13,8 @@ Training, CPU tensors and other shapes take the framework's layers.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Sequence
 
 import torch
@@ -35,7 +37,7 @@ class _ConvModule(nn.Module):
         return F.relu(x, inplace=True) if self.with_act else x
 
 
-_DERIVED = ("_mvs_affine", "_fused", "_mvs_wsplit", "_mvs_wmat")   # tensors computed from parameters and kept on a module
+_DERIVED = ("_mvs_affine", "_fused", "_mvs_wsplit", "_mvs_wmat", "_mvs_sclbuf")   # tensors computed from parameters and kept on a module
 
 
 def drop_derived_tensors(root: nn.Module) -> None:
@@ -88,6 +90,10 @@ def _hip_ok(x: Tensor, module: nn.Module) -> bool:
 # handful of tiles (padded 1.9x): there the kernel splits the 512 / 1024 input channels over blocks and a second kernel
 # adds the partial sums (neck 4.05 -> 3.10 ms).  0 disables the bf16 route.
 BF16X3_MIN_VOXELS = 256
+# stride-1 layers with this many output channels or more (four blocks of 64 per tile) on volumes of at least PACK_INPUT_MIN_VOXELS
+# voxels (grids that are not split over the input channels) read a packed SCL copy of their input by DMA; 0 = never
+PACK_INPUT_FROM_COUT = int(os.environ.get("MVSDET_NECK_PACK_COUT", "256"))
+PACK_INPUT_MIN_VOXELS = 16384
 # the two stride-2 layers on the bf16x3 stride-2 kernel (its 3x16x8 tiles fit their outputs: neck 2.77 -> 2.58 ms; on 4x8x16 tiles
 # it lost to the fp32 kernel, 0.72 against 0.64 ms)
 S2_BF16X3 = True
@@ -136,7 +142,15 @@ def _conv_k3(x: Tensor, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool, residua
     from . import ops
     scale, shift = _bn_affine(bn)
     if conv.stride[0] == 1 and BF16X3_MIN_VOXELS and x[0, 0].numel() >= BF16X3_MIN_VOXELS and conv.out_channels % 64 == 0:
-        return ops.conv3d_k3_bf16x3(x, _split_weight(conv), scale, shift, relu, residual)
+        src = x
+        if PACK_INPUT_FROM_COUT and conv.out_channels >= PACK_INPUT_FROM_COUT and x[0, 0].numel() >= PACK_INPUT_MIN_VOXELS:
+            # four blocks of output channels per tile would each cut the same fp32 values into bf16 pieces: one packing pass
+            # (26 MB at the 40x40x16 level) and the DMA-fed form instead; the buffer is refilled in place
+            key = (tuple(x.shape), x.device, torch.cuda.current_stream(x.device).cuda_stream)
+            cached = conv.__dict__.get("_mvs_sclbuf")
+            src = ops.scl_pack(x, out=cached[1] if cached is not None and cached[0] == key else None)
+            conv.__dict__["_mvs_sclbuf"] = (key, src)
+        return ops.conv3d_k3_bf16x3(src, _split_weight(conv), scale, shift, relu, residual)
     if S2_BF16X3 and conv.stride[0] == 2 and residual is None and conv.out_channels % 64 == 0:
         return ops.conv3d_k3_s2_bf16x3(x, _split_weight(conv), scale, shift, relu)
     return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(conv.weight), scale, shift, relu, conv.stride[0], residual)
