@@ -316,6 +316,9 @@ int mvsdet_conv3d_k3_cout2_dw_f32(const float* x, const float* grad_out, float* 
  * the fp32 call). */
 int mvsdet_conv3d_k3_cout2_dw_bf16x3(const float* x, const float* grad_out, float* partial, size_t partial_bytes, int nsplit,
                                      int N, int Cin, int D, int H, int W, mvsdet_stream_t stream);
+/* 1 if the call above takes this (Cin, W) -- channel count, row width and the LDS of a row stage (W up to ~470 at Cin = 64) --,
+ * else 0: then mvsdet_conv3d_k3_cout2_dw_f32 is the entry point to use. */
+int mvsdet_conv3d_k3_cout2_dw_bf16x3_ok(int Cin, int W);
 
 /* ---------------------------------------------------------------------------------------------
  * a9  backproject_Weigh -- mvsdet.py:1372-1492 (gt_depth=None).
@@ -372,8 +375,9 @@ int mvsdet_backproject_weigh_mean_bwd_f32(const float* feat, const int64_t* feat
  * "SCL" (split channel-last) activations: xs[piece 2][n][c8 = ceil(C/8)][Dp][Hp][Wp][8] bf16, piece = hi | mid,
  * (dp,hp,wp) = (d,h,w) + 1 inside a zero border; Dp/Hp/Wp (the border plus the largest tile overhang of any kernel that
  * reads the form) and the size in bytes come from mvsdet_scl_bytes.
- * mvsdet_scl_pack_f32 cuts an (N,C,D,H,W) fp32 tensor (possibly row-pitched: mvsdet_plane_sweep_variance_tabled_pitched_f32; zero_border != 0: clear the buffer first; a buffer reused for the
- * same shape needs that once).  weight_split: [Cout/64][c8][14 tap pairs][2 groups of 32 outputs][2 pieces][64 lanes][8]
+ * mvsdet_scl_pack_f32 cuts an (N,C,D,H,W) fp32 tensor (possibly row-pitched: mvsdet_plane_sweep_variance_tabled_pitched_f32; zero_border 1: clear the buffer first -- a buffer reused for the
+ * same shape needs that once; 2: the packing kernel runs over the padded volume and writes the border's zeros itself -- for a
+ * buffer fresh from an allocator on every call, no clearing pass).  weight_split: [Cout/64][c8][14 tap pairs][2 groups of 32 outputs][2 pieces][64 lanes][8]
  * bf16, lane = 32 * (tap parity) + MFMA row m, row m carrying output channel 8*((m>>4)*2 + ((m>>2)&1)) + (m&3) + 4*((m>>3)&1)
  * of its group (so that a lane's accumulator registers 8q..8q+7 are eight consecutive channels = one SCL unit), tap 27 and
  * channels >= Cin zero (mvsdet_amd.ops.split_conv_weight).

@@ -65,6 +65,7 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_cout2_dx_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_dw_f32": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_dw_bf16x3": [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_conv3d_k3_cout2_dw_bf16x3_ok": [_i, _i],
     "mvsdet_conv3d_k3_cout2_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_cout2_sum_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvsdet_backproject_weigh_f32": [_vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp,

@@ -25,6 +25,7 @@ import torch
 from torch import nn
 
 from .neck import DerivedTensorsMixin, _bn_affine
+from .scratch import EventPool
 
 
 class _ConvK3S1(torch.autograd.Function):
@@ -54,12 +55,12 @@ class _ConvK3S1(torch.autograd.Function):
                 src = gy
                 if wflip.shape[0] >= 256:
                     # four or more blocks of output channels per tile would each cut the same grad_out values into bf16 pieces:
-                    # one packing pass and the DMA-fed form instead (conv0: 4.78 -> 4.65 ms, the same bits)
-                    key = (tuple(gy.shape), gy.device, torch.cuda.current_stream(gy.device).cuda_stream)
-                    while len(_DX_SCL) >= 4 and key not in _DX_SCL:
-                        _DX_SCL.pop(next(iter(_DX_SCL)))
-                    src = _DX_SCL[key] = ops.scl_pack(gy, out=_DX_SCL.pop(key, None))
+                    # one packing pass and the DMA-fed form instead (conv0: 4.78 -> 4.65 ms, the same bits).  The SCL copy
+                    # (larger than grad_out itself) lives for this one convolution: it comes from the caching allocator and goes
+                    # back to it when `src` dies below -- the packing kernel writes the zero border itself, nothing is kept
+                    src = ops.scl_pack(gy)
                 gx = ops.conv3d_k3_bf16x3(src, ops.split_conv_weight(wflip), None, None, False)
+                del src
             else:
                 gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(wflip), None, None, False)
         if ctx.needs_input_grad[1]:   # bf16x3: csrc/costreg_dw_bf16.hip (rows read as float4)
@@ -159,8 +160,6 @@ def _bn_hip_ok(bn: nn.BatchNorm3d, x: torch.Tensor) -> bool:
     return bn.training and x.is_cuda and x.dtype == torch.float32 and bn.affine
 
 
-_DX_SCL: dict = {}   # (shape, device, stream) -> the SCL buffer an input-gradient convolution packs grad_out into (refilled in place)
-
 # module -> {device: the stream the second half of its views runs on} (CostRegNet3DGS.view_streams); outside the modules because a
 # stream does not pickle, per module because the layers' SCL buffers are keyed by the stream
 _SIDE_STREAMS = weakref.WeakKeyDictionary()
@@ -234,9 +233,10 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # one half's kernel fills with the other half's blocks -- 7.6 -> 7.35 ms, the same bits (three pieces 7.6, four 7.8:
         # tools/study/two_stream_network.py).  1 = one batch on the caller's stream.
         self.view_streams = int(os.environ.get("MVSDET_COSTREG_STREAMS", "2"))
-        # (layer, kind, shape, device, stream) -> the SCL / PSCL buffer a layer writes; its zero border is written once.
-        # Keyed by the stream as well: the buffers are refilled in place, outside the allocator's per-stream reuse tracking
-        self._scl = {}
+        # (layer, kind, shape, device) -> the SCL / PSCL buffers a layer of the chain writes; their zero borders are written once
+        # and the buffers refilled on every call.  Every buffer carries the event behind its last use: whichever stream takes it
+        # next waits for that event (mvsdet_amd/scratch.py) -- no dependence on which stream ran the module before
+        self._scl = EventPool(64)
 
     def _chain_ok(self, x) -> bool:
         """The eval route on which every layer hands the next one its output already cut into bf16 pieces."""
@@ -245,19 +245,15 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
                 and all(c.out_channels % 64 == 0 for c in (self.conv0.conv, self.conv1.conv, self.conv2.conv, self.conv3.conv,
                                                            self.conv4.conv, self.conv9[0], self.conv11[0])))
 
-    def _buf(self, name, kind, shape, dev):
-        """The SCL / PSCL buffer a layer of the chain writes: allocated and zeroed once per (layer, shape, device, stream) -- the
-        kernels write interior voxels only, the zero border stays -- and refilled on every call (outside the allocator's
-        per-stream reuse tracking, hence the stream in the key)."""
+    def _buf(self, leases, name, kind, shape, dev):
+        """The SCL / PSCL buffer a layer of the chain writes: allocated and zeroed once per (layer, shape, device) -- the kernels
+        write interior voxels only, the zero border stays -- and refilled on every call.  Taken from the module's pool for the
+        duration of one `_forward_chain` (`leases` collects what that call must hand back)."""
         from . import ops
-        key = (name, kind, tuple(shape), dev, torch.cuda.current_stream(dev).cuda_stream)
-        buf = self._scl.pop(key, None)
-        if buf is None:
-            while len(self._scl) >= 64:   # varying view counts, two streams: least recently used first
-                self._scl.pop(next(iter(self._scl)))
-            buf = (ops.scl_empty if kind == "scl" else ops.pscl_empty)(shape, dev)
-        self._scl[key] = buf
-        return buf
+        make = ops.scl_empty if kind == "scl" else ops.pscl_empty
+        lease = self._scl.acquire((name, kind, tuple(shape), str(dev)), lambda: make(shape, dev), lambda b: (b.data,), dev)
+        leases.append(lease)
+        return lease.buf
 
     def _forward_chain(self, x):
         """mvsnet.py:104-112 with the layer-to-layer forms of include/mvsdet_hip.h: conv0 -(fp32 skip, PSCL)-> conv1 -(SCL)->
@@ -267,6 +263,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         n, _, d, h, w = x.shape
         dev = x.device
         b = self.conv0.conv.out_channels
+        leases = []
 
         # all seven weight tensors cut into their bf16 pieces by ONE launch, on every call: an in-place update is always seen
         layers = [(self.conv0.conv, 0), (self.conv1.conv, 1), (self.conv2.conv, 0), (self.conv3.conv, 1), (self.conv4.conv, 0),
@@ -278,15 +275,15 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             wq = wsplit[id(layer.conv)]
             kw = {}
             if "scl" in outputs:
-                kw["scl_out"] = self._buf(name, "scl", oshape, dev)
+                kw["scl_out"] = self._buf(leases, name, "scl", oshape, dev)
             if "pscl" in outputs:
-                kw["pscl_out"] = self._buf(name, "pscl", oshape, dev)
+                kw["pscl_out"] = self._buf(leases, name, "pscl", oshape, dev)
             fn = ops.conv3d_k3_bf16x3 if order == 0 else ops.conv3d_k3_s2_bf16x3
             return fn(inp, wq, sc, sh, True, outputs=outputs, **kw)
 
         def up(seq, inp, skip, outputs, name, oshape):
             sc, sh = _bn_affine(seq[1])
-            kw = {"scl_out": self._buf(name, "scl", oshape, dev)} if "scl" in outputs else {}
+            kw = {"scl_out": self._buf(leases, name, "scl", oshape, dev)} if "scl" in outputs else {}
             return ops.convT3d_k3_s2_bf16x3(inp, wsplit[id(seq[0])], sc, sh, skip, True, outputs=outputs, **kw)
 
         full, full_p = cbr(self.conv0, x, 0, ("f32", "pscl"), "conv0", (n, b, d, h, w))
@@ -301,9 +298,12 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # (one fp32 addition of the same two values)
         if self.skip_in_head:
             up11 = up(self.conv11, half2, None, ("f32",), "conv11", (n, b, d, h, w))
-            return ops.conv3d_k3_cout2_sum(full, up11, self.prob.weight.detach(), self.prob.bias.detach())
-        up11 = up(self.conv11, half2, full, ("f32",), "conv11", (n, b, d, h, w))
-        return ops.conv3d_k3_cout2_sum(up11, None, self.prob.weight.detach(), self.prob.bias.detach())
+            logits = ops.conv3d_k3_cout2_sum(full, up11, self.prob.weight.detach(), self.prob.bias.detach())
+        else:
+            up11 = up(self.conv11, half2, full, ("f32",), "conv11", (n, b, d, h, w))
+            logits = ops.conv3d_k3_cout2_sum(up11, None, self.prob.weight.detach(), self.prob.bias.detach())
+        self._scl.release(leases, dev)   # every reader of the buffers is enqueued: one event behind them on this stream
+        return logits
 
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
@@ -382,12 +382,8 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             scale, shift = _bn_affine(bn)
             if self.matrix_precision == "bf16x3":
                 # 8 output parity classes = 8 small stride-1 convolutions over the coarse input (csrc/costreg_bf16.hip)
-                # the coarse input in split channel-last form: refilled in place
-                key = (tuple(x.shape), x.device, torch.cuda.current_stream(x.device).cuda_stream)
-                out = self._scl.pop(key, None)
-                while len(self._scl) >= 8:   # varying view counts: least recently used first
-                    self._scl.pop(next(iter(self._scl)))
-                xs = self._scl[key] = ops.scl_pack(x, out=out)
+                # the coarse input in split channel-last form: a buffer of this call's own (the packing kernel writes its border)
+                xs = ops.scl_pack(x)
                 return ops.convT3d_k3_s2_bf16x3(xs, ops.split_conv_weight(deconv.weight, 2), scale, shift, skip, True)
             wperm = ops.permute_convT_weight(deconv.weight)
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)

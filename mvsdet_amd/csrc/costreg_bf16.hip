@@ -160,6 +160,40 @@ __global__ __launch_bounds__(kThreads) void scl_pack_kernel(const float* __restr
     xs[piece_stride + o] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
 }
 
+// The same cut over the PADDED volume: a thread whose voxel lies in the border stores zeros, so the buffer needs no history
+// (zero_border = 2: a buffer fresh from an allocator, nothing cleared beforehand; interior values bit for bit those above).
+__global__ __launch_bounds__(kThreads) void scl_pack_padded_kernel(const float* __restrict__ x, long long sN, long long sC, long long sD,
+                                                                   long long sH, uint4* __restrict__ xs, int C, int C8, int D, int H,
+                                                                   int W, int Dp, int Hp, int Wp, size_t piece_stride) {
+    const size_t volp = (size_t)Dp * Hp * Wp;
+    const size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (v >= volp) return;
+    const int c8 = blockIdx.y, n = blockIdx.z;
+    const int dp = (int)(v / ((size_t)Hp * Wp)), r = (int)(v - (size_t)dp * Hp * Wp), hp = r / Wp, wp = r - hp * Wp;
+    const int d = dp - 1, h = hp - 1, w = wp - 1;
+    unsigned hi[4] = {0u, 0u, 0u, 0u}, mid[4] = {0u, 0u, 0u, 0u};
+    if (d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W) {
+        const float* src = x + (size_t)n * sN + (size_t)c8 * 8 * sC + (size_t)d * sD + (size_t)h * sH + w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short hb[2], mb[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float f = (c8 * 8 + 2 * j + e < C) ? src[(size_t)(2 * j + e) * sC] : 0.0f;
+                const __bf16 a = (__bf16)f;
+                const __bf16 b = (__bf16)(f - (float)a);
+                hb[e] = __builtin_bit_cast(unsigned short, a);
+                mb[e] = __builtin_bit_cast(unsigned short, b);
+            }
+            hi[j] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+            mid[j] = (unsigned)mb[0] | ((unsigned)mb[1] << 16);
+        }
+    }
+    const size_t o = ((size_t)n * C8 + c8) * volp + v;
+    xs[o] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    xs[piece_stride + o] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+}
+
 // Conv3d weight (Cout,Cin,27) fp32 -> [Cout/64][c8][14][2 row groups][2 pieces][64 lanes][8] bf16 (see the entry point; lane =
 // 32 * (half of the pair) + MFMA row m, which carries output channel bf_mfma_row_channel(m) of its row group):
 // thread = one 16-byte unit.  A few hundred thousand elements: run on every call, so the kernel never multiplies a stale
@@ -1454,7 +1488,7 @@ extern "C" int mvsdet_scl_pack_f32(const float* x, const int64_t* xstr, void* xs
     MVS_REQUIRE(N <= 65535 && C8 <= 65535, "scl_pack: N or C too large");
     const size_t piece = (size_t)N * C8 * p.Dp * p.Hp * p.Wp;
     hipStream_t st = (hipStream_t)stream;
-    if (zero_border && hipMemsetAsync(xs, 0, 2 * piece * 16, st) != hipSuccess) {
+    if (zero_border == 1 && hipMemsetAsync(xs, 0, 2 * piece * 16, st) != hipSuccess) {
         set_error("scl_pack: hipMemsetAsync failed");
         return MVSDET_ERR_HIP;
     }
@@ -1463,6 +1497,14 @@ extern "C" int mvsdet_scl_pack_f32(const float* x, const int64_t* xstr, void* xs
     const long long sN = xstr ? xstr[0] : (long long)C * vol, sC = xstr ? xstr[1] : (long long)vol;
     const long long sD = xstr ? xstr[2] : (long long)H * W, sH = xstr ? xstr[3] : (long long)W;
     MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= W, "scl_pack: bad strides");
+    if (zero_border == 2) {   // one pass over the padded volume: border voxels get their zeros from the kernel itself
+        const size_t volp = (size_t)p.Dp * p.Hp * p.Wp;
+        dim3 gridp((unsigned)((volp + kThreads - 1) / kThreads), (unsigned)C8, (unsigned)N);
+        hipLaunchKernelGGL(scl_pack_padded_kernel, gridp, dim3(kThreads), 0, st, x, sN, sC, sD, sH, static_cast<uint4*>(xs), C, C8, D,
+                           H, W, p.Dp, p.Hp, p.Wp, piece);
+        MVS_LAUNCH_CHECK("scl_pack");
+        return MVSDET_OK;
+    }
     hipLaunchKernelGGL(scl_pack_kernel, grid, dim3(kThreads), 0, st, x, sN, sC, sD, sH, static_cast<uint4*>(xs), C, C8, D, H, W,
                        p.Dp, p.Hp, p.Wp, piece);
     MVS_LAUNCH_CHECK("scl_pack");

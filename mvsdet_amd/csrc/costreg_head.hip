@@ -580,6 +580,12 @@ extern "C" int mvsdet_conv3d_k3_cout2_dw_f32(const float* x, const float* grad_o
     return MVSDET_OK;
 }
 
+// Whether mvsdet_conv3d_k3_cout2_dw_bf16x3 takes this (Cin, W): its shape conditions, the LDS of a row stage included -- what a
+// caller asks before it chooses between that entry point and the fp32 one (the pointer alignment is the caller's to check).
+extern "C" int mvsdet_conv3d_k3_cout2_dw_bf16x3_ok(int Cin, int W) {
+    return (Cin == 16 || Cin == 32 || Cin == 64) && W > 0 && W % 4 == 0 && W <= 4096 && hdw_lds_bytes(Cin, W) <= 160 * 1024;
+}
+
 // bf16x3 form of the weight gradient (see conv3d_k3_cout2_dw_bf16x3_kernel): Cin in {16, 32, 64}, W % 4 == 0, 16-byte aligned
 // tensors; nsplit = blocks = rows of `partial`.  Within ~1e-5 of the fp32 kernel's sums (three-term split operands).
 extern "C" int mvsdet_conv3d_k3_cout2_dw_bf16x3(const float* x, const float* grad_out, float* partial, size_t partial_bytes,

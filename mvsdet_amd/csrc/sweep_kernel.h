@@ -343,23 +343,28 @@ template <int S>
 __device__ __forceinline__ int quad_bcast(int v) {
     return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xf, 0xf, true);
 }
-// quad_bcast<S>(v) + add as ONE instruction.  The operand v must have been written at least two wait states earlier (a DPP
-// operand fresh from the vector pipe is a hazard hipcc cannot see inside inline assembly): dpp_sources_settled() below.
-// All of these statements are volatile: they keep their program order among themselves.
+// quad_bcast<S>(v) + add as ONE instruction (v_add_u32_dpp), for the four tap offsets of a pixel step at once.  A DPP operand
+// fresh from the vector pipe needs two wait states, a hazard hipcc's recogniser cannot see inside inline assembly -- and a
+// separate `s_nop` statement ahead of the additions does not bind the register allocator: it may still place a copy of an
+// operand (a live-range split under the three-blocks-per-CU register budget) between the nop and the DPP read.  So the wait
+// states and the four additions of a step are ONE asm block: whatever wrote the operands, copies included, lies before the
+// nop.  Outputs are early-clobber: none may share a register with an input that a later line of the block still reads.
+#define MVS_QBA(S) \
+    "s_nop 1\n\t" \
+    "v_add_u32_dpp %0, %4, %8 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_u32_dpp %1, %5, %8 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_u32_dpp %2, %6, %8 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_u32_dpp %3, %7, %8 quad_perm:[" #S "," #S "," #S "," #S "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 template <int S>
-__device__ __forceinline__ int quad_bcast_add(int v, int add) {
-    int r;
-    if constexpr (S == 0) asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
-    else if constexpr (S == 1) asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
-    else if constexpr (S == 2) asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
-    else asm volatile("v_add_u32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(add));
-    return r;
+__device__ __forceinline__ void quad_bcast_add4(int v0, int v1, int v2, int v3, int add, int& r0, int& r1, int& r2, int& r3) {
+#define MVS_QBA_IO : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(add)
+    if constexpr (S == 0) asm volatile(MVS_QBA(0) MVS_QBA_IO);
+    else if constexpr (S == 1) asm volatile(MVS_QBA(1) MVS_QBA_IO);
+    else if constexpr (S == 2) asm volatile(MVS_QBA(2) MVS_QBA_IO);
+    else asm volatile(MVS_QBA(3) MVS_QBA_IO);
+#undef MVS_QBA_IO
 }
-// Two wait states between the instructions that wrote the four values (its inputs: they come first) and every
-// quad_bcast_add after it (volatile like it: they come later).
-__device__ __forceinline__ void dpp_sources_settled(int a, int b, int c, int d) {
-    asm volatile("s_nop 1" : : "v"(a), "v"(b), "v"(c), "v"(d));
-}
+#undef MVS_QBA
 // fmaf(-m, m, q) as the one IEEE instruction it is, spelled out so that hipcc does not pair two of them into a v_pk_fma_f32
 // (whose results then need register copies to reach their places in the store vectors)
 __device__ __forceinline__ float fma_neg_sq(float m, float q) {
@@ -376,7 +381,7 @@ __device__ __forceinline__ void variance_of(float (&vout)[4][4], int s, int h, s
     vout[2 * h][s] = fma_neg_sq(m.x, q.x);
     vout[2 * h + 1][s] = fma_neg_sq(m.y, q.y);
 }
-// 16 bytes at an LDS ADDRESS (not an index into a __shared__ array: the address arrives ready-made from quad_bcast_add)
+// 16 bytes at an LDS ADDRESS (not an index into a __shared__ array: the address arrives ready-made from quad_bcast_add4)
 __device__ __forceinline__ float4 lds_f4_at(int addr) {
     typedef float v4 __attribute__((ext_vector_type(4)));
     const v4 t = *(const __attribute__((address_space(3))) v4*)(size_t)(unsigned)addr;
@@ -659,7 +664,8 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
         }
 #define MVS_TAP_STEP(SS, LOADER, OFF)                                                                                 \
         {                                                                                                             \
-            const int o0 = OFF(SS, ro0), o1 = OFF(SS, ro1), o2 = OFF(SS, ro2), o3 = OFF(SS, ro3);                     \
+            int o0, o1, o2, o3;                                                                                       \
+            OFF(SS, o0, o1, o2, o3)                                                                                   \
             const f2 w0 = splat(__int_as_float(quad_bcast<SS>(rw0))), w1 = splat(__int_as_float(quad_bcast<SS>(rw1)));  \
             const f2 w2 = splat(__int_as_float(quad_bcast<SS>(rw2))), w3 = splat(__int_as_float(quad_bcast<SS>(rw3)));  \
             const float4 t0 = LOADER(o0), t1 = LOADER(o1), t2 = LOADER(o2), t3 = LOADER(o3);                          \
@@ -679,11 +685,11 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
         }
         // Tap offsets travel in BYTES, so that the quad broadcast and the addition of the lane's own 16 bytes of the texel are ONE
         // v_add_u32_dpp (an index needs a v_mov_b32_dpp and a v_lshl_add_u32 -- a VOP3, which takes no DPP operand).  hipcc folds
-        // only half of them by itself: the LDS path spells the instruction out (quad_bcast_add).
+        // only half of them by itself: the LDS path spells the instruction out (quad_bcast_add4).
 #define MVS_LDS_TAP(O) lds_f4_at(O)   /* O holds the LDS address itself */
 #define MVS_GLB_TAP(O) (*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nb_img[j]) + (O)))
-#define MVS_LDS_OFF(SS, R) quad_bcast_add<SS>(R, g16_lds)
-#define MVS_GLB_OFF(SS, R) (quad_bcast<SS>(R) + g16)
+#define MVS_LDS_OFF(SS, A, B, C_, D_) quad_bcast_add4<SS>(ro0, ro1, ro2, ro3, g16_lds, A, B, C_, D_);
+#define MVS_GLB_OFF(SS, A, B, C_, D_) A = quad_bcast<SS>(ro0) + g16; B = quad_bcast<SS>(ro1) + g16; C_ = quad_bcast<SS>(ro2) + g16; D_ = quad_bcast<SS>(ro3) + g16;
 #define MVS_TAPS_OF(QQ)                                                                                               \
         {                                                                                                             \
             if constexpr (2 * p + QQ < K) {                                                                           \
@@ -696,7 +702,6 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
                     const int rw0 = from_quad<QQ>(__float_as_int(dw.x)), rw1 = from_quad<QQ>(__float_as_int(dw.y));   \
                     const int rw2 = from_quad<QQ>(__float_as_int(dw.z)), rw3 = from_quad<QQ>(__float_as_int(dw.w));   \
                     if (fj & kFlagStaged) {                                                                           \
-                        dpp_sources_settled(ro0, ro1, ro2, ro3);                                                      \
                         MVS_TAP_STEP(0, MVS_LDS_TAP, MVS_LDS_OFF) MVS_TAP_STEP(1, MVS_LDS_TAP, MVS_LDS_OFF)           \
                         MVS_TAP_STEP(2, MVS_LDS_TAP, MVS_LDS_OFF) MVS_TAP_STEP(3, MVS_LDS_TAP, MVS_LDS_OFF)           \
                     } else {                                                                                          \

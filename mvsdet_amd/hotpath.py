@@ -33,6 +33,54 @@ class SceneGeometry:
     width: int
 
 
+def _tensors_of(v):
+    if isinstance(v, Tensor):
+        yield v
+    elif isinstance(v, (list, tuple)):
+        for x in v:
+            yield from _tensors_of(x)
+
+
+class SceneOutputs(dict):
+    """What `forward_scene` returns.  With `overlap_detector` everything but `variance` was produced on a side stream and is
+    only valid behind the event `ready`: this holder makes the stream that READS a value wait for that event (once the event
+    has completed the check is one query) and tells the caching allocator that the stream uses the value's memory, so a
+    consumer on any stream -- the caller's, a third one -- gets correct data without knowing about the side stream.
+    `ready`, `detector_ready`, `geometry` and `variance` (produced on the caller's own stream) are handed out as they are;
+    `dict.__getitem__(out, key)` / `out.raw(key)` bypass the wait for callers that order the streams themselves."""
+
+    _PLAIN = ("ready", "detector_ready", "geometry", "variance")
+
+    def raw(self, key):
+        return dict.__getitem__(self, key)
+
+    def _guard(self, key, value):
+        ev = dict.get(self, "ready")
+        if ev is None or key in self._PLAIN:
+            return value
+        cur = None
+        for t in _tensors_of(value):
+            if t.is_cuda:
+                if cur is None:
+                    cur = torch.cuda.current_stream(t.device)
+                    if not ev.query():
+                        cur.wait_event(ev)
+                t.record_stream(cur)
+        return value
+
+    def __getitem__(self, key):
+        return self._guard(key, dict.__getitem__(self, key))
+
+    def get(self, key, default=None):
+        return self._guard(key, dict.__getitem__(self, key)) if key in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 class _GeometryWorker:
     """One daemon thread per MVSDetHotPath: evaluates `_host_geometry` (ATen-CPU, one intra-op thread -- set ONCE, in this
     thread; note that torch.set_num_threads also sets MKL's process-wide thread count), packs the results into a pinned
@@ -388,13 +436,8 @@ class MVSDetHotPath:
         nx, ny, nz = self.n_voxels
         return mean.view(C, nx, ny, nz), count.view(1, nx, ny, nz).long()
 
-    def forward_scene(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor] = None,
-                      geo: Optional[SceneGeometry] = None) -> dict:
-        """One scene through a1..a10.  `cost_logits` (N,2,D,Hf,Wf) stands in for the cost regularisation
-        network's output when `self.cost_regularization` is None (benchmarks / parity tests).
-        With `pitched_variance = "auto"` (default) `out["variance"]` may be a NON-CONTIGUOUS (N,C,D,H,W) view of a buffer whose
-        rows are `variance_row_pitch(W)` elements apart (same values; only for widths 16 mod 32 with 48+ planes, and only when
-        the consumer is None or `CostRegNet3DGS`): `.view()` on it raises; set `pitched_variance = False` for a contiguous one."""
+    def _front(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor], geo: Optional[SceneGeometry]):
+        """a1..a4 and the cost network of one scene on the caller's stream -> (geo, packed, variance, cost_logits)."""
         if geo is None:
             geo = self.prepare_scene(img_meta, feature.device)
         if feature.is_cuda and not (feature.requires_grad and torch.is_grad_enabled()) and geo.neighbor_ids.shape[1] > 0:
@@ -421,35 +464,67 @@ class MVSDetHotPath:
                 cost_logits = net(variance)
         elif cost_logits is None:
             raise ValueError("forward_scene needs `cost_logits` when no cost_regularization module is set")
+        return geo, packed, variance, cost_logits
 
-        def tail():
-            prob, off, est_depth, est_dens, est_idx, avg_depth = self.depth_distribution(cost_logits)
-            volume_mean, valid = self.lift(feature, packed, geo, est_depth, est_dens)
-            h, w = geo.height, geo.width
-            out = dict(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
-                       est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
-                       depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo,
-                       # mvsdet.py:582 `opacity = torch.max(prob_volume, dim=1)[0]`: the first of the sorted top-k values IS that
-                       # maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume, cropped at :583
-                       opacity=est_dens[:, 0])
-            if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU)
-                out["neck"] = self.neck_3d(volume_mean.unsqueeze(0))
-                if self.bbox_head is not None:
-                    out["head"] = self.bbox_head(out["neck"])   # (centerness, bbox, cls) lists over the levels
-            return out
+    def _lift_tail(self, feature, geo, packed, variance, cost_logits) -> "SceneOutputs":
+        """a5..a10 of one scene (mvsdet.py:470-515) on the current stream."""
+        prob, off, est_depth, est_dens, est_idx, avg_depth = self.depth_distribution(cost_logits)
+        volume_mean, valid = self.lift(feature, packed, geo, est_depth, est_dens)
+        h, w = geo.height, geo.width
+        return SceneOutputs(volume=volume_mean, valid=valid, variance=variance, prob_volume=prob, off_pred=off,
+                            est_depth=est_depth[:, :, :h, :w], est_densities=est_dens[:, :, :h, :w],
+                            depth_coding=avg_depth[:, :h, :w].unsqueeze(1), geometry=geo,
+                            # mvsdet.py:582 `opacity = torch.max(prob_volume, dim=1)[0]`: the first of the sorted top-k values IS
+                            # that maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume
+                            opacity=est_dens[:, 0])
 
-        if not (self.overlap_detector and variance.is_cuda) or (torch.is_grad_enabled() and (feature.requires_grad or cost_logits.requires_grad)):
-            return tail()   # one stream under autograd: the backward's stream order is left to the ops' own streams
-        # Everything behind the cost network -- depth distribution, lifting, and the neck and head when they are attached -- on a
-        # stream of its own: small kernels that do not fill the chip (one thread per pixel; ONE 40 x 40 x 16 volume: 200 blocks for
-        # 256 CUs at the neck's largest level) run beside the NEXT scene's packing, sweep and first convolution instead of in
-        # front of them.  The caller makes its stream wait for out["ready"] before it touches any output but `variance` (their
-        # memory belongs to the side stream's pool).
-        dev = variance.device
-        cur = torch.cuda.current_stream(dev)
+    def _side_stream(self, dev):
         side = self._detector_streams.get(str(dev))
         if side is None:
             side = self._detector_streams[str(dev)] = torch.cuda.Stream(device=dev)
+        return side
+
+    def _one_stream(self, feature, variance, cost_logits) -> bool:
+        """The tail stays on the caller's stream: no device, no overlap asked for, or autograd (the backward's stream order is
+        left to the ops' own streams)."""
+        return (not (self.overlap_detector and variance.is_cuda)
+                or (torch.is_grad_enabled() and (feature.requires_grad or cost_logits.requires_grad)))
+
+    @staticmethod
+    def _keep_for(side, *values):
+        """Inputs of a side-stream tail that live in another stream's pool must not be recycled while the side stream reads them."""
+        for t in values:
+            if isinstance(t, Tensor) and t.is_cuda:
+                t.record_stream(side)
+
+    def forward_scene(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor] = None,
+                      geo: Optional[SceneGeometry] = None) -> dict:
+        """One scene through a1..a10.  `cost_logits` (N,2,D,Hf,Wf) stands in for the cost regularisation
+        network's output when `self.cost_regularization` is None (benchmarks / parity tests).
+        With `pitched_variance = "auto"` (default) `out["variance"]` may be a NON-CONTIGUOUS (N,C,D,H,W) view of a buffer whose
+        rows are `variance_row_pitch(W)` elements apart (same values; only for widths 16 mod 32 with 48+ planes, and only when
+        the consumer is None or `CostRegNet3DGS`): `.view()` on it raises; set `pitched_variance = False` for a contiguous one.
+        The result is a `SceneOutputs`: with `overlap_detector` a value read from it makes the reading stream wait for the side
+        stream's event first."""
+        geo, packed, variance, cost_logits = self._front(feature, img_meta, cost_logits, geo)
+
+        def tail():
+            out = self._lift_tail(feature, geo, packed, variance, cost_logits)
+            if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU): forward_scenes
+                dict.__setitem__(out, "neck", self.neck_3d(out.raw("volume").unsqueeze(0)))
+                if self.bbox_head is not None:
+                    dict.__setitem__(out, "head", self.bbox_head(out.raw("neck")))   # (centerness, bbox, cls) lists over the levels
+            return out
+
+        if self._one_stream(feature, variance, cost_logits):
+            return tail()
+        # Everything behind the cost network -- depth distribution, lifting, and the neck and head when they are attached -- on a
+        # stream of its own: small kernels that do not fill the chip (one thread per pixel; ONE 40 x 40 x 16 volume: 200 blocks for
+        # 256 CUs at the neck's largest level) run beside the NEXT scene's packing, sweep and first convolution instead of in
+        # front of them.  Reading a value from the returned SceneOutputs makes the reading stream wait for out["ready"].
+        dev = variance.device
+        cur = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
         ready = torch.cuda.Event()
         ready.record(cur)
         with torch.cuda.stream(side):
@@ -457,9 +532,65 @@ class MVSDetHotPath:
             out = tail()
             done = torch.cuda.Event()
             done.record(side)
-        # inputs of the tail that live in another stream's pool must not be recycled while the side stream reads them
-        for t in (cost_logits, packed, feature, geo.neighbor_ids, geo.points):
-            if isinstance(t, Tensor) and t.is_cuda:
-                t.record_stream(side)
-        out["ready"] = out["detector_ready"] = done
+        # (`lift` reads geo.projection -- a view of the ONE uploaded staging buffer, which neighbor_ids, proj_rel and depth_values
+        # share: recording any view records the whole block -- and geo.points, a block of its own)
+        self._keep_for(side, cost_logits, packed, feature, geo.projection, geo.points)
+        dict.__setitem__(out, "ready", done)
+        dict.__setitem__(out, "detector_ready", done)
         return out
+
+    def forward_scenes(self, features: Sequence[Tensor], img_metas: Sequence[dict],
+                       cost_logits: Optional[Sequence[Tensor]] = None) -> dict:
+        """A BATCH of scenes the way mvsdet.py:681-698 runs it: every scene through a1..a10 on its own, then `neck_3d` (and
+        `bbox_head`) ONCE on the stacked (B,C,X,Y,Z) volume -- one 40 x 40 x 16 volume is 200 blocks for 256 CUs at the neck's
+        largest level and a few dozen at the others; a batch fills the chip (throughput runs, `samples_per_gpu` > 1).
+        Returns {"scenes": [SceneOutputs per scene, each with its own rows of the batched neck / head results as views],
+        "volume": (B,C,X,Y,Z), "valid": (B,1,X,Y,Z), "neck": levels of (B,...), "head": the head's lists, "ready": event}.
+        With `overlap_detector` the tails and the batched detector run on the side stream beside the following scenes' sweeps
+        and cost networks; values read through the returned holders wait for it."""
+        B = len(features)
+        if B == 0 or len(img_metas) != B or (cost_logits is not None and len(cost_logits) != B):
+            raise ValueError("forward_scenes: one img_meta (and one cost_logits, if given) per feature tensor")
+        dev = features[0].device
+        for i in range(B):                      # the camera algebra of every scene of the batch starts now, on the worker thread
+            self.prefetch_scene(img_metas[i], dev)
+        outs, side, cur = [], None, None
+        for i in range(B):
+            logits_i = None if cost_logits is None else cost_logits[i]
+            geo, packed, variance, logits_i = self._front(features[i], img_metas[i], logits_i, None)
+            if self._one_stream(features[i], variance, logits_i):
+                outs.append(self._lift_tail(features[i], geo, packed, variance, logits_i))
+                continue
+            cur = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                outs.append(self._lift_tail(features[i], geo, packed, variance, logits_i))
+            self._keep_for(side, logits_i, packed, features[i], geo.projection, geo.points)
+
+        def detector():
+            res = SceneOutputs(scenes=outs)
+            dict.__setitem__(res, "volume", torch.stack([o.raw("volume") for o in outs]))
+            dict.__setitem__(res, "valid", torch.stack([o.raw("valid") for o in outs]))
+            if self.neck_3d is not None:
+                dict.__setitem__(res, "neck", self.neck_3d(res.raw("volume")))
+                for i, o in enumerate(outs):
+                    dict.__setitem__(o, "neck", [lvl[i:i + 1] for lvl in res.raw("neck")])
+                if self.bbox_head is not None:
+                    dict.__setitem__(res, "head", self.bbox_head(res.raw("neck")))
+                    for i, o in enumerate(outs):
+                        dict.__setitem__(o, "head", tuple([lvl[i:i + 1] for lvl in part] for part in res.raw("head")))
+            return res
+
+        if side is None:
+            return detector()
+        with torch.cuda.stream(side):
+            res = detector()
+            done = torch.cuda.Event()
+            done.record(side)
+        for o in outs + [res]:
+            dict.__setitem__(o, "ready", done)
+            dict.__setitem__(o, "detector_ready", done)
+        return res

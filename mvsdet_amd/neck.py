@@ -107,7 +107,10 @@ def _split_weight(conv: nn.Module, order: int | None = None) -> Tensor:
     w = conv.weight
     if order is None:
         order = 1 if conv.stride[0] == 2 else 0
-    key = (w.data_ptr(), w._version, w.device, order)
+    # the layout of an order-0 split follows the library option `conv_mfma16` (16x16x32 or 32x32x16 row order), and the launcher
+    # picks the kernel form from the same option at launch time: the option is part of the key, so weights cut under one setting
+    # are never fed to the other form after `mvsdet_set_option` / an A/B run in one process
+    key = (w.data_ptr(), w._version, w.device, order, ops.get_option("conv_mfma16") if order == 0 and w.is_cuda else 0)
     cached = conv.__dict__.get("_mvs_wsplit")
     if cached is None or cached[0] != key:
         cached = (key, ops.split_conv_weight(w, order=order))
@@ -145,11 +148,9 @@ def _conv_k3(x: Tensor, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool, residua
         src = x
         if PACK_INPUT_FROM_COUT and conv.out_channels >= PACK_INPUT_FROM_COUT and x[0, 0].numel() >= PACK_INPUT_MIN_VOXELS:
             # four blocks of output channels per tile would each cut the same fp32 values into bf16 pieces: one packing pass
-            # (26 MB at the 40x40x16 level) and the DMA-fed form instead; the buffer is refilled in place
-            key = (tuple(x.shape), x.device, torch.cuda.current_stream(x.device).cuda_stream)
-            cached = conv.__dict__.get("_mvs_sclbuf")
-            src = ops.scl_pack(x, out=cached[1] if cached is not None and cached[0] == key else None)
-            conv.__dict__["_mvs_sclbuf"] = (key, src)
+            # (26 MB at the 40x40x16 level) and the DMA-fed form instead; the copy is this call's own (from the caching allocator,
+            # the packing kernel writes its zero border): nothing kept on the module, nothing tied to a stream
+            src = ops.scl_pack(x)
         return ops.conv3d_k3_bf16x3(src, _split_weight(conv), scale, shift, relu, residual)
     if S2_BF16X3 and conv.stride[0] == 2 and residual is None and conv.out_channels % 64 == 0:
         return ops.conv3d_k3_s2_bf16x3(x, _split_weight(conv), scale, shift, relu)

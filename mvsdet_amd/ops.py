@@ -878,7 +878,8 @@ def pscl_from_tensor(x: Tensor) -> PsclTensor:
 
 def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
     """(N,C,D,H,W) fp32 -> SclTensor.  x may be any view whose last dimension has stride 1 (a row-pitched cost volume is
-    read in place).  `out`: a buffer of the same shape to refill (its border is already zero)."""
+    read in place).  `out`: a buffer of the same shape to refill (its border is already zero); without one the result is a
+    new buffer from the caching allocator whose border the packing kernel writes itself (no clearing pass, nothing kept)."""
     import ctypes
     _req(x, "x", dim=5)
     if x.stride(4) != 1 or min(x.stride()) < 0:
@@ -890,7 +891,7 @@ def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
         out = SclTensor(torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=x.device), x.shape, padded)
     xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mvsdet_scl_pack_f32(_lib.ptr(x), xstr, _lib.ptr(out.data), N, C, D, H, W, int(fresh), _stream(x)),
+        _lib.check(_lib.load().mvsdet_scl_pack_f32(_lib.ptr(x), xstr, _lib.ptr(out.data), N, C, D, H, W, 2 if fresh else 0, _stream(x)),
                    "scl_pack")
     return out
 
@@ -1287,7 +1288,10 @@ def conv3d_k3_cout2_backward(x: Tensor, weight: Tensor, grad_out: Tensor, nsplit
     x, weight, grad_out = x.contiguous(), weight.contiguous(), grad_out.contiguous()
     lib = _lib.load()
     gx = torch.empty_like(x)
-    on_mfma = bool(bf16x3) and Cin in (16, 32, 64) and W % 4 == 0 and x.data_ptr() % 16 == 0 and grad_out.data_ptr() % 16 == 0
+    # the library's own shape gate (channel count, W % 4, the LDS of a row stage: W up to ~470 at Cin = 64); wider maps keep the
+    # fp32 kernel instead of raising from the entry point
+    on_mfma = (bool(bf16x3) and bool(lib.mvsdet_conv3d_k3_cout2_dw_bf16x3_ok(int(Cin), int(W)))
+               and x.data_ptr() % 16 == 0 and grad_out.data_ptr() % 16 == 0)
     if on_mfma:
         nsplit = min(768, N * D * H)   # blocks of four waves, a wave takes whole x rows (n, d, h)
     partial = torch.empty((nsplit, 2, Cin, 27), dtype=torch.float32, device=x.device)

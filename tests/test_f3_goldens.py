@@ -96,7 +96,7 @@ def _check_costreg_grads(net, x, y, g, tol_fwd, elementwise_tol, norm_tol, outli
     and every gradient tensor in norm."""
     np.testing.assert_allclose(y.detach().cpu().numpy(), g["logits"], rtol=0, atol=tol_fwd * max(1.0, float(np.abs(g["logits"]).max())))
     for k, b in net.named_buffers():
-        if k.endswith("running_mean") or k.endswith("running_var"):
+        if (k.endswith("running_mean") or k.endswith("running_var")) and "b:" + k in g.files:
             np.testing.assert_allclose(b.cpu().numpy(), g["b:" + k], rtol=1e-4, atol=1e-5, err_msg=k)
     items = [("grad_input", x.grad.reshape(-1)[::97].cpu().numpy(), g["grad_input"], None)]
     params = dict(net.named_parameters())
@@ -133,6 +133,15 @@ def test_g11_heads_on_the_framework_layers(tag):
 
 def test_g12_cost_network_gradients_on_the_framework_layers():
     g = load_golden("g12_cost_regularisation_grads")
+    net, x, y = _costreg_train_step(g, "cpu", "fp32")
+    _check_costreg_grads(net, x, y, g, 1e-5, 1e-4, 1e-4, 0.0)
+
+
+def test_g12b_margin_fixture_on_the_framework_layers():
+    """G12b = G12 on an input whose pre-ReLU activations all keep a margin from zero (make_goldens.g12b_relu_margin_grads):
+    the fixture says so itself, and the package's module on ATen reproduces the reference's gradients on it."""
+    g = load_golden("g12b_cost_regularisation_grads_margin")
+    assert float(g["layer_margins"].min()) > float(g["margin"]) >= 3e-5 and len(g["layer_margins"]) == 7
     net, x, y = _costreg_train_step(g, "cpu", "fp32")
     _check_costreg_grads(net, x, y, g, 1e-5, 1e-4, 1e-4, 0.0)
 
@@ -177,3 +186,52 @@ def test_g12_cost_network_training_step_on_the_hip_kernels(gpu, precision):
         _check_costreg_grads(net, x, y, g, TOL, TOL, TOL, 0.0)
     else:
         _check_costreg_grads(net, x, y, g, TOL, None, 2e-2, 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_g12b_training_step_far_from_every_relu_kink(gpu, precision):
+    """The pin of the bf16x3 TRAINING route (VERDICT r4 task 6).  On G12's input the route can only be held to 2e-2 in norm because
+    one activation within the forward noise of zero flips its ReLU; G12b's input keeps every pre-ReLU value of every layer further
+    than 3e-5 x rms from zero (a 7-sigma error would be needed), so here the route is held ELEMENT-WISE: 1e-3 of each gradient
+    tensor's scale with no outliers allowed, and 1e-4 in norm; the fp32 route 1e-4 element-wise as on G12.  A wrong term in any
+    backward kernel shows at these bounds."""
+    g = load_golden("g12b_cost_regularisation_grads_margin")
+    net, x, y = _costreg_train_step(g, gpu, precision)
+    if precision == "fp32":
+        _check_costreg_grads(net, x, y, g, TOL, TOL, TOL, 0.0)
+    else:
+        _check_costreg_grads(net, x, y, g, TOL, 1e-3, 1e-4, 0.0)
+
+
+@pytest.mark.gpu
+def test_sgd_trajectories_of_the_two_training_routes_agree(gpu):
+    """30 steps of plain SGD on G12's input and loss, once on the fp32 route and once on bf16x3 (the default under autograd):
+    the two loss trajectories stay within 1e-4 relative of each other at EVERY step -- training on the split-bf16 matrix path
+    converges like the fp32 one (tools/train.py over mvs_models/mvsnet.py:73-113)."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    g = load_golden("g12_cost_regularisation_grads")
+    shape = tuple(int(v) for v in g["in_shape"])
+    x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), int(g["input_seed"]))).reshape(shape).abs().to(gpu)
+    losses = {}
+    for precision in ("fp32", "bf16x3"):
+        net = CostRegNet3DGS(256, 64).train()
+        net.matrix_precision = precision
+        with torch.no_grad():
+            lcg_fill_state(net, int(g["weight_seed"]))
+        net = net.to(gpu)
+        R = torch.from_numpy(lcg_uniform(2 * int(np.prod(shape[2:])) * shape[0], int(g["r_seed"]))).reshape(shape[0], 2, *shape[2:]).to(gpu)
+        opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+        tr = []
+        for step in range(30):
+            opt.zero_grad(set_to_none=True)
+            y = net(x)
+            loss = ((y - R) ** 2).mean()          # a loss with a minimum: the trajectory descends instead of running away
+            loss.backward()
+            opt.step()
+            tr.append(float(loss))
+        losses[precision] = np.array(tr)
+    a, b = losses["fp32"], losses["bf16x3"]
+    assert a[-1] < a[0], f"the fp32 trajectory does not descend: {a[0]:.4f} -> {a[-1]:.4f}"
+    rel = np.abs(a - b) / np.abs(a)
+    assert rel.max() <= 1e-4, f"loss trajectories part: max relative difference {rel.max():.2e} at step {int(rel.argmax())}"

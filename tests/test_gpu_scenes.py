@@ -1,0 +1,214 @@
+"""Scene-level GPU tests at the view counts the shipped TEST pipelines run (VERDICT r4 missing #1, tasks 3, 4b, 8).
+
+`configs/mvsdet_res50_2x_low_res.py:105-126` evaluates with n_images = 81 (up to 80 source views; the de-duplication of
+multiview_pipeline.py:432-441 makes the count VARY per scene), `mvsdet_arkit.py:114` with 101.  Everything here runs the
+real modules -- CostRegNet3DGS, IndoorImVoxelNeck, the head convolutions -- on our kernels and demands, scene by scene,
+the bits of that scene run alone.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _modules(C, neck_out, gpu, seed=0, n_classes=18, n_reg=6):
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    from mvsdet_amd.head import NerfDetHeadConvs
+    from mvsdet_amd.neck import IndoorImVoxelNeck
+    torch.manual_seed(seed)
+    net = CostRegNet3DGS(C).to(gpu).eval()
+    neck = IndoorImVoxelNeck(C, neck_out, [1, 1, 1]).to(gpu).eval()
+    head = NerfDetHeadConvs(n_classes, 3, neck_out, n_reg).to(gpu).eval()
+    return net, neck, head
+
+
+def _keep(out):
+    """The small results of a scene, cloned on the CURRENT stream (reading through the holder makes it wait for the side
+    stream), so that the multi-gigabyte variance volume can go."""
+    kept = {k: out[k].clone() for k in ("volume", "valid", "prob_volume", "est_depth", "depth_coding")}
+    kept["neck"] = [t.clone() for t in out["neck"]]
+    kept["head"] = [[t.clone() for t in part] for part in out["head"]]
+    return kept
+
+
+def _same(a, b, what):
+    for k in ("volume", "valid", "prob_volume", "est_depth", "depth_coding"):
+        assert torch.equal(a[k], b[k]), f"{what}: {k} differs"
+    for i, (x, y) in enumerate(zip(a["neck"], b["neck"])):
+        assert torch.equal(x, y), f"{what}: neck level {i} differs"
+    for pa, pb in zip(a["head"], b["head"]):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            assert torch.equal(x, y), f"{what}: head level {i} differs"
+
+
+def _fresh_hotpath(net, neck, head, grid, vox, D):
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    return MVSDetHotPath(grid, vox, [0.2, 5.0], D, topk=3, cost_regularization=net, neck_3d=neck, bbox_head=head)
+
+
+def _solo(net, neck, head, grid, vox, D, feat, meta, gpu):
+    """The scene alone: a new driver, the network's buffer pool emptied, the device idle before and after."""
+    torch.cuda.synchronize(gpu)
+    net._scl.clear()
+    hp = _fresh_hotpath(net, neck, head, grid, vox, D)
+    with torch.no_grad():
+        out = hp.forward_scene(feat, meta)
+        kept = _keep(out)
+    torch.cuda.synchronize(gpu)
+    return kept
+
+
+@pytest.mark.parametrize("per_view_K", [False, True])
+def test_test_time_view_counts_in_sequence(gpu, per_view_K):
+    """79, 80, 63, 80 views back to back (the shipped ScanNet test pipeline: <= 80 source views, fewer after the de-duplication) at
+    the reference-true shape -- 256 channels, 12 planes, 60 x 80 maps, 40 x 40 x 16 grid --, with the real cost network, neck and
+    head: the same bits as each scene alone, on one stream (the network on two halves of the views) and with the detector on the
+    side stream; no synchronisation between the scenes.  `per_view_K`: the ARKit form (a list of intrinsics)."""
+    from mvsdet_amd import synthetic
+    C, D, hw, grid, vox = 256, 12, (60, 80), [40, 40, 16], [0.16, 0.16, 0.2]
+    net, neck, head = _modules(C, 128, gpu)
+    counts = (79, 80, 63, 80)
+    big = synthetic.make_features(80, C, hw, seed=5).to(gpu)
+    scenes = [(big[:n] if i % 2 == 0 else big[80 - n:], synthetic.make_img_meta(n, hw, seed=40 + i, per_view_intrinsics=per_view_K))
+              for i, n in enumerate(counts)]
+    solo = [_solo(net, neck, head, grid, vox, D, f, m, gpu) for f, m in scenes]
+    assert all(int((s["valid"] > 0).sum()) > 0 for s in solo)
+    for overlap in (False, True):
+        hp = _fresh_hotpath(net, neck, head, grid, vox, D)
+        hp.overlap_detector = overlap
+        with torch.no_grad():
+            got = []
+            for f, m in scenes:                      # no synchronisation in between
+                out = hp.forward_scene(f, m)
+                got.append(_keep(out))
+                del out
+        torch.cuda.synchronize(gpu)
+        for i, (a, b) in enumerate(zip(solo, got)):
+            _same(a, b, f"scene {i} ({counts[i]} views), overlap_detector={overlap}")
+
+
+def test_hundred_views_arkit_test_pipeline(gpu):
+    """mvsdet_arkit.py:114: 101 images = 100 source views with per-view intrinsics and the ARKit head: two such scenes and an
+    87-view one in sequence, detector on the side stream, against each scene alone."""
+    from mvsdet_amd import synthetic
+    from mvsdet_amd.head import NerfDetHeadConvs
+    C, D, hw, grid, vox = 256, 12, (60, 80), [40, 40, 16], [0.16, 0.16, 0.2]
+    net, neck, _ = _modules(C, 128, gpu)
+    torch.manual_seed(1)
+    head = NerfDetHeadConvs(17, 3, 128, 7, arkit_head=True).to(gpu).eval()
+    big = synthetic.make_features(100, C, hw, seed=6).to(gpu)
+    scenes = [(big[:n], synthetic.make_img_meta(n, hw, seed=60 + i, per_view_intrinsics=True)) for i, n in enumerate((100, 87, 100))]
+    solo = [_solo(net, neck, head, grid, vox, D, f, m, gpu) for f, m in scenes]
+    hp = _fresh_hotpath(net, neck, head, grid, vox, D)
+    hp.overlap_detector = True
+    with torch.no_grad():
+        got = [_keep(hp.forward_scene(f, m)) for f, m in scenes]
+    torch.cuda.synchronize(gpu)
+    for i, (a, b) in enumerate(zip(solo, got)):
+        _same(a, b, f"scene {i}")
+
+
+def test_soak_random_view_counts_streams_and_cache_flushes(gpu):
+    """200 scenes, view counts drawn from [40, 80], detector on the side stream, the network on one or two streams, the CALLER
+    alternating between the default stream and two streams of its own, results read on yet another stream through the
+    SceneOutputs holder, `torch.cuda.empty_cache()` every 17 scenes: every scene's volume, depth distribution, neck and head
+    bit-equal to that scene alone.  (Buffers kept across calls -- the network's SCL / PSCL pool -- are ordered by events, not
+    by stream ids: mvsdet_amd/scratch.py.)"""
+    from mvsdet_amd import synthetic
+    C, D, hw, grid, vox = 64, 8, (24, 32), [16, 16, 8], [0.4, 0.4, 0.4]
+    net, neck, head = _modules(C, 64, gpu, seed=2)
+    rng = random.Random(7)
+    big = synthetic.make_features(80, C, hw, seed=9).to(gpu)
+    distinct = []
+    for j in range(14):
+        n = rng.randint(40, 80)
+        lo = rng.randint(0, 80 - n)
+        distinct.append((big[lo:lo + n], synthetic.make_img_meta(n, hw, seed=100 + j)))
+    solo = [_solo(net, neck, head, grid, vox, D, f, m, gpu) for f, m in distinct]
+    hp = _fresh_hotpath(net, neck, head, grid, vox, D)
+    hp.overlap_detector = True
+    callers = [torch.cuda.default_stream(gpu), torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
+    reader = torch.cuda.Stream(device=gpu)
+    torch.cuda.synchronize(gpu)
+    results = []
+    with torch.no_grad():
+        for i in range(200):
+            j = rng.randrange(len(distinct))
+            net.view_streams = rng.choice((1, 2))
+            hp.overlap_detector = rng.random() < 0.8
+            f, m = distinct[j]
+            with torch.cuda.stream(callers[i % 3]):
+                out = hp.forward_scene(f, m)
+            # with the side stream the holder orders ANY reading stream; without it the outputs belong to the caller's stream
+            read_on = (reader if i % 2 else callers[(i + 1) % 3]) if hp.overlap_detector else callers[i % 3]
+            with torch.cuda.stream(read_on):
+                kept = _keep(out)
+            results.append((j, kept))
+            del out
+            if i % 17 == 16:
+                torch.cuda.empty_cache()
+    torch.cuda.synchronize(gpu)
+    for i, (j, kept) in enumerate(results):
+        _same(solo[j], kept, f"soak scene {i} (distinct scene {j}, {distinct[j][0].shape[0]} views)")
+    assert len(net._scl) <= net._scl.capacity
+
+
+def test_forward_scenes_runs_the_detector_once_on_the_batch(gpu):
+    """mvsdet.py:681-698 stacks the scenes' volumes and calls neck_3d once.  `forward_scenes`: every scene's own outputs (volume,
+    depth distribution) bit-equal to `forward_scene` of that scene; the batched neck / head rows equal to the per-scene
+    detector's within the summation order of the split levels (1e-5 of each tensor's scale), with and without the side stream."""
+    from mvsdet_amd import synthetic
+    C, D, hw, grid, vox = 64, 8, (24, 32), [16, 16, 8], [0.4, 0.4, 0.4]
+    net, neck, head = _modules(C, 64, gpu, seed=3)
+    scenes = [(synthetic.make_features(n, C, hw, seed=20 + i).to(gpu), synthetic.make_img_meta(n, hw, seed=20 + i))
+              for i, n in enumerate((5, 9, 6, 8))]
+    solo = [_solo(net, neck, head, grid, vox, D, f, m, gpu) for f, m in scenes]
+    for overlap in (False, True):
+        hp = _fresh_hotpath(net, neck, head, grid, vox, D)
+        hp.overlap_detector = overlap
+        with torch.no_grad():
+            res = hp.forward_scenes([f for f, _ in scenes], [m for _, m in scenes])
+            assert tuple(res["volume"].shape) == (4, C, *grid) and len(res["scenes"]) == 4
+            got = [_keep(o) for o in res["scenes"]]
+            stacked = [t.clone() for t in res["neck"]]
+        torch.cuda.synchronize(gpu)
+        for i, (a, b) in enumerate(zip(solo, got)):
+            for k in ("volume", "valid", "prob_volume", "est_depth", "depth_coding"):
+                assert torch.equal(a[k], b[k]), f"scene {i}: {k}"
+            for lvl, (x, y) in enumerate(zip(a["neck"], b["neck"])):
+                assert torch.equal(stacked[lvl][i:i + 1], y)
+                s = float(x.abs().max())
+                assert float((x - y).abs().max()) <= 1e-5 * max(1.0, s), f"scene {i} neck level {lvl}"
+            for pa, pb in zip(a["head"], b["head"]):
+                for lvl, (x, y) in enumerate(zip(pa, pb)):
+                    s = float(x.abs().max())
+                    assert float((x - y).abs().max()) <= 1e-5 * max(1.0, s), f"scene {i} head level {lvl}"
+
+
+def test_event_pool_orders_foreign_streams(gpu):
+    """mvsdet_amd/scratch.EventPool: a buffer released on one stream and acquired on another is only written after the first
+    stream's work on it is done (a long-running fill followed by an overwrite from the other stream must not be overtaken)."""
+    from mvsdet_amd.scratch import EventPool
+    pool = EventPool(4)
+    s1, s2 = torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)
+    n = 1 << 26
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            lease = pool.acquire("k", lambda: torch.zeros(n, device=gpu), lambda b: (b,), gpu)
+            buf = lease.buf
+            for _ in range(20):
+                buf.add_(1.0)              # a long queue of work on s1
+            snap1 = buf.sum(dtype=torch.float64)
+            pool.release([lease], gpu)
+        with torch.cuda.stream(s2):
+            lease2 = pool.acquire("k", lambda: torch.zeros(n, device=gpu), lambda b: (b,), gpu)
+            assert lease2.buf is buf       # the same memory, handed to the other stream
+            lease2.buf.fill_(-5.0)
+            snap2 = lease2.buf.sum(dtype=torch.float64)
+            lease2.buf.zero_()
+            pool.release([lease2], gpu)
+        torch.cuda.synchronize(gpu)
+        assert float(snap1) == 20.0 * n and float(snap2) == -5.0 * n
