@@ -171,33 +171,46 @@ def run_gpu(args, w, rank, world, device):
 
 
 def stage_breakdown(w, hp, scene, device, reps=3):
-    """Per-stage HIP-event timings of one scene (reported as extras; not the headline)."""
+    """Per-stage HIP-event timings of one scene (reported as extras; not the headline).  Stage 1 is timed on the SAME entry points
+    and streams as the timed loop (`sweep_geometry_async` on its side stream, `cost_volume_tabled` behind its event), after one
+    untimed pass that leaves the 50 GB output block in the allocator -- so `plane_sweep_variance` here and `roofline.kernel_ms`
+    are one measurement taken twice, not two routes (round 4's line timed the stand-alone packed entry point here, which
+    allocates inside the event pair and runs the geometry kernel in front of the sweep: 0.8 ms more for the same kernels)."""
     from mvsdet_amd import ops
-    names = ["host_prep+h2d (serial here; prefetched one step ahead in the timed loop)", "pack", "plane_sweep_geometry+variance", "depth_prob_topk",
-             "backproject_mean"]
+    names = ["host_prep+h2d (serial here; prefetched one step ahead in the timed loop)", "pack", "plane_sweep_geometry (side stream, beside the packing)",
+             "plane_sweep_variance", "depth_prob_topk", "backproject_mean"]
     acc = {n: [] for n in names}
-    for rep in range(reps):
+    for rep in range(reps + 1):
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         fresh = dict(scene.meta)                              # jittered cameras: not served from the content cache
         fresh["lidar2img"] = dict(scene.meta["lidar2img"], extrinsic=[e + np.float32(1e-6) * (rep + 1) for e in scene.meta["lidar2img"]["extrinsic"]])
         geo = hp.prepare_scene(fresh, device)
         torch.cuda.synchronize(device)
-        acc[names[0]].append((time.perf_counter() - t0) * 1e3)
-        es = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        host_ms = (time.perf_counter() - t0) * 1e3
+        es = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        tab = hp.sweep_geometry_async(geo, w["H"], w["W"], events=True)
         es[0].record()
         packed = ops.pack_features(scene.features)
         es[1].record()
-        var = ops.plane_sweep_variance_packed(packed, geo.neighbor_ids, geo.proj_rel, geo.depth_values, w["C"], w["H"], w["W"])
+        torch.cuda.current_stream(device).wait_event(tab[1])
         es[2].record()
-        prob, off, ed, en, ei, avg = hp.depth_distribution(scene.cost_logits)
+        var = hp.cost_volume_tabled(packed, geo, tab[:2], w["C"], w["H"], w["W"])
         es[3].record()
-        vol, valid = hp.lift(scene.features, packed, geo, ed, en)
+        prob, off, ed, en, ei, avg = hp.depth_distribution(scene.cost_logits)
         es[4].record()
+        vol, valid = hp.lift(scene.features, packed, geo, ed, en)
+        es[5].record()
         torch.cuda.synchronize(device)
-        for i in range(4):
-            acc[names[i + 1]].append(es[i].elapsed_time(es[i + 1]))
         del var
+        if rep == 0:
+            continue                                          # the pass that grows the allocator's pools
+        acc[names[0]].append(host_ms)
+        acc[names[1]].append(es[0].elapsed_time(es[1]))
+        acc[names[2]].append(tab[2].elapsed_time(tab[3]))
+        acc[names[3]].append(es[2].elapsed_time(es[3]))
+        acc[names[4]].append(es[3].elapsed_time(es[4]))
+        acc[names[5]].append(es[4].elapsed_time(es[5]))
     return {n: round(float(np.median(v)), 4) for n, v in acc.items()}
 
 
@@ -230,7 +243,9 @@ def run_train(args, w, rank, world, device):
         net = CostRegNet3DGS(w["C"]).to(device).train()
     else:
         net = PointwiseCostReg(w["C"]).to(device)
-    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=None) if world > 1 else net
+    # find_unused_parameters=True as the reference sets it (configs/mvsdet_res50_2x_low_res_depth.py:200: three of the four FPN
+    # outputs take no part in the loss); here every parameter of the cost network is used, the flag only costs its graph walk
+    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=None, find_unused_parameters=True) if world > 1 else net
     opt = torch.optim.SGD(net.parameters(), lr=1e-4)
     hp = MVSDetHotPath(N_VOXELS, VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3, cost_regularization=model)
     scenes = [SceneInputs(w, seed=rank * 100 + i, device=device) for i in range(args.scene_pool)]
@@ -738,6 +753,27 @@ def launch_env():
     return env
 
 
+def device_binding(rank, local_rank, world, device):
+    """Which physical device every rank REALLY computes on: (rank, local_rank, torch device index, PCI bus id, the rank's
+    HIP_VISIBLE_DEVICES) of all ranks, gathered through the process group.  `torch.cuda.set_device(local_rank)` is asserted
+    here (current device == the one this rank was given), and on a node with at least `world` devices two ranks on one bus id
+    -- a mis-bound rank -- stop the run instead of producing a number."""
+    cur = torch.cuda.current_device()
+    assert cur == device.index, f"rank {rank}: current device {cur} is not the device it was bound to ({device.index})"
+    props = torch.cuda.get_device_properties(device)
+    bus = getattr(props, "pci_bus_id", None)
+    mine = {"rank": rank, "local_rank": local_rank, "device": int(device.index), "pci_bus_id": bus,
+            "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES")}
+    if world <= 1:
+        return [mine]
+    allb = [None] * world
+    torch.distributed.all_gather_object(allb, mine)
+    if torch.cuda.device_count() >= world:
+        seen = [(b["device"], b["pci_bus_id"], b["HIP_VISIBLE_DEVICES"]) for b in allb]
+        assert len(set(seen)) == world, f"two ranks share a device: {allb}"
+    return allb
+
+
 def count_ranks(world, device=None):
     """How many ranks really take part: every rank adds 1 through the process group (1 without one)."""
     if world <= 1:
@@ -863,6 +899,7 @@ def main():
         from mvsdet_amd import parallel
         # "nccl" is RCCL on ROCm; MVSDET_DIST_BACKEND=gloo lets two ranks share one GPU in a dry run
         parallel.init_distributed(os.environ.get("MVSDET_DIST_BACKEND", "nccl"), device)
+    binding = device_binding(rank, local_rank, world, device)
 
     name = args.workload
     if name == "auto":
@@ -884,7 +921,7 @@ def main():
                 "config": {"workload": name, "views": w["N"], "channels": w["C"], "depth_planes": w["D"],
                            "feat_hw": [w["H"], w["W"]], "voxels": w.get("voxels", N_VOXELS),
                            "parallelism": f"view-sharded x{world}: 1 all-gather (feature shards) + 1 all-reduce (voxel buffer) per scene"},
-                "roofline": None, "ranks_seen": ranks_seen, "launch_env": launch_env(), "checksum": checksum,
+                "roofline": None, "ranks_seen": ranks_seen, "launch_env": launch_env(), "device_binding": binding, "checksum": checksum,
                 "views_in_fullest_voxel": vmax}), flush=True)
         if world > 1:
             import torch.distributed as dist
@@ -907,7 +944,7 @@ def main():
                            "feat_hw": [w["H"], w["W"]], "scenes_per_step_per_gpu": 1,
                            "parallelism": f"ddp x{world}, gradient all-reduce only"},
                 "roofline": backward_rooflines(w, device)["backward_sweep"], "ranks_seen": ranks_seen,
-                "launch_env": launch_env(), "checksum": checksum}), flush=True)
+                "launch_env": launch_env(), "device_binding": binding, "checksum": checksum}), flush=True)
         if world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()
@@ -944,7 +981,7 @@ def main():
                      "kernel_ms_min_median_max": [round(float(f(hp.sweep_ms_each)), 4) for f in (np.min, np.median, np.max)],
                      "stage1_frac_incl_table": round(stage1 / HBM_PEAK_GBPS, 4),
                      "algorithmic_bytes_per_launch": bytes_launch},
-        "ranks_seen": ranks_seen, "launch_env": launch_env(), "checksum": checksum,
+        "ranks_seen": ranks_seen, "launch_env": launch_env(), "device_binding": binding, "checksum": checksum,
     }
     if w.get("chunk"):
         line["config"]["views_per_launch"] = w["chunk"]

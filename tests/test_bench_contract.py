@@ -67,6 +67,23 @@ def test_training_mode_two_rank_ddp_dry_run(gpu):
 
 
 @pytest.mark.timeout(600)
+def test_training_mode_with_the_real_cost_network_two_rank_dry_run(gpu):
+    """`--mode train --with-cost-network`: the real CostRegNet3DGS under DistributedDataParallel with
+    find_unused_parameters=True (configs/mvsdet_res50_2x_low_res_depth.py:200), two ranks over gloo; the record names the
+    device every rank was bound to."""
+    env = dict(os.environ, MVSDET_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--with-cost-network",
+           "--steps", "2", "--warmup", "1", "--workload", "tiny_3v_8d_48x64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["mode"] == "train" and d["n_gpus"] == 2 and d["value"] > 0 and d["checksum"] > 0 and "real cost network" in d["metric"]
+    b = d["device_binding"]
+    assert [x["rank"] for x in b] == [0, 1] and [x["local_rank"] for x in b] == [0, 1] and all(x["device"] == 0 for x in b)   # one GPU on this box
+
+
+@pytest.mark.timeout(600)
 def test_view_sharded_mode_two_rank_dry_run(gpu):
     """--mode view-sharded on the device stages: two ranks share the GPU over gloo, each sweeping its half of the views;
     one all-gather + one all-reduce per scene."""
