@@ -565,17 +565,34 @@ def full_chain_rate(device, steps=10):
         e1.record()
         torch.cuda.synchronize(device)
     neck_ms = e0.elapsed_time(e1) / 3
+    # the detector on a BATCH of scenes (mvsdet.py:695-696 stacks the volumes; MVSDetHotPath.forward_scenes): one 40 x 40 x 16 volume
+    # is 200 blocks for 256 CUs at the neck's largest level, four fill the chip
+    det = {}
+    with torch.no_grad():
+        for bsz in (1, 4):
+            vb = vol.expand(bsz, -1, -1, -1, -1).contiguous()
+            head(neck(vb))
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(3):
+                head(neck(vb))
+            e1.record()
+            torch.cuda.synchronize(device)
+            det[bsz] = e0.elapsed_time(e1) / 3 / bsz
+        del vb
     ntfl = IndoorImVoxelNeck.flops(1, N_VOXELS, wr["C"], 128) / 1e12
     # the 3x3x3 layers (all but ~2 % of the work) run on bf16 MFMA with three terms per product: 3 x useful FLOP
     # against the dense bf16 peak
     neck_roof = {"bound": "mfma", "achieved": round(3 * ntfl / neck_ms * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s",
                  "frac": round(3 * ntfl / neck_ms * 1e3 / 2500.0, 4), "useful_TFLOPs": round(ntfl / neck_ms * 1e3, 1),
                  "kernel": "IndoorImVoxelNeck forward (3x3x3 layers on bf16x3, the small levels split over the input channels; "
-                           "1x1x1 / transposed 2x2x2 layers as GEMMs)",
+                           "1x1x1 / transposed 2x2x2 layers on the bf16x3 GEMM kernel of csrc/neck_gemm.hip)",
                  "kernel_ms": round(neck_ms, 3)}
     return {"workload": "scannet_ref_40v_12d_60x80", "chain": "a1..a10 + CostRegNet_3DGS + IndoorImVoxelNeck + head convolutions, eval",
             "scenes_per_sec": round(steps / el, 3), "scenes_per_sec_pipelined": round(steps / el_overlap, 3),
             "cost_network_roofline": roof, "neck_roofline": neck_roof,
+            "detector_batch1": {"ms_per_scene": round(det[1], 3), "what": "IndoorImVoxelNeck + head convolutions on one volume"},
+            "detector_batch4": {"ms_per_scene": round(det[4], 3), "what": "the same on four stacked volumes (forward_scenes), per scene"},
             "ms_per_scene": round(el / steps * 1e3, 3),
             "detector_on_side_stream": {"scenes_per_sec": round(steps / el_overlap, 3), "ms_per_scene": round(el_overlap / steps * 1e3, 3),
                                         "note": "depth distribution, lifting, neck and head of scene i on their own stream beside scene i+1's packing, sweep and conv0 "

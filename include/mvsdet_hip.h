@@ -483,6 +483,22 @@ int mvsdet_store_pattern_probe_f32(float* var, int N, int C, int D, int H, int W
 int mvsdet_store_pattern_probe_f16(void* var, int N, int C, int D, int H, int W, int out_w_pitch, int tile_w,
                                    int planes_per_block, mvsdet_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The 3-D neck's GEMM-shaped layers (mmdet3d/models/necks/imvoxel_neck.py:166-180, 196-217) on the bf16 matrix cores with
+ * three-term split operands, bias / ReLU / the 2x2x2 interleave in the epilogue (csrc/neck_gemm.hip).
+ * wsplit = mvsdet_gemm_split_weight of the (M, K) fp32 row-major matrix with the eval-mode BatchNorm's scale folded in
+ * (M % 128 == 0, K % 32 == 0): [M/32][K/16][2 pieces][64 lanes][8] bf16.
+ *   mvsdet_conv3d_k1_s2_bf16x3:  out (N,Cout,D/2,H/2,W/2) = [relu](W (Cout,Cin) x[:, :, ::2, ::2, ::2] + bias), D, H, W even
+ *   mvsdet_convT3d_k2_s2_bf16x3: out (N,Cout,2D,2H,2W)[.., 2d+p, 2h+q, 2w+r] = [relu](sum_c x[c][d][h][w] W[c][o][p][q][r] + bias[o]);
+ *                                the matrix has the 8*Cout rows m = 8 o + 4 p + 2 q + r (ConvTranspose3d weight permuted (1,2,3,4,0))
+ * ------------------------------------------------------------------------------------------- */
+size_t mvsdet_gemm_split_weight_bytes(int M, int K);   /* 0 if (M, K) is not supported */
+int mvsdet_gemm_split_weight(const float* wmat, void* wsplit, int M, int K, mvsdet_stream_t stream);
+int mvsdet_conv3d_k1_s2_bf16x3(const float* x, const void* wsplit, const float* bias, float* out, int N, int Cin, int Cout, int D,
+                               int H, int W, int relu, mvsdet_stream_t stream);
+int mvsdet_convT3d_k2_s2_bf16x3(const float* x, const void* wsplit, const float* bias, float* out, int N, int Cin, int Cout, int D,
+                                int H, int W, int relu, mvsdet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,23 +118,35 @@ def _split_weight(conv: nn.Module, order: int | None = None) -> Tensor:
     return cached[1]
 
 
-def _gemm_weight(conv: nn.Module, bn: nn.BatchNorm3d):
-    """The 1x1x1 convolution (Cout x Cin) or the ConvTranspose3d(k=2, s=2) (8*Cout x Cin, rows ordered (p, q, r, o)) as ONE matrix
-    with the eval-mode BatchNorm's scale folded in, and the matching bias column; kept on the module like the split weights
-    (three tiny kernels per layer and call otherwise)."""
+# the 1x1x1 stride-2 shortcut and the kernel-2 stride-2 transposed layers on our GEMM kernel (csrc/neck_gemm.hip: bf16x3, bias, ReLU
+# and the 2x2x2 interleave in the epilogue) where their shapes allow; False: one rocBLAS fp32 GEMM + ATen glue each (rounds 2-4)
+GEMM_BF16X3 = os.environ.get("MVSDET_NECK_GEMM", "bf16x3") == "bf16x3"
+
+
+def _gemm_weight(conv: nn.Module, bn: nn.BatchNorm3d, split: bool = False):
+    """The 1x1x1 convolution (Cout x Cin) or the ConvTranspose3d(k=2, s=2) (8*Cout x Cin) as ONE matrix with the eval-mode
+    BatchNorm's scale folded in, and the matching bias; kept on the module like the split weights (three tiny kernels per layer
+    and call otherwise).  split=False: (wmat fp32 with rows (p, q, r, o), bias column (1, 8 Cout, 1)) for torch.baddbmm;
+    split=True: (the bf16 pieces of the matrix with rows 8 o + 4 p + 2 q + r in the GEMM kernel's fragment order, bias (Cout,))."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.device) + tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    key = (w.data_ptr(), w._version, w.device, bool(split)) + tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
     cached = conv.__dict__.get("_mvs_wmat")
     if cached is None or cached[0] != key:
         scale, shift = _bn_affine(bn)
         with torch.no_grad():
             if isinstance(conv, nn.ConvTranspose3d):
                 cout = conv.out_channels
-                wmat = (w.detach() * scale.view(1, -1, 1, 1, 1)).permute(2, 3, 4, 1, 0).reshape(8 * cout, w.shape[0]).contiguous()
-                bias = shift.repeat(8).view(1, -1, 1).contiguous()
+                ws = w.detach() * scale.view(1, -1, 1, 1, 1)
+                if split:
+                    wmat, bias = ws.permute(1, 2, 3, 4, 0).reshape(8 * cout, w.shape[0]).contiguous(), shift.contiguous()
+                else:
+                    wmat, bias = ws.permute(2, 3, 4, 1, 0).reshape(8 * cout, w.shape[0]).contiguous(), shift.repeat(8).view(1, -1, 1).contiguous()
             else:
                 wmat = (w.detach().reshape(conv.out_channels, -1) * scale[:, None]).contiguous()
-                bias = shift.view(1, -1, 1).contiguous()
+                bias = shift.contiguous() if split else shift.view(1, -1, 1).contiguous()
+            if split:
+                from . import ops
+                wmat = ops.gemm_split_weight(wmat)
         cached = (key, wmat, bias)
         conv.__dict__["_mvs_wmat"] = cached
     return cached[1], cached[2]
@@ -173,11 +185,17 @@ class ResModule(nn.Module):
             identity = x
             if self.stride != 1:   # 1x1x1 stride-2 convolution + BN: one GEMM on the sub-sampled volume
                 ds = self.downsample
-                xs = x[:, :, ::self.stride, ::self.stride, ::self.stride]
-                n, c, d, h, w = xs.shape
-                wmat, bias = _gemm_weight(ds.conv, ds.bn)
-                identity = torch.baddbmm(bias, wmat.unsqueeze(0).expand(n, -1, -1), xs.reshape(n, c, -1))
-                identity = identity.view(n, -1, d, h, w)
+                from . import ops
+                if (GEMM_BF16X3 and self.stride == 2 and ops.gemm_layer_ok(ds.conv.out_channels, ds.conv.in_channels)
+                        and not any(v % 2 for v in x.shape[2:])):
+                    wq, bias = _gemm_weight(ds.conv, ds.bn, split=True)      # the sub-sampling is the kernel's gather
+                    identity = ops.conv3d_k1_s2_bf16x3(x, wq, bias, ds.conv.out_channels)
+                else:
+                    xs = x[:, :, ::self.stride, ::self.stride, ::self.stride]
+                    n, c, d, h, w = xs.shape
+                    wmat, bias = _gemm_weight(ds.conv, ds.bn)
+                    identity = torch.baddbmm(bias, wmat.unsqueeze(0).expand(n, -1, -1), xs.reshape(n, c, -1))
+                    identity = identity.view(n, -1, d, h, w)
             h0 = _conv_k3(x, self.conv0.conv, self.conv0.bn, True)
             return _conv_k3(h0, self.conv1.conv, self.conv1.bn, True, identity)   # relu(bn(conv1) + identity)
         identity = x
@@ -201,6 +219,10 @@ class _UpBlock(nn.Sequential):
             cout = deconv.out_channels
             # out[:, o, 2i+p, 2j+q, 2k+r] = sum_c x[:, c, i, j, k] * W[c, o, p, q, r]: one (8*Cout x Cin) GEMM with the BatchNorm's
             # shift as its bias; the ReLU writes the interleaved (N, Cout, 2D, 2H, 2W) tensor directly (one pass, no copy)
+            from . import ops
+            if GEMM_BF16X3 and ops.gemm_layer_ok(8 * cout, cin):
+                wq, bias = _gemm_weight(deconv, bn, split=True)      # bias, ReLU and the 2x2x2 interleave in the GEMM's epilogue
+                return _conv_k3(ops.convT3d_k2_s2_bf16x3(x, wq, bias, cout, True), self[3], self[4], True)
             wmat, bias = _gemm_weight(deconv, bn)
             y = torch.baddbmm(bias, wmat.unsqueeze(0).expand(n, -1, -1), x.reshape(n, cin, -1)).view(n, 2, 2, 2, cout, d, h, w)
             out = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), dtype=x.dtype, device=x.device)

@@ -896,6 +896,59 @@ def scl_pack(x: Tensor, out: Optional[SclTensor] = None) -> SclTensor:
     return out
 
 
+def gemm_split_weight(wmat: Tensor) -> Tensor:
+    """(M, K) fp32 row-major -> the fragment-ordered bf16 pieces the neck's GEMM-shaped layers stream from L2
+    ([M/32][K/16][2 pieces][64 lanes][8] bf16; M % 128 == 0, K % 32 == 0: include/mvsdet_hip.h)."""
+    _req(wmat, "wmat", dim=2)
+    M, K = wmat.shape
+    lib = _lib.load()
+    nbytes = int(lib.mvsdet_gemm_split_weight_bytes(int(M), int(K)))
+    if nbytes == 0:
+        raise ValueError(f"gemm_split_weight: ({M}, {K}) is not (128 m, 32 k)")
+    w = wmat.detach().contiguous()
+    out = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mvsdet_gemm_split_weight(_lib.ptr(w), _lib.ptr(out), int(M), int(K), _stream(w)), "gemm_split_weight")
+    return out
+
+
+def gemm_layer_ok(rows: int, cin: int) -> bool:
+    """Whether the neck's GEMM kernels take a layer with this many matrix rows (Cout, or 8 Cout for the transposed one) and Cin."""
+    return rows % 128 == 0 and cin % 32 == 0
+
+
+def conv3d_k1_s2_bf16x3(x: Tensor, wsplit: Tensor, bias: Tensor, cout: int, relu: bool = False) -> Tensor:
+    """Conv3d(kernel 1, stride 2) + bias [+ ReLU] of an (N,Cin,D,H,W) tensor with even D, H, W: one GEMM over the sub-sampled voxels,
+    the sub-sampling in its gather (imvoxel_neck.py:196-217 `downsample` with the eval-mode BatchNorm folded in)."""
+    _req(x, "x", dim=5)
+    _req(bias, "bias", dim=1)
+    x = x.contiguous()
+    N, Cin, D, H, W = x.shape
+    if D % 2 or H % 2 or W % 2 or bias.numel() != cout:
+        raise ValueError("conv3d_k1_s2_bf16x3: D, H, W must be even and bias have Cout elements")
+    out = torch.empty((N, cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_conv3d_k1_s2_bf16x3(_lib.ptr(x), _lib.ptr(wsplit), _lib.ptr(bias.contiguous()), _lib.ptr(out), N, Cin,
+                                                          int(cout), D, H, W, int(relu), _stream(x)), "conv3d_k1_s2_bf16x3")
+    return out
+
+
+def convT3d_k2_s2_bf16x3(x: Tensor, wsplit: Tensor, bias: Tensor, cout: int, relu: bool = True) -> Tensor:
+    """ConvTranspose3d(kernel 2, stride 2) + bias [+ ReLU]: (N,Cin,D,H,W) -> (N,Cout,2D,2H,2W), the 2x2x2 interleave written by the
+    GEMM's epilogue (imvoxel_neck.py:166-180).  `wsplit` = gemm_split_weight of the (8 Cout, Cin) matrix with rows 8 o + 4 p + 2 q + r."""
+    _req(x, "x", dim=5)
+    _req(bias, "bias", dim=1)
+    x = x.contiguous()
+    N, Cin, D, H, W = x.shape
+    if bias.numel() != cout:
+        raise ValueError("convT3d_k2_s2_bf16x3: bias must have Cout elements")
+    out = torch.empty((N, cout, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mvsdet_convT3d_k2_s2_bf16x3(_lib.ptr(x), _lib.ptr(wsplit), _lib.ptr(bias.contiguous()), _lib.ptr(out), N, Cin,
+                                                           int(cout), D, H, W, int(relu), _stream(x)), "convT3d_k2_s2_bf16x3")
+    return out
+
+
 def _check_affine(name, scale, shift, Cout):
     if (scale is None) != (shift is None):
         raise ValueError(f"{name}: scale and shift come together")

@@ -137,3 +137,57 @@ def test_conv_split_over_input_channels(gpu, N, Cin, Cout, grid, stride, res):
     # the operator takes the split route by itself
     got = ops.conv3d_k3_mfma(xd, wd, sc, sh, True, stride, rd).cpu()
     assert torch.equal(got, outs[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,grid", [(1, 256, 512, (40, 40, 16)), (2, 512, 1024, (20, 20, 8)), (3, 64, 128, (6, 10, 4))])
+def test_shortcut_gemm_kernel(gpu, N, Cin, Cout, grid):
+    """csrc/neck_gemm.hip MODE 0 -- the 1x1x1 stride-2 shortcut with the BatchNorm folded in (imvoxel_neck.py:196-217): against the
+    framework's Conv3d + BatchNorm3d in float64 (1e-5 of the output's scale: three-term split operands), for the shipped levels,
+    a batch, and a voxel count that is no multiple of the 64-voxel block."""
+    from mvsdet_amd import neck as NK
+    from mvsdet_amd import ops
+    ds = _randomise(NK._ConvModule(Cin, Cout, 1, 2, 0, act=False), 11).to(gpu)
+    x = torch.randn((N, Cin) + grid, generator=torch.Generator().manual_seed(12)).to(gpu)
+    with torch.no_grad():
+        wq, bias = NK._gemm_weight(ds.conv, ds.bn, split=True)
+        got = ops.conv3d_k1_s2_bf16x3(x, wq, bias, Cout)
+        ref = ds.double()(x.double())
+    assert got.shape == ref.shape
+    err = float((got.double() - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,grid", [(1, 512, 256, (20, 20, 8)), (2, 1024, 512, (10, 10, 4)), (3, 64, 32, (3, 5, 2))])
+def test_upsampling_gemm_kernel(gpu, N, Cin, Cout, grid):
+    """csrc/neck_gemm.hip MODE 1 -- ConvTranspose3d(k=2, s=2) + BatchNorm + ReLU with the 2x2x2 interleave in the epilogue
+    (imvoxel_neck.py:166-180): against the framework's layers in float64."""
+    from mvsdet_amd import neck as NK
+    from mvsdet_amd import ops
+    up = _randomise(NK._UpBlock(Cin, Cout), 13).to(gpu)
+    x = torch.randn((N, Cin) + grid, generator=torch.Generator().manual_seed(14)).to(gpu)
+    with torch.no_grad():
+        wq, bias = NK._gemm_weight(up[0], up[1], split=True)
+        got = ops.convT3d_k2_s2_bf16x3(x, wq, bias, Cout, True)
+        upd = up.double()
+        ref = torch.relu(upd[1](upd[0](x.double())))
+    assert got.shape == ref.shape
+    err = float((got.double() - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.gpu
+def test_neck_on_a_batch_equals_the_scenes_one_by_one(gpu):
+    """mvsdet.py:695-696 stacks the scenes' volumes: the shipped neck on (3,256,40,40,16) against each volume alone -- eval-mode
+    BatchNorm is per-sample, the kernels' split decisions depend on the grid size, so equal up to summation order (1e-5 of the scale)."""
+    from mvsdet_amd.neck import IndoorImVoxelNeck
+    m = _randomise(IndoorImVoxelNeck(256, 128, [1, 1, 1]), 7).to(gpu)
+    x = torch.randn((3, 256, 40, 40, 16), generator=torch.Generator().manual_seed(9)).to(gpu)
+    with torch.no_grad():
+        both = m(x)
+        for i in range(3):
+            one = m(x[i:i + 1])
+            for a, b in zip(both, one):
+                s = float(b.abs().max())
+                assert float((a[i:i + 1] - b).abs().max()) <= 1e-5 * max(1.0, s)
