@@ -8,7 +8,7 @@ from mvsdet_amd.neck import IndoorImVoxelNeck
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = IndoorImVoxelNeck(256, 128, [1, 1, 1]).to(dev).eval()
-x = torch.randn(1, 256, 40, 40, 16, device=dev)
+x = torch.randn(int(sys.argv[1]) if len(sys.argv) > 1 else 1, 256, 40, 40, 16, device=dev)
 with torch.no_grad():
     for _ in range(3):
         m(x)
@@ -19,4 +19,4 @@ rows = sorted(prof.key_averages(), key=lambda r: -r.device_time_total)[:24]
 tot = sum(r.device_time_total for r in prof.key_averages())
 print(f"total device time {tot / 1e3:.2f} ms")
 for r in rows:
-    print(f"{r.device_time_total / 1e3:8.3f} ms  x{r.count:<3d} {r.key[:110]}")
+    print(f"{r.device_time_total / 1e3:8.3f} ms  x{r.count:<3d} {r.key[:150]}")
