@@ -43,6 +43,11 @@ MVSDet = ref.MVSDet
 META = dict(torch_version=np.array(torch.__version__), generator=np.array("tests/golden/make_goldens.py"))
 
 
+STAND_IN = np.array("the reference classes' text is executed where it lies, with a 12-line stand-in for mmcv.cnn.ConvModule (Conv3d without "
+                    "bias -> BatchNorm3d -> optional ReLU: what mmcv builds for conv_cfg=Conv3d, norm_cfg=BN3d, act_cfg=ReLU|None), mmcv's "
+                    "Scale and mmdet's multi_apply (tests/golden/_ref_loader.py): mmcv / mmdet / mmengine are not installable here, so the "
+                    "stand-in is the builder's reading of mmcv, not mmcv itself")
+
 def ns_self(near, far, D):
     return SimpleNamespace(depth_interval=(far - near) / D, near_far_range=[near, far],
                            gs_cfg=SimpleNamespace(num_monocular_samples=D))
@@ -429,7 +434,7 @@ def g10_neck():
     assert [tuple(o.shape) for o in outs] == [(1, 128, 40, 40, 16), (1, 128, 20, 20, 8), (1, 128, 10, 10, 4)]
     save("g10_neck", weight_seed=10, input_seed=100, mask_seed=101, mask_threshold=np.float32(0.6), in_shape=np.array(x.shape),
          level0=outs[0][:, ::2, ::2, ::2, ::2], level1=outs[1][:, ::2], level2=outs[2], block0=block0[:, ::4, ::2, ::2, ::2],
-         level_scales=np.array([float(o.abs().max()) for o in outs]), keys=np.array(sorted(net.state_dict())))
+         level_scales=np.array([float(o.abs().max()) for o in outs]), keys=np.array(sorted(net.state_dict())), stand_in=STAND_IN)
     print("g10 levels", [float(o.abs().max()) for o in outs], "non-zero share of the input", float(keep.float().mean()))
 
 
@@ -456,7 +461,7 @@ def g11_heads():
             sl = (slice(None), slice(None), slice(None, None, 2), slice(None, None, 2), slice(None, None, 2)) if i == 0 else ()
             out.update({f"{tag}_center{i}": centers[i][sl], f"{tag}_reg{i}": regs[i][sl], f"{tag}_cls{i}": clss[i][sl]})
         print("g11", tag, [tuple(t.shape) for t in regs], float(max(t.abs().max() for t in regs)))
-    save("g11_heads", weight_seed=11, input_seed=110, **out)
+    save("g11_heads", weight_seed=11, input_seed=110, stand_in=STAND_IN, **out)
 
 
 def g12_cost_regularisation_grads():

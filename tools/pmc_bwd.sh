@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes of the backward sweep (tools/profile_bwd.py runs it four times at the reference-true shape).  $1 = tag under
 # gpurun_out/; MVSDET_BWD_FIXED in the environment chooses the form of the LDS gradient images.
-tag=${1:-r04_bwd_pmc}
+tag=${1:-r05_bwd_pmc}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
