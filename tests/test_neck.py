@@ -191,3 +191,37 @@ def test_neck_on_a_batch_equals_the_scenes_one_by_one(gpu):
             for a, b in zip(both, one):
                 s = float(b.abs().max())
                 assert float((a[i:i + 1] - b).abs().max()) <= 1e-5 * max(1.0, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_gemm_kernels_randomised(gpu, seed):
+    """csrc/neck_gemm.hip over random shapes: channel counts that are any multiple of 32 (K) / 128 rows, grids whose voxel count is
+    no multiple of the 64-voxel block, batches; both modes against the framework's layers in float64, 1e-5 of the scale."""
+    import random
+    from mvsdet_amd import neck as NK
+    from mvsdet_amd import ops
+    rng = random.Random(1000 + seed)
+    N = rng.randint(1, 3)
+    cin = 32 * rng.randint(1, 12)
+    grid = (rng.randint(1, 5), rng.randint(1, 7), rng.randint(1, 6))
+    g = torch.Generator().manual_seed(seed)
+    # mode 1: transposed k2 s2 (rows = 8 Cout: Cout any multiple of 16)
+    cout = 16 * rng.randint(1, 10)
+    up = _randomise(NK._UpBlock(cin, cout), 20 + seed).to(gpu)
+    x = torch.randn((N, cin) + grid, generator=g).to(gpu)
+    with torch.no_grad():
+        wq, bias = NK._gemm_weight(up[0], up[1], split=True)
+        got = ops.convT3d_k2_s2_bf16x3(x, wq, bias, cout, True)
+        upd = up.double()
+        ref = torch.relu(upd[1](upd[0](x.double())))
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), ("convT", N, cin, cout, grid)
+    # mode 0: 1x1x1 stride 2 (rows = Cout: a multiple of 128), even input grid
+    cout0 = 128 * rng.randint(1, 3)
+    ds = _randomise(NK._ConvModule(cin, cout0, 1, 2, 0, act=False), 40 + seed).to(gpu)
+    x0 = torch.randn((N, cin, 2 * grid[0], 2 * grid[1], 2 * grid[2]), generator=g).to(gpu)
+    with torch.no_grad():
+        wq, bias = NK._gemm_weight(ds.conv, ds.bn, split=True)
+        got = ops.conv3d_k1_s2_bf16x3(x0, wq, bias, cout0)
+        ref = ds.double()(x0.double())
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), ("k1s2", N, cin, cout0, grid)
