@@ -310,22 +310,30 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             raise ValueError(f"CostRegNet3DGS: D, H, W must be divisible by 4, got {tuple(x.shape[2:])}")
         if self._chain_ok(x):
             n = x.shape[0]
-            if self.view_streams < 2 or n < 8:
+            k = min(int(self.view_streams), n // 4)
+            if k < 2:
                 return self._forward_chain(x)
+            # the views in k contiguous pieces, piece 0 on the caller's stream, the others on streams of the module's own (views are
+            # independent in eval mode: the same bits whatever the split)
             dev = x.device
             cur = torch.cuda.current_stream(dev)
             mine = _SIDE_STREAMS.setdefault(self, {})
-            side = mine.get(str(dev))
-            if side is None:
-                side = mine[str(dev)] = torch.cuda.Stream(device=dev)
-            cut = (n + 1) // 2
-            side.wait_stream(cur)          # x is ready; the caller keeps it alive until this call returns
-            with torch.cuda.stream(side):
-                second = self._forward_chain(x[cut:])
-            first = self._forward_chain(x[:cut])
-            cur.wait_stream(side)
-            second.record_stream(cur)      # allocated under the side stream, read by the concatenation on this one
-            return torch.cat((first, second), 0)
+            sides = mine.get(str(dev))
+            if sides is None:
+                sides = mine[str(dev)] = []
+            while len(sides) < k - 1:
+                sides.append(torch.cuda.Stream(device=dev))
+            bounds = [(n * i + k - 1) // k for i in range(k + 1)]      # piece i = views bounds[i] .. bounds[i + 1]: the first ones larger
+            parts = [None] * k
+            for i in range(1, k):
+                sides[i - 1].wait_stream(cur)          # x is ready; the caller keeps it alive until this call returns
+                with torch.cuda.stream(sides[i - 1]):
+                    parts[i] = self._forward_chain(x[bounds[i]:bounds[i + 1]])
+            parts[0] = self._forward_chain(x[:bounds[1]])
+            for i in range(1, k):
+                cur.wait_stream(sides[i - 1])
+                parts[i].record_stream(cur)            # allocated under a side stream, read by the concatenation on this one
+            return torch.cat(parts, 0)
         full = self._cbr(self.conv0, x)                           # (N, 64, D, H, W)
         # the stride-2 layers hand their input back as the skip tensor (`_ConvK3S2`: its gradient joins the input gradient in
         # that layer's own kernel)
