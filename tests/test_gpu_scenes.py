@@ -5,6 +5,7 @@ multiview_pipeline.py:432-441 makes the count VARY per scene), `mvsdet_arkit.py:
 real modules -- CostRegNet3DGS, IndoorImVoxelNeck, the head convolutions -- on our kernels and demands, scene by scene,
 the bits of that scene run alone.
 """
+import os
 import random
 
 import numpy as np
@@ -135,7 +136,7 @@ def test_soak_random_view_counts_streams_and_cache_flushes(gpu):
     torch.cuda.synchronize(gpu)
     results = []
     with torch.no_grad():
-        for i in range(200):
+        for i in range(int(os.environ.get("MVSDET_SOAK_SCENES", "200"))):   # 200 in the suite; a long run: MVSDET_SOAK_SCENES=3000
             j = rng.randrange(len(distinct))
             net.view_streams = rng.choice((1, 2))
             hp.overlap_detector = rng.random() < 0.8
