@@ -159,8 +159,9 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
 
     const unsigned* fl_bt = flags + (size_t)bt * D;
     const float* depth_n = depth + (size_t)n * D;
-    // dL/dvar of one plane, the lane's 4 pixels of its 2 channels
-    float4 gnext[2];
+    // dL/dvar of one plane, the lane's 4 pixels of its 2 channels.  One wave group keeps TWO planes in flight (gnext = the next
+    // plane's, gahead = the one after it), see the request below
+    float4 gnext[2], gahead[2];
     auto load_go = [&](int d) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -179,7 +180,15 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
             gnext[i] = v;
         }
     };
-    if constexpr (GROUPS == 1) load_go(0);   // the first plane
+    // two planes in flight where the registers allow it without costing a block per CU (K <= 2: 156 VGPRs; K = 3 would go from 169 to 176)
+    constexpr bool kAhead2 = GROUPS == 1 && K <= 2;
+    if constexpr (kAhead2) {   // planes 0 (-> gnext) and 1 (-> gahead)
+        if (D > 1) load_go(1);
+        gahead[0] = gnext[0]; gahead[1] = gnext[1];
+        load_go(0);
+    } else if constexpr (GROUPS == 1) {
+        load_go(0);
+    }
     // flags and depth of a plane are requested a plane ahead (scalars: two SGPRs), as in the forward kernel
     unsigned fl_next = K > 0 ? fl_bt[0] : 0u;
     float dv_next = K > 0 ? depth_n[0] : 0.0f;
@@ -210,18 +219,20 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
             __syncthreads();  // slots zeroed again before anyone adds into them
         }
         if (GROUPS > 1 && d % GROUPS != plane_group) continue;   // the refills above are everybody's, the plane is one group's
-        // ---- dL/dvar of the lane's pixels and channels (8 channel rows x 128 contiguous bytes per wave-instruction): this
-        //      plane's was requested while the group's previous plane was computed; the next one's is requested now
-        //      (one group: 160 VGPRs, still three blocks per CU, 2.75 -> 2.64 ms at 12 planes; two groups have 128 and spill
-        //      with it: they request their plane here)
+        // ---- dL/dvar of the lane's pixels and channels (8 channel rows x 64 or 128 contiguous bytes per wave-instruction).
+        //      Loads return IN ORDER (vmcnt is one in-order counter): a request for a later plane's dL/dvar issued just ahead of
+        //      this plane's tap gathers turns the wait for the gathers -- L2 hits -- into a wait for that HBM read as well.  So one
+        //      wave group requests plane d+2 BEHIND this plane's gathers (below, after pass 1) and consumes it two planes later:
+        //      it has pass 2 of this plane and the decode and gather latency of the next one to arrive, and the next plane's
+        //      gather wait finds it done.  Round 5: 2.70 -> 2.34 ms at 12 planes (one plane ahead, requested here: the 2.70; one
+        //      plane ahead behind the gathers 2.85; three in flight 2.39; 156 VGPRs, still three blocks per CU).  Two groups have
+        //      128 VGPRs and spill with it: they request their plane here.
         float go[4][2];
         if constexpr (GROUPS > 1) load_go(d);
 #pragma unroll
         for (int i = 0; i < 2; ++i) { go[0][i] = gnext[i].x; go[1][i] = gnext[i].y; go[2][i] = gnext[i].z; go[3][i] = gnext[i].w; }
-        //      (round 5: the same request placed BEHIND this plane's tap gathers -- loads return in order, so ahead of them it makes
-        //      the wait for the gathers a wait for this HBM read too -- measured 2.84-2.89 against 2.69-2.74 ms: it stays here)
-        if constexpr (GROUPS == 1)
-            if (d + 1 < D) load_go(d + 1);
+        if constexpr (GROUPS == 1 && !kAhead2)
+            if (d + 1 < D) load_go(d + 1);   // K > 2: one plane ahead, requested here (round 4's form)
         // ---- pass 1 over the neighbours: warped values (taps gathered from the slab images), S.  The lane keeps what it
         //      decoded (tap offsets in the gradient slot / gradient image, weights) for pass 2, which fetches it again
         //      by DPP instead of holding the broadcast copies of every neighbour.
@@ -292,6 +303,16 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
         if constexpr (NP > 1) pass(std::integral_constant<int, 1>{});
 #undef MVS_BWD_OF
 #undef MVS_BWD_STEP
+        // ---- dL/dvar two planes ahead, behind this plane's gathers (see above): gnext <- plane d+1's, gahead <- the new request
+        if constexpr (kAhead2) {
+            gnext[0] = gahead[0]; gnext[1] = gahead[1];
+            if (d + 2 < D) {
+                const float4 k0 = gnext[0], k1 = gnext[1];
+                load_go(d + 2);
+                gahead[0] = gnext[0]; gahead[1] = gnext[1];
+                gnext[0] = k0; gnext[1] = k1;
+            }
+        }
         // ---- reference term, kept in registers across the planes
 #pragma unroll
         for (int s = 0; s < 4; ++s)
