@@ -23,7 +23,7 @@ from typing import List, Sequence, Tuple
 import torch
 from torch import Tensor, nn
 
-from .neck import DerivedTensorsMixin
+from .neck import DerivedTensorsMixin, _await_made, _mark_made
 
 
 class Scale(nn.Module):
@@ -74,6 +74,8 @@ class NerfDetHeadConvs(DerivedTensorsMixin, nn.Module):
                 w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
             # cut into bf16 pieces in the bf16x3 kernel's layout (csrc/costreg_bf16.hip; HEAD_BF16X3), or permuted for the fp32 MFMA
             self._fused = (key, ops.split_conv_weight(w) if HEAD_BF16X3 else ops.permute_conv_weight(w), HEAD_BF16X3)
+            _mark_made(self._fused[1])
+        _await_made(self._fused[1])   # computed on another stream a moment ago: this stream waits for it (neck._PENDING)
         return self._fused[1]
 
     def _forward_single(self, x: Tensor, scale: Scale) -> Tuple[Tensor, Tensor, Tensor]:

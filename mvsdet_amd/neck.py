@@ -14,6 +14,7 @@ Training, CPU tensors and other shapes take the framework's layers.
 from __future__ import annotations
 
 import os
+import weakref
 
 from typing import List, Sequence
 
@@ -68,6 +69,32 @@ class DerivedTensorsMixin:
         return super().train(mode)
 
 
+# Derived tensors are computed by whichever stream first needs them and kept on the module; a call on ANOTHER stream shortly
+# afterwards (the two halves of CostRegNet3DGS.view_streams; a detector moved to a side stream) must not read them before the
+# kernels that fill them ran.  Every derived tensor is therefore registered with the event recorded behind its computation, and every
+# use makes the using stream wait for it while it is pending.  Kept outside the modules (events do not pickle), by the tensor.
+_PENDING = weakref.WeakKeyDictionary()
+
+
+def _mark_made(*tensors: Tensor) -> None:
+    ts = [t for t in tensors if isinstance(t, Tensor) and t.is_cuda]
+    if ts:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(ts[0].device))
+        for t in ts:
+            _PENDING[t] = ev
+
+
+def _await_made(*tensors: Tensor) -> None:
+    for t in tensors:
+        ev = _PENDING.get(t) if isinstance(t, Tensor) else None
+        if ev is not None:
+            if ev.query():
+                _PENDING.pop(t, None)
+            else:
+                torch.cuda.current_stream(t.device).wait_event(ev)
+
+
 def _bn_affine(bn: nn.BatchNorm3d):
     """Eval-mode BatchNorm as a per-channel affine; kept on the module until one of its four tensors changes (five tiny
     kernels per layer otherwise: a twentieth of the neck's time at one scene) or `drop_derived_tensors` runs."""
@@ -77,7 +104,9 @@ def _bn_affine(bn: nn.BatchNorm3d):
         with torch.no_grad():
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
             cached = (key, scale, bn.bias - bn.running_mean * scale)
+        _mark_made(cached[1], cached[2])
         bn._mvs_affine = cached
+    _await_made(cached[1], cached[2])
     return cached[1], cached[2]
 
 
@@ -114,7 +143,9 @@ def _split_weight(conv: nn.Module, order: int | None = None) -> Tensor:
     cached = conv.__dict__.get("_mvs_wsplit")
     if cached is None or cached[0] != key:
         cached = (key, ops.split_conv_weight(w, order=order))
+        _mark_made(cached[1])
         conv.__dict__["_mvs_wsplit"] = cached
+    _await_made(cached[1])
     return cached[1]
 
 
@@ -148,7 +179,9 @@ def _gemm_weight(conv: nn.Module, bn: nn.BatchNorm3d, split: bool = False):
                 from . import ops
                 wmat = ops.gemm_split_weight(wmat)
         cached = (key, wmat, bias)
+        _mark_made(wmat, bias)
         conv.__dict__["_mvs_wmat"] = cached
+    _await_made(cached[1], cached[2])
     return cached[1], cached[2]
 
 
