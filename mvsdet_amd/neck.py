@@ -73,7 +73,7 @@ class DerivedTensorsMixin:
 # afterwards (the two halves of CostRegNet3DGS.view_streams; a detector moved to a side stream) must not read them before the
 # kernels that fill them ran.  Every derived tensor is therefore registered with the event recorded behind its computation, and every
 # use makes the using stream wait for it while it is pending.  Kept outside the modules (events do not pickle), by the tensor.
-_PENDING = weakref.WeakKeyDictionary()
+_PENDING: dict = {}   # id(tensor) -> (weak reference to it, event); by identity: tensors compare element-wise
 
 
 def _mark_made(*tensors: Tensor) -> None:
@@ -82,17 +82,20 @@ def _mark_made(*tensors: Tensor) -> None:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(ts[0].device))
         for t in ts:
-            _PENDING[t] = ev
+            _PENDING[id(t)] = (weakref.ref(t), ev)
+        if len(_PENDING) > 4096:   # entries of tensors that died before anyone asked again
+            for k in [k for k, (r, e) in _PENDING.items() if r() is None or e.query()]:
+                _PENDING.pop(k, None)
 
 
 def _await_made(*tensors: Tensor) -> None:
     for t in tensors:
-        ev = _PENDING.get(t) if isinstance(t, Tensor) else None
-        if ev is not None:
-            if ev.query():
-                _PENDING.pop(t, None)
+        ent = _PENDING.get(id(t)) if isinstance(t, Tensor) else None
+        if ent is not None and ent[0]() is t:
+            if ent[1].query():
+                _PENDING.pop(id(t), None)
             else:
-                torch.cuda.current_stream(t.device).wait_event(ev)
+                torch.cuda.current_stream(t.device).wait_event(ent[1])
 
 
 def _bn_affine(bn: nn.BatchNorm3d):
