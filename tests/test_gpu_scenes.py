@@ -232,3 +232,30 @@ def test_event_pool_orders_foreign_streams(gpu):
         assert c.buf is a.buf or c.buf is b.buf    # everything finished: free buffers are reused, none made
         pool.release([c], gpu)
     assert len(pool) == 2
+
+
+def test_first_call_on_two_streams_waits_for_the_derived_tensors(gpu):
+    """The BatchNorm affines (and every other tensor derived from parameters) are computed by whichever stream first needs them.  On
+    the FIRST call of a fresh CostRegNet3DGS with the views on two streams that is the side stream's chain -- and the main stream's
+    chain, running layers ahead or behind, read them before the kernels that fill them had run (stale small blocks recycled by the
+    allocator: wrong logits by ~1e-2, found in round 5 by the 100-view test in a full-suite run; latent since the halves exist).
+    Every derived tensor now carries the event behind its computation (neck._mark_made / _await_made).  Here the allocator's small
+    blocks are poisoned first, so that a premature read cannot go unnoticed, and a long kernel is enqueued in front, so that both
+    chains are enqueued before either starts."""
+    from mvsdet_amd.costreg import CostRegNet3DGS
+    x = torch.rand(40, 256, 12, 60, 80, device=gpu)
+    for it in range(6):
+        torch.manual_seed(it)
+        net = CostRegNet3DGS(256).to(gpu).eval()
+        junk = [torch.full((n,), float("nan"), device=gpu) for n in (64, 128, 256, 64, 128, 256) * 16]
+        torch.cuda.synchronize(gpu)
+        del junk
+        busy = torch.rand(8, 256, 32, 120, 160, device=gpu) * 2.0     # noqa: F841 -- the kernel both chains queue up behind
+        with torch.no_grad():
+            net.view_streams = 2
+            first = net(x)
+            torch.cuda.synchronize(gpu)
+            net.view_streams = 1
+            again = net(x)
+        torch.cuda.synchronize(gpu)
+        assert torch.equal(first, again), f"fresh module {it}: the first two-stream call differs by {float((first - again).abs().max()):.2e}"
