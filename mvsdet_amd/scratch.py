@@ -60,8 +60,12 @@ class EventPool:
                 # layers side by side (the halves of CostRegNet3DGS.view_streams) would otherwise hand ONE buffer back and forth
                 # and serialise on its events (measured: 8.1 instead of 7.3 ms for the network) -- a new one is made instead; only
                 # a key that already owns `max_per_key` buffers waits for its oldest
-                pick = next((i for i in range(len(lst) - 1, -1, -1)
-                             if lst[i].event is None or lst[i].event[0] == cur.cuda_stream or lst[i].event[1].query()), None)
+                # (first a buffer this stream released itself, then one that is finished: a stream that took the OTHER stream's
+                # finished buffer would leave its own to the other stream, which may find it still busy and make a third one --
+                # allocations and clears of 0.4-0.75 GB inside the steady state: 14.1 instead of 11.0 ms per scene in one bench run)
+                pick = next((i for i in range(len(lst) - 1, -1, -1) if lst[i].event is None or lst[i].event[0] == cur.cuda_stream), None)
+                if pick is None:
+                    pick = next((i for i in range(len(lst) - 1, -1, -1) if lst[i].event[1].query()), None)
                 if pick is None and len(lst) >= self.max_per_key:
                     pick = 0
                 if pick is not None:
