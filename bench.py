@@ -172,22 +172,28 @@ def run_gpu(args, w, rank, world, device):
 
 def stage_breakdown(w, hp, scene, device, reps=3):
     """Per-stage HIP-event timings of one scene (reported as extras; not the headline).  Stage 1 is timed on the SAME entry points
-    and streams as the timed loop (`sweep_geometry_async` on its side stream, `cost_volume_tabled` behind its event), after one
-    untimed pass that leaves the 50 GB output block in the allocator -- so `plane_sweep_variance` here and `roofline.kernel_ms`
-    are one measurement taken twice, not two routes (round 4's line timed the stand-alone packed entry point here, which
-    allocates inside the event pair and runs the geometry kernel in front of the sweep: 0.8 ms more for the same kernels)."""
+    and streams as the timed loop (`sweep_geometry_async` on its side stream, `cost_volume_tabled` behind its event), the scenes of
+    the repetitions enqueued back to back without a host synchronisation in between (as the loop runs them; the first one, which
+    grows the allocator's pools and starts from an idle device, is not counted) -- so `plane_sweep_variance` here and
+    `roofline.kernel_ms` are one measurement taken twice.  The host part (camera algebra + upload, which needs a synchronisation to
+    be timed at all) is timed separately, before."""
     from mvsdet_amd import ops
     names = ["host_prep+h2d (serial here; prefetched one step ahead in the timed loop)", "pack", "plane_sweep_geometry (side stream, beside the packing)",
              "plane_sweep_variance", "depth_prob_topk", "backproject_mean"]
     acc = {n: [] for n in names}
+    geos = []
     for rep in range(reps + 1):
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         fresh = dict(scene.meta)                              # jittered cameras: not served from the content cache
         fresh["lidar2img"] = dict(scene.meta["lidar2img"], extrinsic=[e + np.float32(1e-6) * (rep + 1) for e in scene.meta["lidar2img"]["extrinsic"]])
-        geo = hp.prepare_scene(fresh, device)
+        geos.append(hp.prepare_scene(fresh, device))
         torch.cuda.synchronize(device)
-        host_ms = (time.perf_counter() - t0) * 1e3
+        if rep:
+            acc[names[0]].append((time.perf_counter() - t0) * 1e3)
+    marks = []
+    for rep in range(reps + 1):
+        geo = geos[rep]
         es = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         tab = hp.sweep_geometry_async(geo, w["H"], w["W"], events=True)
         es[0].record()
@@ -201,11 +207,10 @@ def stage_breakdown(w, hp, scene, device, reps=3):
         es[4].record()
         vol, valid = hp.lift(scene.features, packed, geo, ed, en)
         es[5].record()
-        torch.cuda.synchronize(device)
-        del var
-        if rep == 0:
-            continue                                          # the pass that grows the allocator's pools
-        acc[names[0]].append(host_ms)
+        del var                                               # the next scene's volume takes this one's block (stream order)
+        marks.append((es, tab))
+    torch.cuda.synchronize(device)
+    for es, tab in marks[1:]:                                 # the first pass grows the allocator's pools
         acc[names[1]].append(es[0].elapsed_time(es[1]))
         acc[names[2]].append(tab[2].elapsed_time(tab[3]))
         acc[names[3]].append(es[2].elapsed_time(es[3]))
