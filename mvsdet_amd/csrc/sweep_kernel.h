@@ -417,6 +417,7 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
     const unsigned* __restrict__ flags, const unsigned short* __restrict__ groups, OutT* __restrict__ var, int N, int C, int S,
     int D, int H, int W, int Wo, int tiles_x, int tiles, int d_per_block, int box_cap, int n_bt, int xcd_parts) {
     constexpr int KK = K > 0 ? K : 1;
+    constexpr bool kTapsAhead = TW == 32 && K <= 2;   // all four steps' taps of a neighbour requested ahead of their arithmetic (two blocks per CU: registers to spare)
     constexpr int NP = (K + 1) / 2;             // decode passes: a lane decodes ONE (pixel-step, neighbour) pair per pass
     constexpr int NPP = NP > 0 ? NP : 1;
     constexpr int TH = kTilePix / TW;
@@ -662,13 +663,22 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
                 Q_[s][0] = fsq[s][0]; Q_[s][1] = fsq[s][1];
             }
         }
-#define MVS_TAP_STEP(SS, LOADER, OFF)                                                                                 \
+        // A pixel step = the 4 taps of the lane's pixel SS of neighbour j: LOAD fetches them (tap address = quad broadcast of the decoding
+        // lane's offset + the lane's own 16 bytes), MATH weighs and sums them into the step's sums.  32x4 tiles run two blocks per CU and
+        // have ~80 registers to spare: there all four steps' taps of a neighbour are requested before the first step's arithmetic
+        // (16 float4 in flight: one exposed LDS round trip per neighbour instead of four).  16x8 tiles (three blocks per CU, 170
+        // registers) keep load - use - load - use.
+#define MVS_TAP_LOAD(SS, LOADER, OFF)                                                                                 \
         {                                                                                                             \
             int o0, o1, o2, o3;                                                                                       \
             OFF(SS, o0, o1, o2, o3)                                                                                   \
+            tq[SS][0] = LOADER(o0); tq[SS][1] = LOADER(o1); tq[SS][2] = LOADER(o2); tq[SS][3] = LOADER(o3);           \
+        }
+#define MVS_TAP_MATH(SS)                                                                                              \
+        {                                                                                                             \
             const f2 w0 = splat(__int_as_float(quad_bcast<SS>(rw0))), w1 = splat(__int_as_float(quad_bcast<SS>(rw1)));  \
             const f2 w2 = splat(__int_as_float(quad_bcast<SS>(rw2))), w3 = splat(__int_as_float(quad_bcast<SS>(rw3)));  \
-            const float4 t0 = LOADER(o0), t1 = LOADER(o1), t2 = LOADER(o2), t3 = LOADER(o3);                          \
+            const float4 t0 = tq[SS][0], t1 = tq[SS][1], t2 = tq[SS][2], t3 = tq[SS][3];                              \
             f2 va = (f2){t0.x, t0.y} * w0, vb = (f2){t0.z, t0.w} * w0;                                                \
             va = pk_fma((f2){t1.x, t1.y}, w1, va); vb = pk_fma((f2){t1.z, t1.w}, w1, vb);                             \
             va = pk_fma((f2){t2.x, t2.y}, w2, va); vb = pk_fma((f2){t2.z, t2.w}, w2, vb);                             \
@@ -681,6 +691,18 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
                 variance_of(vout, SS, 1, sb, qb, rcp);                                                                \
             } else {                                                                                                  \
                 S_[SS][0] = sa; S_[SS][1] = sb; Q_[SS][0] = qa; Q_[SS][1] = qb;                                       \
+            }                                                                                                         \
+        }
+#define MVS_TAP_STEPS(LOADER, OFF)                                                                                    \
+        {                                                                                                             \
+            float4 tq[4][4];                                                                                          \
+            if constexpr (kTapsAhead) {                                                                               \
+                MVS_TAP_LOAD(0, LOADER, OFF) MVS_TAP_LOAD(1, LOADER, OFF) MVS_TAP_LOAD(2, LOADER, OFF) MVS_TAP_LOAD(3, LOADER, OFF) \
+                __builtin_amdgcn_sched_barrier(0);   /* the scheduler sinks the requests back to their uses otherwise */ \
+                MVS_TAP_MATH(0) MVS_TAP_MATH(1) MVS_TAP_MATH(2) MVS_TAP_MATH(3)                                       \
+            } else {                                                                                                  \
+                MVS_TAP_LOAD(0, LOADER, OFF) MVS_TAP_MATH(0) MVS_TAP_LOAD(1, LOADER, OFF) MVS_TAP_MATH(1)             \
+                MVS_TAP_LOAD(2, LOADER, OFF) MVS_TAP_MATH(2) MVS_TAP_LOAD(3, LOADER, OFF) MVS_TAP_MATH(3)             \
             }                                                                                                         \
         }
         // Tap offsets travel in BYTES, so that the quad broadcast and the addition of the lane's own 16 bytes of the texel are ONE
@@ -702,11 +724,9 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
                     const int rw0 = from_quad<QQ>(__float_as_int(dw.x)), rw1 = from_quad<QQ>(__float_as_int(dw.y));   \
                     const int rw2 = from_quad<QQ>(__float_as_int(dw.z)), rw3 = from_quad<QQ>(__float_as_int(dw.w));   \
                     if (fj & kFlagStaged) {                                                                           \
-                        MVS_TAP_STEP(0, MVS_LDS_TAP, MVS_LDS_OFF) MVS_TAP_STEP(1, MVS_LDS_TAP, MVS_LDS_OFF)           \
-                        MVS_TAP_STEP(2, MVS_LDS_TAP, MVS_LDS_OFF) MVS_TAP_STEP(3, MVS_LDS_TAP, MVS_LDS_OFF)           \
+                        MVS_TAP_STEPS(MVS_LDS_TAP, MVS_LDS_OFF)                                                       \
                     } else {                                                                                          \
-                        MVS_TAP_STEP(0, MVS_GLB_TAP, MVS_GLB_OFF) MVS_TAP_STEP(1, MVS_GLB_TAP, MVS_GLB_OFF)           \
-                        MVS_TAP_STEP(2, MVS_GLB_TAP, MVS_GLB_OFF) MVS_TAP_STEP(3, MVS_GLB_TAP, MVS_GLB_OFF)           \
+                        MVS_TAP_STEPS(MVS_GLB_TAP, MVS_GLB_OFF)                                                       \
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
@@ -740,7 +760,9 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
         if constexpr (NP > 0) pass(std::integral_constant<int, 0>{});
         if constexpr (NP > 1) pass(std::integral_constant<int, 1>{});
 #undef MVS_TAPS_OF
-#undef MVS_TAP_STEP
+#undef MVS_TAP_STEPS
+#undef MVS_TAP_MATH
+#undef MVS_TAP_LOAD
 #undef MVS_LDS_TAP
 #undef MVS_GLB_TAP
 #undef MVS_LDS_OFF
