@@ -309,14 +309,23 @@ def backward_rooflines(w, device, reps=5):
             ts.append(e0.elapsed_time(e1))
         return float(np.mean(ts)), float(np.min(ts))
 
-    bwd_ms, bwd_min = timed(lambda: ops.plane_sweep_variance_backward(s.features, geo.neighbor_ids, geo.proj_rel, geo.depth_values, gvar))
+    # the operator as a training step runs it since round 5: the packed maps and the sweep geometry are the FORWARD pass's
+    # (ops.plane_sweep_variance_keep hands them out), the backward is memset + kernel + unpack; the stand-alone entry point that packs
+    # and builds the geometry itself is timed beside it
+    with torch.no_grad():
+        _, packed, table = ops.plane_sweep_variance_keep(s.features, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+    bwd_ms, bwd_min = timed(lambda: ops.plane_sweep_variance_backward_packed(packed, geo.neighbor_ids, table, gvar))
+    alone_ms, _ = timed(lambda: ops.plane_sweep_variance_backward(s.features, geo.neighbor_ids, geo.proj_rel, geo.depth_values, gvar))
+    del packed, table
     # dL/dvar is read once, the features once, dL/dfeat written once (float atomics on a packed copy, then unpacked)
     bwd_bytes = N * C * D * H * W * 4 + 2 * N * C * H * W * 4
     out = {"backward_sweep": {"bound": "hbm", "achieved": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                               "unit": "GB/s", "frac": round(bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                              "kernel": "plane_sweep_variance_bwd_kernel<K,TW,HALF> (+ geometry kernel, memset and unpack of the "
-                                        "packed gradient: the whole operator between two HIP events)",
+                              "kernel": "plane_sweep_variance_bwd_kernel<K,TW,HALF> (+ memset and unpack of the packed gradient: the whole "
+                                        "operator between two HIP events, as the training step runs it -- packed maps and geometry kept "
+                                        "from the forward pass)",
                               "kernel_ms": round(bwd_ms, 4), "min_ms": round(bwd_min, 4), "algorithmic_bytes_per_launch": bwd_bytes,
+                              "standalone_entry_ms": round(alone_ms, 4),   # packs the features and builds the geometry itself
                               "bytes_formula": "N*C*D*H*W*4 (dL/dvar read once) + 2*N*C*H*W*4 (features read, gradient written)"}}
     x = gvar                                             # the variance-shaped input of conv0 (values do not matter to the timing)
     gy = torch.randn((N, 64, D, H, W), device=device)

@@ -165,6 +165,13 @@ int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, c
                                         const float* depth, const float* g, float* gfeat, void* workspace,
                                         size_t workspace_bytes, int N, int K, int C, int D, int H, int W,
                                         mvsdet_stream_t stream);
+/* The same from what the forward pass already made (a training step keeps them instead of making them again): `packed` =
+ * mvsdet_pack_features_f32 of the features, `table` = the scratch buffer the forward call
+ * (mvsdet_plane_sweep_variance_packed_f32 / mvsdet_plane_sweep_table_f32, same N, K, D, H, W and tile options; contiguous, not
+ * pitched) left its sweep geometry in.  workspace >= mvsdet_packed_bytes(N,C,H,W) rounded up to 256 (the packed gradient map). */
+int mvsdet_plane_sweep_variance_bwd_packed_f32(const float* packed, const int64_t* nbr, const void* table, size_t table_bytes,
+                                               const float* g, float* gfeat, void* workspace, size_t workspace_bytes, int N, int K,
+                                               int C, int D, int H, int W, mvsdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a5-a7  depth probability, top-k plane selection, depth expectation --

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mvsdet_plane_sweep_variance_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_plane_sweep_bwd_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "mvsdet_plane_sweep_variance_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_plane_sweep_variance_bwd_packed_f32": [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_depth_prob_topk_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "mvsdet_depth_prob_topk_strided_f32": [_vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "mvsdet_sample_depth_prob_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],

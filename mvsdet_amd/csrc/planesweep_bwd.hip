@@ -734,6 +734,10 @@ extern "C" size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, in
     return 2 * pb + mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W);
 }
 
+// the kernels behind both entry points: packed maps and a sweep geometry in, the gradient of the features out
+static int bwd_launch(const float* packed, const int64_t* nbr, void* scratch, const float* g, float* gfeat, float* gpacked, size_t pb,
+                      int N, int K, int C, int D, int H, int W, hipStream_t stream);
+
 extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int64_t* nbr, const float* proj,
                                                    const float* depth, const float* g, float* gfeat, void* workspace,
                                                    size_t workspace_bytes, int N, int K, int C, int D, int H, int W,
@@ -756,12 +760,40 @@ extern "C" int mvsdet_plane_sweep_variance_bwd_f32(const float* feat, const int6
     void* scratch = (char*)workspace + 2 * pb;
     const int64_t fs[4] = {(int64_t)C * H * W, (int64_t)H * W, W, 1};
     if (int rc = mvsdet_pack_features_f32(feat, fs, packed, N, C, H, W, stream_)) return rc;
+    if (K > 0)
+        if (int rc = mvsdet_plane_sweep_table_f32(proj, depth, scratch, sb, N, K, D, H, W, stream_)) return rc;
+    return bwd_launch(packed, nbr, scratch, g, gfeat, gpacked, pb, N, K, C, D, H, W, stream);
+}
+
+// The same with what the FORWARD pass already made: the packed maps (mvsdet_pack_features_f32) and the sweep geometry the forward
+// call left in its scratch buffer (mvsdet_plane_sweep_variance_packed_f32 / mvsdet_plane_sweep_table_f32 of the same N, K, D, H,
+// W and tile options: contiguous, not pitched).  Saves a packing pass and a geometry kernel per training step (0.18 of 2.4 ms at
+// the reference-true shape).  workspace: mvsdet_packed_bytes rounded up to 256 (the packed gradient map).
+extern "C" int mvsdet_plane_sweep_variance_bwd_packed_f32(const float* packed, const int64_t* nbr, const void* table,
+                                                          size_t table_bytes, const float* g, float* gfeat, void* workspace,
+                                                          size_t workspace_bytes, int N, int K, int C, int D, int H, int W,
+                                                          mvsdet_stream_t stream_) {
+    MVS_REQUIRE(packed && g && gfeat && workspace, "plane_sweep_variance_bwd_packed: NULL pointer");
+    MVS_REQUIRE(K == 0 || (nbr && table), "plane_sweep_variance_bwd_packed: NULL neighbour ids or geometry with K=%d", K);
+    MVS_REQUIRE(N > 0 && C > 0 && D > 0 && H > 1 && W > 1, "plane_sweep_variance_bwd_packed: bad shape");
+    MVS_REQUIRE(K >= 0 && K <= MVSDET_MAX_NEIGHBORS, "plane_sweep_variance_bwd_packed: K=%d outside [0,%d]", K, MVSDET_MAX_NEIGHBORS);
+    MVS_REQUIRE(D <= MVSDET_MAX_DEPTH && H < 65535 && W < 65535, "plane_sweep_variance_bwd_packed: D > %d, or H or W > 65534", MVSDET_MAX_DEPTH);
+    MVS_REQUIRE((size_t)H * W * kSlab < (size_t)INT32_MAX, "plane_sweep_variance_bwd_packed: one slab image exceeds 2^31 elements");
+    const size_t pb = (mvsdet_packed_bytes(N, C, H, W) + 255) / 256 * 256;
+    if (workspace_bytes < pb) {
+        set_error("plane_sweep_variance_bwd_packed: workspace %zu B < %zu B", workspace_bytes, pb);
+        return MVSDET_ERR_WORKSPACE;
+    }
+    MVS_REQUIRE(K == 0 || table_bytes >= mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W), "plane_sweep_variance_bwd_packed: geometry buffer too small");
+    return bwd_launch(packed, nbr, const_cast<void*>(table), g, gfeat, (float*)workspace, pb, N, K, C, D, H, W, (hipStream_t)stream_);
+}
+
+static int bwd_launch(const float* packed, const int64_t* nbr, void* scratch, const float* g, float* gfeat, float* gpacked, size_t pb,
+                      int N, int K, int C, int D, int H, int W, hipStream_t stream) {
     if (hipMemsetAsync(gpacked, 0, pb, stream) != hipSuccess) {
         set_error("plane_sweep_variance_bwd: hipMemsetAsync failed");
         return MVSDET_ERR_HIP;
     }
-    if (K > 0)
-        if (int rc = mvsdet_plane_sweep_table_f32(proj, depth, scratch, sb, N, K, D, H, W, stream_)) return rc;
     const int tw = sweep_tile_width(W, D);
     const int th = kTilePix / tw;
     const int S = num_slabs(C);

@@ -445,6 +445,9 @@ class MVSDetHotPath:
             tab = self.sweep_geometry_async(geo, h_, w_)     # side stream: beside the packing
             packed = ops.pack_features(feature.detach())
             variance = self.cost_volume_tabled(packed, geo, tab, c, h_, w_)
+        elif feature.is_cuda and feature.requires_grad and torch.is_grad_enabled() and geo.neighbor_ids.shape[1] > 0:
+            # training: ONE packing pass and ONE geometry for the forward sweep, the lifting and the backward sweep
+            variance, packed, _ = ops.plane_sweep_variance_keep(feature, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
         else:
             packed = ops.pack_features(feature.detach())
             variance = self.cost_volume(feature, geo, packed)

@@ -334,6 +334,72 @@ def _sweep_bwd(ctx, grad):
 plane_sweep_variance.register_autograd(_sweep_bwd, setup_context=_sweep_setup)
 
 
+@torch.library.custom_op(f"{_NS}::plane_sweep_variance_keep", mutates_args=(), device_types="cuda")
+def plane_sweep_variance_keep(feat: Tensor, nbr: Tensor, proj: Tensor, depth: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """a3+a4 for a TRAINING step: (variance (N,C,D,H,W), the packed maps, the sweep geometry) -- what the forward pass makes on its
+    way is handed out instead of dropped: the lifting reads the packed maps, and the backward pass takes both
+    (`plane_sweep_variance_backward_packed`) instead of packing the features and building the geometry a second time."""
+    N, K, C, D, H, W = _check_sweep(feat, nbr, proj, depth)
+    packed = pack_features(feat)
+    nbr, proj, depth = nbr.contiguous(), proj.contiguous(), depth.contiguous()
+    lib = _lib.load()
+    out = torch.empty((N, C, D, H, W), dtype=torch.float32, device=feat.device)
+    sbytes = lib.mvsdet_plane_sweep_scratch_bytes(N, K, D, H, W)
+    table = torch.empty(max(sbytes // 4, 4), dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        _lib.check(lib.mvsdet_plane_sweep_variance_packed_f32(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(proj), _lib.ptr(depth),
+                                                              _lib.ptr(out), _lib.ptr(table), sbytes, N, K, C, D, H, W,
+                                                              _stream(feat)), "plane_sweep_variance_keep")
+    return out, packed, table
+
+
+@plane_sweep_variance_keep.register_fake
+def _(feat, nbr, proj, depth):
+    N, C, H, W = feat.shape
+    return (feat.new_empty((N, C, depth.shape[1], H, W)), feat.new_empty((N * ((C + 31) // 32) * H * W * 32,)),
+            feat.new_empty((4,)))
+
+
+@torch.library.custom_op(f"{_NS}::plane_sweep_variance_backward_packed", mutates_args=(), device_types="cuda")
+def plane_sweep_variance_backward_packed(packed: Tensor, nbr: Tensor, table: Tensor, grad: Tensor) -> Tensor:
+    """dL/dfeat (N,C,H,W) from dL/dvar (N,C,D,H,W), the packed maps and the sweep geometry of the forward pass."""
+    _req(grad, "grad", dim=5)
+    _req(nbr, "nbr", dtype=torch.int64, dim=2)
+    N, C, D, H, W = grad.shape
+    K = nbr.shape[1]
+    lib = _lib.load()
+    if nbr.shape[0] != N or packed.numel() * 4 != lib.mvsdet_packed_bytes(N, C, H, W):
+        raise ValueError("plane_sweep_variance_backward_packed: packed maps / neighbour ids do not match the gradient")
+    grad, nbr = grad.contiguous(), nbr.contiguous()
+    pb = (int(lib.mvsdet_packed_bytes(N, C, H, W)) + 255) // 256 * 256
+    ws = torch.empty(pb // 4, dtype=torch.float32, device=grad.device)
+    gfeat = torch.empty((N, C, H, W), dtype=torch.float32, device=grad.device)
+    with torch.cuda.device(grad.device):
+        _lib.check(lib.mvsdet_plane_sweep_variance_bwd_packed_f32(_lib.ptr(packed), _lib.ptr(nbr), _lib.ptr(table), table.numel() * 4,
+                                                                  _lib.ptr(grad), _lib.ptr(gfeat), _lib.ptr(ws), pb, N, K, C, D, H, W,
+                                                                  _stream(grad)), "plane_sweep_variance_backward_packed")
+    return gfeat
+
+
+@plane_sweep_variance_backward_packed.register_fake
+def _(packed, nbr, table, grad):
+    N, C, D, H, W = grad.shape
+    return grad.new_empty((N, C, H, W))
+
+
+def _sweep_keep_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1], inputs[1], output[2])
+    ctx.mark_non_differentiable(output[1], output[2])
+
+
+def _sweep_keep_bwd(ctx, grad, g_packed, g_table):
+    packed, nbr, table = ctx.saved_tensors
+    return plane_sweep_variance_backward_packed(packed, nbr, table, grad), None, None, None
+
+
+plane_sweep_variance_keep.register_autograd(_sweep_keep_bwd, setup_context=_sweep_keep_setup)
+
+
 # ------------------------------------------------------------------------------------------- a5-a7
 @torch.library.custom_op(f"{_NS}::depth_prob_topk", mutates_args=(), device_types="cuda")
 def depth_prob_topk(cost_reg: Tensor, off_logit: Tensor, near: float, interval: float,

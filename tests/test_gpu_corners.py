@@ -466,3 +466,29 @@ def test_detector_on_a_side_stream_gives_the_same_outputs(gpu, with_network):
         for la, lb in zip(a["head"], b["head"]):
             for x, y in zip(la, lb):
                 assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_backward_sweep_from_the_forward_pass_packed_maps_and_geometry(gpu):
+    """ops.plane_sweep_variance_keep hands out what the forward sweep made on its way (packed maps, sweep geometry); its autograd
+    backward (mvsdet_plane_sweep_variance_bwd_packed_f32) takes them instead of packing and building the geometry again: the same
+    variance bit for bit, the same feature gradient up to the order of the float atomics (1e-6 of its scale), K = 1 and 2."""
+    from mvsdet_amd import ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    for n_views, C, D, hw in ((5, 40, 12, (24, 40)), (2, 64, 8, (20, 32))):
+        hp = MVSDetHotPath([16, 16, 8], [0.4, 0.4, 0.4], [0.2, 5.0], D, topk=3)
+        meta = synthetic.make_img_meta(n_views, hw, seed=31)
+        geo = hp.prepare_scene(meta, gpu)
+        feat = synthetic.make_features(n_views, C, hw, seed=31).to(gpu)
+        R = torch.randn((n_views, C, D) + hw, device=gpu, generator=torch.Generator(device=gpu).manual_seed(5))
+        f1 = feat.clone().requires_grad_(True)
+        v1 = ops.plane_sweep_variance(f1, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+        (v1 * R).sum().backward()
+        f2 = feat.clone().requires_grad_(True)
+        v2, packed, table = ops.plane_sweep_variance_keep(f2, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
+        assert not packed.requires_grad and not table.requires_grad
+        (v2 * R).sum().backward()
+        assert torch.equal(v1, v2)
+        assert torch.equal(packed, ops.pack_features(feat))
+        scale = float(f1.grad.abs().max())
+        assert float((f1.grad - f2.grad).abs().max()) <= 1e-6 * scale
