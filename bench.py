@@ -18,6 +18,7 @@ cpu_baseline = the CPU restatement of the same stage (oracle/) timed on this box
            sample (rank 0, N=1 only).  It is a checker-side measurement: nothing shipped runs on it.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -143,6 +144,7 @@ def run_gpu(args, w, rank, world, device):
         out = None
         out = step(i, False)
     del out
+    collect_garbage()
     barrier()
     torch.cuda.synchronize(device)
     stats0 = dict(hp._geometry.stats)
@@ -236,6 +238,16 @@ class PointwiseCostReg(torch.nn.Module):
         return out.view(n, 2, d, h, w)
 
 
+def collect_garbage():
+    """Called once before every timed region.  CPython's full (generation-2) collection walks every object torch's import
+    created: 100-130 ms on this image, measured (MVSDET_BENCH_TRACE=1 prints the per-step host times).  When it falls is a matter
+    of allocation counts, so it landed in the first of ten timed training steps of one code version and in the warm-up of
+    another: a 5.5 ms step read as 12.8-21.9 ms.  A long-running job pays it once per many thousand steps; a 10-step
+    measurement must not.  freeze() then keeps what exists now out of later collections."""
+    gc.collect()
+    gc.freeze()
+
+
 def run_train(args, w, rank, world, device):
     """BASELINE.json configs[2]: training step of the hot path -- forward a1..a10, loss, backward through the custom
     ops' autograd, optimiser step -- with a trainable stand-in for CostRegNet_3DGS (PointwiseCostReg) wrapped in DistributedDataParallel when N > 1: the gradient all-reduce
@@ -270,15 +282,23 @@ def run_train(args, w, rank, world, device):
     barrier = parallel.barrier if world > 1 else (lambda: None)
     for i in range(args.warmup):
         step(-1 - i)
+    collect_garbage()
     barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     checksum = 0.0
+    trace = []
     for i in range(args.steps):
+        ta = time.perf_counter()
         checksum += step(i)
+        if os.environ.get("MVSDET_BENCH_TRACE") == "2":
+            torch.cuda.synchronize(device)
+        trace.append(round((time.perf_counter() - ta) * 1e3, 2))
     torch.cuda.synchronize(device)
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("MVSDET_BENCH_TRACE"):
+        print("step host ms:", trace, "total", round(elapsed * 1e3, 1), file=sys.stderr, flush=True)
     if world > 1:
         elapsed = parallel.max_over_ranks(elapsed, device)
     return elapsed, checksum
@@ -430,6 +450,7 @@ def run_view_sharded(args, w, rank, world, device, dry=False):
     out = None
     for i in range(args.warmup):
         out = step(i)
+    collect_garbage()
     parallel.barrier()
     if device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -466,6 +487,7 @@ def test_shape_chain_rate(device, name, steps=8):
             for i in range(2):
                 hp.prefetch_scene(metas[i + 1], device)
                 out = hp.forward_scene(scene.features, metas[i])
+            collect_garbage()
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             for i in range(2, steps + 2):
@@ -513,6 +535,7 @@ def full_chain_rate(device, steps=10):
         for i in range(2):
             hp.prefetch_scene(metas[i + 1], device)
             out = hp.forward_scene(scene.features, metas[i])
+        collect_garbage()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for i in range(2, steps + 2):
