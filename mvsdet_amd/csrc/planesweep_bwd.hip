@@ -47,6 +47,14 @@ __device__ __forceinline__ int grad_swizzle(int base) { return (base >> 6) & 1; 
 
 constexpr int kHalfSlab = kSlab / 2;  // packed floats of a texel one kernel instance owns
 
+// byte offset, inside the LDS images, of the FIRST double of a lane's pair (add 16 * g) of the texel at double index `base`, swizzle
+// applied: doubles (2g, 2g+1) of the texel live at 2g + (0 ^ sw), 2g + (1 ^ sw), i.e. at this address and at it with bit 3 flipped
+__device__ __forceinline__ int grad_byte(int base) { return base * 8 + 8 * grad_swizzle(base); }
+__device__ __forceinline__ void lds_add_f64_at(int addr, double v) {
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) double*)(size_t)(unsigned)addr, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int K, int TW, int HALF, int GROUPS>
 __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_variance_bwd_kernel(
     const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
@@ -77,15 +85,23 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
     const size_t slab_stride = (size_t)HW * kSlab;
     // float2 views of the slab images, already at the lane's two floats: texel t is element 16 * t
     const float2* ref_img = reinterpret_cast<const float2*>(packed + ((size_t)n * S + slab) * slab_stride) + 8 * half + g;
-    const float2* nb_img[KK];
+    // Tap offsets travel in BYTES (as in the forward kernel): the slab bases are block-uniform (scalar registers), the decoding lane
+    // sends the byte offset of the texel, and the receiving lane's address is ONE v_add_u32_dpp (quad broadcast + its own bytes of the
+    // texel) -- a gather is `global_load_dwordx2 v, v_off, s[base]`, an LDS add takes its address ready-made.  Round 4 measured this
+    // form at no gain (the waves waited on memory 54 % of their cycles); with two planes of dL/dvar in flight the vector pipe is what
+    // the kernel runs on (9.2e8 vector instructions per launch x 4 cycles on 1024 SIMDs = 3.6 of its 4.9 M cycles).
+    const char* nb_img[KK];
     float* nb_grad[KK];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         int64_t v = nbr[(size_t)n * K + j];
         v = v < 0 ? 0 : (v >= N ? N - 1 : v);
-        nb_img[j] = reinterpret_cast<const float2*>(packed + ((size_t)v * S + slab) * slab_stride) + 8 * half + g;
+        nb_img[j] = reinterpret_cast<const char*>(packed + ((size_t)v * S + slab) * slab_stride);
         nb_grad[j] = gpacked + ((size_t)v * S + slab) * slab_stride + kHalfSlab * half;
     }
+    const int lane_b = (8 * half + g) * 8;   // the lane's float2 of a texel of the slab image, in bytes
+    const int g8 = g * 8;                    // ... of a texel's half of the gradient map (nb_grad is already at the half)
+    const int g16_lds = g * 16 + (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)s_grad;   // the lane's two doubles of a texel of the LDS image
     const float r = 1.0f / (float)(K + 1);
     const float two_r = 2.0f * r, two_r2 = 2.0f * r * r;
     const int slot_el = (box_cap + kBoxPad) * kHalfSlab;  // doubles per LDS slot
@@ -241,12 +257,18 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
         float dwx[NPP][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { S_[s][0] = f[s][0]; S_[s][1] = f[s][1]; }
-#define MVS_BWD_STEP(SS)                                                                                              \
+#define MVS_BWD_TAP(O) (*reinterpret_cast<const float2*>(nb_img[j] + (size_t)(unsigned)(O)))
+#define MVS_BWD_LOAD(SS)                                                                                              \
         {                                                                                                             \
-            const int i0 = quad_bcast<SS>(ri0), i1 = quad_bcast<SS>(ri1), i2 = quad_bcast<SS>(ri2), i3 = quad_bcast<SS>(ri3); \
+            int i0, i1, i2, i3;                                                                                       \
+            quad_bcast_add4<SS>(ri0, ri1, ri2, ri3, lane_b, i0, i1, i2, i3);                                          \
+            tq[SS][0] = MVS_BWD_TAP(i0); tq[SS][1] = MVS_BWD_TAP(i1); tq[SS][2] = MVS_BWD_TAP(i2); tq[SS][3] = MVS_BWD_TAP(i3); \
+        }
+#define MVS_BWD_MATH(SS)                                                                                              \
+        {                                                                                                             \
             const float w0 = __int_as_float(quad_bcast<SS>(rw0)), w1 = __int_as_float(quad_bcast<SS>(rw1));           \
             const float w2 = __int_as_float(quad_bcast<SS>(rw2)), w3 = __int_as_float(quad_bcast<SS>(rw3));           \
-            const float2 t0 = nb_img[j][i0], t1 = nb_img[j][i1], t2 = nb_img[j][i2], t3 = nb_img[j][i3];              \
+            const float2 t0 = tq[SS][0], t1 = tq[SS][1], t2 = tq[SS][2], t3 = tq[SS][3];                              \
             const float a0[2] = {t0.x, t0.y}, a1[2] = {t1.x, t1.y}, a2[2] = {t2.x, t2.y}, a3[2] = {t3.x, t3.y};       \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
                 float v = a0[i] * w0;                                                                                 \
@@ -264,7 +286,12 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
                 const int ri0 = from_quad<QQ>(di0), ri1 = from_quad<QQ>(di1), ri2 = from_quad<QQ>(di2), ri3 = from_quad<QQ>(di3); \
                 const int rw0 = from_quad<QQ>(__float_as_int(dw.x)), rw1 = from_quad<QQ>(__float_as_int(dw.y));       \
                 const int rw2 = from_quad<QQ>(__float_as_int(dw.z)), rw3 = from_quad<QQ>(__float_as_int(dw.w));       \
-                MVS_BWD_STEP(0) MVS_BWD_STEP(1) MVS_BWD_STEP(2) MVS_BWD_STEP(3)                                       \
+                /* the 16 gathers of the neighbour are requested before the first of them is used: one exposed L2 round */ \
+                /* trip per neighbour, not four (the scheduler sinks the requests back to their uses otherwise)         */ \
+                float2 tq[4][4];                                                                                      \
+                MVS_BWD_LOAD(0) MVS_BWD_LOAD(1) MVS_BWD_LOAD(2) MVS_BWD_LOAD(3)                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+                MVS_BWD_MATH(0) MVS_BWD_MATH(1) MVS_BWD_MATH(2) MVS_BWD_MATH(3)                                       \
             } else {                                                                                                  \
                 _Pragma("unroll") for (int s = 0; s < 4; ++s) wv[j][s][0] = wv[j][s][1] = 0.0f;                       \
             }                                                                                                         \
@@ -284,17 +311,18 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
             const int loy = l_staged ? ly0[p] : 0, hiy = l_staged ? ly1[p] : H - 1;
             const int xa = clampi(tp.x0, lox, hix), xb = clampi(tp.x0 + 1, lox, hix);
             const int ya = clampi(tp.y0, loy, hiy), yb = clampi(tp.y0 + 1, loy, hiy);
-            // float2 elements of the slab image
-            const int di0 = (ya * W + xa) * kHalfSlab, di1 = (ya * W + xb) * kHalfSlab;
-            const int di2 = (yb * W + xa) * kHalfSlab, di3 = (yb * W + xb) * kHalfSlab;
+            // byte offsets of the texels in the slab image (and in the gradient map, which has its layout)
+            const int di0 = (ya * W + xa) * (kSlab * 4), di1 = (ya * W + xb) * (kSlab * 4);
+            const int di2 = (yb * W + xa) * (kSlab * 4), di3 = (yb * W + xb) * (kSlab * 4);
             const int pitch = hix - lox + 1;
             const int sbase = min(2 * p + qd, K - 1) * slot_el;
             const int ta = (ya - loy) * pitch - lox, tb = (yb - loy) * pitch - lox;
-            // doubles of the gradient slot (staged) or floats of the gradient map
-            dox[p][0] = l_staged ? box_slot(ta + xa) * kHalfSlab + sbase : di0 * 2;
-            dox[p][1] = l_staged ? box_slot(ta + xb) * kHalfSlab + sbase : di1 * 2;
-            dox[p][2] = l_staged ? box_slot(tb + xa) * kHalfSlab + sbase : di2 * 2;
-            dox[p][3] = l_staged ? box_slot(tb + xb) * kHalfSlab + sbase : di3 * 2;
+            // staged: byte offset of the texel in the LDS image with the bank swizzle already applied to the lane's FIRST double
+            // (grad_byte: the second one is that address with bit 3 flipped); else the byte offset in the gradient map
+            dox[p][0] = l_staged ? grad_byte(box_slot(ta + xa) * kHalfSlab + sbase) : di0;
+            dox[p][1] = l_staged ? grad_byte(box_slot(ta + xb) * kHalfSlab + sbase) : di1;
+            dox[p][2] = l_staged ? grad_byte(box_slot(tb + xa) * kHalfSlab + sbase) : di2;
+            dox[p][3] = l_staged ? grad_byte(box_slot(tb + xb) * kHalfSlab + sbase) : di3;
             dwx[p][0] = dw.x; dwx[p][1] = dw.y; dwx[p][2] = dw.z; dwx[p][3] = dw.w;
             MVS_BWD_OF(0)
             MVS_BWD_OF(1)
@@ -302,7 +330,9 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
         if constexpr (NP > 0) pass(std::integral_constant<int, 0>{});
         if constexpr (NP > 1) pass(std::integral_constant<int, 1>{});
 #undef MVS_BWD_OF
-#undef MVS_BWD_STEP
+#undef MVS_BWD_LOAD
+#undef MVS_BWD_MATH
+#undef MVS_BWD_TAP
         // ---- dL/dvar two planes ahead, behind this plane's gathers (see above): gnext <- plane d+1's, gahead <- the new request
         if constexpr (kAhead2) {
             gnext[0] = gahead[0]; gnext[1] = gahead[1];
@@ -320,28 +350,36 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
             for (int i = 0; i < 2; ++i)
                 if (pok[s]) gref[s][i] = fmaf(go[s][i], two_r * f[s][i] - two_r2 * S_[s][i], gref[s][i]);
         // ---- pass 2: tap gradients of every live neighbour
-#define MVS_GRAD_STEP(SS, ADD, COND)                                                                                  \
-        if (!COND || pok[SS]) {                                                                                       \
-            int to[4];                                                                                                \
-            float tw[4];                                                                                              \
+        // A step = the 4 taps of the lane's pixel SS of neighbour j, both channels of the lane: the 4 addresses are one v_add_u32_dpp each
+        // (quad broadcast of the decoding lane's byte offset + the lane's own bytes), the two gradients of a tap one packed product.
+        // LDS adds are unconditional: an invalid tap (weight 0) and a pixel outside the map (gradient 0) add 0.0 to a clamped
+        // texel of the box -- a test per tap would put every one of the 64 ds_add_f64 of a plane under its own branch.  Larger
+        // than the box: one global fp32 atomic per tap.
+#define MVS_GRAD_STEP_LDS(SS)                                                                                         \
+        {                                                                                                             \
+            int a0, a1, a2, a3;                                                                                       \
+            quad_bcast_add4<SS>(ro[0], ro[1], ro[2], ro[3], g16_lds, a0, a1, a2, a3);                                 \
+            const f2 gw = pok[SS] ? (f2){go[SS][0], go[SS][1]} * ((f2){wv[j][SS][0], wv[j][SS][1]} * splat(two_r) -   \
+                                                                   (f2){S_[SS][0], S_[SS][1]} * splat(two_r2))          \
+                                  : splat(0.0f);                                                                      \
+            const int aa[4] = {a0, a1, a2, a3};                                                                       \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
-                to[t] = quad_bcast<SS>(ro[t]);                                                                        \
-                tw[t] = __int_as_float(quad_bcast<SS>(rw[t]));                                                        \
-            }                                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
-                float gw = go[SS][i] * (two_r * wv[j][SS][i] - two_r2 * S_[SS][i]);                                   \
-                if (!COND) gw = pok[SS] ? gw : 0.0f;                                                                  \
-                _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
-                    if (!COND || tw[t] != 0.0f) ADD(to[t], i, gw * tw[t]);                                            \
+                const f2 pr = gw * splat(__int_as_float(quad_bcast<SS>(rw[t])));                                      \
+                lds_add_f64_at(aa[t], (double)pr.x);                                                                  \
+                lds_add_f64_at(aa[t] ^ 8, (double)pr.y);                                                              \
             }                                                                                                         \
         }
-        // LDS adds are unconditional: an invalid tap (weight 0) and a pixel outside the map (gradient 0) add 0.0 to a clamped
-        // texel of the box -- a test per tap would put every one of the 64 ds_add_f64 of a plane under its own branch.
-        // LDS: ds_add_f64 on the swizzled gradient image (s_grad is used directly: a select between an LDS and a global
-        // address would make hipcc emit flat atomics); larger than the box: one global fp32 atomic per tap
-#define MVS_ADD_LDS(O, I, V) \
-    __hip_atomic_fetch_add(s_grad + (O) + 2 * g + ((I) ^ grad_swizzle(O)), (double)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define MVS_ADD_GLB(O, I, V) atomicAdd(nb_grad[j] + (O) + 2 * g + (I), (V))
+#define MVS_GRAD_STEP_GLB(SS)                                                                                         \
+        if (pok[SS]) {                                                                                                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
+                const float tw = __int_as_float(quad_bcast<SS>(rw[t]));                                               \
+                float* cell = reinterpret_cast<float*>(reinterpret_cast<char*>(nb_grad[j]) + (size_t)(unsigned)(quad_bcast<SS>(ro[t]) + g8)); \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+                    const float gw = go[SS][i] * (two_r * wv[j][SS][i] - two_r2 * S_[SS][i]);                         \
+                    if (tw != 0.0f) atomicAdd(cell + i, gw * tw);                                                     \
+                }                                                                                                     \
+            }                                                                                                         \
+        }
 #define MVS_GRAD_OF(QQ)                                                                                               \
         if constexpr (2 * p + QQ < K) {                                                                               \
             constexpr int j = 2 * p + QQ;                                                                             \
@@ -353,11 +391,9 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
                     rw[t] = from_quad<QQ>(__float_as_int(dwx[p][t]));                                                 \
                 }                                                                                                     \
                 if (fj & kFlagStaged) {                                                                               \
-                    MVS_GRAD_STEP(0, MVS_ADD_LDS, false) MVS_GRAD_STEP(1, MVS_ADD_LDS, false)                         \
-                    MVS_GRAD_STEP(2, MVS_ADD_LDS, false) MVS_GRAD_STEP(3, MVS_ADD_LDS, false)                         \
+                    MVS_GRAD_STEP_LDS(0) MVS_GRAD_STEP_LDS(1) MVS_GRAD_STEP_LDS(2) MVS_GRAD_STEP_LDS(3)               \
                 } else {                                                                                              \
-                    MVS_GRAD_STEP(0, MVS_ADD_GLB, true) MVS_GRAD_STEP(1, MVS_ADD_GLB, true)                           \
-                    MVS_GRAD_STEP(2, MVS_ADD_GLB, true) MVS_GRAD_STEP(3, MVS_ADD_GLB, true)                           \
+                    MVS_GRAD_STEP_GLB(0) MVS_GRAD_STEP_GLB(1) MVS_GRAD_STEP_GLB(2) MVS_GRAD_STEP_GLB(3)               \
                 }                                                                                                     \
             }                                                                                                         \
         }
@@ -369,9 +405,8 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
         if constexpr (NP > 0) grads(std::integral_constant<int, 0>{});
         if constexpr (NP > 1) grads(std::integral_constant<int, 1>{});
 #undef MVS_GRAD_OF
-#undef MVS_GRAD_STEP
-#undef MVS_ADD_LDS
-#undef MVS_ADD_GLB
+#undef MVS_GRAD_STEP_LDS
+#undef MVS_GRAD_STEP_GLB
     }
     // ---- the boxes still resident, then the reference term: once per block
     __syncthreads();
