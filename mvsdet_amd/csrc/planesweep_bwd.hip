@@ -87,9 +87,13 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
     const float2* ref_img = reinterpret_cast<const float2*>(packed + ((size_t)n * S + slab) * slab_stride) + 8 * half + g;
     // Tap offsets travel in BYTES (as in the forward kernel): the slab bases are block-uniform (scalar registers), the decoding lane
     // sends the byte offset of the texel, and the receiving lane's address is ONE v_add_u32_dpp (quad broadcast + its own bytes of the
-    // texel) -- a gather is `global_load_dwordx2 v, v_off, s[base]`, an LDS add takes its address ready-made.  Round 4 measured this
-    // form at no gain (the waves waited on memory 54 % of their cycles); with two planes of dL/dvar in flight the vector pipe is what
-    // the kernel runs on (9.2e8 vector instructions per launch x 4 cycles on 1024 SIMDs = 3.6 of its 4.9 M cycles).
+    // texel) -- a gather is `global_load_dwordx2 v, v_off, s[base]`, an LDS add takes its address ready-made, the second double of
+    // a lane's pair is that address with bit 3 flipped, the two gradients of a tap are one packed product: 56 -> 29 vector
+    // instructions per pixel step of pass 2, 17 -> 13 of pass 1.  Round 4 measured this form at no gain (the waves waited on memory
+    // 54 % of their cycles); round 5, with two planes of dL/dvar in flight: 2.39 -> 2.31 ms at 12 planes of 60 x 80, 6.27 -> 6.10 at
+    // 100 views, 44.7 -> 39.2 ms at 64 planes of 120 x 160 (same box, tools/ab_libs.sh) -- PROVIDED the 16 gathers of a neighbour are
+    // requested ahead of the first use (below): left to the scheduler, the first neighbour's became load - wait - 3 loads - wait per
+    // pixel step under the register budget (eight exposed L2 round trips instead of one: 2.56 ms).
     const char* nb_img[KK];
     float* nb_grad[KK];
 #pragma unroll
