@@ -243,7 +243,10 @@ def collect_garbage():
     created: 100-130 ms on this image, measured (MVSDET_BENCH_TRACE=1 prints the per-step host times).  When it falls is a matter
     of allocation counts, so it landed in the first of ten timed training steps of one code version and in the warm-up of
     another: a 5.5 ms step read as 12.8-21.9 ms.  A long-running job pays it once per many thousand steps; a 10-step
-    measurement must not.  freeze() then keeps what exists now out of later collections."""
+    measurement must not.  freeze() then keeps what exists now out of later collections -- after an unfreeze(), or the networks
+    of the PREVIOUS measurement (frozen while alive, unreachable since, and cyclic through their hooks) would never be collected:
+    3.8 GB of device memory per measurement."""
+    gc.unfreeze()
     gc.collect()
     gc.freeze()
 
@@ -537,12 +540,16 @@ def full_chain_rate(device, steps=10):
             out = hp.forward_scene(scene.features, metas[i])
         collect_garbage()
         torch.cuda.synchronize(device)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        marks[0].record()
         t0 = time.perf_counter()
         for i in range(2, steps + 2):
             hp.prefetch_scene(metas[i + 1], device)
             out = hp.forward_scene(scene.features, metas[i])
+            marks[i - 1].record()
         torch.cuda.synchronize(device)
         el = time.perf_counter() - t0
+        per_scene = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
         # the same loop with the neck and the head of a scene on a stream of their own (MVSDetHotPath.overlap_detector): they run
         # beside the next scene's packing, sweep and first convolution; one synchronisation of the device at the end
         hp.overlap_detector = True
@@ -631,6 +638,9 @@ def full_chain_rate(device, steps=10):
             "detector_batch1": {"ms_per_scene": round(det[1], 3), "what": "IndoorImVoxelNeck + head convolutions on one volume"},
             "detector_batch4": {"ms_per_scene": round(det[4], 3), "what": "the same on four stacked volumes (forward_scenes), per scene"},
             "ms_per_scene": round(el / steps * 1e3, 3),
+            # intervals between events recorded on the caller's stream behind every scene of the one-stream loop: a mean far above the
+            # median is one stalled scene (an allocation, the host), not a slow chain
+            "ms_per_scene_min_median_max": [round(per_scene[0], 3), round(per_scene[len(per_scene) // 2], 3), round(per_scene[-1], 3)],
             "detector_on_side_stream": {"scenes_per_sec": round(steps / el_overlap, 3), "ms_per_scene": round(el_overlap / steps * 1e3, 3),
                                         "note": "depth distribution, lifting, neck and head of scene i on their own stream beside scene i+1's packing, sweep and conv0 "
                                                 "(MVSDetHotPath.overlap_detector); the device is synchronised once, after the last scene; "

@@ -89,6 +89,10 @@ def main():
     c = "with_cost_network"
     cw = get(d, c + ".workload")
     row(cw, "chain a1..a10 + cost network + neck + head, one stream", c + ".ms_per_scene", None, None, c + ".scenes_per_sec", "scenes/s")
+    mmm = get(d, c + ".ms_per_scene_min_median_max")
+    if mmm:
+        rows.append((cw, "  same, per scene (events behind every scene): min / median / max", "-", " / ".join(fmt(v) for v in mmm), "-", "-",
+                     c + ".ms_per_scene_min_median_max"))
     row(cw, "  same, detector on the side stream", c + ".detector_on_side_stream.ms_per_scene", None, None, c + ".scenes_per_sec_pipelined", "scenes/s")
     row(cw, "  CostRegNet_3DGS forward (eval)", c + ".cost_network_roofline.network_ms", c + ".cost_network_roofline.network_vs_fp32_mfma_peak",
         "fp32 MFMA peak 157 TFLOP/s, useful FLOP")
