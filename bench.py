@@ -140,11 +140,11 @@ def run_gpu(args, w, rank, world, device):
     barrier = parallel.barrier if world > 1 else (lambda: None)
 
     out = None
+    collect_garbage()   # AHEAD of the warm-up: 100 ms of host work between warm-up and timing let the device clock down (first timed step 13.0 instead of 10.6 ms)
     for i in range(args.warmup):
         out = None
         out = step(i, False)
     del out
-    collect_garbage()
     barrier()
     torch.cuda.synchronize(device)
     stats0 = dict(hp._geometry.stats)
@@ -239,7 +239,8 @@ class PointwiseCostReg(torch.nn.Module):
 
 
 def collect_garbage():
-    """Called once before every timed region.  CPython's full (generation-2) collection walks every object torch's import
+    """Called once ahead of the WARM-UP of every timed region (between warm-up and timing its 100 ms of host work let the device
+    clock down: the first timed step of the headline loop took 13.0 instead of 10.6 ms, 3 % of the value).  CPython's full (generation-2) collection walks every object torch's import
     created: 100-130 ms on this image, measured (MVSDET_BENCH_TRACE=1 prints the per-step host times).  When it falls is a matter
     of allocation counts, so it landed in the first of ten timed training steps of one code version and in the warm-up of
     another: a 5.5 ms step read as 12.8-21.9 ms.  A long-running job pays it once per many thousand steps; a 10-step
@@ -283,9 +284,9 @@ def run_train(args, w, rank, world, device):
         return float(feat.grad.abs().sum().item()) if i == args.steps - 1 else 0.0
 
     barrier = parallel.barrier if world > 1 else (lambda: None)
+    collect_garbage()
     for i in range(args.warmup):
         step(-1 - i)
-    collect_garbage()
     barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -451,9 +452,9 @@ def run_view_sharded(args, w, rank, world, device, dry=False):
         return out
 
     out = None
+    collect_garbage()
     for i in range(args.warmup):
         out = step(i)
-    collect_garbage()
     parallel.barrier()
     if device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -487,10 +488,10 @@ def test_shape_chain_rate(device, name, steps=8):
     with torch.no_grad():
         for overlap, key in ((False, "scenes_per_sec"), (True, "scenes_per_sec_pipelined")):
             hp.overlap_detector = overlap
+            collect_garbage()
             for i in range(2):
                 hp.prefetch_scene(metas[i + 1], device)
                 out = hp.forward_scene(scene.features, metas[i])
-            collect_garbage()
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             for i in range(2, steps + 2):
@@ -535,10 +536,10 @@ def full_chain_rate(device, steps=10):
     scene = SceneInputs(wr, seed=0, device=device)
     metas = unseen_metas(wr, 7, steps + 3)   # new cameras every scene, announced one scene ahead (as in run_gpu)
     with torch.no_grad():
+        collect_garbage()
         for i in range(2):
             hp.prefetch_scene(metas[i + 1], device)
             out = hp.forward_scene(scene.features, metas[i])
-        collect_garbage()
         torch.cuda.synchronize(device)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         marks[0].record()
