@@ -299,6 +299,13 @@ int mvsdet_bn3d_relu_train_fwd_res_f32(const float* x, const float* gamma, const
                                        float* running_mean, float* running_var, float* out, float* save_mean, float* save_invstd,
                                        void* workspace, size_t workspace_bytes, int N, int C, long long vol, float momentum, float eps,
                                        int relu, mvsdet_stream_t stream);
+/* The same with the statistics taken from partial sums a producing convolution left (mvsdet_conv3d_k3_bf16x3_stats): partial[c * parts
+ * + i] = (sum, sum of squares) of (x - pivot[c]) of channel c over block i, double2; pivot as given to the producer (NULL = zeros);
+ * the entries are added in a fixed order. */
+int mvsdet_bn3d_relu_train_fwd_parts_f32(const float* x, const void* partial, size_t parts, const float* pivot, const float* gamma, const float* beta,
+                                         const float* residual, float* running_mean, float* running_var, float* out, float* save_mean,
+                                         float* save_invstd, void* workspace, size_t workspace_bytes, int N, int C, long long vol,
+                                         float momentum, float eps, int relu, mvsdet_stream_t stream);
 int mvsdet_bn3d_relu_bwd_f32(const float* x, const float* grad_out, const float* gamma, const float* beta,
                              const float* save_mean, const float* save_invstd, float* grad_x, float* grad_gamma,
                              float* grad_beta, void* workspace, size_t workspace_bytes, int N, int C, long long vol, int relu,
@@ -461,6 +468,16 @@ int mvsdet_conv3d_k3_bf16x3_io(const void* xs, const float* x, const int64_t* x_
                                const void* weight_split, const float* scale, const float* shift, const float* residual,
                                float* out_f32, void* out_scl, void* out_pscl, void* workspace, size_t workspace_bytes, int N,
                                int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* stride 1 in front of a training-mode BatchNorm (module.py:26-37 ConvBnReLU3D under model.train()): the raw fp32 output plus, from
+ * the kernel's epilogue, per-channel partial sums of the outputs and of their squares -- stats[c * parts + i] = double2 of channel c
+ * in block i of the grid, parts = mvsdet_conv3d_k3_bf16x3_stats_parts(N, D, H, W, x != NULL); stats_bytes >= Cout * parts * 16.
+ * The sums are those of (value - pivot[c]) (pivot: Cout floats near the channels' means, e.g. the BatchNorm's running mean; NULL =
+ * zeros): fp32 lane sums of raw values cancel when |mean| >> spread.  mvsdet_bn3d_relu_train_fwd_parts_f32 (same pivot) finishes
+ * them: the BatchNorm reads the tensor once instead of twice. */
+size_t mvsdet_conv3d_k3_bf16x3_stats_parts(int N, int D, int H, int W, int f32_input);
+int mvsdet_conv3d_k3_bf16x3_stats(const void* xs, const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/,
+                                  const void* weight_split, float* out_f32, void* stats, size_t stats_bytes, const float* pivot, int N,
+                                  int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
 /* stride 2: input = x (fp32 + x_strides) or x_pscl (the PSCL form of the (N,Cin,D,H,W) input), exactly one of them */
 int mvsdet_conv3d_k3_s2_bf16x3_io(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* x_pscl,
                                   const void* weight_split, const float* scale, const float* shift, float* out_f32,

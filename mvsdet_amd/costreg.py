@@ -35,16 +35,22 @@ class _ConvK3S1(torch.autograd.Function):
     reference-true shape, these kernels 15 + 15 + 22 ms."""
 
     @staticmethod
-    def forward(ctx, x, weight, bf16x3=False):
+    def forward(ctx, x, weight, bf16x3=False, stats=False, pivot=None):
+        """stats (bf16x3 only): also return the per-channel partial sums of the output and of its squares from the kernel's
+        epilogue (`ops.conv3d_k3_bf16x3_stats`, sums of value - pivot_c), for the training-mode BatchNorm behind the layer."""
         from . import ops
         ctx.save_for_backward(x, weight)
         ctx.bf16x3 = bool(bf16x3)
+        if ctx.bf16x3 and stats:
+            y, parts = ops.conv3d_k3_bf16x3_stats(x, ops.split_conv_weight(weight), pivot)
+            ctx.mark_non_differentiable(parts)
+            return y, parts
         if ctx.bf16x3:   # forward and input gradient on the bf16 matrix cores, three-term split (csrc/costreg_bf16.hip)
             return ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(weight), None, None, False)
         return ops.conv3d_k3_mfma(x, ops.permute_conv_weight(weight), None, None, False)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gparts=None):
         from . import ops
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
@@ -65,7 +71,7 @@ class _ConvK3S1(torch.autograd.Function):
                 gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(wflip), None, None, False)
         if ctx.needs_input_grad[1]:   # bf16x3: csrc/costreg_dw_bf16.hip (rows read as float4)
             gw = ops.conv3d_k3_dw(x, gy, 0, 1, ctx.bf16x3 and x.shape[-1] % 4 == 0)
-        return gx, gw, None
+        return gx, gw, None, None, None
 
 
 class _ConvK3S2(torch.autograd.Function):
@@ -139,12 +145,14 @@ class _ConvT3S2(torch.autograd.Function):
         return gx, gw, None
 
 
-def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                   parts: Optional[torch.Tensor] = None, pivot: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu(bn(x)) with batch statistics (module.py:26-37; mvsnet.py:92-100) on the streaming kernels of
     csrc/costreg_bn.hip -- two passes over x forward, ReLU in the second, the mask recomputed going backward -- and the
     running statistics updated the way torch.nn.BatchNorm3d does (momentum, unbiased variance, num_batches_tracked)."""
     from . import ops
-    out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True, residual)   # residual: added after the ReLU
+    # residual: added after the ReLU; parts: the statistics' partial sums from the convolution's epilogue (no pass over x for them)
+    out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True, residual, parts, pivot)
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             m = x.numel() // x.shape[1]
@@ -154,6 +162,16 @@ def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor, residual: Optional[torch
             bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1.0 - mom).add_(var, alpha=mom)
     return out
+
+
+# training: the statistics of a BatchNorm behind a stride-1 bf16x3 convolution come from that convolution's epilogue (partial sums
+# per block, finished in a fixed order) instead of a pass of their own over the tensor; MVSDET_FUSED_BN_STATS=0: the separate pass
+FUSED_BN_STATS = os.environ.get("MVSDET_FUSED_BN_STATS", "1") != "0"
+
+
+def ops_option(name: str) -> int:
+    from . import ops
+    return int(ops.get_option(name))
 
 
 def _bn_hip_ok(bn: nn.BatchNorm3d, x: torch.Tensor) -> bool:
@@ -370,13 +388,22 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
                 and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.out_channels % 64 == 0 and conv.in_channels % 64 == 0):
             # autograd: convolution forward / backward on our kernels; BatchNorm + ReLU too when it uses batch statistics
             skip = x
+            parts = pivot = None
             if conv.stride == (1, 1, 1):
-                y = _ConvK3S1.apply(x, conv.weight, self.matrix_precision == "bf16x3")
+                # the BatchNorm's statistics from the convolution's epilogue (16x16x32 form of the kernel: the default)
+                if (FUSED_BN_STATS and self.matrix_precision == "bf16x3" and _bn_hip_ok(bn, x) and x.shape[0] * x[0, 0].numel() > 1
+                        and ops_option("conv_mfma16") and ops_option("conv_subpairs") != 2):
+                    # sums around the running mean (read by the convolution and by the BatchNorm's finishing kernel before the
+                    # in-place update of the buffer that follows them on the same stream)
+                    pivot = bn.running_mean.detach() if bn.running_mean is not None else None
+                    y, parts = _ConvK3S1.apply(x, conv.weight, True, True, pivot)
+                else:
+                    y = _ConvK3S1.apply(x, conv.weight, self.matrix_precision == "bf16x3")
             elif split_skip:
                 y, skip = _ConvK3S2.apply(x, conv.weight, self.matrix_precision == "bf16x3", True)
             else:
                 y = _ConvK3S2.apply(x, conv.weight, self.matrix_precision == "bf16x3")
-            y = _bn_relu_train(bn, y) if _bn_hip_ok(bn, y) else torch.relu_(bn(y))
+            y = _bn_relu_train(bn, y, None, parts, pivot) if _bn_hip_ok(bn, y) else torch.relu_(bn(y))
             return (y, skip) if split_skip else y
         return (layer(x), x) if split_skip else layer(x)
 

@@ -305,7 +305,8 @@ __global__ __launch_bounds__(TD * TH * TW * 4 / CGN) void conv3d_k3_bf16x3_kerne
     const uint4* __restrict__ xs, const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin,
     const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, BfOut dst, int C8, int Cout, int D, int H, int W, int Dp, int Hp, int Wp,
-    size_t piece_stride, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total, int xcd_map) {
+    size_t piece_stride, int tiles_w, int relu, int nsplit, float* __restrict__ partial, size_t total, int xcd_map,
+    double2* __restrict__ stats, const float* __restrict__ stats_pivot) {
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;                           // h-rows of one column group
     static_assert(TH % RG == 0 && (TD * TH * TW) % 64 == 0, "whole column groups, two per wave");
@@ -584,6 +585,19 @@ __global__ __launch_bounds__(TD * TH * TW * 4 / CGN) void conv3d_k3_bf16x3_kerne
         // 16x16: column = lane & 15 (voxel), register r of lane group kg = row 4*kg + r of the row group; the weights are laid out
         // so that row m of row group rg carries channel 32*(rg >> 1) + 8*(m >> 2) + 4*(rg & 1) + (m & 3): row groups 2q and 2q+1
         // together give a lane the eight consecutive channels 32q + 8kg .. + 7
+        // stats (training-mode BatchNorm behind this layer, costreg_bn.hip): the lane's sums of its outputs and of their squares,
+        // per channel, over its CGN voxels -- reduced over the block below, so that the BatchNorm needs no pass of its own over the
+        // tensor for its statistics
+        // (sums of v - pivot_c: E[v^2] - mean^2 on raw values cancels in fp32 when |mean| >> spread; the pivot is any value near the
+        // channel's mean -- the BatchNorm's running mean -- and is requested here, ahead of the stores)
+        float st_s[2][8], st_q[2][8], st_p[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                st_s[q][j] = st_q[q][j] = 0.0f;
+                st_p[q][j] = (stats && stats_pivot) ? stats_pivot[ob64 * 64 + 32 * q + 8 * kg + j] : 0.0f;
+            }
 #pragma unroll
         for (int cg = 0; cg < CGN; ++cg) {
             const int g = CGN * wave + cg;
@@ -614,6 +628,44 @@ __global__ __launch_bounds__(TD * TH * TW * 4 / CGN) void conv3d_k3_bf16x3_kerne
                     if (out) out[idx0 + (size_t)j * vol] = v[j];
                 }
                 if (nsplit == 1 && (dst.scl || dst.pscl)) bf_store_units(dst, v, n, Cout / 8, ob64 * 8 + 4 * q + kg, d, h, w);
+                if (stats) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float dv = v[j] - st_p[q][j];
+                        st_s[q][j] += dv;
+                        st_q[q][j] = fmaf(dv, dv, st_q[q][j]);
+                    }
+                }
+            }
+        }
+        if (stats) {   // block-uniform; the launcher allows it with nsplit == 1 and a raw fp32 output only
+            // channel 32q + 8kg + j of the block has NW * 16 contributors (wave, voxel lane): all of them into the LDS the loop has
+            // left, then four threads per channel add theirs up in double, in a fixed order (the same bits on every run)
+            constexpr int NCON = NW * 16;
+            static_assert(NT >= 256 && (size_t)64 * NCON * sizeof(float2) <= bf_lds_bytes(TD, TH, TW, SUBP), "the reduction's LDS image");
+            float2* red = reinterpret_cast<float2*>(s_bf);
+            __syncthreads();   // every wave is past its last read of the stage buffers
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[(32 * q + 8 * kg + j) * NCON + wave * 16 + col16] = make_float2(st_s[q][j], st_q[q][j]);
+            __syncthreads();
+            if (tid < 256) {
+                const int ch = tid >> 2, part = tid & 3;
+                double a = 0.0, b = 0.0;
+                for (int i = part * (NCON / 4); i < (part + 1) * (NCON / 4); ++i) {
+                    const float2 e = red[ch * NCON + i];
+                    a += (double)e.x;
+                    b += (double)e.y;
+                }
+                a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64);
+                a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64);
+                if (part == 0) {
+                    // partial sums of channel c: [c][view][tile]: one entry per block that holds outputs of the channel
+                    const size_t tiles = (size_t)gridDim.x * gridDim.y;
+                    const size_t bidx = ((size_t)n * gridDim.y + by) * gridDim.x + bx;
+                    stats[(size_t)(ob64 * 64 + ch) * ((size_t)(gridDim.z / nob) * tiles) + bidx] = make_double2(a, b);
+                }
             }
         }
         return;
@@ -1624,7 +1676,7 @@ extern "C" size_t mvsdet_conv3d_k3_bf16x3_workspace_bytes(int N, int Cin, int Co
 static int launch_bf16x3(const char* name, const void* xs, const float* xf, const int64_t* xstr, const void* weight_split,
                          const float* scale, const float* shift, const float* residual, float* out, void* out_scl, void* out_pscl,
                          int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream, void* workspace = nullptr,
-                         size_t workspace_bytes = 0) {
+                         size_t workspace_bytes = 0, void* stats = nullptr, size_t stats_bytes = 0, const float* stats_pivot = nullptr) {
     MVS_REQUIRE((xs || xf) && weight_split && (out || out_scl || out_pscl), "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
@@ -1639,8 +1691,14 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
     // EVERY input form and tile shape, so that all of them add up the same partial sums.  The split form writes fp32 only.
     const BfPlan ps = bf_plan(D, H, W);
     int nsplit = bf_nsplit((long long)ps.tiles_w * ps.tiles_h * ps.tiles_d * N * (Cout / 64), C8);
-    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float) || out_scl || out_pscl) nsplit = 1;
+    if (!workspace || workspace_bytes < (size_t)nsplit * total * sizeof(float) || out_scl || out_pscl || stats) nsplit = 1;
     MVS_REQUIRE(nsplit == 1 || out, "%s: the split form needs the fp32 output", name);
+    if (stats) {
+        MVS_REQUIRE(options().conv_mfma16 != 0 && options().conv_subpairs != 2, "%s: the statistics epilogue exists in the 16x16x32 form only", name);
+        MVS_REQUIRE(!scale && !residual && !relu && out && !out_scl && !out_pscl, "%s: statistics are those of the raw fp32 output", name);
+        MVS_REQUIRE(stats_bytes >= (size_t)Cout * N * p.tiles_w * p.tiles_h * p.tiles_d * sizeof(double2) && ((uintptr_t)stats & 15u) == 0,
+                    "%s: the statistics buffer holds Cout x mvsdet_conv3d_k3_bf16x3_stats_parts double2", name);
+    }
     MVS_REQUIRE((long long)N * (Cout / 64) * nsplit <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
     const long long sN = xstr ? xstr[0] : (long long)Cin * vol, sC = xstr ? xstr[1] : (long long)vol;
     const long long sD = xstr ? xstr[2] : (long long)H * W, sH = xstr ? xstr[3] : (long long)W;
@@ -1665,7 +1723,8 @@ static int launch_bf16x3(const char* name, const void* xs, const float* xf, cons
         }                                                                                                                   \
         hipLaunchKernelGGL(k, grid, dim3(TD_ * TH_ * TW_ * 4 / CGN_), lds, st, static_cast<const uint4*>(xs), xf, sN, sC, sD, sH, \
                            Cin, static_cast<const uint4*>(weight_split), scale, shift, residual, dst, C8, Cout, D, H, W,    \
-                           p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total, xcd_map);        \
+                           p.Dp, p.Hp, p.Wp, piece, p.tiles_w, relu, nsplit, static_cast<float*>(workspace), total, xcd_map,         \
+                           static_cast<double2*>(stats), stats_pivot);                                                      \
     }
 #define MVS_BF_TILE(TD_, TH_, F32_, TW_) { if (m16) MVS_BF_CASE(TD_, TH_, F32_, TW_, 6, true) else MVS_BF_CASE(TD_, TH_, F32_, TW_, 5, false) }
     // option "conv_subpairs" = 2: weight sub-stages of 2 tap pairs (instead of 5) bring the 3 x 16 x 8 tile's LDS to 77 KiB, two
@@ -1726,6 +1785,27 @@ extern "C" int mvsdet_conv3d_k3_bf16x3_f32in(const float* x, const int64_t* x_st
                                              int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
     return launch_bf16x3("conv3d_k3_bf16x3_f32in", nullptr, x, x_strides, weight_split, scale, shift, residual, out, nullptr, nullptr,
                          N, Cin, Cout, D, H, W, relu, stream);
+}
+
+// The convolution in front of a training-mode BatchNorm (module.py:26-37): raw fp32 output + per-channel partial sums of the
+// outputs and of their squares, one double2 per (channel, block of the grid), stats[c * parts + i] -- what
+// mvsdet_bn3d_relu_train_fwd_parts_f32 finishes, so that the BatchNorm reads the tensor once instead of twice.
+// parts = mvsdet_conv3d_k3_bf16x3_stats_parts(N, D, H, W, fp32 input form).  x / xs as for mvsdet_conv3d_k3_bf16x3_io.
+// pivot (Cout floats or NULL = zeros): the sums are those of (value - pivot_c) -- any value near the channel's mean (the
+// BatchNorm's running mean) keeps the fp32 lane sums from cancelling; the finishing call gets the same vector.
+extern "C" size_t mvsdet_conv3d_k3_bf16x3_stats_parts(int N, int D, int H, int W, int f32_input) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const BfPlan p = bf_plan_tile(D, H, W, f32_input != 0);
+    return (size_t)N * p.tiles_w * p.tiles_h * p.tiles_d;
+}
+
+extern "C" int mvsdet_conv3d_k3_bf16x3_stats(const void* xs, const float* x, const int64_t* x_strides, const void* weight_split,
+                                             float* out_f32, void* stats, size_t stats_bytes, const float* pivot, int N, int Cin,
+                                             int Cout, int D, int H, int W, mvsdet_stream_t stream) {
+    MVS_REQUIRE((xs == nullptr) != (x == nullptr), "conv3d_k3_bf16x3_stats: exactly one of xs (SCL) and x (fp32)");
+    MVS_REQUIRE(stats != nullptr, "conv3d_k3_bf16x3_stats: NULL statistics buffer");
+    return launch_bf16x3("conv3d_k3_bf16x3_stats", xs, x, x_strides, weight_split, nullptr, nullptr, nullptr, out_f32, nullptr, nullptr, N,
+                         Cin, Cout, D, H, W, 0, stream, nullptr, 0, stats, stats_bytes, pivot);
 }
 
 // The two forms with a workspace (mvsdet_conv3d_k3_bf16x3_workspace_bytes; NULL or too small: unsplit) for small volumes.

@@ -98,6 +98,38 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, size_t vol, cons
     if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(M > 1.0 ? var * M / (M - 1.0) : var);
 }
 
+// The same, from the partial sums a convolution's epilogue left (costreg_bf16.hip: sums of the raw values and of their squares, one
+// double2 per (channel, block), of (value - pivot_c), added up in double from the block's fp32 lane sums).  One block per
+// channel: the `parts` entries are added in a fixed order (strided over the threads, then block_sum2): the same bits on every run.
+__global__ __launch_bounds__(kThreads) void bn_finalize_parts_kernel(const double2* __restrict__ partial, size_t parts, const float* __restrict__ pivot,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                                     float* __restrict__ save_invstd, float* __restrict__ scale,
+                                                                     float* __restrict__ shift, double M, float momentum, float eps) {
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (size_t i = threadIdx.x; i < parts; i += kThreads) {
+        const double2 e = partial[(size_t)c * parts + i];
+        s += e.x;
+        q += e.y;
+    }
+    const double2 r = block_sum2(s, q);
+    if (threadIdx.x != 0) return;
+    const double dm = r.x / M;                    // mean of (x - pivot)
+    const double mean = (pivot ? (double)pivot[c] : 0.0) + dm;
+    double var = r.y / M - dm * dm;
+    var = var < 0.0 ? 0.0 : var;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    scale[c] = g * invstd;
+    shift[c] = b - (float)mean * (g * invstd);
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(M > 1.0 ? var * M / (M - 1.0) : var);
+}
+
 // y = [relu](x * scale_c + shift_c) [+ residual]; grid (chunks of a (view, channel) volume, C, N)
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -251,6 +283,30 @@ extern "C" int mvsdet_bn3d_relu_train_fwd_res_f32(const float* x, const float* g
     if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, residual, out, C, (size_t)vol, relu);
     else hipLaunchKernelGGL(bn_apply_kernel<false>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, residual, out, C, (size_t)vol, relu);
     MVS_LAUNCH_CHECK("bn3d_relu_train_fwd");
+    return MVSDET_OK;
+}
+
+// Training-mode BatchNorm3d [+ ReLU] [+ residual] whose statistics arrive as partial sums from the producing convolution
+// (mvsdet_conv3d_k3_bf16x3_stats: partial[c * parts + i] = (sum, sum of squares) of (x - pivot_c) over channel c in block i; pivot as
+// given to that call, NULL = zeros): x is read ONCE.
+extern "C" int mvsdet_bn3d_relu_train_fwd_parts_f32(const float* x, const void* partial, size_t parts, const float* pivot, const float* gamma,
+                                                    const float* beta, const float* residual, float* running_mean, float* running_var,
+                                                    float* out, float* save_mean, float* save_invstd, void* workspace,
+                                                    size_t workspace_bytes, int N, int C, long long vol, float momentum, float eps,
+                                                    int relu, mvsdet_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    MVS_REQUIRE(x && out && save_mean && save_invstd && partial && parts > 0, "bn3d_relu_train_fwd_parts: NULL pointer or no partial sums");
+    MVS_REQUIRE(((uintptr_t)partial & 15u) == 0, "bn3d_relu_train_fwd_parts: partial sums must be 16-byte aligned");
+    if (int rc = bn_check("bn3d_relu_train_fwd_parts", N, C, vol, workspace, workspace_bytes)) return rc;
+    const BnWs w = bn_ws(workspace, C);
+    const bool vec = (vol % 4 == 0) && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual) & 15u) == 0;
+    hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3((unsigned)C), dim3(kThreads), 0, stream, static_cast<const double2*>(partial), parts, pivot, gamma,
+                       beta, running_mean, running_var, save_mean, save_invstd, w.scale, w.shift, (double)N * (double)vol, momentum, eps);
+    const size_t cnt = (size_t)vol / (vec ? 4 : 1);
+    dim3 agrid((unsigned)std::min<size_t>((cnt + kThreads - 1) / kThreads, 64), (unsigned)C, (unsigned)N);
+    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, residual, out, C, (size_t)vol, relu);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, agrid, dim3(kThreads), 0, stream, x, w.scale, w.shift, residual, out, C, (size_t)vol, relu);
+    MVS_LAUNCH_CHECK("bn3d_relu_train_fwd_parts");
     return MVSDET_OK;
 }
 

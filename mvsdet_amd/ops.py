@@ -1097,6 +1097,45 @@ def conv3d_k3_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Op
     return _ret(outputs, res)
 
 
+def conv3d_k3_bf16x3_stats(x, weight_split: Tensor, pivot: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """`conv3d_k3_bf16x3(x, weight_split, None, None, False)` in front of a training-mode BatchNorm (module.py:26-37): the raw
+    fp32 output and, from the kernel's epilogue, the per-channel partial sums of the outputs and of their squares -- a float64
+    tensor (Cout, parts, 2), one entry per block of the grid -- that `bn3d_relu_train(..., parts=)` finishes: the BatchNorm then
+    reads the tensor once.  pivot (Cout floats, e.g. the BatchNorm's running mean): the sums are those of (value - pivot_c), which
+    keeps fp32 lane sums from cancelling when a channel's mean is far from zero; pass the same vector to `bn3d_relu_train`.
+    Needs the 16x16x32 form of the kernel (library option conv_mfma16, the default)."""
+    import ctypes
+    scl = isinstance(x, SclTensor)
+    if scl:
+        N, Cin, D, H, W = x.shape
+        dev = x.data.device
+    else:
+        _req(x, "x", dim=5)
+        if x.stride(4) != 1 or min(x.stride()) < 0:
+            x = x.contiguous()
+        N, Cin, D, H, W = x.shape
+        dev = x.device
+    if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
+        raise ValueError(f"conv3d_k3_bf16x3_stats: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
+    Cout = weight_split.shape[0] * 64
+    weight_split = weight_split.contiguous()
+    if pivot is not None:
+        if pivot.dtype != torch.float32 or pivot.numel() != Cout or pivot.device != dev:
+            raise ValueError(f"conv3d_k3_bf16x3_stats: pivot must be {Cout} fp32 values on {dev}")
+        pivot = pivot.detach().contiguous()
+    lib = _lib.load()
+    parts = int(lib.mvsdet_conv3d_k3_bf16x3_stats_parts(N, D, H, W, 0 if scl else 1))
+    out = torch.empty((N, Cout, D, H, W), dtype=torch.float32, device=dev)
+    stats = torch.empty((Cout, parts, 2), dtype=torch.float64, device=dev)
+    xstr = None if scl else (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
+    with torch.cuda.device(dev):
+        _lib.check(lib.mvsdet_conv3d_k3_bf16x3_stats(_lib.ptr(x.data) if scl else None, None if scl else _lib.ptr(x), xstr,
+                                                     _lib.ptr(weight_split), _lib.ptr(out), _lib.ptr(stats), stats.numel() * 8,
+                                                     _lib.ptr(pivot), N, Cin, Cout, D, H, W, _lib.current_stream(dev)),
+                   "conv3d_k3_bf16x3_stats")
+    return out, stats
+
+
 def conv3d_k3_s2_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
                         outputs=("f32",), scl_out: Optional[SclTensor] = None):
     """Conv3d(Cin -> Cout = 64*m, kernel 3, stride 2, padding 1, no bias) [+ affine] [+ ReLU] (mvsnet.py:77,79) on the bf16
@@ -1430,11 +1469,14 @@ def _(x, weight, grad_out, nsplit=32, bf16x3=False):
 
 @torch.library.custom_op(f"{_NS}::bn3d_relu_train", mutates_args=(), device_types="cuda")
 def bn3d_relu_train(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float,
-                    relu: bool, residual: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                    relu: bool, residual: Optional[Tensor] = None, parts: Optional[Tensor] = None,
+                    pivot: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """Training-mode BatchNorm3d [+ ReLU] (mvs_models/module.py:26-37) on the batch statistics of x (N,C,D,H,W) fp32 ->
     (out, batch mean, 1/sqrt(biased batch variance + eps)).  The running statistics are the caller's to update (a custom
     operator with an autograd formula must not mutate its inputs): mvsdet_amd.costreg does it from the returned vectors.
-    residual (same shape as x): out = [relu](bn(x)) + residual in the same pass (mvsnet.py:109-111, the skip additions)."""
+    residual (same shape as x): out = [relu](bn(x)) + residual in the same pass (mvsnet.py:109-111, the skip additions).
+    parts: float64 (C, n, 2) partial sums of x and of its squares per channel, left by the convolution that produced x
+    (`conv3d_k3_bf16x3_stats`): the statistics pass over x is skipped; pivot: the vector that call was given (None = zeros)."""
     _req(x, "x", dim=5)
     if residual is not None:
         _req(residual, "residual", dim=5)
@@ -1457,15 +1499,31 @@ def bn3d_relu_train(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor],
     lib = _lib.load()
     wb = lib.mvsdet_bn3d_workspace_bytes(C)
     ws = torch.empty(wb // 8, dtype=torch.float64, device=x.device)
+    if parts is not None:
+        if parts.dtype != torch.float64 or parts.dim() != 3 or parts.shape[0] != C or parts.shape[2] != 2 or parts.device != x.device:
+            raise ValueError(f"bn3d_relu_train: parts must be float64 ({C}, n, 2) on {x.device}, got {parts.dtype} {tuple(parts.shape)}")
+        parts = parts.contiguous()
+        if pivot is not None:
+            if pivot.dtype != torch.float32 or pivot.numel() != C or pivot.device != x.device:
+                raise ValueError(f"bn3d_relu_train: pivot must be {C} fp32 values on {x.device}")
+            pivot = pivot.contiguous()
+    elif pivot is not None:
+        raise ValueError("bn3d_relu_train: a pivot belongs to partial sums")
     with torch.cuda.device(x.device):
-        _lib.check(lib.mvsdet_bn3d_relu_train_fwd_res_f32(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(residual), None, None,
-                                                          _lib.ptr(out), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(ws), wb, N, C, vol,
-                                                          0.0, float(eps), int(relu), _stream(x)), "bn3d_relu_train")
+        if parts is not None:
+            _lib.check(lib.mvsdet_bn3d_relu_train_fwd_parts_f32(_lib.ptr(x), _lib.ptr(parts), int(parts.shape[1]), _lib.ptr(pivot), _lib.ptr(weight), _lib.ptr(bias),
+                                                                _lib.ptr(residual), None, None, _lib.ptr(out), _lib.ptr(mean), _lib.ptr(invstd),
+                                                                _lib.ptr(ws), wb, N, C, vol, 0.0, float(eps), int(relu), _stream(x)),
+                       "bn3d_relu_train")
+        else:
+            _lib.check(lib.mvsdet_bn3d_relu_train_fwd_res_f32(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(residual), None, None,
+                                                              _lib.ptr(out), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(ws), wb, N, C, vol,
+                                                              0.0, float(eps), int(relu), _stream(x)), "bn3d_relu_train")
     return out, mean, invstd
 
 
 @bn3d_relu_train.register_fake
-def _(x, weight, bias, eps, relu, residual=None):
+def _(x, weight, bias, eps, relu, residual=None, parts=None, pivot=None):
     return torch.empty_like(x), x.new_empty(x.shape[1]), x.new_empty(x.shape[1])
 
 
@@ -1501,7 +1559,7 @@ def _(x, grad_out, weight, bias, save_mean, save_invstd, relu):
 
 
 def _bn_setup(ctx, inputs, output):
-    x, weight, bias, _, relu, residual = inputs
+    x, weight, bias, _, relu, residual, _parts, _pivot = inputs
     ctx.save_for_backward(x, weight, bias, output[1], output[2])
     ctx.relu = relu
     ctx.has_residual = residual is not None
@@ -1511,7 +1569,7 @@ def _bn_bwd(ctx, g_out, g_mean, g_invstd):
     x, weight, bias, mean, invstd = ctx.saved_tensors
     gx, gw, gb = bn3d_relu_backward(x, g_out.contiguous(), weight, bias, mean, invstd, ctx.relu)
     # the residual is added after the activation: its gradient is grad_out itself
-    return gx, (gw if weight is not None else None), (gb if bias is not None else None), None, None, (g_out if ctx.has_residual else None)
+    return gx, (gw if weight is not None else None), (gb if bias is not None else None), None, None, (g_out if ctx.has_residual else None), None, None
 
 
 bn3d_relu_train.register_autograd(_bn_bwd, setup_context=_bn_setup)

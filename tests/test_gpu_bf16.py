@@ -98,6 +98,63 @@ def test_conv3d_k3_bf16x3(gpu, N, Cin, Cout, D, H, W):
         assert torch.equal(ops.conv3d_k3_bf16x3(scl, w2, None, None, False), ops.conv3d_k3_bf16x3(f32, w2, None, None, False))
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(2, 64, 64, 12, 60, 80), (3, 24, 128, 6, 30, 40), (2, 16, 64, 3, 15, 20), (1, 16, 64, 16, 40, 40),
+                                               (2, 8, 64, 5, 13, 21), (1, 5, 64, 1, 1, 2)])
+def test_conv3d_k3_bf16x3_statistics_for_the_batchnorm_behind_it(gpu, N, Cin, Cout, D, H, W):
+    """module.py:26-37 under model.train(): the convolution's epilogue leaves per-channel partial sums of its outputs and of their
+    squares (one float64 pair per channel and block) and the BatchNorm finishes them instead of reading the tensor for its
+    statistics.  The output tensor is the plain call's bit for bit; the sums are those of that tensor (float64, 1e-6 relative to the
+    sum of magnitudes); BatchNorm + ReLU [+ residual] from the partial sums agree with the two-pass operator; the same bits on a
+    second run (fixed summation order); a channel far from zero mean keeps its variance when the sums are taken around a pivot
+    near its mean (the BatchNorm's running mean in the network)."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + Cin + D)
+    x = (torch.randn(N, Cin, D, H, W, generator=g).abs() * 2.0).to(gpu)
+    wgt = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    wgt[1] = wgt[1].abs() * 20.0          # a channel whose mean is many times its spread
+    wq = ops.split_conv_weight(wgt.to(gpu))
+    from mvsdet_amd import _lib
+    plain = ops.conv3d_k3_bf16x3(x, wq, None, None, False)
+    y, parts = ops.conv3d_k3_bf16x3_stats(x, wq)
+    if _lib.load().mvsdet_conv3d_k3_bf16x3_workspace_bytes(N, Cin, Cout, D, H, W) > 0:
+        # a small grid's plain call is split over the input channels (other partial sums); the statistics form never is
+        assert float((y - plain).abs().max()) <= 4e-6 * float(plain.abs().max())
+    else:
+        assert torch.equal(y, plain)
+    assert parts.dtype == torch.float64 and parts.shape[0] == Cout and parts.shape[2] == 2
+    plain = y
+    y64 = plain.double()
+    # a pivot that is near every channel's mean but not equal to it (the running mean of a BatchNorm a few steps into training)
+    pivot = (y64.mean(dim=(0, 2, 3, 4)) * 0.97).float()
+    y2, parts2 = ops.conv3d_k3_bf16x3_stats(ops.scl_pack(x), wq, pivot)      # the SCL input form: another tile plan; sums around the pivot
+    assert torch.equal(y2, y)
+    for pt, pv in ((parts, None), (parts2, pivot)):
+        d64 = y64 if pv is None else y64 - pv.double().view(1, -1, 1, 1, 1)
+        s, q = pt[:, :, 0].sum(1), pt[:, :, 1].sum(1)
+        np.testing.assert_allclose(s.cpu().numpy(), d64.sum(dim=(0, 2, 3, 4)).cpu().numpy(), rtol=0,
+                                   atol=1e-6 * float(d64.abs().sum(dim=(0, 2, 3, 4)).max()))
+        np.testing.assert_allclose(q.cpu().numpy(), (d64 * d64).sum(dim=(0, 2, 3, 4)).cpu().numpy(), rtol=1e-6)
+    assert torch.equal(ops.conv3d_k3_bf16x3_stats(x, wq)[1], parts)   # a fixed summation order
+    parts = parts2
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(gpu), (torch.randn(Cout, generator=g) * 0.1).to(gpu)
+    res = torch.randn(N, Cout, D, H, W, generator=g).to(gpu)
+    for residual in (None, res):
+        two = ops.bn3d_relu_train(plain, gamma, beta, 1e-5, True, residual)
+        one = ops.bn3d_relu_train(plain, gamma, beta, 1e-5, True, residual, parts, pivot)
+        m64 = y64.mean(dim=(0, 2, 3, 4))
+        v64 = y64.var(dim=(0, 2, 3, 4), unbiased=False)
+        np.testing.assert_allclose(one[1].cpu().numpy(), m64.cpu().numpy(), rtol=1e-6, atol=1e-7 * float(y64.abs().max()))
+        np.testing.assert_allclose(one[2].cpu().numpy(), (1.0 / torch.sqrt(v64 + 1e-5)).cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(one[2].cpu().numpy(), two[2].cpu().numpy(), rtol=2e-5)
+        scale = float((two[0].abs().max()).cpu())
+        assert float((one[0] - two[0]).abs().max()) <= 2e-5 * max(1.0, scale)
+    # autograd through the partial-sums form: the same backward as the two-pass operator's
+    xa, xb = plain.clone().requires_grad_(True), plain.clone().requires_grad_(True)
+    ops.bn3d_relu_train(xa, gamma, beta, 1e-5, True, None, parts, pivot)[0].square().mean().backward()
+    ops.bn3d_relu_train(xb, gamma, beta, 1e-5, True, None)[0].square().mean().backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-4 * float(xb.grad.abs().max()) + 1e-12
+
+
 def test_scl_pack_reads_a_pitched_volume_in_place(gpu):
     from mvsdet_amd import ops
     buf = torch.randn(2, 9, 3, 5, 32, device=gpu)
