@@ -21,7 +21,10 @@
 //           plane -1 is never staged (it is padding) and the waves of kd=0 sit out the last step of a column.
 //           Two fine plane pairs (one multiplied, one being committed) and three Y tiles (s, s+1, s+2 being committed).
 //   waves : 8 multiplying waves = the (kd,kh) pairs 0..7 with their three kw, the ninth pair's taps one each on waves 0..2
-//           (7,7,7,6 taps per SIMD); 4 staging waves, one per SIMD: global loads two steps ahead in registers, cut, LDS stores.
+//           (7,7,7,6 taps per SIMD); 8 staging waves (round 5; 4 until then): six stage the fine planes, two the Y tile, global
+//           loads three steps ahead in registers, cut, LDS stores.  Their loads are COALESCED: four consecutive lanes read the 64
+//           contiguous bytes of a (plane, fine row, channel) -- a thread per row (five float4 of its own) made every lane of a
+//           load a 64-byte request of its own, and the address path bounded the kernel: conv1 0.74 -> 0.63 ms, conv3 0.39 -> 0.335.
 // partial[split][o][c][27] as the other weight-gradient kernels: the caller adds the splits up.
 #include "common.h"
 
@@ -30,12 +33,20 @@ namespace mvsdet {
 typedef short ds2_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float ds2_f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MVS_S2DW_FINE
+#define MVS_S2DW_FINE 6
+#endif
+#ifndef MVS_S2DW_DEPTH
+#define MVS_S2DW_DEPTH 3
+#endif
 constexpr int kS2dRows = 4, kS2dW = 8;                    // coarse tile
 constexpr int kS2dFRows = 2 * kS2dRows + 1;               // 9 fine rows
 constexpr int kS2dCo = 64, kS2dCi = 16;                   // channels of a block: coarse (M, four groups of 16), fine (N)
-constexpr int kS2dComputeWaves = 8, kS2dLoaderWaves = 4;
+// staging waves: six that stage the fine planes (1152 items (plane, fine row, channel, quarter row): three per thread and step) and
+// two that stage the Y tile (512 items (channel, row, half row): four per thread and step); 16 waves = four per SIMD, 128 VGPRs
+constexpr int kS2dComputeWaves = 8, kS2dFineWaves = MVS_S2DW_FINE, kS2dYWaves = 2, kS2dLoaderWaves = kS2dFineWaves + kS2dYWaves;
 constexpr int kS2dComputeThreads = kS2dComputeWaves * 64, kS2dLoaders = kS2dLoaderWaves * 64;
-constexpr int kS2dThreads = kS2dComputeThreads + kS2dLoaders;          // 768
+constexpr int kS2dThreads = kS2dComputeThreads + kS2dLoaders;          // 1024
 constexpr int kS2dFUnitB = kS2dCi * 16;                                // 256: one (fine row, unit) of 16 channels
 constexpr int kS2dFRowB = 3 * kS2dFUnitB;                              // 768
 constexpr int kS2dFPieceB = kS2dFRows * kS2dFRowB;                     // 6912: one plane, one piece
@@ -44,14 +55,14 @@ constexpr int kS2dFPairB = 2 * kS2dFPlaneB;                            // 27648
 constexpr int kS2dYRowB = kS2dCo * 16;                                 // 1024
 constexpr int kS2dYPieceB = kS2dRows * kS2dYRowB;                      // 4096
 constexpr int kS2dYBufB = 2 * kS2dYPieceB;
-constexpr int kS2dDepth = 2;                                           // steps of global loads in flight
+constexpr int kS2dDepth = MVS_S2DW_DEPTH;                              // steps of global loads in flight
 constexpr int kS2dTabCap = 4096;
 constexpr int kS2dYOff = 2 * kS2dFPairB;                               // 55296
 constexpr int kS2dTabOff = kS2dYOff + 3 * kS2dYBufB;                   // 79872
 constexpr int kS2dLdsB = kS2dTabOff + kS2dTabCap * 8;                  // 112640: one block of 12 waves per CU
 constexpr int kS2dFRoles = 2 * kS2dFRows * kS2dCi;                     // 288 (plane, fine row, channel)
 constexpr int kS2dYRoles = kS2dCo * kS2dRows;                          // 256 (channel, row)
-static_assert(kS2dYRoles == kS2dLoaders && kS2dFRoles <= kS2dLoaders + 64, "one Y role per loader thread; the first staging wave carries a second fine role");
+static_assert(kS2dFRoles <= kS2dFineWaves * 64 && kS2dYRoles == 2 * kS2dYWaves * 64, "a fine role per thread of the fine waves, two Y rows per thread of the Y waves");
 
 __device__ float4 g_ds2_zero;   // zero-initialised: the source of every padding element
 
@@ -105,134 +116,162 @@ __global__ __launch_bounds__(kS2dThreads) void conv3d_k3_s2_dw_bf16x3_kernel(con
     if (loader) {
         // ---------------------------------------------------------------------------------------------- staging waves
         const int lt = tid - kS2dComputeThreads;
-        const bool first = wave == kS2dComputeWaves;                   // carries the fine roles 256 .. 287 on lanes 0..31
-        struct FRole { int ch, pl, frow, lds; const float* chan; bool ok, live; };
-        auto frole = [&](int fr, bool live) {
-            FRole r;
-            r.ch = fr & (kS2dCi - 1);
-            const int pr = fr >> 4;
-            r.pl = pr >= kS2dFRows;
-            r.frow = pr - r.pl * kS2dFRows;
-            r.lds = r.pl * kS2dFPlaneB + r.frow * kS2dFRowB + r.ch * 16;
-            r.chan = x + (size_t)min(c0 + r.ch, Cin - 1) * fvol;
-            r.ok = live && c0 + r.ch < Cin;
-            r.live = live;
-            return r;
-        };
-        const FRole fa = frole(lt, true);
-        const FRole fb = frole(min(256 + (lt & 63), kS2dFRoles - 1), first && lane < kS2dFRoles - 256);
-        const int yo = lt >> 2, yrow = lt & 3;
-        const int y_lds = yrow * kS2dYRowB + yo * 16;
-        const float* const ychan = gy + (size_t)min(o0 + yo, Cout - 1) * cvol;
-        const bool yo_ok = o0 + yo < Cout;
-
+        const bool fine_wave = wave < kS2dComputeWaves + kS2dFineWaves;   // wave-uniform: the two kinds run separate loops
         struct Pos { int i, s; };
         auto at = [&](int q) { return Pos{q / Dc, q % Dc}; };
         auto next = [&](Pos p) { return p.s + 1 == Dc ? Pos{p.i + 1, 0} : Pos{p.i, p.s + 1}; };
-        struct Regs { ds2_f32x4 fv[5], yv[2]; };
-        struct RegsB { ds2_f32x4 fv[5]; };
-        Regs sets[kS2dDepth];
-        RegsB setsb[kS2dDepth];
 
-        // fine row of role r at stream position p: x[2w0-4 .. 2w0+15] as five float4 (padding and idle roles: the zero word)
-        auto fetch_fine = [&](ds2_f32x4* fv, const FRole& r, Pos p) {
-            const int2 e = tab[min(p.i, mine - 1)];
-            const int h0 = e.y >> 16, w0 = e.y & 0xffff;
-            const int h = 2 * h0 - 1 + r.frow, d = 2 * p.s + r.pl;
-            const bool ok = (p.i < mine) & r.ok & (h >= 0) & (h < H);   // '&': no short-circuit branches
-            const float* row = r.chan + (size_t)e.x * Cin * fvol + (size_t)d * HW + min(max(h, 0), H - 1) * W;
+        if (fine_wave) {
+            // COALESCED staging.  An item = (role (plane of the pair, fine row, channel), quarter k of the row's 16 fine voxels
+            // x[2w0 .. 2w0+15]): four consecutive lanes read the 64 contiguous, 64-byte-aligned bytes of a role -- with a role per
+            // thread (five float4 of ITS row) every lane of a load was a 64-byte request of its own and the address path, not the
+            // latency, bounded the kernel (what-if build with contiguous addresses: conv1 0.72 -> 0.48 ms).  The de-interleave
+            // needs no exchange: quarter k holds even[2k], even[2k+1] (elements 0, 2), odd[2k], odd[2k+1] (1, 3) and, with the
+            // element to its left -- the previous lane's last one by DPP, x[2w0-1] from memory for k = 0 --, oddm[2k], oddm[2k+1]:
+            // three aligned 4-byte stores per piece.  1152 items on 384 threads: kS2dFPasses = 3 per step.
+            constexpr int kItems = kS2dFRoles * 4, kFThreads = kS2dFineWaves * 64;
+            constexpr int kS2dFPasses = (kItems + kFThreads - 1) / kFThreads;     // 3
+            int it_lds[kS2dFPasses], it_frow[kS2dFPasses], it_pl[kS2dFPasses], it_k[kS2dFPasses];
+            unsigned it_chan[kS2dFPasses];   // element offset of the item's channel inside a view (< 2^31: host check)
+            bool it_ok[kS2dFPasses], it_live[kS2dFPasses];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int w = 2 * w0 - 4 + 4 * k;
-                fv[k] = *reinterpret_cast<const ds2_f32x4*>((ok & (w >= 0) & (w < W)) ? row + w : zero);
+            for (int ps = 0; ps < kS2dFPasses; ++ps) {
+                const int item = lt + ps * kFThreads;
+                it_live[ps] = item < kItems;
+                const int role = min(item, kItems - 1) >> 2;
+                it_k[ps] = item & 3;
+                const int ch = role & (kS2dCi - 1), pr = role >> 4;
+                it_pl[ps] = pr >= kS2dFRows;
+                it_frow[ps] = pr - it_pl[ps] * kS2dFRows;
+                it_lds[ps] = it_pl[ps] * kS2dFPlaneB + it_frow[ps] * kS2dFRowB + ch * 16 + it_k[ps] * 4;
+                it_chan[ps] = (unsigned)((size_t)min(c0 + ch, Cin - 1) * fvol);
+                it_ok[ps] = it_live[ps] && c0 + ch < Cin;
             }
-        };
+            struct FSet { ds2_f32x4 v[kS2dFPasses]; float left[kS2dFPasses]; };
+            FSet sets[kS2dDepth];
+            auto fetch_fine = [&](FSet& g, Pos p) {
+                const int2 e = tab[min(p.i, mine - 1)];
+                const int h0 = e.y >> 16, w0 = e.y & 0xffff;
+                const float* const view = x + (size_t)e.x * Cin * fvol;
+#pragma unroll
+                for (int ps = 0; ps < kS2dFPasses; ++ps) {
+                    const int h = 2 * h0 - 1 + it_frow[ps], d = 2 * p.s + it_pl[ps];
+                    const bool ok = (p.i < mine) & it_ok[ps] & (h >= 0) & (h < H);   // '&': no short-circuit branches
+                    const float* row = view + it_chan[ps] + (size_t)d * HW + min(max(h, 0), H - 1) * W;
+                    const int w = 2 * w0 + 4 * it_k[ps];
+                    g.v[ps] = *reinterpret_cast<const ds2_f32x4*>((ok & (w < W)) ? row + w : zero);
+                    g.left[ps] = *((ok & (w0 > 0) & (2 * w0 <= W)) ? row + 2 * w0 - 1 : zero);   // x[2w0-1]: used by quarter 0
+                }
+            };
+            auto commit_fine = [&](FSet& g, int pair) {
+#pragma unroll
+                for (int ps = 0; ps < kS2dFPasses; ++ps) {
+                    asm volatile("" : "+v"(g.v[ps]));   // conversion pinned behind the barrier (see costreg_dw_bf16.hip)
+                    asm volatile("" : "+v"(g.left[ps]));
+                }
+#pragma unroll
+                for (int ps = 0; ps < kS2dFPasses; ++ps) {
+                    // the element to the left of the quarter: the previous lane's last one (same role: lanes 4r .. 4r+3)
+                    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g.v[ps].w), 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+                    const float lft = it_k[ps] == 0 ? g.left[ps] : prev;
+                    unsigned eh, em, oh, om, mh, mm;
+                    ds2_split2(g.v[ps].x, g.v[ps].z, eh, em);
+                    ds2_split2(g.v[ps].y, g.v[ps].w, oh, om);
+                    ds2_split2(lft, g.v[ps].y, mh, mm);
+                    if (it_live[ps]) {
+                        char* dst = sf + pair * kS2dFPairB + it_lds[ps];
+                        *reinterpret_cast<unsigned*>(dst) = eh;
+                        *reinterpret_cast<unsigned*>(dst + kS2dFUnitB) = oh;
+                        *reinterpret_cast<unsigned*>(dst + 2 * kS2dFUnitB) = mh;
+                        *reinterpret_cast<unsigned*>(dst + kS2dFPieceB) = em;
+                        *reinterpret_cast<unsigned*>(dst + kS2dFPieceB + kS2dFUnitB) = om;
+                        *reinterpret_cast<unsigned*>(dst + kS2dFPieceB + 2 * kS2dFUnitB) = mm;
+                    }
+                }
+            };
+            // before the loop: fine pair 0 -> slot 0; then the loads of the first kS2dDepth steps (step q commits position q + 1)
+            if (steps > 0) {
+                fetch_fine(sets[0], at(0));
+                commit_fine(sets[0], 0);
+#pragma unroll
+                for (int k = 0; k < kS2dDepth; ++k) fetch_fine(sets[k], at(1 + k));
+            }
+            Pos pf = at(1 + kS2dDepth);
+            for (int q = 0; q < steps; q += kS2dDepth) {
+#pragma unroll
+                for (int k = 0; k < kS2dDepth; ++k) {
+                    __syncthreads();   // step q+k-1 fully consumed; its commits visible
+                    commit_fine(sets[k], (q + k + 1) & 1);
+                    fetch_fine(sets[k], pf);
+                    pf = next(pf);
+                }
+            }
+            return;
+        }
+
+        // the Y tile, coalesced the same way: item = (role (channel, row), half of the row's 8 coarse voxels): two lanes read a role's
+        // 32 contiguous bytes and store 8 bytes per piece; 512 items on 128 threads: four per step
+        constexpr int kYThreads = kS2dYWaves * 64, kS2dYPasses = 2 * kS2dYRoles / kYThreads;   // 4
+        const int yt = lt - kS2dFineWaves * 64;
+        int y_lds[kS2dYPasses], y_row[kS2dYPasses], y_half[kS2dYPasses];
+        unsigned y_chan[kS2dYPasses];
+        bool y_ok[kS2dYPasses];
+#pragma unroll
+        for (int ps = 0; ps < kS2dYPasses; ++ps) {
+            const int item = yt + ps * kYThreads, role = item >> 1;
+            const int yo = role >> 2;
+            y_half[ps] = item & 1;
+            y_row[ps] = role & 3;
+            y_lds[ps] = y_row[ps] * kS2dYRowB + yo * 16 + y_half[ps] * 8;
+            y_chan[ps] = (unsigned)((size_t)min(o0 + yo, Cout - 1) * cvol);
+            y_ok[ps] = o0 + yo < Cout;
+        }
+        ds2_f32x4 ysets[kS2dDepth][kS2dYPasses];
         auto fetch_y = [&](ds2_f32x4* yv, Pos p) {
             const int2 e = tab[min(p.i, mine - 1)];
             const int h0 = e.y >> 16, w0 = e.y & 0xffff;
-            const int h = h0 + yrow;
-            const bool ok = (p.i < mine) & yo_ok & (h < Hc);
-            const float* row = ychan + (size_t)e.x * Cout * cvol + (size_t)p.s * HWc + min(h, Hc - 1) * Wc;
+            const float* const view = gy + (size_t)e.x * Cout * cvol;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int w = w0 + 4 * k;
-                yv[k] = *reinterpret_cast<const ds2_f32x4*>((ok & (w < Wc)) ? row + w : zero);
+            for (int ps = 0; ps < kS2dYPasses; ++ps) {
+                const int h = h0 + y_row[ps], w = w0 + 4 * y_half[ps];
+                const bool ok = (p.i < mine) & y_ok[ps] & (h < Hc) & (w < Wc);
+                const float* row = view + y_chan[ps] + (size_t)p.s * HWc + min(h, Hc - 1) * Wc;
+                yv[ps] = *reinterpret_cast<const ds2_f32x4*>(ok ? row + w : zero);
             }
-        };
-        // five float4 -> the even / odd / shifted-odd units of both pieces
-        auto commit_fine = [&](ds2_f32x4* fv, const FRole& r, int pair) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) asm volatile("" : "+v"(fv[k]));   // conversion pinned behind the barrier (see costreg_dw_bf16.hip)
-            uint4 eh, em, oh, om;
-            ds2_split2(fv[1].x, fv[1].z, eh.x, em.x);
-            ds2_split2(fv[2].x, fv[2].z, eh.y, em.y);
-            ds2_split2(fv[3].x, fv[3].z, eh.z, em.z);
-            ds2_split2(fv[4].x, fv[4].z, eh.w, em.w);
-            ds2_split2(fv[1].y, fv[1].w, oh.x, om.x);
-            ds2_split2(fv[2].y, fv[2].w, oh.y, om.y);
-            ds2_split2(fv[3].y, fv[3].w, oh.z, om.z);
-            ds2_split2(fv[4].y, fv[4].w, oh.w, om.w);
-            unsigned lh, lm;                                             // x[2w0-1] in the HIGH half
-            ds2_split2(0.0f, fv[0].w, lh, lm);
-            const uint4 mh = make_uint4(__builtin_amdgcn_alignbit(oh.x, lh, 16), __builtin_amdgcn_alignbit(oh.y, oh.x, 16),
-                                        __builtin_amdgcn_alignbit(oh.z, oh.y, 16), __builtin_amdgcn_alignbit(oh.w, oh.z, 16));
-            const uint4 mm = make_uint4(__builtin_amdgcn_alignbit(om.x, lm, 16), __builtin_amdgcn_alignbit(om.y, om.x, 16),
-                                        __builtin_amdgcn_alignbit(om.z, om.y, 16), __builtin_amdgcn_alignbit(om.w, om.z, 16));
-            char* dst = sf + pair * kS2dFPairB + r.lds;
-            *reinterpret_cast<uint4*>(dst) = eh;
-            *reinterpret_cast<uint4*>(dst + kS2dFUnitB) = oh;
-            *reinterpret_cast<uint4*>(dst + 2 * kS2dFUnitB) = mh;
-            *reinterpret_cast<uint4*>(dst + kS2dFPieceB) = em;
-            *reinterpret_cast<uint4*>(dst + kS2dFPieceB + kS2dFUnitB) = om;
-            *reinterpret_cast<uint4*>(dst + kS2dFPieceB + 2 * kS2dFUnitB) = mm;
         };
         auto commit_y = [&](ds2_f32x4* yv, int buf) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(yv[k]));
-            uint4 hi, mid;
-            ds2_split2(yv[0].x, yv[0].y, hi.x, mid.x);
-            ds2_split2(yv[0].z, yv[0].w, hi.y, mid.y);
-            ds2_split2(yv[1].x, yv[1].y, hi.z, mid.z);
-            ds2_split2(yv[1].z, yv[1].w, hi.w, mid.w);
-            char* dst = sy + buf * kS2dYBufB + y_lds;
-            *reinterpret_cast<uint4*>(dst) = hi;
-            *reinterpret_cast<uint4*>(dst + kS2dYPieceB) = mid;
-        };
-
-        // before the loop: fine pair 0 -> slot 0, Y tiles 0, 1 -> buffers 0, 1; then the loads of the first two steps
-        if (steps > 0) {
-            fetch_fine(sets[0].fv, fa, at(0));
-            fetch_y(sets[0].yv, at(0));
-            fetch_y(sets[1].yv, at(1));
-            if (first) fetch_fine(setsb[0].fv, fb, at(0));
-            commit_fine(sets[0].fv, fa, 0);
-            commit_y(sets[0].yv, 0);
-            commit_y(sets[1].yv, 1);
-            if (first && fb.live) commit_fine(setsb[0].fv, fb, 0);
+            for (int ps = 0; ps < kS2dYPasses; ++ps) asm volatile("" : "+v"(yv[ps]));
 #pragma unroll
-            for (int k = 0; k < kS2dDepth; ++k) {
-                fetch_fine(sets[k].fv, fa, at(1 + k));
-                fetch_y(sets[k].yv, at(2 + k));
-                if (first) fetch_fine(setsb[k].fv, fb, at(1 + k));
+            for (int ps = 0; ps < kS2dYPasses; ++ps) {
+                uint2 hi, mid;
+                ds2_split2(yv[ps].x, yv[ps].y, hi.x, mid.x);
+                ds2_split2(yv[ps].z, yv[ps].w, hi.y, mid.y);
+                char* dst = sy + buf * kS2dYBufB + y_lds[ps];
+                *reinterpret_cast<uint2*>(dst) = hi;
+                *reinterpret_cast<uint2*>(dst + kS2dYPieceB) = mid;
             }
-        }
-        Pos pf = at(1 + kS2dDepth), py = at(2 + kS2dDepth);   // what the first step fetches
-        int ybuf = 2;                                         // (q + 2) mod 3
-        auto step = [&](int q, Regs& g, RegsB& gb) {
-            __syncthreads();   // step q-1 fully consumed; its commits visible
-            commit_fine(g.fv, fa, (q + 1) & 1);
-            commit_y(g.yv, ybuf);
-            if (first && fb.live) commit_fine(gb.fv, fb, (q + 1) & 1);
-            ybuf = ybuf == 2 ? 0 : ybuf + 1;
-            fetch_fine(g.fv, fa, pf);
-            fetch_y(g.yv, py);
-            if (first) fetch_fine(gb.fv, fb, pf);
-            pf = next(pf);
-            py = next(py);
         };
+        // before the loop: Y tiles 0, 1 -> buffers 0, 1; then the loads of the first kS2dDepth steps (step q commits position q + 2)
+        if (steps > 0) {
+            fetch_y(ysets[0], at(0));
+            fetch_y(ysets[1], at(1));
+            commit_y(ysets[0], 0);
+            commit_y(ysets[1], 1);
+#pragma unroll
+            for (int k = 0; k < kS2dDepth; ++k) fetch_y(ysets[k], at(2 + k));
+        }
+        Pos py = at(2 + kS2dDepth);
+        int ybuf = 2;                                         // (q + 2) mod 3
         for (int q = 0; q < steps; q += kS2dDepth) {
 #pragma unroll
-            for (int k = 0; k < kS2dDepth; ++k) step(q + k, sets[k], setsb[k]);
+            for (int k = 0; k < kS2dDepth; ++k) {
+                __syncthreads();
+                commit_y(ysets[k], ybuf);
+                ybuf = ybuf == 2 ? 0 : ybuf + 1;
+                fetch_y(ysets[k], py);
+                py = next(py);
+            }
         }
         return;
     }
