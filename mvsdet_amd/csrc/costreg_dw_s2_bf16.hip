@@ -374,6 +374,9 @@ extern "C" int mvsdet_conv3d_k3_s2_dw_bf16x3(const float* x, const float* grad_o
     MVS_REQUIRE(D % 2 == 0 && H % 2 == 0, "conv3d_k3_s2_dw_bf16x3: D=%d, H=%d must be even", D, H);
     MVS_REQUIRE(nsplit > 0 && nsplit <= 65535, "conv3d_k3_s2_dw_bf16x3: nsplit=%d outside [1,65535]", nsplit);
     MVS_REQUIRE((long long)D * H * W < INT32_MAX, "conv3d_k3_s2_dw_bf16x3: one channel volume exceeds 2^31 elements");
+    // the staging waves keep a channel's offset inside its view as 32 bits
+    MVS_REQUIRE((long long)Cin * D * H * W < (1LL << 32) && (long long)Cout * (D / 2) * (H / 2) * (W / 2) < (1LL << 32),
+                "conv3d_k3_s2_dw_bf16x3: one view of either tensor exceeds 2^32 elements");
     MVS_REQUIRE(W % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)grad_out % 16 == 0,
                 "conv3d_k3_s2_dw_bf16x3: rows of both tensors are read as float4 (W=%d must be a multiple of 8, tensors 16-byte aligned)", W);
     if (partial_bytes < mvsdet_conv3d_k3_dw_partial_bytes(Cin, Cout, nsplit)) {
