@@ -478,6 +478,11 @@ size_t mvsdet_conv3d_k3_bf16x3_stats_parts(int N, int D, int H, int W, int f32_i
 int mvsdet_conv3d_k3_bf16x3_stats(const void* xs, const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/,
                                   const void* weight_split, float* out_f32, void* stats, size_t stats_bytes, const float* pivot, int N,
                                   int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
+/* ... and of the transposed layer (mvsnet.py:92-100): xs = SCL form of the coarse (N,Cin,D,H,W) input, out_f32 (N,Cout,2D,2H,2W) raw;
+ * parts = mvsdet_convT3d_k3_s2_bf16x3_stats_parts(N, D, H, W), 0 where the shape has no statistics form (use the plain call then). */
+size_t mvsdet_convT3d_k3_s2_bf16x3_stats_parts(int N, int D, int H, int W);
+int mvsdet_convT3d_k3_s2_bf16x3_stats(const void* xs, const void* weight_split, float* out_f32, void* stats, size_t stats_bytes,
+                                      const float* pivot, int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream);
 /* stride 2: input = x (fp32 + x_strides) or x_pscl (the PSCL form of the (N,Cin,D,H,W) input), exactly one of them */
 int mvsdet_conv3d_k3_s2_bf16x3_io(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* x_pscl,
                                   const void* weight_split, const float* scale, const float* shift, float* out_f32,

@@ -121,16 +121,26 @@ class _ConvT3S2(torch.autograd.Function):
     weight-gradient kernel with the two tensors exchanged."""
 
     @staticmethod
-    def forward(ctx, x, weight, bf16x3=False):
+    def forward(ctx, x, weight, bf16x3=False, stats=False, pivot=None):
+        """stats (bf16x3 only): also return the partial sums of the output's BatchNorm statistics from the kernel's epilogue
+        (`ops.convT3d_k3_s2_bf16x3_stats`); an empty tensor where the shape has no such form."""
         from . import ops
         ctx.save_for_backward(x, weight)
         ctx.bf16x3 = bool(bf16x3)
+        if ctx.bf16x3 and stats:
+            got = ops.convT3d_k3_s2_bf16x3_stats(x, ops.split_conv_weight(weight, 2), pivot)
+            if got is None:
+                y, parts = ops.convT3d_k3_s2_bf16x3(x, ops.split_conv_weight(weight, 2), None, None, None, False), x.new_empty(0, dtype=torch.float64)
+            else:
+                y, parts = got
+            ctx.mark_non_differentiable(parts)
+            return y, parts
         if ctx.bf16x3:
             return ops.convT3d_k3_s2_bf16x3(x, ops.split_conv_weight(weight, 2), None, None, None, False)
         return ops.convT3d_k3_s2_mfma(x, ops.permute_convT_weight(weight), None, None, None, False)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gparts=None):
         from . import ops
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
@@ -142,7 +152,7 @@ class _ConvT3S2(torch.autograd.Function):
                 gx = ops.conv3d_k3_mfma(gy, ops.permute_conv_weight(weight.detach()), None, None, False, 2)
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_k3_dw(gy, x, 0, 2, ctx.bf16x3 and gy.shape[-1] % 8 == 0)
-        return gx, gw, None
+        return gx, gw, None, None, None
 
 
 def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
@@ -424,6 +434,13 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             return ops.convT3d_k3_s2_mfma(x, wperm, scale, shift, skip, True)
         if (self.hip_backward and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
                 and deconv.out_channels % 64 == 0 and deconv.in_channels % 64 == 0):
+            if FUSED_BN_STATS and self.matrix_precision == "bf16x3" and _bn_hip_ok(bn, x):
+                # the BatchNorm's statistics from the transposed kernel's epilogue, around the running mean
+                pivot = bn.running_mean.detach() if bn.running_mean is not None else None
+                y, parts = _ConvT3S2.apply(x, deconv.weight, True, True, pivot)
+                if parts.numel():
+                    return _bn_relu_train(bn, y, skip, parts, pivot)
+                return _bn_relu_train(bn, y, skip)
             y = _ConvT3S2.apply(x, deconv.weight, self.matrix_precision == "bf16x3")
             if _bn_hip_ok(bn, y):
                 return _bn_relu_train(bn, y, skip)   # the skip addition in the BatchNorm's second pass

@@ -1270,11 +1270,16 @@ constexpr int kCtfWSlots = kBfPairs * 2 * 64;   // 14 pairs x 2 pieces x one row
 __host__ __device__ constexpr size_t ctf_lds_bytes(int TD, int TH, int TW) {
     return (size_t)(3 * 2 * ct_ins(TD, TH, TW, 1) + 3 * kCtfWSlots) * 16;
 }
-template <int TD, int TH, int TW>
+// STATS (training: a BatchNorm on batch statistics follows, costreg_bn.hip): the raw fp32 output plus per-channel partial sums of
+// (value - pivot_c) and of its square, one double2 per (channel, block) -- stats[c * parts + block], parts = views x tiles -- as the
+// stride-1 kernel's statistics epilogue leaves them.  The epilogue has no registers to spare (168 + spills), so a lane keeps its 16
+// channels' running sums in LDS slots of its own (the stage buffers are free by then): read - add - write per group of 8 values, no
+// atomics, then four threads per channel add the 384 contributors in double, in a fixed order.
+template <int TD, int TH, int TW, bool STATS = false>
 __global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_kernel(
     const uint4* __restrict__ xs, const uint4* __restrict__ wq, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ residual, BfOut dst, int C8, int Cout, int Di, int Hi, int Wi, int Dp, int Hp, int Wp,
-    size_t piece_stride, int tiles_w, int relu, int xcd_map) {
+    size_t piece_stride, int tiles_w, int relu, int xcd_map, double2* __restrict__ stats, const float* __restrict__ stats_pivot) {
     float* __restrict__ out = dst.f32;
     constexpr int RG = 32 / TW;
     static_assert(TH % RG == 0 && (TD * TH * TW) % 32 == 0, "whole column groups");
@@ -1375,7 +1380,18 @@ __global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_k
     const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
     const size_t oplane = (size_t)Ho * Wo, ovol = (size_t)Do * oplane;
     const int di = d0 + g / (TH / RG), hi = h0 + RG * (g % (TH / RG)) + col / TW, wi = w0 + col % TW;
-    if (di >= Di || hi >= Hi || wi >= Wi) return;
+    const bool inside = di < Di && hi < Hi && wi < Wi;
+    constexpr int NT = 64 * NW;
+    float2* const slot = reinterpret_cast<float2*>(s_bf) + tid;            // [register r 0..15][thread]: the lane's (sum, sum of squares) of channel r
+    float* const s_pivot = reinterpret_cast<float*>(reinterpret_cast<float2*>(s_bf) + 16 * NT);   // the block's 32 pivots
+    if constexpr (STATS) {
+        static_assert((size_t)16 * NT * sizeof(float2) + 32 * sizeof(float) <= ctf_lds_bytes(TD, TH, TW), "the statistics' LDS image");
+        __syncthreads();   // every wave is past its last read of the stage buffers
+        if (tid < 32) s_pivot[tid] = stats_pivot ? stats_pivot[ob64 * 64 + rg * 32 + tid] : 0.0f;
+        __syncthreads();
+    } else {
+        if (!inside) return;
+    }
 #pragma unroll
     for (int cls = 0; cls < 4; ++cls) {
         const int pd = cls >> 1, ph = cls & 1;
@@ -1386,6 +1402,20 @@ __global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_k
             float sc[8], sh[8];
             const int o0 = ob64 * 64 + rg * 32 + bf_row_channel(8 * q, hh);
             const size_t idx0 = ((size_t)n * Cout + o0) * ovol + pos;
+            if constexpr (STATS) {   // raw outputs; sums of both w parities of the lane's 8 channels into its slots
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 v = make_float2(acc[2 * cls][8 * q + j], acc[2 * cls + 1][8 * q + j]);
+                    const float pv = s_pivot[bf_row_channel(8 * q + j, hh)];
+                    const float d0v = inside ? v.x - pv : 0.0f, d1v = inside ? v.y - pv : 0.0f;
+                    float2 e = cls == 0 ? make_float2(0.0f, 0.0f) : slot[(8 * q + j) * NT];
+                    e.x += d0v + d1v;
+                    e.y = fmaf(d0v, d0v, fmaf(d1v, d1v, e.y));
+                    slot[(8 * q + j) * NT] = e;
+                    if (inside) *reinterpret_cast<float2*>(out + idx0 + (size_t)j * ovol) = v;
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 rv[j] = residual ? *reinterpret_cast<const float2*>(residual + idx0 + (size_t)j * ovol) : make_float2(0.f, 0.f);
@@ -1416,6 +1446,29 @@ __global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_k
                 const int c8o = ob64 * 8 + rg * 4 + 2 * q + hh;
                 bf_store_units(dst, v0, n, Cout / 8, c8o, 2 * di + pd, 2 * hi + ph, 2 * wi);
                 bf_store_units(dst, v1, n, Cout / 8, c8o, 2 * di + pd, 2 * hi + ph, 2 * wi + 1);
+            }
+        }
+    }
+    if constexpr (STATS) {
+        __syncthreads();
+        if (tid < 128) {
+            // channel c of the block = register r = 8 (c >> 4) + (c & 7) of the lanes with hh = (c >> 3) & 1: 12 waves x 32 lanes
+            const int c = tid >> 2, part = tid & 3;
+            const int r = 8 * (c >> 4) + (c & 7), chh = (c >> 3) & 1;
+            const float2* col0 = reinterpret_cast<const float2*>(s_bf) + (size_t)r * NT + chh * 32;
+            double a = 0.0, b2 = 0.0;
+            constexpr int NCON = NW * 32;
+            for (int i = part * (NCON / 4); i < (part + 1) * (NCON / 4); ++i) {
+                const float2 e = col0[(i >> 5) * 64 + (i & 31)];
+                a += (double)e.x;
+                b2 += (double)e.y;
+            }
+            a += __shfl_xor(a, 1, 64); b2 += __shfl_xor(b2, 1, 64);
+            a += __shfl_xor(a, 2, 64); b2 += __shfl_xor(b2, 2, 64);
+            if (part == 0) {
+                const size_t tiles = (size_t)gridDim.x * gridDim.y;
+                const size_t bidx = ((size_t)n * gridDim.y + by) * gridDim.x + bx;
+                stats[(size_t)(ob64 * 64 + rg * 32 + c) * ((size_t)(gridDim.z / nob) * tiles) + bidx] = make_double2(a, b2);
             }
         }
     }
@@ -1946,8 +1999,15 @@ extern "C" int mvsdet_conv3d_k3_s2_bf16x3_io(const float* x, const int64_t* x_st
 // added last] of mvsnet.py:92-100,110-111 on the bf16 matrix cores, three-term split.  xs: SCL form of the input (N,Cin,D,H,W)
 // (mvsdet_scl_pack_f32 or a producing layer's out_scl); weight_split: mvsdet_split_conv_weight_ordered(order = 2) of the
 // (Cin,Cout,3,3,3) weight; out_f32 / residual (N,Cout,2D,2H,2W) fp32, 8-byte aligned; out_scl: the SCL form of the result.
+static bool convT_tile38(int D, int H, int W) {
+    const long long pad416 = (long long)((W + kBfW - 1) / kBfW) * kBfW * ((H + kS2TH - 1) / kS2TH) * kS2TH * ((D + kS2TD - 1) / kS2TD) * kS2TD;
+    const long long pad38 = (long long)((W + 7) / 8) * 8 * ((H + 15) / 16) * 16 * ((D + 2) / 3) * 3;
+    return pad38 < pad416;
+}
+
 static int launch_convT(const void* xs, const void* weight_split, const float* scale, const float* shift, const float* residual,
-                        float* out, void* out_scl, int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream) {
+                        float* out, void* out_scl, int N, int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream,
+                        void* stats = nullptr, size_t stats_bytes = 0, const float* stats_pivot = nullptr) {
     const char* name = "convT3d_k3_s2_bf16x3";
     MVS_REQUIRE(xs && weight_split && (out || out_scl), "%s: NULL pointer", name);
     MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
@@ -1959,9 +2019,7 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
     const BfPlan p = bf_plan(D, H, W);   // the padded extents of the SCL input
     const int C8 = (Cin + 7) / 8;
     // input tile 4 x 8 x 16, or 3 x 16 x 8 where that pads (D, H, W) less
-    const long long pad416 = (long long)((W + kBfW - 1) / kBfW) * kBfW * ((H + kS2TH - 1) / kS2TH) * kS2TH * ((D + kS2TD - 1) / kS2TD) * kS2TD;
-    const long long pad38 = (long long)((W + 7) / 8) * 8 * ((H + 15) / 16) * 16 * ((D + 2) / 3) * 3;
-    const bool t38 = pad38 < pad416;
+    const bool t38 = convT_tile38(D, H, W);
     const int ttd = t38 ? 3 : kS2TD, tth = t38 ? 16 : kS2TH, ttw = t38 ? 8 : kBfW;
     const int tiles_w = (W + ttw - 1) / ttw, tiles_h = (H + tth - 1) / tth, tiles_d = (D + ttd - 1) / ttd;
     // the halo tile reaches one voxel past the last tile: padded index tiles*T + 1 must exist
@@ -1987,6 +2045,26 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
     }
     // the 3 x 16 x 8 tile: all eight output parity classes in one block of 32 output channels (conv9 0.40 -> 0.30, conv11 0.66 ->
     // 0.48 ms, the same bits); option "convT_cg" = 1: one block per (PD, PH) on 12 waves of one column group, 2: on 6 waves of two
+    if (stats) {
+        MVS_REQUIRE(t38 && options().convT_cg != 1 && options().convT_cg != 2,
+                    "%s: the statistics epilogue exists in the all-classes kernel on 3 x 16 x 8 tiles only (mvsdet_convT3d_k3_s2_bf16x3_stats_parts = 0 otherwise)", name);
+        MVS_REQUIRE(!scale && !residual && !relu && out && !out_scl, "%s: statistics are those of the raw fp32 output", name);
+        MVS_REQUIRE(stats_bytes >= (size_t)Cout * N * tiles_w * tiles_h * tiles_d * sizeof(double2) && ((uintptr_t)stats & 15u) == 0,
+                    "%s: the statistics buffer holds Cout x mvsdet_convT3d_k3_s2_bf16x3_stats_parts double2", name);
+        const size_t lds = ctf_lds_bytes(3, 16, 8);
+        auto* k = convT3d_k3_s2_bf16x3_fused_kernel<3, 16, 8, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
+            return MVSDET_ERR_HIP;
+        }
+        MVS_REQUIRE((long long)N * (Cout / 32) <= 65535, "%s: N*Cout/32 too large", name);
+        dim3 fgrid((unsigned)(tiles_w * tiles_h), (unsigned)tiles_d, (unsigned)(N * (Cout / 32)));
+        hipLaunchKernelGGL(k, fgrid, dim3(3 * 16 * 8 * 2), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split),
+                           scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, relu,
+                           (int)(options().conv_xcd != 0 && ((long long)fgrid.x * fgrid.y * fgrid.z) % 8 == 0 &&
+                                 (long long)fgrid.x * fgrid.y * fgrid.z >= 64),
+                           static_cast<double2*>(stats), stats_pivot);
+    } else
     if (t38 && options().convT_cg != 1 && options().convT_cg != 2) {
         const size_t lds = ctf_lds_bytes(3, 16, 8);
         auto* k = convT3d_k3_s2_bf16x3_fused_kernel<3, 16, 8>;
@@ -1999,7 +2077,8 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
         hipLaunchKernelGGL(k, fgrid, dim3(3 * 16 * 8 * 2), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split),
                            scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, relu,
                            (int)(options().conv_xcd != 0 && ((long long)fgrid.x * fgrid.y * fgrid.z) % 8 == 0 &&
-                                 (long long)fgrid.x * fgrid.y * fgrid.z >= 64));
+                                 (long long)fgrid.x * fgrid.y * fgrid.z >= 64),
+                           static_cast<double2*>(nullptr), static_cast<const float*>(nullptr));
     } else
     if (t38) { if (options().convT_cg == 2) MVS_CT_CASE(3, 16, 8, 2) else MVS_CT_CASE(3, 16, 8, 1) }
     else MVS_CT_CASE(kS2TD, kS2TH, kBfW, 2)
@@ -2012,6 +2091,21 @@ extern "C" int mvsdet_convT3d_k3_s2_bf16x3(const void* xs, const void* weight_sp
                                            const float* residual, float* out, int N, int Cin, int Cout, int D, int H, int W,
                                            int relu, mvsdet_stream_t stream) {
     return launch_convT(xs, weight_split, scale, shift, residual, out, nullptr, N, Cin, Cout, D, H, W, relu, stream);
+}
+
+// The transposed layer in front of a training-mode BatchNorm (mvsnet.py:92-100 under model.train()): raw fp32 output + per-channel
+// partial sums as mvsdet_conv3d_k3_bf16x3_stats leaves them (sums of value - pivot_c and of its square, one double2 per channel and
+// block; parts = mvsdet_convT3d_k3_s2_bf16x3_stats_parts(N, D, H, W) of the COARSE input extents, 0 = this shape has no such form).
+extern "C" size_t mvsdet_convT3d_k3_s2_bf16x3_stats_parts(int N, int D, int H, int W) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (!convT_tile38(D, H, W) || options().convT_cg == 1 || options().convT_cg == 2) return 0;
+    return (size_t)N * ((W + 7) / 8) * ((H + 15) / 16) * ((D + 2) / 3);
+}
+
+extern "C" int mvsdet_convT3d_k3_s2_bf16x3_stats(const void* xs, const void* weight_split, float* out_f32, void* stats, size_t stats_bytes,
+                                                 const float* pivot, int N, int Cin, int Cout, int D, int H, int W, mvsdet_stream_t stream) {
+    MVS_REQUIRE(stats != nullptr, "convT3d_k3_s2_bf16x3_stats: NULL statistics buffer");
+    return launch_convT(xs, weight_split, nullptr, nullptr, nullptr, out_f32, nullptr, N, Cin, Cout, D, H, W, 0, stream, stats, stats_bytes, pivot);
 }
 
 extern "C" int mvsdet_convT3d_k3_s2_bf16x3_io(const void* xs, const void* weight_split, const float* scale, const float* shift,

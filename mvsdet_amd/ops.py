@@ -1200,6 +1200,34 @@ def convT3d_k3_s2_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift
     return _ret(outputs, res)
 
 
+def convT3d_k3_s2_bf16x3_stats(x, weight_split: Tensor, pivot: Optional[Tensor] = None) -> Optional[Tuple[Tensor, Tensor]]:
+    """`convT3d_k3_s2_bf16x3(x, weight_split, None, None, None, False)` in front of a training-mode BatchNorm (mvsnet.py:92-100): the
+    raw fp32 output and the per-channel partial sums (float64 (Cout, parts, 2), sums of value - pivot_c and of its square) that
+    `bn3d_relu_train(..., parts=, pivot=)` finishes.  None where the shape has no statistics form (the plain call applies)."""
+    xs = x if isinstance(x, SclTensor) else scl_pack(x)
+    N, Cin, D, H, W = xs.shape
+    if weight_split.dtype != torch.bfloat16 or weight_split.dim() != 7 or tuple(weight_split.shape[1:]) != ((Cin + 7) // 8, 14, 2, 2, 64, 8):
+        raise ValueError(f"convT3d_k3_s2_bf16x3_stats: weight_split {tuple(weight_split.shape)} does not match Cin={Cin}")
+    Cout = weight_split.shape[0] * 64
+    dev = xs.data.device
+    lib = _lib.load()
+    parts = int(lib.mvsdet_convT3d_k3_s2_bf16x3_stats_parts(N, D, H, W))
+    if parts == 0:
+        return None
+    if pivot is not None:
+        if pivot.dtype != torch.float32 or pivot.numel() != Cout or pivot.device != dev:
+            raise ValueError(f"convT3d_k3_s2_bf16x3_stats: pivot must be {Cout} fp32 values on {dev}")
+        pivot = pivot.detach().contiguous()
+    weight_split = weight_split.contiguous()
+    out = torch.empty((N, Cout, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=dev)
+    stats = torch.empty((Cout, parts, 2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mvsdet_convT3d_k3_s2_bf16x3_stats(_lib.ptr(xs.data), _lib.ptr(weight_split), _lib.ptr(out), _lib.ptr(stats),
+                                                         stats.numel() * 8, _lib.ptr(pivot), N, Cin, Cout, D, H, W,
+                                                         _lib.current_stream(dev)), "convT3d_k3_s2_bf16x3_stats")
+    return out, stats
+
+
 # ------------------------------------------------------------------------------------------- misc
 def device_copy(src: Tensor, dst: Tensor):
     """float4 device-to-device copy kernel (bench.py's achievable-HBM yardstick)."""

@@ -155,6 +155,39 @@ def test_conv3d_k3_bf16x3_statistics_for_the_batchnorm_behind_it(gpu, N, Cin, Co
     assert float((xa.grad - xb.grad).abs().max()) <= 1e-4 * float(xb.grad.abs().max()) + 1e-12
 
 
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(2, 128, 64, 6, 30, 40), (3, 64, 128, 3, 15, 20), (1, 16, 64, 5, 13, 7)])
+def test_convT3d_k3_s2_bf16x3_statistics_for_the_batchnorm_behind_it(gpu, N, Cin, Cout, D, H, W):
+    """mvsnet.py:92-100 under model.train(): the transposed layer's epilogue leaves the partial sums of its BatchNorm's statistics
+    (a lane's running sums in LDS slots of its own, added up in a fixed order); same output bits as the plain call, sums of the
+    tensor it wrote, the BatchNorm + ReLU + skip from them agrees with the two-pass operator, the same bits on a second run."""
+    from mvsdet_amd import ops
+    g = torch.Generator().manual_seed(N * 10 + D)
+    x = torch.randn(N, Cin, D, H, W, generator=g).to(gpu)
+    wq = ops.split_conv_weight((torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5 * 3.0).to(gpu), 2)
+    plain = ops.convT3d_k3_s2_bf16x3(x, wq, None, None, None, False)
+    y64 = plain.double()
+    pivot = (y64.mean(dim=(0, 2, 3, 4)) * 0.9 + 0.01).float()
+    got = ops.convT3d_k3_s2_bf16x3_stats(x, wq, pivot)
+    if got is None:      # shapes whose tiles are not 3 x 16 x 8 keep the separate statistics pass
+        from mvsdet_amd import _lib
+        assert _lib.load().mvsdet_convT3d_k3_s2_bf16x3_stats_parts(N, D, H, W) == 0
+        return
+    y, parts = got
+    assert torch.equal(y, plain)
+    d64 = y64 - pivot.double().view(1, -1, 1, 1, 1)
+    s, q = parts[:, :, 0].sum(1), parts[:, :, 1].sum(1)
+    np.testing.assert_allclose(s.cpu().numpy(), d64.sum(dim=(0, 2, 3, 4)).cpu().numpy(), rtol=0, atol=1e-6 * float(d64.abs().sum(dim=(0, 2, 3, 4)).max()))
+    np.testing.assert_allclose(q.cpu().numpy(), (d64 * d64).sum(dim=(0, 2, 3, 4)).cpu().numpy(), rtol=1e-6)
+    assert torch.equal(ops.convT3d_k3_s2_bf16x3_stats(x, wq, pivot)[1], parts)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(gpu), (torch.randn(Cout, generator=g) * 0.1).to(gpu)
+    skip = torch.randn(plain.shape, generator=g).to(gpu)
+    two = ops.bn3d_relu_train(plain, gamma, beta, 1e-5, True, skip)
+    one = ops.bn3d_relu_train(plain, gamma, beta, 1e-5, True, skip, parts, pivot)
+    np.testing.assert_allclose(one[1].cpu().numpy(), y64.mean(dim=(0, 2, 3, 4)).cpu().numpy(), rtol=1e-6, atol=1e-7 * float(y64.abs().max()))
+    np.testing.assert_allclose(one[2].cpu().numpy(), two[2].cpu().numpy(), rtol=2e-5)
+    assert float((one[0] - two[0]).abs().max()) <= 2e-5 * max(1.0, float(two[0].abs().max()))
+
+
 def test_scl_pack_reads_a_pitched_volume_in_place(gpu):
     from mvsdet_amd import ops
     buf = torch.randn(2, 9, 3, 5, 32, device=gpu)
