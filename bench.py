@@ -238,6 +238,14 @@ class PointwiseCostReg(torch.nn.Module):
         return out.view(n, 2, d, h, w)
 
 
+# untimed scenes ahead of a chain measurement.  The caching allocator's pool keeps growing for a few scenes (a block released while
+# another stream still reads it cannot be handed out again yet: the next request of that size is a hipMalloc; 4-8 new segments per ten
+# scenes after two warm-up scenes, 4-5 after four: `device_allocations_in_timed_loop`), and when the block is the 2.4 GB variance volume
+# the one scene that pays for it takes 29.9 ms instead of 10.8 -- 12.7-13.8 ms per scene in the mean of ten, seen in two of a dozen
+# runs.  `ms_per_scene_min_median_max`, `ms_per_scene_sequence` and `scenes_per_sec_at_the_median_scene` tell such a run from a slow chain
+CHAIN_WARMUP = 4
+
+
 def collect_garbage():
     """Called once ahead of the WARM-UP of every timed region (between warm-up and timing its 100 ms of host work let the device
     clock down: the first timed step of the headline loop took 13.0 instead of 10.6 ms, 3 % of the value).  CPython's full (generation-2) collection walks every object torch's import
@@ -489,9 +497,9 @@ def test_shape_chain_rate(device, name, steps=8):
         for overlap, key in ((False, "scenes_per_sec"), (True, "scenes_per_sec_pipelined")):
             hp.overlap_detector = overlap
             collect_garbage()
-            for i in range(2):
-                hp.prefetch_scene(metas[i + 1], device)
-                out = hp.forward_scene(scene.features, metas[i])
+            for i in range(CHAIN_WARMUP):   # (the last one announces metas[2], the first timed scene's)
+                hp.prefetch_scene(metas[i % 2 + 1], device)
+                out = hp.forward_scene(scene.features, metas[i % 2])
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             for i in range(2, steps + 2):
@@ -537,11 +545,12 @@ def full_chain_rate(device, steps=10):
     metas = unseen_metas(wr, 7, steps + 3)   # new cameras every scene, announced one scene ahead (as in run_gpu)
     with torch.no_grad():
         collect_garbage()
-        for i in range(2):
-            hp.prefetch_scene(metas[i + 1], device)
-            out = hp.forward_scene(scene.features, metas[i])
+        for i in range(CHAIN_WARMUP):
+            hp.prefetch_scene(metas[i % 2 + 1], device)
+            out = hp.forward_scene(scene.features, metas[i % 2])
         torch.cuda.synchronize(device)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        segs0 = torch.cuda.memory_stats(device).get("segment.all.allocated", 0)
         marks[0].record()
         t0 = time.perf_counter()
         for i in range(2, steps + 2):
@@ -550,12 +559,14 @@ def full_chain_rate(device, steps=10):
             marks[i - 1].record()
         torch.cuda.synchronize(device)
         el = time.perf_counter() - t0
-        per_scene = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
+        new_segments = torch.cuda.memory_stats(device).get("segment.all.allocated", 0) - segs0   # hipMalloc calls of the caching allocator
+        scene_sequence = [round(marks[k].elapsed_time(marks[k + 1]), 2) for k in range(steps)]
+        per_scene = sorted(scene_sequence)
         # the same loop with the neck and the head of a scene on a stream of their own (MVSDetHotPath.overlap_detector): they run
         # beside the next scene's packing, sweep and first convolution; one synchronisation of the device at the end
         hp.overlap_detector = True
-        for i in range(2):
-            out2 = hp.forward_scene(scene.features, metas[i])
+        for i in range(CHAIN_WARMUP):
+            out2 = hp.forward_scene(scene.features, metas[i % 2])
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         for i in range(2, steps + 2):
@@ -642,6 +653,8 @@ def full_chain_rate(device, steps=10):
             # intervals between events recorded on the caller's stream behind every scene of the one-stream loop: a mean far above the
             # median is one stalled scene (an allocation, the host), not a slow chain
             "ms_per_scene_min_median_max": [round(per_scene[0], 3), round(per_scene[len(per_scene) // 2], 3), round(per_scene[-1], 3)],
+            "ms_per_scene_sequence": scene_sequence, "device_allocations_in_timed_loop": int(new_segments),
+            "scenes_per_sec_at_the_median_scene": round(1e3 / per_scene[len(per_scene) // 2], 3),
             "detector_on_side_stream": {"scenes_per_sec": round(steps / el_overlap, 3), "ms_per_scene": round(el_overlap / steps * 1e3, 3),
                                         "note": "depth distribution, lifting, neck and head of scene i on their own stream beside scene i+1's packing, sweep and conv0 "
                                                 "(MVSDetHotPath.overlap_detector); the device is synchronised once, after the last scene; "

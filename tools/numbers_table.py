@@ -93,6 +93,10 @@ def main():
     if mmm:
         rows.append((cw, "  same, per scene (events behind every scene): min / median / max", "-", " / ".join(fmt(v) for v in mmm), "-", "-",
                      c + ".ms_per_scene_min_median_max"))
+        na = get(d, c + ".device_allocations_in_timed_loop")
+        if na is not None:
+            rows.append((cw, "  same, hipMalloc calls of the caching allocator inside the ten timed scenes", str(na), "-", "-", "-",
+                         c + ".device_allocations_in_timed_loop"))
     row(cw, "  same, detector on the side stream", c + ".detector_on_side_stream.ms_per_scene", None, None, c + ".scenes_per_sec_pipelined", "scenes/s")
     row(cw, "  CostRegNet_3DGS forward (eval)", c + ".cost_network_roofline.network_ms", c + ".cost_network_roofline.network_vs_fp32_mfma_peak",
         "fp32 MFMA peak 157 TFLOP/s, useful FLOP")
