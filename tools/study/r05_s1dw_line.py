@@ -1,0 +1,21 @@
+"""One line of medians for tools/ab_libs.sh: the stride-1 weight gradient at the conv0 / conv2 shapes.  Run on the GPU box from the repository root."""
+import sys
+sys.path.insert(0, ".")
+import torch
+from mvsdet_amd import ops
+dev = torch.device("cuda:0")
+out = []
+for name, N, Cin, Cout, D, H, W in [("conv0", 40, 256, 64, 12, 60, 80), ("conv2", 40, 128, 128, 6, 30, 40)]:
+    x = torch.randn(N, Cin, D, H, W, device=dev)
+    gy = torch.randn(N, Cout, D, H, W, device=dev)
+    for _ in range(2):
+        ops.conv3d_k3_dw(x, gy, 0, 1, True)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = ops.conv3d_k3_dw(x, gy, 0, 1, True); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    out.append(f"{name} median {ts[3]:.3f} min {ts[0]:.3f} ms")
+print(" | ".join(out))
