@@ -567,10 +567,114 @@ def g12b_relu_margin_grads(max_seeds=4000, margin=3e-5):
     print("g12b seed", found, "margins", layer_margins)
 
 
+# --------------------------------------------------------------------------- G13
+def g13_composed_chain():
+    """The COMPOSED chain as the reference runs it: an instance of the reference's own `MVSDet` class, its own `extract_feat`
+    (mvsdet.py:336-698) called as it stands in eval mode, with the REAL `CostRegNet_3DGS` (mvs_models/mvsnet.py:73-113) at
+    mvsdet.py:470 and the REAL `IndoorImVoxelNeck` (imvoxel_neck.py:70-231) at :696, then `NerfDetHead.forward`
+    (nerfdet_head.py:90-118) on the neck's levels.  Weights and BatchNorm statistics of all three and the feature maps come from
+    the committed LCG (only seeds stored); cameras from mvsdet_amd.synthetic.  The 2-D backbone / neck hand out the LCG feature
+    maps, the NVS branch is off (ray_batch=None), `.cuda()` of the depth-scale helpers (:1283-1313) is a no-op for the call.
+    Nothing on the path is restated: intermediates are RECORDED from the running reference by forward hooks on the modules and
+    by wrappers around `sample_depth_prob` / `compute_avg_depth` that call the reference's methods (inline_restated=0).
+    Shape: N=6 views, C=256, D=12, 60x80 maps (59x80 after the crop), 40x40x16 voxels -- the shipped configuration with fewer views."""
+    from _ref_loader import load_reference_head, load_reference_neck
+    from lcg import lcg_fill_state, lcg_uniform
+    mvsnet = sys.modules["refpkg.mvs_models.mvsnet"]
+    N, C, D, hw, nf = 6, 256, 12, (60, 80), (0.2, 5.0)
+    n_voxels, voxel_size = [40, 40, 16], [0.16, 0.16, 0.2]
+    seeds = dict(camera_seed=131, feature_seed=1300, cost_seed=13, neck_seed=113, head_seed=213)
+    PROB_GAIN = float(os.environ.get("G13_PROB_GAIN", 32.0))
+    meta = synthetic.make_img_meta(N, hw, seed=seeds["camera_seed"])
+    feature = torch.from_numpy(lcg_uniform(N * C * hw[0] * hw[1], seeds["feature_seed"])).reshape(N, C, *hw)
+    torch.manual_seed(0)
+    cost = mvsnet.CostRegNet_3DGS().eval()
+    neck = load_reference_neck()(256, 128, [1, 1, 1]).eval()
+    head = load_reference_head("NerfDetHead")(128, 6, 18, 3).eval()
+    with torch.no_grad():
+        lcg_fill_state(cost, seeds["cost_seed"])
+        # LCG weights shrink the signal layer by layer (logits within +-0.23: a flat soft-max whose top-3 hinge on 1e-6 at
+        # every seventh pixel); a trained network's depth distribution is peaked.  The last layer's gain makes it so -- and
+        # multiplies whatever error the layers before it made by the same factor, which is the point of this fixture.
+        cost.prob.weight.mul_(PROB_GAIN)
+        lcg_fill_state(neck, seeds["neck_seed"])
+        lcg_fill_state(head, seeds["head_seed"])
+        for i, s in enumerate(head.scales):
+            s.scale.fill_(0.5 + 0.25 * i)
+
+    det = MVSDet.__new__(MVSDet)                     # the reference class; its __init__ needs mmengine's registry
+    torch.nn.Module.__init__(det)
+    det.backbone = lambda img: feature
+    det.neck = lambda x: [x]
+    det.head_2d = None
+    det.n_voxels, det.voxel_size, det.near_far_range, det.topk = n_voxels, voxel_size, list(nf), 3
+    det.gs_cfg = SimpleNamespace(num_monocular_samples=D)
+    det.depth_interval = (nf[1] - nf[0]) / D         # mvsdet.py:221-225
+    det.depth_values = depth_planes(*nf, D)
+    det.cost_regularization = cost
+    det.neck_3d = neck
+    det.eval()
+
+    rec = {}
+    cost.register_forward_hook(lambda m, i, o: rec.__setitem__("logits", o.detach().clone()))
+    neck.register_forward_pre_hook(lambda m, i: rec.__setitem__("volume", i[0].detach().clone()))
+
+    def sample_depth_prob(prob_volume, off_pred, topk=3):
+        rec["prob"], rec["off"] = prob_volume.detach().clone(), off_pred.detach().clone()
+        rec["est_depth"], rec["est_dens"] = MVSDet.sample_depth_prob(det, prob_volume, off_pred, topk=topk)
+        return rec["est_depth"], rec["est_dens"]
+
+    def compute_avg_depth(prob_volume, off_pred):
+        rec["avg_depth"] = MVSDet.compute_avg_depth(det, prob_volume, off_pred)
+        return rec["avg_depth"]
+
+    det.sample_depth_prob, det.compute_avg_depth = sample_depth_prob, compute_avg_depth
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            res = det.extract_feat({"imgs": torch.zeros(1, N, 3, 4 * hw[0], 4 * hw[1])}, [SimpleNamespace(metainfo=meta)], "test")
+            levels, valids = res[0], res[1]
+            centers, regs, clss = head(levels)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    height, width = meta["img_shape"][0] // 4, meta["img_shape"][1] // 4
+    volume = rec["volume"][0]
+    cnt = valids[0]
+    assert tuple(volume.shape) == (C, 40, 40, 16) and tuple(cnt.shape) == (1, 40, 40, 16)
+    assert [tuple(o.shape) for o in levels] == [(1, 128, 40, 40, 16), (1, 128, 20, 20, 8), (1, 128, 10, 10, 4)]
+    prob = rec["prob"]
+    srt = prob.sort(dim=1, descending=True)[0]
+    gaps = (srt[:, :3] - srt[:, 1:4]).min(dim=1)[0][:, :height, :width]
+    print("g13 logits |max|", float(rec["logits"].abs().max()), "prob max mean", float(srt[:, 0].mean()),
+          "pixels with a top-4 gap under 1e-5 / 5e-5 / 1e-4:", [float((gaps < t).float().mean()) for t in (1e-5, 5e-5, 1e-4)],
+          "non-empty voxels", int((cnt[0] > 0).sum()), "max count", int(cnt.max()))
+    # geometry as the reference evaluated it on this machine (kernel parity in isolation from the host's LAPACK, see g1)
+    w2c, Kf = feat_level_proj(meta)
+    c2w = w2c.inverse()
+    nbr = ref.get_nearest_pose_ids(c2w, c2w, 2, maskself=True)
+    ref_proj, nei_projs = MVSDet.collect_proj(None, w2c, Kf, nbr)
+    proj_rel = torch.stack([torch.matmul(p, torch.inverse(ref_proj)) for p in nei_projs], 1)
+    projection = MVSDet._compute_projection(meta, 4, None)
+    out = dict(prob=prob, off=rec["off"], logits_sample=rec["logits"][:, :, :, ::6, ::8],
+               est_depth=rec["est_depth"][:, :, :height, :width], est_dens=rec["est_dens"][:, :, :height, :width],
+               depth_coding=rec["avg_depth"][:, :height, :width].unsqueeze(1), volume_mean=volume, valid_count=cnt.long(),
+               level0=levels[0][:, ::2, ::2, ::2, ::2], level1=levels[1][:, ::2], level2=levels[2],
+               level_scales=np.array([float(o.abs().max()) for o in levels]))
+    for i in range(3):
+        sl = (slice(None), slice(None), slice(None, None, 2), slice(None, None, 2), slice(None, None, 2)) if i == 0 else ()
+        out.update({f"center{i}": centers[i][sl], f"reg{i}": regs[i][sl], f"cls{i}": clss[i][sl]})
+    save("g13_composed_chain", extrinsic=np.array(meta["lidar2img"]["extrinsic"]), intrinsic=np.array(meta["lidar2img"]["intrinsic"]),
+         origin=meta["lidar2img"]["origin"], img_shape=np.array(meta["img_shape"]), ori_shape=np.array(meta["ori_shape"]),
+         near_far=np.array(nf, dtype=np.float64), n_voxels=np.array(n_voxels), voxel_size=np.array(voxel_size, dtype=np.float64),
+         feature_shape=np.array(feature.shape), neighbor_ids=nbr, proj_rel=proj_rel, projection=projection,
+         inline_restated=0, stand_in=STAND_IN, prob_weight_gain=np.float32(PROB_GAIN), **{k: np.int64(v) for k, v in seeds.items()}, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g12b"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g12b", "g13"]
     fns = dict(g1=g1_homo_warping, g2=g2_variance, g3=g3_knn, g4=g4_depth_prob, g5=g5_backproject,
                g6=g6_backward, g7=g7_end_to_end, g8=g8_cost_regularisation, g9=g9_depth_scale, g10=g10_neck, g11=g11_heads,
-               g12=g12_cost_regularisation_grads, g12b=g12b_relu_margin_grads)
+               g12=g12_cost_regularisation_grads, g12b=g12b_relu_margin_grads, g13=g13_composed_chain)
     for w in which:
         fns[w]()
