@@ -38,8 +38,6 @@ struct Options {
     int conv_split_min_groups; // ... and a split keeps at least this many groups of 8 input channels (default 2: neck + head 2.39 -> 2.35 ms against 4)
     int bwd_groups;    // backward sweep: wave groups of a block that share its gradient images and split its planes; 0 = by the plane
                        // count (2 from 32 planes), 1 / 2 force
-    int bwd_pipe;      // backward sweep with one wave group and K <= 2: 1 = the software-pipelined plane loop (the next plane's decode and
-                       // tap gathers issued before this plane's atomics: 211 VGPRs, two blocks per CU, 3.37 against 2.74 ms), 0 (default)
     int conv_mfma16;   // 1 (default): the bf16x3 stride-1 convolution on v_mfma_f32_16x16x32_bf16 (conv0 of the cost network 5.37 -> 4.91 ms:
                        // the chip holds a higher clock on this shape); 0: 32x32x16.  Weights must be split under the same setting.
 };
@@ -47,7 +45,7 @@ Options& options();
 
 // where plane_sweep_coords_kernel leaves the sweep geometry inside the scratch buffer (planesweep.hip)
 struct SweepGeometry {
-    int4* header;   // {kGeoMagic, tile width, W, (D << 8) | K} written by plane_sweep_coords_kernel: the layout below hangs on the
+    int4* header;   // {kGeoMagic, tile width | (box capacity << 8), W, (D << 8) | K} written by plane_sweep_coords_kernel: the layout below hangs on the
                     // tile shape, so a consumer whose own choice differs (a pitched table fed to the contiguous call, another
                     // "sweep_tw") must not touch it -- the slab kernel checks the header and fills its output with NaN instead
     int4* boxes;

@@ -57,10 +57,10 @@ __device__ __forceinline__ void lds_add_f64_at(int addr, double v) {
 
 template <int K, int TW, int HALF, int GROUPS>
 __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_variance_bwd_kernel(
-    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
-    const float* __restrict__ depth, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
-    const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int box_cap) {
+    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const int4* __restrict__ header,
+    const float* __restrict__ proj, const float* __restrict__ depth, const int4* __restrict__ boxes,
+    const unsigned* __restrict__ flags, const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S, int D,
+    int H, int W, int tiles_x, int tiles, int box_cap) {
     constexpr int KK = K > 0 ? K : 1;
     constexpr int NP = (K + 1) / 2;
     constexpr int NPP = NP > 0 ? NP : 1;
@@ -68,6 +68,20 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
     extern __shared__ double s_grad[];  // K slots of (box_cap + kBoxPad) texels x 16 doubles: gradient images of the resident boxes
 
     const int HW = H * W;
+    if constexpr (K > 0) {
+        // The geometry may come from the FORWARD pass (mvsdet_plane_sweep_variance_bwd_packed_f32): its layout hangs on the tile
+        // shape of the launch that built it, and its boxes must fit this launch's LDS slots (sized for the largest capacity a
+        // geometry of this shape can have, so "sweep_boxcap" may move in between).  When `mvsdet_set_option` moved the tile
+        // shape in between (or the buffer is not a geometry at all) nothing of it is read: the whole gradient becomes NaN (block-uniform exit before any
+        // barrier), as the forward kernel does with its output.
+        const int4 hd = *header;
+        if (hd.x != kGeoMagic || (hd.y & 0xff) != TW || (hd.y >> 8) > box_cap || hd.z != W || hd.w != ((D << 8) | K)) {
+            const size_t total = (size_t)N * S * HW * kSlab;
+            const size_t step = (size_t)gridDim.x * blockDim.x;
+            for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) gpacked[i] = __builtin_nanf("");
+            return;
+        }
+    }
     // HALF == 2: both halves in one launch; blocks 16k .. 16k+7 are the lower halves of eight (view, tile, slab) units and
     // blocks 16k+8 .. 16k+15 the upper halves of the same eight, so a unit's two halves run on the same XCD (block id modulo
     // 8) at about the same time and the second finds the 128-byte texel lines of the first in its L2
@@ -428,333 +442,6 @@ __global__ __launch_bounds__(kThreads * GROUPS, 2 * GROUPS) void plane_sweep_var
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same operator with the plane loop SOFTWARE-PIPELINED (round 5; K <= 2, one wave group).  What bounds the kernel above is
-// a latency chain per plane -- decode -> 32 tap gathers from L2 -> arithmetic -> 64 LDS atomics -- that three waves per SIMD
-// do not cover (profiles/r04_bwd_pmc.txt: waves wait 54 % of their cycles).  Here a wave has TWO planes in flight:
-//
-//     plane d :  [wait for its taps]  warped values, S        [its 64 atomics ...................]
-//     plane d+1:                                        decode, 32 gathers issued --------------> (arrive under the atomics)
-//
-// The taps of plane d+1 land in the registers plane d's taps have just left (they are consumed by the warped values), so the
-// price is the decode state of a second plane, not a second tap set.  The tap GATHER of a plane does not depend on the
-// resident boxes (it reads the slab image; a tap outside the image carries weight 0 and may read any texel), only the LDS
-// offsets of its gradient adds do: those are derived from the saved tap origin at the top of the plane's own iteration, behind
-// a possible refill, so refills keep their place.  Values: the same sums as the kernel above up to the order in which the
-// atomics of different planes reach a cell (already free between waves).
-template <int K, int TW, int HALF>
-__global__ __launch_bounds__(kThreads, 2) void plane_sweep_variance_bwd_pipe_kernel(
-    const float* __restrict__ packed, const int64_t* __restrict__ nbr, const float* __restrict__ proj,
-    const float* __restrict__ depth, const int4* __restrict__ boxes, const unsigned* __restrict__ flags,
-    const float* __restrict__ gvar, float* __restrict__ gpacked, int N, int C, int S, int D, int H, int W, int tiles_x,
-    int tiles, int box_cap) {
-    static_assert(K >= 1 && K <= 2, "one decode pass: neighbours 0 and 1");
-    constexpr int TH = kTilePix / TW;
-    extern __shared__ double s_grad[];
-
-    const int HW = H * W;
-    const int half = HALF == 2 ? (int)((blockIdx.x >> 3) & 1) : HALF;
-    const int id = HALF == 2 ? (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7)) : (int)blockIdx.x;
-    if (HALF == 2 && id >= N * tiles * S) return;
-    const int slab = id % S;
-    const int bt = id / S;
-    const int tile = bt % tiles, n = bt / tiles;
-    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane & 7, ps = lane >> 3;
-    const size_t slab_stride = (size_t)HW * kSlab;
-    const float2* ref_img = reinterpret_cast<const float2*>(packed + ((size_t)n * S + slab) * slab_stride) + 8 * half + g;
-    const float2* nb_img[K];
-    float* nb_grad[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        int64_t v = nbr[(size_t)n * K + j];
-        v = v < 0 ? 0 : (v >= N ? N - 1 : v);
-        nb_img[j] = reinterpret_cast<const float2*>(packed + ((size_t)v * S + slab) * slab_stride) + 8 * half + g;
-        nb_grad[j] = gpacked + ((size_t)v * S + slab) * slab_stride + kHalfSlab * half;
-    }
-    const float r = 1.0f / (float)(K + 1);
-    const float two_r = 2.0f * r, two_r2 = 2.0f * r * r;
-    const int slot_el = (box_cap + kBoxPad) * kHalfSlab;
-
-    const int p0 = 32 * wave + 4 * ps;
-    const int px0 = tx0 + p0 % TW, py = ty0 + p0 / TW;
-    float f[4][2], gref[4][2];
-    bool pok[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        pok[s] = (px0 + s < W) && (py < H);
-        const int pix = min(py, H - 1) * W + min(px0 + s, W - 1);
-        const float2 v = ref_img[(size_t)pix * kHalfSlab];
-        f[s][0] = v.x; f[s][1] = v.y;
-        gref[s][0] = gref[s][1] = 0.0f;
-    }
-    const int st_n = (py < H) ? max(0, min(4, W - px0)) : 0;
-    const bool st_vec = (st_n == 4) && ((W & 3) == 0) && ((HW & 3) == 0);
-    size_t g_off[2];
-    bool g_ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = slab * kSlab + 16 * (g & 1) + 8 * i + 4 * half + (g >> 1);
-        g_ok[i] = (c < C) && (st_n > 0);
-        g_off[i] = ((size_t)n * C + min(c, C - 1)) * D * HW + (size_t)py * W + px0;
-    }
-
-    // decode duty: pixel p0 + (g & 3), neighbour g >> 2 (clamped to K - 1)
-    const int sd = g & 3, qd = g >> 2;
-    const int jd = min(qd, K - 1);
-    const int dx = px0 + sd;
-    const bool d_inside = (dx < W) && (py < H);
-    const float* P = proj + ((size_t)n * K + jd) * 16;
-    const SampleRay ray = sample_ray(P, (float)dx, (float)py);
-    const float tr0 = P[3], tr1 = P[7], tr2 = P[11];
-    int lx0 = 0, lx1 = 0, ly0 = 0, ly1 = 0;          // resident box of the lane's neighbour
-    int rx0[K], ry0[K], rx1[K], ry1[K];
-    bool have[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) { rx0[j] = 0; ry0[j] = 0; rx1[j] = -1; ry1[j] = -1; have[j] = false; }
-
-    auto flush_box = [&](int j) {
-        const int nc = rx1[j] - rx0[j] + 1, ntex = nc * (ry1[j] - ry0[j] + 1);
-        const float inv_nc = 1.0f / (float)nc;
-        for (int t0 = wave * 4; t0 < ntex; t0 += 16) {
-            const int t = t0 + (lane >> 4), q = lane & 15;
-            if (t < ntex) {
-                const int row = (int)(((float)t + 0.5f) * inv_nc), col = t - row * nc;
-                const int base = j * slot_el + box_slot(t) * kHalfSlab;
-                double* cell = s_grad + base + (q ^ grad_swizzle(base));
-                const float v = (float)*cell;
-                if (v != 0.0f) atomicAdd(nb_grad[j] + ((size_t)(ry0[j] + row) * W + (rx0[j] + col)) * kSlab + q, v);
-                *cell = 0.0;
-            }
-        }
-    };
-
-    for (int e = tid; e < K * slot_el / 2; e += kThreads) reinterpret_cast<double2*>(s_grad)[e] = make_double2(0.0, 0.0);
-    __syncthreads();
-
-    const unsigned* fl_bt = flags + (size_t)bt * D;
-    const float* depth_n = depth + (size_t)n * D;
-    float4 gnext[2];
-    auto load_go = [&](int d) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g_ok[i]) {
-                const float* src = gvar + g_off[i] + (size_t)d * HW;
-                if (st_vec) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    v.x = src[0];
-                    if (st_n > 1) v.y = src[1];
-                    if (st_n > 2) v.z = src[2];
-                    if (st_n > 3) v.w = src[3];
-                }
-            }
-            gnext[i] = v;
-        }
-    };
-
-    // ---- the plane in flight: tap origin and weights of the lane's (pixel, neighbour), and the gathered taps of the lane's
-    //      own 4 pixels x K neighbours x 4 taps (2 floats each)
-    int nx0 = 0, ny0 = 0;
-    float4 nw = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 T[K][4][4];
-    // decode plane (flags fln, depth dv) and issue its gathers into T
-    auto decode_and_gather = [&](unsigned fln, float dv) {
-        float2 e = make_float2(kNoSample, kNoSample);
-        if (d_inside) e = sample_at(ray, tr0, tr1, tr2, dv, H, W);
-        const SampleTaps tp = decode_sample(e.x, e.y, H, W);
-        nw = tap_weights(tp);
-        nx0 = tp.x0; ny0 = tp.y0;
-        // image-clamped float2 offsets of the four taps in the slab image (a tap outside carries weight 0: any texel will do)
-        const int xa = clampi(tp.x0, 0, W - 1), xb = clampi(tp.x0 + 1, 0, W - 1);
-        const int ya = clampi(tp.y0, 0, H - 1) * W, yb = clampi(tp.y0 + 1, 0, H - 1) * W;
-        const int di0 = (ya + xa) * kHalfSlab, di1 = (ya + xb) * kHalfSlab, di2 = (yb + xa) * kHalfSlab, di3 = (yb + xb) * kHalfSlab;
-#define MVS_PIPE_GATHER(QQ)                                                                                            \
-        if constexpr (QQ < K) {                                                                                       \
-            if ((fln >> (4 * QQ)) & kFlagLive) {                                                                      \
-                const int ri0 = from_quad<QQ>(di0), ri1 = from_quad<QQ>(di1), ri2 = from_quad<QQ>(di2), ri3 = from_quad<QQ>(di3); \
-                T[QQ][0][0] = nb_img[QQ][quad_bcast<0>(ri0)]; T[QQ][0][1] = nb_img[QQ][quad_bcast<0>(ri1)];           \
-                T[QQ][0][2] = nb_img[QQ][quad_bcast<0>(ri2)]; T[QQ][0][3] = nb_img[QQ][quad_bcast<0>(ri3)];           \
-                T[QQ][1][0] = nb_img[QQ][quad_bcast<1>(ri0)]; T[QQ][1][1] = nb_img[QQ][quad_bcast<1>(ri1)];           \
-                T[QQ][1][2] = nb_img[QQ][quad_bcast<1>(ri2)]; T[QQ][1][3] = nb_img[QQ][quad_bcast<1>(ri3)];           \
-                T[QQ][2][0] = nb_img[QQ][quad_bcast<2>(ri0)]; T[QQ][2][1] = nb_img[QQ][quad_bcast<2>(ri1)];           \
-                T[QQ][2][2] = nb_img[QQ][quad_bcast<2>(ri2)]; T[QQ][2][3] = nb_img[QQ][quad_bcast<2>(ri3)];           \
-                T[QQ][3][0] = nb_img[QQ][quad_bcast<3>(ri0)]; T[QQ][3][1] = nb_img[QQ][quad_bcast<3>(ri1)];           \
-                T[QQ][3][2] = nb_img[QQ][quad_bcast<3>(ri2)]; T[QQ][3][3] = nb_img[QQ][quad_bcast<3>(ri3)];           \
-            }                                                                                                         \
-        }
-        MVS_PIPE_GATHER(0)
-        MVS_PIPE_GATHER(1)
-#undef MVS_PIPE_GATHER
-    };
-
-    unsigned fl_cur = fl_bt[0];
-    float dv_cur = depth_n[0];
-    fl_cur = __builtin_amdgcn_readfirstlane(fl_cur);
-    dv_cur = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dv_cur)));
-    decode_and_gather(fl_cur, dv_cur);
-    load_go(0);
-    unsigned fl_next = D > 1 ? fl_bt[1] : 0u;
-    float dv_next = D > 1 ? depth_n[1] : 0.0f;
-
-    for (int d = 0; d < D; ++d) {
-        const unsigned fl = fl_cur;
-        bool refill = false;
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-            if ((fl >> (4 * j)) & kFlagStaged)
-                if (((fl >> (4 * j)) & kFlagRefill) || !have[j]) refill = true;
-        if (refill) {
-            __syncthreads();  // every wave has added its taps of the planes that used the old boxes
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                if (((fl >> (4 * j)) & kFlagStaged) && (((fl >> (4 * j)) & kFlagRefill) || !have[j])) {
-                    if (have[j]) flush_box(j);
-                    const int4 b = boxes[((size_t)bt * D + d) * K + j];
-                    rx0[j] = __builtin_amdgcn_readfirstlane(b.x);
-                    rx1[j] = __builtin_amdgcn_readfirstlane(b.y);
-                    ry0[j] = __builtin_amdgcn_readfirstlane(b.z);
-                    ry1[j] = __builtin_amdgcn_readfirstlane(b.w);
-                    have[j] = true;
-                    if (jd == j) { lx0 = rx0[j]; lx1 = rx1[j]; ly0 = ry0[j]; ly1 = ry1[j]; }
-                }
-            }
-            __syncthreads();  // slots zeroed again before anyone adds into them
-        }
-        // ---- this plane's add offsets and weights, from the tap origin saved when its gathers were issued: inside the resident
-        //      box of the lane's neighbour (doubles of the gradient slot) or inside the gradient map (floats)
-        int dox[4];
-        float dwx[4];
-        {
-            const unsigned fq = qd ? ((1 < K) ? (fl >> 4) : fl) : fl;
-            const bool l_staged = (fq & kFlagStaged) != 0;
-            const int lox = l_staged ? lx0 : 0, hix = l_staged ? lx1 : W - 1;
-            const int loy = l_staged ? ly0 : 0, hiy = l_staged ? ly1 : H - 1;
-            const int xa = clampi(nx0, lox, hix), xb = clampi(nx0 + 1, lox, hix);
-            const int ya = clampi(ny0, loy, hiy), yb = clampi(ny0 + 1, loy, hiy);
-            const int pitch = hix - lox + 1;
-            const int sbase = jd * slot_el;
-            const int ta = (ya - loy) * pitch - lox, tb = (yb - loy) * pitch - lox;
-            dox[0] = l_staged ? box_slot(ta + xa) * kHalfSlab + sbase : (ya * W + xa) * kHalfSlab * 2;
-            dox[1] = l_staged ? box_slot(ta + xb) * kHalfSlab + sbase : (ya * W + xb) * kHalfSlab * 2;
-            dox[2] = l_staged ? box_slot(tb + xa) * kHalfSlab + sbase : (yb * W + xa) * kHalfSlab * 2;
-            dox[3] = l_staged ? box_slot(tb + xb) * kHalfSlab + sbase : (yb * W + xb) * kHalfSlab * 2;
-            dwx[0] = nw.x; dwx[1] = nw.y; dwx[2] = nw.z; dwx[3] = nw.w;
-        }
-        float go[4][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { go[0][i] = gnext[i].x; go[1][i] = gnext[i].y; go[2][i] = gnext[i].z; go[3][i] = gnext[i].w; }
-
-        // ---- warped values and S from this plane's taps (they were requested a plane ago)
-        float S_[4][2], wv[K][4][2];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { S_[s][0] = f[s][0]; S_[s][1] = f[s][1]; }
-#define MVS_PIPE_WARP_STEP(QQ, SS)                                                                                     \
-        {                                                                                                             \
-            const float w0 = __int_as_float(quad_bcast<SS>(rw0)), w1 = __int_as_float(quad_bcast<SS>(rw1));           \
-            const float w2 = __int_as_float(quad_bcast<SS>(rw2)), w3 = __int_as_float(quad_bcast<SS>(rw3));           \
-            const float a0[2] = {T[QQ][SS][0].x, T[QQ][SS][0].y}, a1[2] = {T[QQ][SS][1].x, T[QQ][SS][1].y};           \
-            const float a2[2] = {T[QQ][SS][2].x, T[QQ][SS][2].y}, a3[2] = {T[QQ][SS][3].x, T[QQ][SS][3].y};           \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
-                float v = a0[i] * w0;                                                                                 \
-                v = fmaf(a1[i], w1, v);                                                                               \
-                v = fmaf(a2[i], w2, v);                                                                               \
-                v = fmaf(a3[i], w3, v);                                                                               \
-                wv[QQ][SS][i] = v;                                                                                    \
-                S_[SS][i] += v;                                                                                       \
-            }                                                                                                         \
-        }
-#define MVS_PIPE_WARP(QQ)                                                                                              \
-        if constexpr (QQ < K) {                                                                                       \
-            if ((fl >> (4 * QQ)) & kFlagLive) {                                                                       \
-                const int rw0 = from_quad<QQ>(__float_as_int(dwx[0])), rw1 = from_quad<QQ>(__float_as_int(dwx[1]));   \
-                const int rw2 = from_quad<QQ>(__float_as_int(dwx[2])), rw3 = from_quad<QQ>(__float_as_int(dwx[3]));   \
-                MVS_PIPE_WARP_STEP(QQ, 0) MVS_PIPE_WARP_STEP(QQ, 1) MVS_PIPE_WARP_STEP(QQ, 2) MVS_PIPE_WARP_STEP(QQ, 3) \
-            } else {                                                                                                  \
-                _Pragma("unroll") for (int s = 0; s < 4; ++s) wv[QQ][s][0] = wv[QQ][s][1] = 0.0f;                     \
-            }                                                                                                         \
-        }
-        MVS_PIPE_WARP(0)
-        MVS_PIPE_WARP(1)
-#undef MVS_PIPE_WARP
-#undef MVS_PIPE_WARP_STEP
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (pok[s]) gref[s][i] = fmaf(go[s][i], two_r * f[s][i] - two_r2 * S_[s][i], gref[s][i]);
-
-        // ---- the NEXT plane: decode, gathers and dL/dvar on their way before this plane's atomics start
-        if (d + 1 < D) {
-            fl_cur = __builtin_amdgcn_readfirstlane(fl_next);
-            dv_cur = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dv_next)));
-            if (d + 2 < D) { fl_next = fl_bt[d + 2]; dv_next = depth_n[d + 2]; }
-            decode_and_gather(fl_cur, dv_cur);
-            load_go(d + 1);
-        }
-
-        // ---- this plane's tap gradients
-#define MVS_GRAD_STEP(SS, ADD, COND)                                                                                  \
-        if (!COND || pok[SS]) {                                                                                       \
-            int to[4];                                                                                                \
-            float tw[4];                                                                                              \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                           \
-                to[t] = quad_bcast<SS>(ro[t]);                                                                        \
-                tw[t] = __int_as_float(quad_bcast<SS>(rw[t]));                                                        \
-            }                                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
-                float gw = go[SS][i] * (two_r * wv[j][SS][i] - two_r2 * S_[SS][i]);                                   \
-                if (!COND) gw = pok[SS] ? gw : 0.0f;                                                                  \
-                _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
-                    if (!COND || tw[t] != 0.0f) ADD(to[t], i, gw * tw[t]);                                            \
-            }                                                                                                         \
-        }
-#define MVS_ADD_LDS(O, I, V) \
-    __hip_atomic_fetch_add(s_grad + (O) + 2 * g + ((I) ^ grad_swizzle(O)), (double)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define MVS_ADD_GLB(O, I, V) atomicAdd(nb_grad[j] + (O) + 2 * g + (I), (V))
-#define MVS_GRAD_OF(QQ)                                                                                               \
-        if constexpr (QQ < K) {                                                                                       \
-            constexpr int j = QQ;                                                                                     \
-            const unsigned fj = fl >> (4 * j);                                                                        \
-            if (fj & kFlagLive) {                                                                                     \
-                int ro[4], rw[4];                                                                                     \
-                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                       \
-                    ro[t] = from_quad<QQ>(dox[t]);                                                                    \
-                    rw[t] = from_quad<QQ>(__float_as_int(dwx[t]));                                                    \
-                }                                                                                                     \
-                if (fj & kFlagStaged) {                                                                               \
-                    MVS_GRAD_STEP(0, MVS_ADD_LDS, false) MVS_GRAD_STEP(1, MVS_ADD_LDS, false)                         \
-                    MVS_GRAD_STEP(2, MVS_ADD_LDS, false) MVS_GRAD_STEP(3, MVS_ADD_LDS, false)                         \
-                } else {                                                                                              \
-                    MVS_GRAD_STEP(0, MVS_ADD_GLB, true) MVS_GRAD_STEP(1, MVS_ADD_GLB, true)                           \
-                    MVS_GRAD_STEP(2, MVS_ADD_GLB, true) MVS_GRAD_STEP(3, MVS_ADD_GLB, true)                           \
-                }                                                                                                     \
-            }                                                                                                         \
-        }
-        MVS_GRAD_OF(0)
-        MVS_GRAD_OF(1)
-#undef MVS_GRAD_OF
-#undef MVS_GRAD_STEP
-#undef MVS_ADD_LDS
-#undef MVS_ADD_GLB
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (have[j]) flush_box(j);
-    float* gr = gpacked + ((size_t)n * S + slab) * slab_stride + kHalfSlab * half;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (pok[s]) {
-            const int pix = py * W + px0 + s;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) atomicAdd(gr + (size_t)pix * kSlab + 2 * g + i, gref[s][i]);
-        }
-}
-
 }  // namespace mvsdet
 
 using namespace mvsdet;
@@ -766,6 +453,7 @@ extern "C" int mvsdet_plane_sweep_table_f32(const float* proj, const float* dept
 namespace mvsdet {
 int sweep_tile_width(int W, int D);  // the tile shape the sweep geometry is built for
 int sweep_box_cap(int K, int tw);
+int sweep_max_box_cap(int K, int tw);
 }
 
 extern "C" size_t mvsdet_plane_sweep_bwd_workspace_bytes(int N, int K, int C, int D, int H, int W) {
@@ -841,13 +529,11 @@ static int bwd_launch(const float* packed, const int64_t* nbr, void* scratch, co
     const long long nblocks = (long long)N * tiles * S;
     MVS_REQUIRE(nblocks <= INT32_MAX / 2 - 16, "plane_sweep_variance_bwd: grid too large");
     const SweepGeometry geo = sweep_geometry(scratch, N, K, D, tiles);
-    const int box_cap = sweep_box_cap(K, tw);
+    const int box_cap = sweep_max_box_cap(K, tw);   // the geometry may be the forward pass's: slots for the largest capacity it can have been built with
     const size_t lds = sweep_lds_bytes(K, box_cap);
     dim3 grid((unsigned)nblocks);
     // plane groups of a block (header comment): option "bwd_groups" 0 = by the plane count, 1 / 2 force
     const int groups = options().bwd_groups ? std::min(2, std::max(1, options().bwd_groups)) : (D >= 32 ? 2 : 1);
-    // one wave group, K <= 2: the software-pipelined plane loop (option "bwd_pipe", default on; 0 = the kernel of round 4)
-    const bool pipe = options().bwd_pipe != 0;   // measured: 3.37 against 2.74 ms at the reference-true shape (two blocks per CU): off by default
     // two instances: the lower and the upper 16 packed floats of every texel = channels 8i + {0..3} and 8i + {4..7} of the
     // slab (pack.h), so the upper one has nothing to do only when C <= 4
 #define MVS_BWD_LAUNCH1(KV, TWV, HV, GV)                                                                                 \
@@ -858,18 +544,7 @@ static int bwd_launch(const float* packed, const int64_t* nbr, void* scratch, co
             set_error("plane_sweep_variance_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");             \
             return MVSDET_ERR_HIP;                                                                                     \
         }                                                                                                              \
-        hipLaunchKernelGGL(k, grid, dim3(kThreads * GV), lds, stream, packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
-                           gpacked, N, C, S, D, H, W, tiles_x, tiles, box_cap);                                        \
-    }
-#define MVS_BWD_LAUNCH_PIPE(KV, TWV)                                                                                     \
-    {                                                                                                                  \
-        auto* k = plane_sweep_variance_bwd_pipe_kernel<(KV >= 1 && KV <= 2) ? KV : 1, TWV, 2>;                         \
-        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                   80 * 1024) != hipSuccess) {                                         \
-            set_error("plane_sweep_variance_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");             \
-            return MVSDET_ERR_HIP;                                                                                     \
-        }                                                                                                              \
-        hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, stream, packed, nbr, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
+        hipLaunchKernelGGL(k, grid, dim3(kThreads * GV), lds, stream, packed, nbr, geo.header, geo.proj, geo.depth, geo.boxes, geo.flags, g, \
                            gpacked, N, C, S, D, H, W, tiles_x, tiles, box_cap);                                        \
     }
 #define MVS_BWD_LAUNCH(KV, TWV)                        \
@@ -877,7 +552,6 @@ static int bwd_launch(const float* packed, const int64_t* nbr, void* scratch, co
         if (C > 4) {                                   \
             grid = dim3((unsigned)((nblocks + 7) / 8 * 16)); \
             if (groups == 2) MVS_BWD_LAUNCH1(KV, TWV, 2, 2) \
-            else if (pipe && KV >= 1 && KV <= 2) MVS_BWD_LAUNCH_PIPE(KV, TWV) \
             else MVS_BWD_LAUNCH1(KV, TWV, 2, 1)        \
         } else                                         \
             MVS_BWD_LAUNCH1(KV, TWV, 0, 1)             \
@@ -897,7 +571,6 @@ static int bwd_launch(const float* packed, const int64_t* nbr, void* scratch, co
 #undef MVS_BWD_CASE
 #undef MVS_BWD_LAUNCH
 #undef MVS_BWD_LAUNCH1
-#undef MVS_BWD_LAUNCH_PIPE
     MVS_LAUNCH_CHECK("plane_sweep_variance_bwd");
     if (HW % 4 == 0 && (uintptr_t)gfeat % 16 == 0) {
         dim3 dgrid((HW + 127) / 128, S, N);

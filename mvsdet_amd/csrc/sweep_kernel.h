@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void plane_sweep_coords_kernel(const floa
         s_dv[d] = depth[(size_t)n * D + d];   // one global round trip for all planes instead of one per plane
     }
     __syncthreads();
-    if (bt == 0 && tid == 0) *header = make_int4(kGeoMagic, TW, W, (D << 8) | K);   // what this layout was built for
+    if (bt == 0 && tid == 0) *header = make_int4(kGeoMagic, TW | (box_cap << 8), W, (D << 8) | K);   // what this layout was built for
     if (tile == 0) {  // the slab kernel reads the camera data from the scratch buffer (the tabled entry point has no other)
         for (int i = tid; i < K * 16; i += kThreads) proj_copy[(size_t)n * K * 16 + i] = proj[(size_t)n * K * 16 + i];
         for (int d = tid; d < D; d += kThreads) depth_copy[(size_t)n * D + d] = depth[(size_t)n * D + d];
@@ -425,11 +425,12 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
 
     if constexpr (K > 0) {
         // The geometry's layout hangs on the tile shape it was built for: one that was built for another (a pitched table handed
-        // to the contiguous call or the other way round, another "sweep_tw") holds boxes of other tiles -- or nothing at all --
+        // to the contiguous call or the other way round, another "sweep_tw" or "sweep_boxcap") holds boxes of other tiles, boxes
+        // larger than this launch's LDS slots -- or nothing at all --
         // where this kernel would look.  Nothing of it is touched: the whole output becomes NaN instead (block-uniform exit
         // before any barrier).
         const int4 hd = *header;
-        if (hd.x != kGeoMagic || hd.y != TW || hd.z != W || hd.w != ((D << 8) | K)) {
+        if (hd.x != kGeoMagic || (hd.y & 0xff) != TW || (hd.y >> 8) > box_cap || hd.z != W || hd.w != ((D << 8) | K)) {
             const size_t total = (size_t)(n_bt / tiles) * C * D * H * Wo;
             const size_t step = (size_t)gridDim.x * gridDim.y * kThreads;
             for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; i < total; i += step)

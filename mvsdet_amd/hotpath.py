@@ -10,6 +10,7 @@ pack -> plane-sweep variance -> [cost regularisation network, not ours] -> depth
 """
 from __future__ import annotations
 
+from collections.abc import Mapping
 from dataclasses import dataclass
 from typing import Callable, Optional, Sequence
 
@@ -41,21 +42,33 @@ def _tensors_of(v):
             yield from _tensors_of(x)
 
 
-class SceneOutputs(dict):
-    """What `forward_scene` returns.  With `overlap_detector` everything but `variance` was produced on a side stream and is
-    only valid behind the event `ready`: this holder makes the stream that READS a value wait for that event (once the event
-    has completed the check is one query) and tells the caching allocator that the stream uses the value's memory, so a
-    consumer on any stream -- the caller's, a third one -- gets correct data without knowing about the side stream.
+class SceneOutputs(Mapping):
+    """What `forward_scene` returns: a read-only mapping.  With `overlap_detector` everything but `variance` was produced on a
+    side stream and is only valid behind the event `ready`: this holder makes the stream that READS a value wait for that event
+    (once the event has completed the check is one query) and tells the caching allocator that the stream uses the value's
+    memory, so a consumer on any stream -- the caller's, a third one -- gets correct data without knowing about the side stream.
+    It is a `collections.abc.Mapping`, not a `dict` subclass: `dict(out)`, `{**out}`, iteration over `items()` / `values()` and
+    `get` all go through `__getitem__` and therefore through the wait (CPython copies a dict SUBCLASS with its fast path,
+    past any override); there is no `pop` / `setdefault` / item assignment to get around it.
     `ready`, `detector_ready`, `geometry` and `variance` (produced on the caller's own stream) are handed out as they are;
-    `dict.__getitem__(out, key)` / `out.raw(key)` bypass the wait for callers that order the streams themselves."""
+    `out.raw(key)` bypasses the wait for callers that order the streams themselves."""
 
     _PLAIN = ("ready", "detector_ready", "geometry", "variance")
+    __slots__ = ("_d",)
+
+    def __init__(self, **values):
+        self._d = dict(values)
 
     def raw(self, key):
-        return dict.__getitem__(self, key)
+        return self._d[key]
 
-    def _guard(self, key, value):
-        ev = dict.get(self, "ready")
+    def _put(self, key, value):
+        """The producer's own write (this module only; the side stream is current or ordered by the caller)."""
+        self._d[key] = value
+
+    def __getitem__(self, key):
+        value = self._d[key]
+        ev = self._d.get("ready")
         if ev is None or key in self._PLAIN:
             return value
         cur = None
@@ -68,17 +81,20 @@ class SceneOutputs(dict):
                 t.record_stream(cur)
         return value
 
-    def __getitem__(self, key):
-        return self._guard(key, dict.__getitem__(self, key))
+    def __iter__(self):
+        return iter(self._d)
 
-    def get(self, key, default=None):
-        return self._guard(key, dict.__getitem__(self, key)) if key in self else default
+    def __len__(self):
+        return len(self._d)
 
-    def items(self):
-        return [(k, self[k]) for k in self.keys()]
+    def __contains__(self, key):
+        return key in self._d
 
-    def values(self):
-        return [self[k] for k in self.keys()]
+    def copy(self) -> dict:
+        return dict(self)          # through __getitem__: the copy's values are safe on the current stream
+
+    def __repr__(self):
+        return f"SceneOutputs({list(self._d)})"
 
 
 class _GeometryWorker:
@@ -514,9 +530,9 @@ class MVSDetHotPath:
         def tail():
             out = self._lift_tail(feature, geo, packed, variance, cost_logits)
             if self.neck_3d is not None:   # the reference stacks the scenes of a batch first (batch_size = 1 per GPU): forward_scenes
-                dict.__setitem__(out, "neck", self.neck_3d(out.raw("volume").unsqueeze(0)))
+                out._put("neck", self.neck_3d(out.raw("volume").unsqueeze(0)))
                 if self.bbox_head is not None:
-                    dict.__setitem__(out, "head", self.bbox_head(out.raw("neck")))   # (centerness, bbox, cls) lists over the levels
+                    out._put("head", self.bbox_head(out.raw("neck")))   # (centerness, bbox, cls) lists over the levels
             return out
 
         if self._one_stream(feature, variance, cost_logits):
@@ -538,30 +554,41 @@ class MVSDetHotPath:
         # (`lift` reads geo.projection -- a view of the ONE uploaded staging buffer, which neighbor_ids, proj_rel and depth_values
         # share: recording any view records the whole block -- and geo.points, a block of its own)
         self._keep_for(side, cost_logits, packed, feature, geo.projection, geo.points)
-        dict.__setitem__(out, "ready", done)
-        dict.__setitem__(out, "detector_ready", done)
+        out._put("ready", done)
+        out._put("detector_ready", done)
         return out
 
     def forward_scenes(self, features: Sequence[Tensor], img_metas: Sequence[dict],
-                       cost_logits: Optional[Sequence[Tensor]] = None) -> dict:
+                       cost_logits: Optional[Sequence[Tensor]] = None, keep_variance: bool = False) -> dict:
         """A BATCH of scenes the way mvsdet.py:681-698 runs it: every scene through a1..a10 on its own, then `neck_3d` (and
         `bbox_head`) ONCE on the stacked (B,C,X,Y,Z) volume -- one 40 x 40 x 16 volume is 200 blocks for 256 CUs at the neck's
         largest level and a few dozen at the others; a batch fills the chip (throughput runs, `samples_per_gpu` > 1).
         Returns {"scenes": [SceneOutputs per scene, each with its own rows of the batched neck / head results as views],
         "volume": (B,C,X,Y,Z), "valid": (B,1,X,Y,Z), "neck": levels of (B,...), "head": the head's lists, "ready": event}.
         With `overlap_detector` the tails and the batched detector run on the side stream beside the following scenes' sweeps
-        and cost networks; values read through the returned holders wait for it."""
+        and cost networks; values read through the returned holders wait for it.  ONE decision for the whole batch: if any
+        scene has to keep its tail on the caller's stream (autograd), every tail and the detector stay there -- a detector on
+        the side stream would stack volumes the caller's stream is still writing.
+        A scene's `variance` (2.4 GB at the reference-true shape) is dropped as soon as its cost network has read it unless
+        `keep_variance`: B of them alive until the batch returns is what would bound B."""
         B = len(features)
         if B == 0 or len(img_metas) != B or (cost_logits is not None and len(cost_logits) != B):
             raise ValueError("forward_scenes: one img_meta (and one cost_logits, if given) per feature tensor")
         dev = features[0].device
         for i in range(B):                      # the camera algebra of every scene of the batch starts now, on the worker thread
             self.prefetch_scene(img_metas[i], dev)
+        grad = torch.is_grad_enabled()
+        one_stream = (not (self.overlap_detector and dev.type == "cuda")
+                      or (grad and (any(f.requires_grad for f in features)
+                                    or (cost_logits is not None and any(c.requires_grad for c in cost_logits))
+                                    or any(p.requires_grad for p in getattr(self.cost_regularization, "parameters", lambda: ())()))))
         outs, side, cur = [], None, None
         for i in range(B):
             logits_i = None if cost_logits is None else cost_logits[i]
             geo, packed, variance, logits_i = self._front(features[i], img_metas[i], logits_i, None)
-            if self._one_stream(features[i], variance, logits_i):
+            if not keep_variance and not (grad and variance.requires_grad):
+                variance = variance.new_empty(0)   # the holder's slot; the volume itself goes back to the allocator
+            if one_stream:
                 outs.append(self._lift_tail(features[i], geo, packed, variance, logits_i))
                 continue
             cur = torch.cuda.current_stream(dev)
@@ -575,16 +602,16 @@ class MVSDetHotPath:
 
         def detector():
             res = SceneOutputs(scenes=outs)
-            dict.__setitem__(res, "volume", torch.stack([o.raw("volume") for o in outs]))
-            dict.__setitem__(res, "valid", torch.stack([o.raw("valid") for o in outs]))
+            res._put("volume", torch.stack([o.raw("volume") for o in outs]))
+            res._put("valid", torch.stack([o.raw("valid") for o in outs]))
             if self.neck_3d is not None:
-                dict.__setitem__(res, "neck", self.neck_3d(res.raw("volume")))
+                res._put("neck", self.neck_3d(res.raw("volume")))
                 for i, o in enumerate(outs):
-                    dict.__setitem__(o, "neck", [lvl[i:i + 1] for lvl in res.raw("neck")])
+                    o._put("neck", [lvl[i:i + 1] for lvl in res.raw("neck")])
                 if self.bbox_head is not None:
-                    dict.__setitem__(res, "head", self.bbox_head(res.raw("neck")))
+                    res._put("head", self.bbox_head(res.raw("neck")))
                     for i, o in enumerate(outs):
-                        dict.__setitem__(o, "head", tuple([lvl[i:i + 1] for lvl in part] for part in res.raw("head")))
+                        o._put("head", tuple([lvl[i:i + 1] for lvl in part] for part in res.raw("head")))
             return res
 
         if side is None:
@@ -594,6 +621,6 @@ class MVSDetHotPath:
             done = torch.cuda.Event()
             done.record(side)
         for o in outs + [res]:
-            dict.__setitem__(o, "ready", done)
-            dict.__setitem__(o, "detector_ready", done)
+            o._put("ready", done)
+            o._put("detector_ready", done)
         return res

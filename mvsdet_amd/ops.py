@@ -356,8 +356,9 @@ def plane_sweep_variance_keep(feat: Tensor, nbr: Tensor, proj: Tensor, depth: Te
 @plane_sweep_variance_keep.register_fake
 def _(feat, nbr, proj, depth):
     N, C, H, W = feat.shape
+    sbytes = int(_lib.load().mvsdet_plane_sweep_scratch_bytes(N, nbr.shape[1], depth.shape[1], H, W))   # a host-side size function
     return (feat.new_empty((N, C, depth.shape[1], H, W)), feat.new_empty((N * ((C + 31) // 32) * H * W * 32,)),
-            feat.new_empty((4,)))
+            feat.new_empty((max(sbytes // 4, 4),)))
 
 
 @torch.library.custom_op(f"{_NS}::plane_sweep_variance_backward_packed", mutates_args=(), device_types="cuda")
@@ -978,6 +979,18 @@ def gemm_split_weight(wmat: Tensor) -> Tensor:
     return out
 
 
+def _check_wsplit(name: str, wsplit: Tensor, rows: int, cin: int, like: Tensor):
+    """A split weight is read as [rows/32][cin/16][2][64][8] bf16 with no further check in the kernel: one made for another
+    (rows, Cin) would be read out of bounds."""
+    need = int(_lib.load().mvsdet_gemm_split_weight_bytes(int(rows), int(cin)))
+    if need == 0:
+        raise ValueError(f"{name}: ({rows}, {cin}) is not a (128 m, 32 k) layer")
+    if not isinstance(wsplit, Tensor) or wsplit.dtype != torch.bfloat16 or not wsplit.is_contiguous() or wsplit.device != like.device:
+        raise TypeError(f"{name}: wsplit must be the contiguous bfloat16 tensor gemm_split_weight made, on the input's device")
+    if wsplit.numel() * 2 != need:
+        raise ValueError(f"{name}: wsplit holds {wsplit.numel() * 2} bytes, a ({rows}, {cin}) layer's split weight {need}")
+
+
 def gemm_layer_ok(rows: int, cin: int) -> bool:
     """Whether the neck's GEMM kernels take a layer with this many matrix rows (Cout, or 8 Cout for the transposed one) and Cin."""
     return rows % 128 == 0 and cin % 32 == 0
@@ -992,6 +1005,7 @@ def conv3d_k1_s2_bf16x3(x: Tensor, wsplit: Tensor, bias: Tensor, cout: int, relu
     N, Cin, D, H, W = x.shape
     if D % 2 or H % 2 or W % 2 or bias.numel() != cout:
         raise ValueError("conv3d_k1_s2_bf16x3: D, H, W must be even and bias have Cout elements")
+    _check_wsplit("conv3d_k1_s2_bf16x3", wsplit, cout, Cin, x)
     out = torch.empty((N, cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().mvsdet_conv3d_k1_s2_bf16x3(_lib.ptr(x), _lib.ptr(wsplit), _lib.ptr(bias.contiguous()), _lib.ptr(out), N, Cin,
@@ -1008,6 +1022,7 @@ def convT3d_k2_s2_bf16x3(x: Tensor, wsplit: Tensor, bias: Tensor, cout: int, rel
     N, Cin, D, H, W = x.shape
     if bias.numel() != cout:
         raise ValueError("convT3d_k2_s2_bf16x3: bias must have Cout elements")
+    _check_wsplit("convT3d_k2_s2_bf16x3", wsplit, 8 * cout, Cin, x)
     out = torch.empty((N, cout, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().mvsdet_convT3d_k2_s2_bf16x3(_lib.ptr(x), _lib.ptr(wsplit), _lib.ptr(bias.contiguous()), _lib.ptr(out), N, Cin,

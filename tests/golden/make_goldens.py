@@ -560,6 +560,9 @@ def g12b_relu_margin_grads(max_seeds=4000, margin=3e-5):
         out["n:" + k] = np.float64((g.double() ** 2).sum())
         out["s:" + k] = np.int64(stride)
         out["m:" + k] = np.float32(g.abs().max())
+    for k, b in net.named_buffers():       # the BatchNorm running statistics after the step, as in G12
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["b:" + k] = b.clone()
     save("g12b_cost_regularisation_grads_margin", weight_seed=12, input_seed=found, r_seed=121, in_shape=np.array(shape),
          param_keys=np.array(keys), margin=np.float64(margin), seeds_tried=np.int64(found - 12000 + 1),
          layer_names=np.array(sorted(layer_margins)), layer_margins=np.array([layer_margins[k] for k in sorted(layer_margins)]),

@@ -63,7 +63,9 @@ def test_training_mode_two_rank_ddp_dry_run(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["mode"] == "train" and d["n_gpus"] == 2 and d["value"] > 0 and d["checksum"] > 0
-    assert d["config"]["parallelism"].startswith("ddp x2")
+    assert d["config"]["parallelism"].startswith("ddp x2") and "find_unused_parameters=True" in d["config"]["parallelism"]
+    # the training config's optimiser (mvsdet_res50_2x_low_res_depth.py:179-184), its share of the step measured
+    assert d["config"]["optimizer"] == "AdamW+clip35" and 0 < d["optimizer_ms"] < d["ms_per_step"]
 
 
 @pytest.mark.timeout(600)
@@ -79,6 +81,7 @@ def test_training_mode_with_the_real_cost_network_two_rank_dry_run(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["mode"] == "train" and d["n_gpus"] == 2 and d["value"] > 0 and d["checksum"] > 0 and "real cost network" in d["metric"]
+    assert d["config"]["optimizer"] == "AdamW+clip35" and d["optimizer_ms"] > 0 and "1e-3" in d["gradient_tolerance"]
     b = d["device_binding"]
     assert [x["rank"] for x in b] == [0, 1] and [x["local_rank"] for x in b] == [0, 1] and all(x["device"] == 0 for x in b)   # one GPU on this box
 

@@ -492,3 +492,38 @@ def test_backward_sweep_from_the_forward_pass_packed_maps_and_geometry(gpu):
         assert torch.equal(packed, ops.pack_features(feat))
         scale = float(f1.grad.abs().max())
         assert float((f1.grad - f2.grad).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.gpu
+def test_backward_sweep_checks_the_geometry_it_is_handed(gpu):
+    """The forward pass's geometry is laid out for ONE tile shape with boxes up to ONE capacity (`mvsdet_set_option`
+    between forward and backward -- the A/B tools do it).  The backward kernel reads the header the geometry kernel left: another
+    tile shape -> the whole gradient is NaN, nothing of the table is read; a capacity option moved in between -> still the right
+    gradient (the backward's LDS slots are sized for the largest capacity a geometry can have been built with)."""
+    from mvsdet_amd import _lib, ops, synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    n_views, C, D, hw = 4, 40, 6, (24, 64)
+    hp = MVSDetHotPath([16, 16, 8], [0.4, 0.4, 0.4], [0.2, 5.0], D, topk=3)
+    geo = hp.prepare_scene(synthetic.make_img_meta(n_views, hw, seed=33), gpu)
+    feat = synthetic.make_features(n_views, C, hw, seed=33).to(gpu)
+    R = torch.randn((n_views, C, D) + hw, device=gpu, generator=torch.Generator(device=gpu).manual_seed(6))
+    good = ops.plane_sweep_variance_backward(feat, geo.neighbor_ids, geo.proj_rel, geo.depth_values, R)
+    scale = float(good.abs().max())
+    saved = {k: _lib.get_option(k) for k in ("sweep_tw", "sweep_boxcap")}
+    try:
+        _, packed, table = ops.plane_sweep_variance_keep(feat, geo.neighbor_ids, geo.proj_rel, geo.depth_values)   # W = 64: 32x4 tiles
+        _lib.set_option("sweep_boxcap", 64)          # smaller boxes asked for AFTER the geometry was built
+        g = ops.plane_sweep_variance_backward_packed(packed, geo.neighbor_ids, table, R)
+        assert float((g - good).abs().max()) <= 1e-6 * scale
+        _, packed, small = ops.plane_sweep_variance_keep(feat, geo.neighbor_ids, geo.proj_rel, geo.depth_values)   # built with 64-texel boxes
+        _lib.set_option("sweep_boxcap", saved["sweep_boxcap"])
+        g = ops.plane_sweep_variance_backward_packed(packed, geo.neighbor_ids, small, R)
+        assert float((g - good).abs().max()) <= 1e-6 * scale
+        _lib.set_option("sweep_tw", 16)              # another tile shape: the table's layout is not this launch's
+        bad = ops.plane_sweep_variance_backward_packed(packed, geo.neighbor_ids, table, R)
+        torch.cuda.synchronize()
+        assert torch.isnan(bad).all()
+        assert torch.isnan(ops.plane_sweep_variance_backward_packed(packed, geo.neighbor_ids, torch.zeros_like(table), R)).all()
+    finally:
+        for k, v in saved.items():
+            _lib.set_option(k, v)

@@ -153,6 +153,13 @@ def test_shortcut_gemm_kernel(gpu, N, Cin, Cout, grid):
         wq, bias = NK._gemm_weight(ds.conv, ds.bn, split=True)
         got = ops.conv3d_k1_s2_bf16x3(x, wq, bias, Cout)
         ref = ds.double()(x.double())
+        # a split weight made for another layer, or not a split weight at all, is refused instead of read out of bounds
+        with pytest.raises(ValueError):
+            ops.conv3d_k1_s2_bf16x3(x, wq[: wq.numel() // 2].contiguous(), bias, Cout)
+        with pytest.raises(TypeError):
+            ops.conv3d_k1_s2_bf16x3(x, wq.float(), bias, Cout)
+        with pytest.raises(ValueError):
+            ops.convT3d_k2_s2_bf16x3(x, wq, bias.repeat(8)[: Cout], Cout, True)     # (8 Cout, Cin) rows asked of a (Cout, Cin) split
     assert got.shape == ref.shape
     err = float((got.double() - ref).abs().max())
     assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Time of the backward sweep's whole operator at a bench workload with the round-4 kernel (bwd_pipe = 0): the target of
-tools/ab_libs.sh runs over what-if builds of the kernel (a part of its work removed: the RESULT is then wrong, the time tells what
-that part costs).  python tools/bwd_time.py [workload] [bwd_pipe]"""
+"""Time of the backward sweep's whole operator at a bench workload: the target of tools/ab_libs.sh runs over what-if builds of
+the kernel (a part of its work removed: the RESULT is then wrong, the time tells what that part costs).
+python tools/bwd_time.py [workload] [option=value ...]"""
 import os
 import sys
 
@@ -13,7 +13,8 @@ from mvsdet_amd import _lib, ops  # noqa: E402
 from mvsdet_amd.hotpath import MVSDetHotPath  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "scannet_ref_40v_12d_60x80"
-_lib.set_option("bwd_pipe", int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+for kv in sys.argv[2:]:
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 w = bench.WORKLOADS[name]
 dev = torch.device("cuda:0")
 hp = MVSDetHotPath(bench.N_VOXELS, bench.VOXEL_SIZE, list(w["near_far"]), w["D"])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Backward sweep at a bench workload under option settings given as name=value[,value] (swept as a product), e.g.
-python tools/bwd_tw_ab.py scannet_ref_40v_12d_60x80 sweep_tw=0,32 bwd_pipe=0,1"""
+python tools/bwd_tw_ab.py scannet_ref_40v_12d_60x80 sweep_tw=0,32 bwd_groups=1,2"""
 import itertools
 import os
 import sys
