@@ -24,7 +24,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from .neck import DerivedTensorsMixin, _bn_affine
+from .neck import DerivedTensorsMixin, _bn_affine, fp32_under_autocast
 from .scratch import EventPool
 
 
@@ -333,6 +333,7 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         self._scl.release(leases, dev)   # every reader of the buffers is enqueued: one event behind them on this stream
         return logits
 
+    @fp32_under_autocast
     def forward(self, x):
         if any(s % 4 for s in x.shape[2:]):
             raise ValueError(f"CostRegNet3DGS: D, H, W must be divisible by 4, got {tuple(x.shape[2:])}")

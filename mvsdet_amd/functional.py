@@ -35,6 +35,17 @@ LAZY_ANY_DEVICE = False   # tests only: defer on CPU tensors too (the fused laun
 _SCENE_PROJ: dict = {}
 
 
+def amp_fp32(*tensors):
+    """`--amp` (tools/train.py:24-28; mmengine's AmpOptimWrapper = torch.autocast around the forward pass): while autocast is on,
+    low-precision floating tensors become float32 -- the hot path computes in float32, as torch's own autocast rule for
+    `grid_sampler` / `softmax` has the reference do at these very calls.  Outside autocast nothing is touched: a float16 tensor
+    handed to the float32 operators then raises their TypeError (the fp16-storage sweep is a separate, explicit entry)."""
+    if not torch.is_autocast_enabled("cuda"):
+        return tensors if len(tensors) != 1 else tensors[0]
+    out = tuple(t.float() if isinstance(t, Tensor) and t.is_floating_point() and t.dtype != torch.float32 else t for t in tensors)
+    return out if len(out) != 1 else out[0]
+
+
 def relative_projection(src_proj: Tensor, ref_proj: Tensor) -> Tensor:
     """module.py:116  proj = src_proj @ inverse(ref_proj), fp32, evaluated with ATen-CPU; result on CPU."""
     hit = _SCENE_PROJ.get((id(src_proj), id(ref_proj)))
@@ -130,6 +141,7 @@ def homo_warping(src_fea: Tensor, src_proj: Tensor, ref_proj: Tensor, depth_valu
     -> warped (B,C,D,H,W)."""
     if depth_values.dim() != 2:
         raise NotImplementedError("per-pixel depth_values (B,D,H,W) (module.py:130-133) is unused by MVSDet")
+    src_fea, depth_values = amp_fp32(src_fea, depth_values)
     proj = relative_projection(src_proj, ref_proj).to(src_fea.device)
     depth_values = depth_values.to(src_fea.device)
     if LAZY_WARP and (src_fea.is_cuda or LAZY_ANY_DEVICE) and src_fea.dtype == torch.float32:
@@ -146,6 +158,7 @@ def backproject_Weigh(features: Tensor, points: Tensor, projection: Tensor, dept
     depth, prob (N, h*w, 1, J) -> (volume (N,C,X,Y,Z), valid (N,1,X,Y,Z) bool, gap_all, rmse)."""
     if gt_depth is not None:
         raise NotImplementedError("the gt_depth debug branch (mvsdet.py:1435-1481) is outside the hot path")
+    features, points, projection, depth, prob = amp_fp32(features, points, projection, depth, prob)
     n, c, h, w = features.shape
     nx, ny, nz = points.shape[-3:]
     j = depth.shape[-1] * depth.shape[-2]

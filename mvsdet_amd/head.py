@@ -23,7 +23,7 @@ from typing import List, Sequence, Tuple
 import torch
 from torch import Tensor, nn
 
-from .neck import DerivedTensorsMixin, _await_made, _mark_made
+from .neck import DerivedTensorsMixin, _await_made, _mark_made, fp32_under_autocast
 
 
 class Scale(nn.Module):
@@ -98,6 +98,7 @@ class NerfDetHeadConvs(DerivedTensorsMixin, nn.Module):
             return self.conv_center(x), torch.cat((torch.exp(scale(reg_final[:, :6])), reg_final[:, 6:]), dim=1), self.conv_cls(x)
         return self.conv_center(x), torch.exp(scale(self.conv_reg(x))), self.conv_cls(x)
 
+    @fp32_under_autocast
     def forward(self, x: Sequence[Tensor]) -> Tuple[List[Tensor], List[Tensor], List[Tensor]]:
         """mmdet's multi_apply(self._forward_single, x, self.scales): a tuple of three per-level lists."""
         res = [self._forward_single(xi, s) for xi, s in zip(x, self.scales)]

@@ -29,6 +29,7 @@ from . import functional as F_
 
 def _sample_depth_prob(self, prob_volume, off_pred, topk=3):
     from . import ops
+    prob_volume, off_pred = F_.amp_fp32(prob_volume, off_pred)
     est_depth, est_dens, _, _ = ops.sample_depth_prob(prob_volume, off_pred, float(self.near_far_range[0]),
                                                       float(self.depth_interval), int(topk))
     return est_depth, est_dens
@@ -36,6 +37,7 @@ def _sample_depth_prob(self, prob_volume, off_pred, topk=3):
 
 def _compute_avg_depth(self, prob_volume, off_pred):
     from . import ops
+    prob_volume, off_pred = F_.amp_fp32(prob_volume, off_pred)
     k = min(3, prob_volume.shape[1])
     return ops.sample_depth_prob(prob_volume, off_pred, float(self.near_far_range[0]), float(self.depth_interval), k)[3]
 

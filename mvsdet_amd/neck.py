@@ -5,14 +5,17 @@ mmdet3d/models/necks/imvoxel_neck.py:70-231 -- a three-level 3-D FPN of residual
 The module is plain PyTorch with the reference's parameter names (mmcv's ConvModule registers its layers as `conv`
 and `bn`, so `down_layer_1.0.conv0.conv.weight`, `down_layer_1.0.downsample.bn.running_mean`, `up_block_2.0.weight`,
 `out_block_0.1.bias` ... load from a reference checkpoint's `neck_3d.*` entries with `load_state_dict`).  In eval mode
-without autograd, on a ROCm device, every 3x3x3 convolution runs on the fp32-MFMA kernels of csrc/costreg_conv0.hip
-with eval-mode BatchNorm, ReLU and the residual addition folded into the epilogue (exact fp32 FMA sums, like ATen's in
-another order); the 1x1x1 stride-2 shortcut and the kernel-2 stride-2 transposed convolutions are one dense GEMM each
-(rocBLAS through torch.matmul: a kernel-2 stride-2 transposed convolution is 8 independent single-tap classes).
+without autograd, on a ROCm device, every 3x3x3 convolution runs on the bf16x3 MFMA kernels of csrc/costreg_bf16.hip
+(three bf16 products per fp32-equivalent product, fp32 accumulation: DESIGN 4.3; `matrix_precision = "fp32"` keeps the
+fp32-MFMA kernels of csrc/costreg_conv0.hip) with eval-mode BatchNorm, ReLU and the residual addition folded into the
+epilogue; the small levels split their input channels until ~768 blocks run.  The 1x1x1 stride-2 shortcut and the
+kernel-2 stride-2 transposed convolutions are one GEMM each on csrc/neck_gemm.hip (a kernel-2 stride-2 transposed
+convolution is 8 independent single-tap classes; bias, ReLU and the 2x2x2 interleave in the epilogue; no rocBLAS call).
 Training, CPU tensors and other shapes take the framework's layers.
 """
 from __future__ import annotations
 
+import functools
 import os
 import weakref
 
@@ -21,6 +24,26 @@ from typing import List, Sequence
 import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
+
+
+def fp32_under_autocast(forward):
+    """`--amp` (tools/train.py:24-28): under torch.autocast a module of this package still computes in float32 (bf16x3 on the
+    matrix cores is fp32-equivalent; the framework's layers it falls back to would otherwise run float16 convolutions beside
+    it): low-precision inputs are cast up and autocast is off for the call.  Outside autocast the call is untouched."""
+    def _up(v):
+        if isinstance(v, Tensor):
+            return v.float() if v.is_floating_point() and v.dtype != torch.float32 else v
+        if isinstance(v, (list, tuple)):
+            return type(v)(_up(t) for t in v)
+        return v
+
+    @functools.wraps(forward)
+    def wrapped(self, x, *args, **kwargs):
+        if torch.is_autocast_enabled("cuda"):
+            with torch.autocast("cuda", enabled=False):
+                return forward(self, _up(x), *args, **kwargs)
+        return forward(self, x, *args, **kwargs)
+    return wrapped
 
 
 class _ConvModule(nn.Module):
@@ -301,6 +324,7 @@ class IndoorImVoxelNeck(DerivedTensorsMixin, nn.Module):
                 setattr(self, f"up_block_{i}", _UpBlock(n_channels, n_channels // 2))
             setattr(self, f"out_block_{i}", _OutBlock(n_channels, out_channels))
 
+    @fp32_under_autocast
     def forward(self, x: Tensor) -> List[Tensor]:
         down_outs = []
         for i in range(self.n_scales):

@@ -1616,3 +1616,17 @@ def _bn_bwd(ctx, g_out, g_mean, g_invstd):
 
 
 bn3d_relu_train.register_autograd(_bn_bwd, setup_context=_bn_setup)
+
+
+# ------------------------------------------------------------------------------------------- --amp (tools/train.py:24-28)
+# Under torch.autocast the 2-D backbone hands out float16 / bfloat16 maps.  The hot path computes in float32 -- the rule torch's own
+# autocast applies to `grid_sampler`, `softmax` and the reductions the reference runs here -- so these operators CAST low-precision
+# floating inputs to float32 while autocast is on (and return float32), instead of raising the TypeError a non-float32 tensor gets
+# outside autocast.  The fp16-STORAGE sweep (pack_features on float16 maps, plane_sweep_variance_shard(half_out=True)) is an explicit
+# opt-in and keeps its dtypes: it has no autocast rule.
+AUTOCAST_FP32_OPS = (homo_warp, plane_sweep_variance, plane_sweep_variance_keep, depth_prob_topk, sample_depth_prob,
+                     backproject_weigh, backproject_weigh_mean)
+for _op in AUTOCAST_FP32_OPS:
+    _op.register_autocast("cuda", torch.float32)
+del _op
+
