@@ -155,14 +155,32 @@ class _ConvT3S2(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
+# Test hook (tests/test_gpu_parity.py, tests/test_f3_goldens.py G12c): the ReLU DECISIONS of a training pass recorded, or imposed.
+# None (always, outside those tests) | ("record", {}) -- filled with {BatchNorm module: mask of relu's positive side} -- |
+# ("apply", {BatchNorm module: bool mask}): the layer computes bn(x) * mask (+ residual) instead of relu(bn(x)) (+ residual).
+# With the decisions of ONE pass imposed on two routes (or the reference's on ours) no activation can fall on the other side
+# of zero, and gradients can be compared element-wise instead of by direction.
+RELU_MASKS = None
+
+
 def _bn_relu_train(bn: nn.BatchNorm3d, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
                    parts: Optional[torch.Tensor] = None, pivot: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu(bn(x)) with batch statistics (module.py:26-37; mvsnet.py:92-100) on the streaming kernels of
     csrc/costreg_bn.hip -- two passes over x forward, ReLU in the second, the mask recomputed going backward -- and the
     running statistics updated the way torch.nn.BatchNorm3d does (momentum, unbiased variance, num_batches_tracked)."""
     from . import ops
+    hook = RELU_MASKS
     # residual: added after the ReLU; parts: the statistics' partial sums from the convolution's epilogue (no pass over x for them)
-    out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True, residual, parts, pivot)
+    if hook is None:
+        out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True, residual, parts, pivot)
+    elif hook[0] == "record":
+        out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, True, None, parts, pivot)
+        hook[1][bn] = out.detach() > 0
+        out = out if residual is None else out + residual
+    else:
+        out, mean, invstd = ops.bn3d_relu_train(x, bn.weight, bn.bias, bn.eps, False, None, parts, pivot)
+        out = out * hook[1][bn].to(out.dtype)
+        out = out if residual is None else out + residual
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             m = x.numel() // x.shape[1]

@@ -253,6 +253,8 @@ class MVSDetHotPath:
         # True: what follows the cost network (depth distribution, lifting, neck_3d / bbox_head) runs on a side stream; forward_scene
         # returns out["ready"] (= out["detector_ready"]), a CUDA event the consumer's stream waits for
         self.overlap_detector = False
+        # view streams of the cost network while the detector tail of the previous scene runs beside it (`overlap_view_streams`)
+        self.overlap_network_streams = 1
         self._detector_streams: dict = {}
 
     # ---- reference-named methods (mvsdet.py:249, 266, 298) -------------------------------------------
@@ -470,11 +472,12 @@ class MVSDetHotPath:
         if self.cost_regularization is not None:
             net = self.cost_regularization
             halves = getattr(net, "view_streams", 1)
-            if self.overlap_detector and halves > 1 and not torch.is_grad_enabled():
+            keep = self.overlap_view_streams(variance.shape[0]) if self.overlap_detector and not torch.is_grad_enabled() else halves
+            if keep != halves:
                 # the previous scene's neck and head are running beside this network on their own stream: a second stream
                 # INSIDE the network (CostRegNet3DGS.view_streams: 89.5 -> 90.4 scenes/s alone) then takes from them what it
-                # gives (pipelined 97 against 99-103 scenes/s on one box)
-                net.view_streams = 1
+                # gives (pipelined 97 against 99-103 scenes/s on one box at 40 views)
+                net.view_streams = keep
                 try:
                     cost_logits = net(variance)
                 finally:
@@ -496,6 +499,10 @@ class MVSDetHotPath:
                             # mvsdet.py:582 `opacity = torch.max(prob_volume, dim=1)[0]`: the first of the sorted top-k values IS
                             # that maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume
                             opacity=est_dens[:, 0])
+
+    def overlap_view_streams(self, n_views: int) -> int:
+        """CostRegNet3DGS.view_streams to use for a scene of `n_views` views under `overlap_detector`."""
+        return int(self.overlap_network_streams)
 
     def _side_stream(self, dev):
         side = self._detector_streams.get(str(dev))

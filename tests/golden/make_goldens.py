@@ -570,6 +570,56 @@ def g12b_relu_margin_grads(max_seeds=4000, margin=3e-5):
     print("g12b seed", found, "margins", layer_margins)
 
 
+# --------------------------------------------------------------------------- G12c
+def g12c_relu_masks_grads():
+    """G12 at a shape where EVERY training form of the package is active -- (2,256,12,64,32): the stride-1 and the transposed
+    layers' BatchNorm statistics from the producing kernel's epilogue (the transposed form exists on 3 x 16 x 8 coarse tiles:
+    conv9 reads 3 x 16 x 8, conv11 6 x 32 x 16) -- with the reference's seven ReLU DECISIONS stored: the mask `bn_out > 0` of every
+    BatchNorm3d of mvsnet.py:76-100, taken by a forward hook before the in-place ReLU that follows it (bit-packed).  A route
+    whose sums differ from fp32's in the last bits cannot be held element-wise on a free input (an activation within that noise
+    of zero flips, and one flip among N moves a layer's gradient by sqrt(2/N) in norm: G12b needed a seed search at a smaller
+    shape to avoid it); with the reference's own decisions imposed on it (costreg.RELU_MASKS) it computes the same piecewise
+    linear function and its gradients can be.  Stored as in G12, plus the masks."""
+    from lcg import lcg_fill_state, lcg_uniform
+    mvsnet = sys.modules["refpkg.mvs_models.mvsnet"]
+    torch.manual_seed(0)
+    net = mvsnet.CostRegNet_3DGS().train()
+    shape = (2, 256, 12, 64, 32)
+    with torch.no_grad():
+        lcg_fill_state(net, 12)
+    masks = {}
+    for name, m in net.named_modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.register_forward_hook(lambda mod, inp, out, name=name: masks.__setitem__(name, (out.detach() > 0).clone()))
+    x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), 125)).reshape(shape).abs().requires_grad_(True)
+    y = net(x)
+    R = torch.from_numpy(lcg_uniform(y.numel(), 126)).reshape(y.shape)
+    (y * R).sum().backward()
+    out = dict(logits=y, grad_input=x.grad.reshape(-1)[::97].clone())
+    keys = []
+    for k, p in sorted(net.named_parameters()):
+        g = p.grad.reshape(-1)
+        stride = max(1, g.numel() // 8192)
+        while stride > 1 and (stride % 2 == 0 or stride % 3 == 0):
+            stride += 1
+        keys.append(k)
+        out["g:" + k] = g[::stride].clone()
+        out["n:" + k] = np.float64((g.double() ** 2).sum())
+        out["s:" + k] = np.int64(stride)
+        out["m:" + k] = np.float32(g.abs().max())
+    for k, b in net.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["b:" + k] = b.clone()
+    assert sorted(masks) == ["conv0.bn", "conv1.bn", "conv11.1", "conv2.bn", "conv3.bn", "conv4.bn", "conv9.1"]
+    for name, m in masks.items():
+        out["mask:" + name] = np.packbits(m.numpy().reshape(-1))
+        out["maskshape:" + name] = np.array(m.shape)
+    save("g12c_cost_regularisation_grads_masks", weight_seed=12, input_seed=125, r_seed=126, in_shape=np.array(shape),
+         param_keys=np.array(keys), mask_names=np.array(sorted(masks)), **out)
+    print("g12c logits", tuple(y.shape), float(y.abs().max()), "positive share per layer",
+          {k: round(float(m.float().mean()), 3) for k, m in masks.items()})
+
+
 # --------------------------------------------------------------------------- G13
 def g13_composed_chain():
     """The COMPOSED chain as the reference runs it: an instance of the reference's own `MVSDet` class, its own `extract_feat`
@@ -675,9 +725,9 @@ def g13_composed_chain():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g12b", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g12b", "g12c", "g13"]
     fns = dict(g1=g1_homo_warping, g2=g2_variance, g3=g3_knn, g4=g4_depth_prob, g5=g5_backproject,
                g6=g6_backward, g7=g7_end_to_end, g8=g8_cost_regularisation, g9=g9_depth_scale, g10=g10_neck, g11=g11_heads,
-               g12=g12_cost_regularisation_grads, g12b=g12b_relu_margin_grads, g13=g13_composed_chain)
+               g12=g12_cost_regularisation_grads, g12b=g12b_relu_margin_grads, g12c=g12c_relu_masks_grads, g13=g13_composed_chain)
     for w in which:
         fns[w]()

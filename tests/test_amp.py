@@ -92,12 +92,14 @@ def test_hot_path_under_autocast_computes_in_float32(gpu):
             assert out[k].dtype == torch.float32 and torch.equal(out[k], want_out[k]), k
         assert torch.equal(out["valid"], want_out["valid"])
         assert logits16.dtype == torch.float32 and torch.equal(logits16, net(want.half().float()))
-    # training under autocast: the gradient arrives at the float16 leaf through the cast
+    # training under autocast: the gradient arrives at the float16 leaf through the cast.  The loss is scaled as AMP's GradScaler
+    # scales it (gradients of ~1e-6 sit in float16's subnormal range, 6e-8 apart)
+    scale = 65536.0
     leaf = half.clone().requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.float16):
         v = ops.plane_sweep_variance(leaf, geo.neighbor_ids, geo.proj_rel, geo.depth_values)
-    v.square().mean().backward()
+    (v.square().mean() * scale).backward()
     ref = full.clone().requires_grad_(True)
-    ops.plane_sweep_variance(ref, geo.neighbor_ids, geo.proj_rel, geo.depth_values).square().mean().backward()
+    (ops.plane_sweep_variance(ref, geo.neighbor_ids, geo.proj_rel, geo.depth_values).square().mean() * scale).backward()
     assert leaf.grad.dtype == torch.float16 and torch.isfinite(leaf.grad).all()
-    np.testing.assert_allclose(leaf.grad.float().cpu().numpy(), ref.grad.cpu().numpy(), rtol=2e-3, atol=1e-6 * float(ref.grad.abs().max()))
+    np.testing.assert_allclose(leaf.grad.float().cpu().numpy(), ref.grad.cpu().numpy(), rtol=2e-3, atol=1e-4 * float(ref.grad.abs().max()))

@@ -1394,39 +1394,54 @@ def test_cost_network_training_mode_batchnorm(gpu):
 def test_cost_network_batchnorm_statistics_from_the_epilogues_or_from_their_own_pass(gpu):
     """The two training routes of the BatchNorm statistics -- partial sums left by the producing convolution's epilogue (default) and
     the separate pass over the tensor (`costreg.FUSED_BN_STATS = False`, MVSDET_FUSED_BN_STATS=0) -- on one network at a shape whose
-    stride-1 and transposed layers all have the fused form (12 x 60 x 80, as the reference-true shape): logits, running statistics and
-    every parameter gradient agree to summation order; a second step starts from running means that are no longer zero (the pivots)."""
+    stride-1 and transposed layers all have the fused form (12 x 60 x 80, as the reference-true shape), ELEMENT-WISE: statistics
+    that differ in the last bits move activations by ~1e-7, and one activation of a layer's N on the other side of zero would
+    move that layer's gradient by sqrt(2 / N) in norm (round 5 could only hold the gradients to their direction for that reason).
+    So the ReLU decisions of ONE pass (the separate-pass route, on a copy of the network) are imposed on both routes
+    (costreg.RELU_MASKS): both then compute the same piecewise-linear function, and logits, running statistics and every parameter
+    gradient must agree to 1e-5 of each tensor's scale -- a wrong term in either statistics form shows.  A second step starts from
+    running means that are no longer zero (the pivots).  Against the REFERENCE's gradients the same routes are held by G12c
+    (tests/test_f3_goldens.py)."""
+    import copy
     from mvsdet_amd import costreg
     from mvsdet_amd.costreg import CostRegNet3DGS
     torch.manual_seed(9)
     nets = [CostRegNet3DGS(64, base=64).to(gpu).train() for _ in range(2)]
     nets[1].load_state_dict(nets[0].state_dict())
     x = torch.rand(2, 64, 12, 60, 80, device=gpu)
-    was = costreg.FUSED_BN_STATS
+    was = costreg.FUSED_BN_STATS, costreg.RELU_MASKS
     try:
         for step in range(2):
+            xin = x + 0.1 * step
+            # the decisions of this step: one pass of the separate-pass route on a copy (its running statistics move, not the nets')
+            probe = copy.deepcopy(nets[1])
+            costreg.FUSED_BN_STATS, costreg.RELU_MASKS = False, ("record", {})
+            with torch.enable_grad():
+                probe(xin)
+            by_name = {name: costreg.RELU_MASKS[1][m] for name, m in probe.named_modules() if m in costreg.RELU_MASKS[1]}
+            assert len(by_name) == 7 and all(0.2 < float(v.float().mean()) < 0.8 for v in by_name.values())
             outs = []
             for fused, net in zip((True, False), nets):
-                costreg.FUSED_BN_STATS = fused
+                mods = dict(net.named_modules())
+                costreg.FUSED_BN_STATS, costreg.RELU_MASKS = fused, ("apply", {mods[k]: v for k, v in by_name.items()})
                 net.zero_grad(set_to_none=True)
-                out = net(x + 0.1 * step)
+                out = net(xin)
                 out.square().mean().backward()
                 outs.append(out.detach())
-            torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=2e-5 * float(outs[1].abs().max()))
+            torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-5 * float(outs[1].abs().max()))
             sd0, sd1 = nets[0].state_dict(), nets[1].state_dict()
             for k in sd0:
                 if "running_" in k:
                     torch.testing.assert_close(sd0[k], sd1[k], rtol=1e-5, atol=1e-7, msg=k)
+            worst = 0.0
             for (name, p0), (_, p1) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-                # statistics that differ in the last bits move activations by ~1e-7; ONE activation of a layer's N on the other side of
-                # zero moves that layer's gradient by sqrt(2 / N) in norm: 5e-4 at the full-resolution layers, 2e-3 at the
-                # quarter-resolution ones (INTEGRATION.md, "Precision of the two routes"): the bound of the G12 test
-                # (and 2 views make the quarter-resolution layers' N small: a few per cent there) -- so the gradients are held to
-                # their direction here, the element-wise pins are G12 / G12b
-                cos = float((p0.grad * p1.grad).sum() / (p0.grad.norm() * p1.grad.norm() + 1e-30))
-                assert cos >= 0.999 and float((p0.grad - p1.grad).norm()) <= 5e-2 * float(p1.grad.norm()) + 1e-12, (step, name, cos)
+                scale = float(p1.grad.abs().max())
+                err = float((p0.grad - p1.grad).abs().max())
+                worst = max(worst, err / max(scale, 1e-30))
+                assert err <= 1e-5 * scale, (step, name, err, scale)
+            print(f"BatchNorm statistics routes, step {step}: max |d grad| / scale = {worst:.2e}")
     finally:
-        costreg.FUSED_BN_STATS = was
+        costreg.FUSED_BN_STATS, costreg.RELU_MASKS = was
 
 
 def test_depth_prob_topk_reads_the_network_output_in_place(gpu):

@@ -1,0 +1,163 @@
+"""Numerical GATE for VERDICT r5 next #2: conv0's three bf16 MFMAs per product replaced by ONE fp16 product plus two
+low-precision correction terms on the block-scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4: e4m3 at 2x, e2m3 at 4x
+the bf16 rate, MI355X_MICROARCH.md "MFMA" table) -- 2.0 or 1.5 bf16-equivalent MFMAs per product instead of 3.
+
+    x = xh + xr,  w = wh + wr        xh = fp16(x * 2^sx) / 2^sx  (11 significant bits; per-tensor power-of-two scale), xr = x - xh
+    x * w  ~=  xh * wh               fp16 MFMA: the product of two 11-bit numbers is exact in fp32, fp32 accumulation
+            +  Q(xh) * Q(wr)         correction 1: 2^-11 of the result, needs ~5 bits
+            +  Q(xr) * Q(wh)         correction 2
+    Q = OCP MX block format: 32 consecutive INPUT CHANNELS (the K direction of the implicit GEMM at one tap: a voxel's 32 channels /
+        a weight's 32 input channels of one (cout, tap)) share one e8m0 power-of-two scale 2^(floor(log2 max|v|) - emax); the elements
+        are e4m3 (emax 8, max 448), e2m3 (emax 2, max 7.5) or, for comparison, bf16 without block scale.
+
+Everything is emulated on the CPU in float32 convolutions of the pieces (every product of two pieces is exact in fp32, as on the
+matrix cores; only the summation order differs), the way tools/study/split_bf16_emulation.py models bf16x3.  Evaluated on the whole
+eval network (mvs_models/mvsnet.py:73-113) against float64, on the G8 input and on the G12b input; conv0 alone in the new scheme
+(the other six layers on bf16x3, as shipped) and all seven layers.  PASS = logits within 3e-5 of float64 (margin to the 1e-4 bar).
+Run: python tools/study/mixed_format_gate.py   (CPU, about two minutes)"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from lcg import lcg_fill_state, lcg_uniform  # noqa: E402
+from mvsdet_amd.costreg import CostRegNet3DGS  # noqa: E402
+
+GATE = 3e-5
+
+
+def bf16_pieces(t, n):
+    out, r = [], t
+    for _ in range(n):
+        p = r.bfloat16().float()
+        out.append(p)
+        r = r - p
+    return out
+
+
+def fp16_cut(t):
+    """(hi, remainder): hi = fp16 of the tensor scaled by a per-tensor power of two that puts its largest magnitude at ~2^14."""
+    m = float(t.abs().max())
+    s = 2.0 ** (14 - int(np.floor(np.log2(m)))) if m > 0 else 1.0
+    hi = (t * s).half().float() / s
+    return hi, t - hi
+
+
+def q_e2m3(v):
+    """Round-to-nearest-even onto the e2m3 grid (OCP MX FP6: sign, 2 exponent bits bias 1, 3 mantissa bits; max 7.5), saturating."""
+    a = v.abs().clamp(max=7.5)
+    step = torch.where(a < 2.0, torch.full_like(a, 0.125), torch.where(a < 4.0, torch.full_like(a, 0.25), torch.full_like(a, 0.5)))
+    return torch.sign(v) * torch.round(a / step) * step       # torch.round is half-to-even
+
+
+def q_e4m3(v):
+    return v.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def mx_quant(t, fmt, dim=1, block=32):
+    """OCP MX: blocks of `block` consecutive elements along `dim` share a power-of-two scale; elements in `fmt`."""
+    if fmt == "bf16":
+        return t.bfloat16().float()
+    if fmt == "fp32":
+        return t
+    emax, q = {"e4m3": (8, q_e4m3), "e2m3": (2, q_e2m3)}[fmt]
+    t = t.movedim(dim, -1)
+    shape = t.shape
+    c = shape[-1]
+    pad = (-c) % block
+    if pad:
+        t = F.pad(t, (0, pad))
+    tb = t.reshape(*shape[:-1], -1, block)
+    amax = tb.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38))) - emax
+    scale = torch.exp2(e.clamp(-127, 127))
+    out = q(tb / scale) * scale
+    out = torch.where(amax > 0, out, torch.zeros_like(out))
+    out = out.reshape(*shape[:-1], -1)[..., :c]
+    return out.movedim(-1, dim)
+
+
+def conv_pieces(fn, x, w, scheme, wdim, **kw):
+    """One layer in the given scheme.  wdim: the weight's input-channel dimension (1 for Conv3d, 0 for ConvTranspose3d)."""
+    if scheme == "fp32":
+        return fn(x, w, **kw)
+    if scheme == "bf16x3":
+        (xh, xm), (wh, wm) = bf16_pieces(x, 2), bf16_pieces(w, 2)
+        return fn(xm, wh, **kw) + fn(xh, wm, **kw) + fn(xh, wh, **kw)
+    kind, fmt = scheme.split("+")           # "fp16+e4m3", "fp16+e2m3", "fp16+bf16", "fp16+none", "fp16+e4m3/e2m3" (corr1 / corr2 formats)
+    assert kind == "fp16"
+    xh, xr = fp16_cut(x)
+    wh, wr = fp16_cut(w)
+    y = fn(xh, wh, **kw)
+    if fmt == "none":
+        return y
+    f1, f2 = fmt.split("/") if "/" in fmt else (fmt, fmt)
+    c1 = fn(mx_quant(xh, f1, 1), mx_quant(wr, f1, wdim), **kw)
+    c2 = fn(mx_quant(xr, f2, 1), mx_quant(wh, f2, wdim), **kw)
+    return (c1 + c2) + y
+
+
+def forward(net, x, scheme_of):
+    """scheme_of: layer name -> scheme."""
+    def cbr(name, layer, t):
+        conv, bn = layer.conv, layer.bn
+        return torch.relu(bn(conv_pieces(F.conv3d, t, conv.weight, scheme_of[name], 1, stride=conv.stride, padding=1)))
+
+    def up(name, seq, t, skip):
+        dc, bn = seq[0], seq[1]
+        return skip + torch.relu(bn(conv_pieces(F.conv_transpose3d, t, dc.weight, scheme_of[name], 0, stride=2, padding=1, output_padding=1)))
+    full = cbr("conv0", net.conv0, x)
+    half = cbr("conv2", net.conv2, cbr("conv1", net.conv1, full))
+    quarter = cbr("conv4", net.conv4, cbr("conv3", net.conv3, half))
+    half = up("conv9", net.conv9, quarter, half)
+    full = up("conv11", net.conv11, half, full)
+    return net.prob(full)
+
+
+LAYERS = ("conv0", "conv1", "conv2", "conv3", "conv4", "conv9", "conv11")
+
+
+def main():
+    torch.set_num_threads(8)
+    g8 = np.load(os.path.join(ROOT, "tests", "golden", "g8_cost_regularisation.npz"))
+    g12b = np.load(os.path.join(ROOT, "tests", "golden", "g12b_cost_regularisation_grads_margin.npz"))
+    cases = []
+    for tag, g in (("G8", g8), ("G12b", g12b)):
+        shape = tuple(int(v) for v in g["in_shape"])
+        x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), int(g["input_seed"]))).reshape(shape).abs()
+        cases.append((f"{tag} input {shape}, weights seed {int(g['weight_seed'])}", int(g["weight_seed"]), x))
+    # a variance-like input (chi-square-ish, what the sweep produces from N(0,1) features), G8's weights
+    shape = tuple(int(v) for v in g8["in_shape"])
+    f = torch.randn((3,) + shape, generator=torch.Generator().manual_seed(3))
+    cases.append((f"variance-like input {shape}, weights seed 8", 8, (f * f).mean(0) - f.mean(0) ** 2))
+    worst = {}
+    with torch.no_grad():
+        for tag, wseed, x in cases:
+            net = CostRegNet3DGS(256, 64).eval()
+            lcg_fill_state(net, wseed)
+            net64 = CostRegNet3DGS(256, 64).eval().double()
+            net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+            y64 = net64(x.double())
+            print(f"== {tag}: logits |max| {float(y64.abs().max()):.3f}", flush=True)
+            for scheme in ("fp32", "bf16x3", "fp16+none", "fp16+bf16", "fp16+e4m3", "fp16+e4m3/e2m3", "fp16+e2m3"):
+                for lay_tag, lays in (("conv0 only, rest bf16x3", ("conv0",)), ("all seven layers", LAYERS)):
+                    if scheme in ("fp32", "bf16x3") and lays != LAYERS:
+                        continue
+                    so = {k: (scheme if k in lays else "bf16x3") for k in LAYERS}
+                    y = forward(net, x, so)
+                    err = float((y - y64).abs().max())
+                    worst[(scheme, lay_tag)] = max(worst.get((scheme, lay_tag), 0.0), err)
+                    print(f"   {scheme:15s} {lay_tag:24s}: logits max |d| vs float64 {err:.2e}", flush=True)
+    print("== gate (worst over the inputs; PASS = <= %.0e)" % GATE)
+    cost = {"fp32": "-", "bf16x3": "3.0", "fp16+none": "1.0", "fp16+bf16": "3.0", "fp16+e4m3": "2.0", "fp16+e4m3/e2m3": "1.75", "fp16+e2m3": "1.5"}
+    for (scheme, lay_tag), err in worst.items():
+        print(f"   {scheme:15s} {lay_tag:24s}: {err:.2e}  {'PASS' if err <= GATE else 'FAIL'}   bf16-equivalent MFMAs per product: {cost[scheme]}")
+
+
+if __name__ == "__main__":
+    main()
