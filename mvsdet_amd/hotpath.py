@@ -252,9 +252,15 @@ class MVSDetHotPath:
         self.pitched_variance = "auto"
         # True: what follows the cost network (depth distribution, lifting, neck_3d / bbox_head) runs on a side stream; forward_scene
         # returns out["ready"] (= out["detector_ready"]), a CUDA event the consumer's stream waits for
+        # "auto": the route is MEASURED per scene shape -- the first scenes of a shape run each route of `OVERLAP_ROUTES` for a few
+        # scenes (period between consecutive scenes' cost networks finishing on the caller's stream, HIP events, no host wait) and the
+        # fastest is kept (a side route only if it beats the one-stream route by 1 %): what the side stream buys depends on the view
+        # count, on how many hardware queues the process's streams share and on the box (profiles/r06_overlap_routes.txt: +10 % at
+        # 40 views, -1.7 % .. +5 % at 80, +2 % at 100 for the same code), so no fixed rule is right everywhere.
         self.overlap_detector = False
-        # view streams of the cost network while the detector tail of the previous scene runs beside it (`overlap_view_streams`)
+        # view streams of the cost network while the detector tail of the previous scene runs beside it (overlap_detector = True)
         self.overlap_network_streams = 1
+        self._overlap_tuning: dict = {}
         self._detector_streams: dict = {}
 
     # ---- reference-named methods (mvsdet.py:249, 266, 298) -------------------------------------------
@@ -454,8 +460,10 @@ class MVSDetHotPath:
         nx, ny, nz = self.n_voxels
         return mean.view(C, nx, ny, nz), count.view(1, nx, ny, nz).long()
 
-    def _front(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor], geo: Optional[SceneGeometry]):
-        """a1..a4 and the cost network of one scene on the caller's stream -> (geo, packed, variance, cost_logits)."""
+    def _front(self, feature: Tensor, img_meta: dict, cost_logits: Optional[Tensor], geo: Optional[SceneGeometry],
+               net_streams: Optional[int] = None):
+        """a1..a4 and the cost network of one scene on the caller's stream -> (geo, packed, variance, cost_logits).
+        net_streams: CostRegNet3DGS.view_streams for this call (None: the module's own setting)."""
         if geo is None:
             geo = self.prepare_scene(img_meta, feature.device)
         if feature.is_cuda and not (feature.requires_grad and torch.is_grad_enabled()) and geo.neighbor_ids.shape[1] > 0:
@@ -472,7 +480,7 @@ class MVSDetHotPath:
         if self.cost_regularization is not None:
             net = self.cost_regularization
             halves = getattr(net, "view_streams", 1)
-            keep = self.overlap_view_streams(variance.shape[0]) if self.overlap_detector and not torch.is_grad_enabled() else halves
+            keep = halves if net_streams is None or torch.is_grad_enabled() else int(net_streams)
             if keep != halves:
                 # the previous scene's neck and head are running beside this network on their own stream: a second stream
                 # INSIDE the network (CostRegNet3DGS.view_streams: 89.5 -> 90.4 scenes/s alone) then takes from them what it
@@ -500,21 +508,65 @@ class MVSDetHotPath:
                             # that maximum (the depth-distribution kernel has it in registers); uncropped like prob_volume
                             opacity=est_dens[:, 0])
 
-    def overlap_view_streams(self, n_views: int) -> int:
-        """CostRegNet3DGS.view_streams to use for a scene of `n_views` views under `overlap_detector`."""
-        return int(self.overlap_network_streams)
+    # name -> (detector tail on the side stream, view streams of the cost network beside it; None = the module's own setting)
+    OVERLAP_ROUTES = {"one": (False, None), "side1": (True, 1), "side2": (True, 2)}
+    _TUNE_WARM, _TUNE_SPAN = 2, 4    # scenes of a route left out (the previous route drains), scenes measured
+
+    def _route(self, feature: Tensor, cost_logits: Optional[Tensor]):
+        """(route name, side stream?, network streams, tuning state or None) for this call."""
+        mode = self.overlap_detector
+        grad = torch.is_grad_enabled() and (feature.requires_grad or (cost_logits is not None and cost_logits.requires_grad)
+                                            or any(p.requires_grad for p in getattr(self.cost_regularization, "parameters", lambda: ())()))
+        if not mode or not feature.is_cuda or grad:
+            return "one", False, None, None          # autograd: the backward's stream order is left to the ops' own streams
+        if mode != "auto":
+            return "side", True, int(self.overlap_network_streams), None
+        key = (tuple(feature.shape), self.num_depth, str(feature.device))
+        st = self._overlap_tuning.get(key)
+        if st is None:
+            st = self._overlap_tuning[key] = {"cand": 0, "marks": [], "side_marks": [], "spans": {}, "choice": None, "periods_ms": None}
+        names = list(self.OVERLAP_ROUTES)
+        if st["choice"] is None and len(st["spans"]) == len(names) and all(e.query() for sp in st["spans"].values() for e in sp[1::2]):
+            # a route's period: the slower of its two streams (the tails must keep up with the fronts)
+            per = {k: max(sp[i].elapsed_time(sp[i + 1]) for i in range(0, len(sp), 2)) / self._TUNE_SPAN for k, sp in st["spans"].items()}
+            best_side = min((k for k in names if k != "one"), key=lambda k: per[k])
+            st["choice"] = best_side if per[best_side] < 0.99 * per["one"] else "one"
+            st["periods_ms"] = {k: round(v, 4) for k, v in per.items()}
+        name = st["choice"] or names[min(st["cand"], len(names) - 1)]
+        side, streams = self.OVERLAP_ROUTES[name]
+        return name, side, streams, (st if st["choice"] is None else None)
+
+    def _tune_mark(self, st: dict, name: str, device, side_done=None) -> None:
+        """Timing events of a tuning scene: one behind its cost network on the caller's stream (side_done is None), one behind
+        its tail on the side stream."""
+        if name in st["spans"]:
+            return                                   # every route has been run; waiting for the events to complete
+        if side_done is not None:
+            st["side_marks"].append(side_done)
+        else:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(device))
+            st["marks"].append(ev)
+        full = self._TUNE_WARM + self._TUNE_SPAN + 1
+        if len(st["marks"]) == full and len(st["side_marks"]) in (0, full):
+            span = (st["marks"][self._TUNE_WARM], st["marks"][-1])
+            if st["side_marks"]:
+                span += (st["side_marks"][self._TUNE_WARM], st["side_marks"][-1])
+            st["spans"][name] = span
+            st["marks"], st["side_marks"] = [], []
+            st["cand"] += 1
+
+    def overlap_choice(self, feature_shape, device="cuda:0"):
+        """What `overlap_detector = "auto"` decided for scenes of this feature shape: (route name or None while it is still
+        measuring, {route: ms per scene} or None)."""
+        st = self._overlap_tuning.get((tuple(feature_shape), self.num_depth, str(torch.device(device))))
+        return (None, None) if st is None else (st["choice"], st["periods_ms"])
 
     def _side_stream(self, dev):
         side = self._detector_streams.get(str(dev))
         if side is None:
             side = self._detector_streams[str(dev)] = torch.cuda.Stream(device=dev)
         return side
-
-    def _one_stream(self, feature, variance, cost_logits) -> bool:
-        """The tail stays on the caller's stream: no device, no overlap asked for, or autograd (the backward's stream order is
-        left to the ops' own streams)."""
-        return (not (self.overlap_detector and variance.is_cuda)
-                or (torch.is_grad_enabled() and (feature.requires_grad or cost_logits.requires_grad)))
 
     @staticmethod
     def _keep_for(side, *values):
@@ -532,7 +584,10 @@ class MVSDetHotPath:
         the consumer is None or `CostRegNet3DGS`): `.view()` on it raises; set `pitched_variance = False` for a contiguous one.
         The result is a `SceneOutputs`: with `overlap_detector` a value read from it makes the reading stream wait for the side
         stream's event first."""
-        geo, packed, variance, cost_logits = self._front(feature, img_meta, cost_logits, geo)
+        route, on_side, net_streams, tuning = self._route(feature, cost_logits)
+        geo, packed, variance, cost_logits = self._front(feature, img_meta, cost_logits, geo, net_streams)
+        if tuning is not None:
+            self._tune_mark(tuning, route, variance.device)
 
         def tail():
             out = self._lift_tail(feature, geo, packed, variance, cost_logits)
@@ -542,7 +597,7 @@ class MVSDetHotPath:
                     out._put("head", self.bbox_head(out.raw("neck")))   # (centerness, bbox, cls) lists over the levels
             return out
 
-        if self._one_stream(feature, variance, cost_logits):
+        if not on_side or (torch.is_grad_enabled() and cost_logits.requires_grad):
             return tail()
         # Everything behind the cost network -- depth distribution, lifting, and the neck and head when they are attached -- on a
         # stream of its own: small kernels that do not fill the chip (one thread per pixel; ONE 40 x 40 x 16 volume: 200 blocks for
@@ -556,8 +611,10 @@ class MVSDetHotPath:
         with torch.cuda.stream(side):
             side.wait_event(ready)
             out = tail()
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=tuning is not None)
             done.record(side)
+        if tuning is not None:
+            self._tune_mark(tuning, route, dev, side_done=done)
         # (`lift` reads geo.projection -- a view of the ONE uploaded staging buffer, which neighbor_ids, proj_rel and depth_values
         # share: recording any view records the whole block -- and geo.points, a block of its own)
         self._keep_for(side, cost_logits, packed, feature, geo.projection, geo.points)
@@ -589,10 +646,11 @@ class MVSDetHotPath:
                       or (grad and (any(f.requires_grad for f in features)
                                     or (cost_logits is not None and any(c.requires_grad for c in cost_logits))
                                     or any(p.requires_grad for p in getattr(self.cost_regularization, "parameters", lambda: ())()))))
+        net_streams = None if one_stream else (1 if self.overlap_detector == "auto" else int(self.overlap_network_streams))
         outs, side, cur = [], None, None
         for i in range(B):
             logits_i = None if cost_logits is None else cost_logits[i]
-            geo, packed, variance, logits_i = self._front(features[i], img_metas[i], logits_i, None)
+            geo, packed, variance, logits_i = self._front(features[i], img_metas[i], logits_i, None, net_streams)
             if not keep_variance and not (grad and variance.requires_grad):
                 variance = variance.new_empty(0)   # the holder's slot; the volume itself goes back to the allocator
             if one_stream:

@@ -189,6 +189,43 @@ def test_forward_scenes_runs_the_detector_once_on_the_batch(gpu):
                     assert float((x - y).abs().max()) <= 1e-5 * max(1.0, s), f"scene {i} head level {lvl}"
 
 
+def test_measured_overlap_route(gpu):
+    """`overlap_detector = "auto"` (the pipelined route must never lose): the first scenes of a shape run every
+    route of MVSDetHotPath.OVERLAP_ROUTES for a few scenes, the period between consecutive scenes' cost networks is measured with
+    HIP events (no host wait), and the fastest route is kept -- a side route only if it beats the one-stream route by 1 %.  Every
+    scene on the way, whatever route it ran on, gives the bits of that scene alone; two shapes are tuned independently."""
+    from mvsdet_amd import synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    C, D, hw, grid, vox = 64, 8, (24, 32), [16, 16, 8], [0.4, 0.4, 0.4]
+    net, neck, head = _modules(C, 64, gpu, seed=4)
+    shapes = {n: (synthetic.make_features(n, C, hw, seed=60 + n).to(gpu), synthetic.make_img_meta(n, hw, seed=60 + n)) for n in (8, 12)}
+    solo = {n: _solo(net, neck, head, grid, vox, D, f, m, gpu) for n, (f, m) in shapes.items()}
+    hp = _fresh_hotpath(net, neck, head, grid, vox, D)
+    hp.overlap_detector = "auto"
+    need = len(MVSDetHotPath.OVERLAP_ROUTES) * (MVSDetHotPath._TUNE_WARM + MVSDetHotPath._TUNE_SPAN + 1)
+    assert hp.overlap_choice(shapes[8][0].shape) == (None, None)
+    with torch.no_grad():
+        for i in range(need + 6):
+            for n, (f, m) in shapes.items():
+                got = _keep(hp.forward_scene(f, m))
+                if i % 5 == 0 or i >= need:
+                    torch.cuda.synchronize(gpu)
+                    _same(solo[n], got, f"scene {i} of the {n}-view shape while the route is being measured")
+    torch.cuda.synchronize(gpu)
+    for n, (f, m) in shapes.items():
+        with torch.no_grad():
+            hp.forward_scene(f, m)                   # the call that finds every span's events complete decides
+        choice, periods = hp.overlap_choice(f.shape)
+        assert choice in MVSDetHotPath.OVERLAP_ROUTES and set(periods) == set(MVSDetHotPath.OVERLAP_ROUTES), (choice, periods)
+        assert all(v > 0 for v in periods.values())
+        assert choice == "one" or periods[choice] < 0.99 * periods["one"]
+        print(f"{n} views: route {choice}, periods {periods}")
+    # under autograd the tail stays on the caller's stream whatever was measured
+    f, m = shapes[8]
+    out = hp.forward_scene(f.clone().requires_grad_(True), m)
+    assert "ready" not in out
+
+
 def test_event_pool_orders_foreign_streams(gpu):
     """mvsdet_amd/scratch.EventPool: (1) a key at its buffer limit hands a buffer that another stream is still working on to the
     next stream, which then WAITS for that work (a long queue of adds followed by an overwrite from the other stream must not be

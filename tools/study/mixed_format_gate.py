@@ -65,6 +65,13 @@ def mx_quant(t, fmt, dim=1, block=32):
         return t.bfloat16().float()
     if fmt == "fp32":
         return t
+    if fmt in ("e4m3t", "e2m3t"):     # ONE power-of-two scale for the whole tensor: what k-blocks of (4 taps x 8 channels) would force on
+        emax, q = (8, q_e4m3) if fmt == "e4m3t" else (2, q_e2m3)   # the activations (a block scale must then be the same for every voxel)
+        amax = float(t.abs().max())
+        if amax == 0:
+            return t
+        scale = 2.0 ** (np.floor(np.log2(amax)) - emax)
+        return q(t / scale) * scale
     emax, q = {"e4m3": (8, q_e4m3), "e2m3": (2, q_e2m3)}[fmt]
     t = t.movedim(dim, -1)
     shape = t.shape
@@ -97,8 +104,9 @@ def conv_pieces(fn, x, w, scheme, wdim, **kw):
     if fmt == "none":
         return y
     f1, f2 = fmt.split("/") if "/" in fmt else (fmt, fmt)
-    c1 = fn(mx_quant(xh, f1, 1), mx_quant(wr, f1, wdim), **kw)
-    c2 = fn(mx_quant(xr, f2, 1), mx_quant(wh, f2, wdim), **kw)
+    wf1, wf2 = f1.rstrip("t"), f2.rstrip("t")       # the weights keep their per-(cout, 32 k) block scales in every variant
+    c1 = fn(mx_quant(xh, f1, 1), mx_quant(wr, wf1, wdim), **kw)
+    c2 = fn(mx_quant(xr, f2, 1), mx_quant(wh, wf2, wdim), **kw)
     return (c1 + c2) + y
 
 
@@ -144,7 +152,7 @@ def main():
             net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
             y64 = net64(x.double())
             print(f"== {tag}: logits |max| {float(y64.abs().max()):.3f}", flush=True)
-            for scheme in ("fp32", "bf16x3", "fp16+none", "fp16+bf16", "fp16+e4m3", "fp16+e4m3/e2m3", "fp16+e2m3"):
+            for scheme in ("fp32", "bf16x3", "fp16+none", "fp16+bf16", "fp16+e4m3", "fp16+e4m3/e2m3", "fp16+e2m3", "fp16+e4m3t", "fp16+e2m3t"):
                 for lay_tag, lays in (("conv0 only, rest bf16x3", ("conv0",)), ("all seven layers", LAYERS)):
                     if scheme in ("fp32", "bf16x3") and lays != LAYERS:
                         continue
@@ -154,7 +162,8 @@ def main():
                     worst[(scheme, lay_tag)] = max(worst.get((scheme, lay_tag), 0.0), err)
                     print(f"   {scheme:15s} {lay_tag:24s}: logits max |d| vs float64 {err:.2e}", flush=True)
     print("== gate (worst over the inputs; PASS = <= %.0e)" % GATE)
-    cost = {"fp32": "-", "bf16x3": "3.0", "fp16+none": "1.0", "fp16+bf16": "3.0", "fp16+e4m3": "2.0", "fp16+e4m3/e2m3": "1.75", "fp16+e2m3": "1.5"}
+    cost = {"fp32": "-", "bf16x3": "3.0", "fp16+none": "1.0", "fp16+bf16": "3.0", "fp16+e4m3": "2.0", "fp16+e4m3/e2m3": "1.75", "fp16+e2m3": "1.5",
+            "fp16+e4m3t": "2.0 (activations: one scale per tensor)", "fp16+e2m3t": "1.5 (activations: one scale per tensor)"}
     for (scheme, lay_tag), err in worst.items():
         print(f"   {scheme:15s} {lay_tag:24s}: {err:.2e}  {'PASS' if err <= GATE else 'FAIL'}   bf16-equivalent MFMAs per product: {cost[scheme]}")
 

@@ -22,7 +22,15 @@ torch.manual_seed(0)
 net = CostRegNet3DGS(256).to(dev).eval()
 neck = IndoorImVoxelNeck(256, 128, [1, 1, 1]).to(dev).eval()
 head = NerfDetHeadConvs(18, 3, 128, 6).to(dev).eval()
-MODES = {"one": (False, 1), "side1": (True, 1), "side2": (True, 2)}
+MODES = {"one": (False, 1, 0), "side1": (True, 1, 0), "side2": (True, 2, 0), "side1_lo": (True, 1, 1), "side2_lo": (True, 2, 1)}
+print("stream priority range (least, greatest):", torch.cuda.Stream.priority_range(), flush=True)
+try:
+    LOW = torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[0])
+    print("low-priority stream:", LOW.priority, flush=True)
+except Exception as exc:  # noqa: BLE001
+    LOW = None
+    print("no low-priority stream:", exc, flush=True)
+NORMAL = torch.cuda.Stream(device=dev)
 for name in sys.argv[1:] or ("scannet_ref_40v_12d_60x80", "scannet_test_80v_12d_60x80", "arkit_test_100v_12d_60x80"):
     w = bench.WORKLOADS[name]
     hp = MVSDetHotPath(bench.N_VOXELS, bench.VOXEL_SIZE, list(w["near_far"]), w["D"], topk=3, cost_regularization=net, neck_3d=neck, bbox_head=head)
@@ -30,9 +38,12 @@ for name in sys.argv[1:] or ("scannet_ref_40v_12d_60x80", "scannet_test_80v_12d_
     metas = bench.unseen_metas(w, 3, 20)
     res = {m: [] for m in MODES}
     with torch.no_grad():
-        for rnd in range(3):
-            for mode, (overlap, streams) in MODES.items():
+        for rnd in range(4):
+            for mode, (overlap, streams, low) in MODES.items():
+                if low and LOW is None:
+                    continue
                 hp.overlap_detector, hp.overlap_network_streams = overlap, streams
+                hp._detector_streams[str(dev)] = LOW if low else NORMAL   # _lo: the detector tail on a stream of the lowest priority
                 bench.collect_garbage()
                 outs = [hp.forward_scene(pool[i % 2].features, metas[i]) for i in range(4)]
                 torch.cuda.synchronize()
@@ -44,6 +55,6 @@ for name in sys.argv[1:] or ("scannet_ref_40v_12d_60x80", "scannet_test_80v_12d_
                 torch.cuda.synchronize()
                 res[mode].append((time.perf_counter() - t0) / 12 * 1e3)
                 del outs
-    print(name, {m: [round(v, 3) for v in ts] for m, ts in res.items()}, "min:", {m: round(min(ts), 3) for m, ts in res.items()}, flush=True)
+    print(name, {m: [round(v, 3) for v in ts] for m, ts in res.items() if ts}, "min:", {m: round(min(ts), 3) for m, ts in res.items() if ts}, flush=True)
     del pool, hp
     torch.cuda.empty_cache()
