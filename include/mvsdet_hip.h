@@ -468,6 +468,17 @@ int mvsdet_conv3d_k3_bf16x3_io(const void* xs, const float* x, const int64_t* x_
                                const void* weight_split, const float* scale, const float* shift, const float* residual,
                                float* out_f32, void* out_scl, void* out_pscl, void* workspace, size_t workspace_bytes, int N,
                                int Cin, int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
+/* stride 1 on ONE fp16 and TWO block-scaled FP6 (OCP MX e2m3) products per fp32-equivalent product instead of three bf16 ones
+ * (csrc/costreg_mx.h; v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4): the layer that reads the fp32 variance volume in
+ * place, mvs_models/mvsnet.py:76 (conv0).  x, x_strides, scale / shift / relu and the three outputs as for
+ * mvsdet_conv3d_k3_bf16x3_io (no residual, no split over the input channels); weight_split_mx from mvsdet_split_conv_weight_mx
+ * (mvsdet_split_conv_weight_mx_bytes).  Values within ~2^-15 relative of the exact convolution (bf16x3: 2^-16; whole-network logits
+ * 1-2e-5 from float64, the bar is 1e-4).  Inputs of magnitude >= 65520 have no fp16: the block that meets one answers NaN. */
+size_t mvsdet_split_conv_weight_mx_bytes(int Cout, int Cin);   /* 0 unless Cout is a positive multiple of 64 */
+int mvsdet_split_conv_weight_mx(const float* weight, void* weight_split_mx, int Cout, int Cin, mvsdet_stream_t stream);
+int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split_mx,
+                                  const float* scale, const float* shift, float* out_f32, void* out_scl, void* out_pscl, int N, int Cin,
+                                  int Cout, int D, int H, int W, int relu, mvsdet_stream_t stream);
 /* stride 1 in front of a training-mode BatchNorm (module.py:26-37 ConvBnReLU3D under model.train()): the raw fp32 output plus, from
  * the kernel's epilogue, per-channel partial sums of the outputs and of their squares -- stats[c * parts + i] = double2 of channel c
  * in block i of the grid, parts = mvsdet_conv3d_k3_bf16x3_stats_parts(N, D, H, W, x != NULL); stats_bytes >= Cout * parts * 16.

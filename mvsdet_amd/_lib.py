@@ -112,9 +112,13 @@ SIGNATURES = {
     "mvsdet_conv3d_k3_s2_bf16x3_f32in_ws": [_vp, _i64p, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_bf16x3_ws": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvsdet_conv3d_k3_bf16x3_f32in_ws": [_vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "mvsdet_split_conv_weight_mx_bytes": [_i, _i],
+    "mvsdet_split_conv_weight_mx": [_vp, _vp, _i, _i, _vp],
+    "mvsdet_conv3d_k3_fp16mx_f32in": [_vp, _i64p, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 _RESTYPE = {"mvsdet_last_error": ctypes.c_char_p, "mvsdet_conv3d_k3_bf16x3_stats_parts": ctypes.c_size_t, "mvsdet_convT3d_k3_s2_bf16x3_stats_parts": ctypes.c_size_t, "mvsdet_gemm_split_weight_bytes": ctypes.c_size_t, "mvsdet_scl_bytes": ctypes.c_size_t, "mvsdet_pscl_bytes": ctypes.c_size_t,
             "mvsdet_split_conv_weight_bytes": ctypes.c_size_t, "mvsdet_packed_bytes": ctypes.c_size_t,
+            "mvsdet_split_conv_weight_mx_bytes": ctypes.c_size_t,
             "mvsdet_plane_sweep_scratch_bytes": ctypes.c_size_t, "mvsdet_plane_sweep_workspace_bytes": ctypes.c_size_t,
             "mvsdet_plane_sweep_bwd_workspace_bytes": ctypes.c_size_t,
             "mvsdet_conv3d_k3_dw_partial_bytes": ctypes.c_size_t,

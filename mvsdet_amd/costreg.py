@@ -272,6 +272,12 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # eval route on bf16x3: "scl" = every layer hands the next one its output already cut into bf16 pieces (SCL / PSCL
         # forms: no fp32 round trip through a packing pass or a strided gather, inputs by LDS-DMA); "f32" = fp32 tensors
         # between the layers (round 3).  Same values bit for bit.
+        # conv0 (256 -> 64 on the fp32 variance volume, 41 % of a scene) in the eval chain: "bf16x3" = three bf16 products per
+        # fp32-equivalent product; "fp16mx" = one fp16 product + two block-scaled FP6 correction products (csrc/costreg_mx.h:
+        # 11.6 instead of 21 matrix-pipe units per 8 channels; logits 1-2e-5 from float64 instead of 2-4e-6, the bar is 1e-4)
+        self.conv0_precision = os.environ.get("MVSDET_CONV0_PRECISION", "bf16x3")
+        if self.conv0_precision not in ("bf16x3", "fp16mx"):
+            raise ValueError(f"MVSDET_CONV0_PRECISION must be 'bf16x3' or 'fp16mx', got {self.conv0_precision!r}")
         self.skip_in_head = False   # True: conv0 + conv11(x) formed by the head while it stages its input (round 4's first form)
         self.layer_forms = "scl"
         # The eval chain on TWO halves of the views, the second on a stream of its own (views are independent: BatchNorm is an
@@ -332,7 +338,12 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             kw = {"scl_out": self._buf(leases, name, "scl", oshape, dev)} if "scl" in outputs else {}
             return ops.convT3d_k3_s2_bf16x3(inp, wsplit[id(seq[0])], sc, sh, skip, True, outputs=outputs, **kw)
 
-        full, full_p = cbr(self.conv0, x, 0, ("f32", "pscl"), "conv0", (n, b, d, h, w))
+        if self.conv0_precision == "fp16mx":
+            sc0, sh0 = _bn_affine(self.conv0.bn)
+            full, full_p = ops.conv3d_k3_fp16mx(x, ops.split_conv_weight_mx(self.conv0.conv.weight), sc0, sh0, True, outputs=("f32", "pscl"),
+                                                pscl_out=self._buf(leases, "conv0", "pscl", (n, b, d, h, w), dev))
+        else:
+            full, full_p = cbr(self.conv0, x, 0, ("f32", "pscl"), "conv0", (n, b, d, h, w))
         h1 = cbr(self.conv1, full_p, 1, ("scl",), "conv1", (n, 2 * b, d // 2, h // 2, w // 2))
         half, half_p = cbr(self.conv2, h1, 0, ("f32", "pscl"), "conv2", (n, 2 * b, d // 2, h // 2, w // 2))
         q1 = cbr(self.conv3, half_p, 1, ("scl",), "conv3", (n, 4 * b, d // 4, h // 4, w // 4))

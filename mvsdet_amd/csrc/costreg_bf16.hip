@@ -1492,6 +1492,8 @@ __global__ __launch_bounds__(TD * TH * TW * 2 / CG) void convT3d_k3_s2_bf16x3_ke
 
 using namespace mvsdet;
 
+#include "costreg_mx.h"   // conv0 on one fp16 + two block-scaled FP6 products per fp32-equivalent product (kernels)
+
 namespace {
 struct BfPlan {
     int td, th, tiles_d, tiles_h, tiles_w, Dp, Hp, Wp, tw = kBfW;
@@ -2113,3 +2115,64 @@ extern "C" int mvsdet_convT3d_k3_s2_bf16x3_io(const void* xs, const void* weight
                                               int H, int W, int relu, mvsdet_stream_t stream) {
     return launch_convT(xs, weight_split, scale, shift, residual, out_f32, out_scl, N, Cin, Cout, D, H, W, relu, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv0 on ONE fp16 and TWO block-scaled FP6 (OCP MX e2m3) products per fp32-equivalent product (costreg_mx.h): the fp32
+// (N,Cin,D,H,W) tensor read in place (x_strides as for mvsdet_conv3d_k3_bf16x3_f32in), weights from mvsdet_split_conv_weight_mx,
+// outputs as for mvsdet_conv3d_k3_bf16x3_io.  Values within ~2^-15 relative of the exact convolution (bf16x3: 2^-16); inputs of
+// magnitude >= 65520 (no fp16) make the block that meets them answer NaN.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t mvsdet_split_conv_weight_mx_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cout % 64 || Cin <= 0) return 0;
+    return (size_t)(Cout / 64) * ((Cin + 7) / 8) * 2 * kMxSlots * 64 * 16;
+}
+
+extern "C" int mvsdet_split_conv_weight_mx(const float* weight, void* weight_split, int Cout, int Cin, mvsdet_stream_t stream) {
+    MVS_REQUIRE(weight && weight_split, "split_conv_weight_mx: NULL pointer");
+    MVS_REQUIRE(Cout > 0 && Cout % 64 == 0 && Cin > 0, "split_conv_weight_mx: Cout=%d must be a positive multiple of 64, Cin=%d > 0", Cout, Cin);
+    MVS_REQUIRE(((uintptr_t)weight_split & 15u) == 0, "split_conv_weight_mx: output must be 16-byte aligned");
+    const size_t units = mvsdet_split_conv_weight_mx_bytes(Cout, Cin) / 16;
+    hipLaunchKernelGGL(split_conv_weight_mx_kernel, dim3((unsigned)((units + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, weight, static_cast<uint4*>(weight_split), Cin, (Cin + 7) / 8, units);
+    MVS_LAUNCH_CHECK("split_conv_weight_mx");
+    return MVSDET_OK;
+}
+
+extern "C" int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_strides, const void* weight_split_mx, const float* scale,
+                                             const float* shift, float* out_f32, void* out_scl, void* out_pscl, int N, int Cin, int Cout,
+                                             int D, int H, int W, int relu, mvsdet_stream_t stream) {
+    const char* name = "conv3d_k3_fp16mx_f32in";
+    MVS_REQUIRE(x && weight_split_mx && (out_f32 || out_scl || out_pscl), "%s: NULL pointer", name);
+    MVS_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift come together", name);
+    MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
+    MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
+    MVS_REQUIRE((((uintptr_t)weight_split_mx | (uintptr_t)out_scl | (uintptr_t)out_pscl) & 15u) == 0, "%s: SCL buffers and weights must be 16-byte aligned", name);
+    const BfPlan p = bf_plan(D, H, W);   // 4 x {12, 8} x 16 tiles
+    const int C8 = (Cin + 7) / 8;
+    const size_t vol = (size_t)D * H * W;
+    MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
+    const long long sN = x_strides ? x_strides[0] : (long long)Cin * vol, sC = x_strides ? x_strides[1] : (long long)vol;
+    const long long sD = x_strides ? x_strides[2] : (long long)H * W, sH = x_strides ? x_strides[3] : (long long)W;
+    MVS_REQUIRE(sN >= 0 && sC >= 0 && sD >= 0 && sH >= W, "%s: bad strides", name);
+    MVS_REQUIRE((long long)(D - 1) * sD + (long long)(H - 1) * sH + W < (1LL << 31), "%s: one channel volume spans more than 2^31 elements", name);
+    const BfOut dst = make_out(out_f32, out_scl, out_pscl, N, Cout, D, H, W);
+    dim3 grid((unsigned)(p.tiles_w * p.tiles_h), (unsigned)p.tiles_d, (unsigned)(N * (Cout / 64)));
+    const int xcd_map = options().conv_xcd != 0 && ((long long)grid.x * grid.y * grid.z) % 8 == 0 && (long long)grid.x * grid.y * grid.z >= 64;
+    hipStream_t st = (hipStream_t)stream;
+#define MVS_MX_CASE(TH_)                                                                                                     \
+    {                                                                                                                        \
+        auto* k = conv3d_k3_fp16mx_kernel<4, TH_>;                                                                           \
+        const size_t lds = ((size_t)2 * 2 * bf_in_slots(4, TH_, kBfW) + 2 * kMxSlots * 64) * 16;                             \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                  \
+            return MVSDET_ERR_HIP;                                                                                           \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(k, grid, dim3(4 * TH_ * 16), lds, st, x, sN, sC, sD, sH, Cin, static_cast<const uint4*>(weight_split_mx), \
+                           scale, shift, dst, C8, Cout, D, H, W, p.tiles_w, relu, xcd_map);                                  \
+    }
+    if (p.th == 12) MVS_MX_CASE(12) else MVS_MX_CASE(8)
+#undef MVS_MX_CASE
+    MVS_LAUNCH_CHECK(name);
+    return MVSDET_OK;
+}
+

@@ -1112,6 +1112,50 @@ def conv3d_k3_bf16x3(x, weight_split: Tensor, scale: Optional[Tensor], shift: Op
     return _ret(outputs, res)
 
 
+def split_conv_weight_mx(weight: Tensor) -> Tensor:
+    """(Cout = 64 m, Cin, 3,3,3) fp32 -> the operand image of `conv3d_k3_fp16mx`: per (block of 64 outputs, 8 input channels, sub-stage)
+    32 x 64 sixteen-byte units -- fp16 fragments of the weights and block-scaled e2m3 fragments of their fp16 roundings and of the
+    remainders (csrc/costreg_mx.h).  A few hundred thousand elements: cut on every call, like the bf16x3 pieces."""
+    _req(weight, "weight", dim=5)
+    Cout, Cin = weight.shape[:2]
+    lib = _lib.load()
+    nbytes = int(lib.mvsdet_split_conv_weight_mx_bytes(int(Cout), int(Cin)))
+    if nbytes == 0 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"split_conv_weight_mx: weight {tuple(weight.shape)} is not (64 m, Cin, 3, 3, 3)")
+    w = weight.detach().contiguous()
+    out = torch.empty((Cout // 64, (Cin + 7) // 8, 2, 32, 64, 4), dtype=torch.int32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.mvsdet_split_conv_weight_mx(_lib.ptr(w), _lib.ptr(out), int(Cout), int(Cin), _stream(w)), "split_conv_weight_mx")
+    return out
+
+
+def conv3d_k3_fp16mx(x: Tensor, weight_split_mx: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], relu: bool,
+                     outputs=("f32",), scl_out: Optional[SclTensor] = None, pscl_out: Optional[PsclTensor] = None):
+    """Conv3d(Cin -> Cout = 64 m, kernel 3, stride 1, padding 1, no bias) [+ affine] [+ ReLU] of the fp32 (N,Cin,D,H,W) tensor read in
+    place (any view with w stride 1), on ONE fp16 and TWO block-scaled FP6 products per fp32-equivalent product (csrc/costreg_mx.h:
+    v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4) instead of bf16x3's three: mvsnet.py:76, the layer that reads the
+    variance volume.  weight_split_mx: `split_conv_weight_mx`.  outputs as for `conv3d_k3_bf16x3`.  |x| must stay below 65520."""
+    import ctypes
+    _req(x, "x", dim=5)
+    if x.stride(4) != 1 or min(x.stride()) < 0:
+        x = x.contiguous()
+    N, Cin, D, H, W = x.shape
+    dev = x.device
+    if (weight_split_mx.dtype != torch.int32 or weight_split_mx.dim() != 6 or not weight_split_mx.is_contiguous()
+            or tuple(weight_split_mx.shape[1:]) != ((Cin + 7) // 8, 2, 32, 64, 4) or weight_split_mx.device != dev):
+        raise ValueError(f"conv3d_k3_fp16mx: weight_split_mx {tuple(weight_split_mx.shape)} {weight_split_mx.dtype} does not match Cin={Cin}")
+    Cout = weight_split_mx.shape[0] * 64
+    scale, shift = _check_affine("conv3d_k3_fp16mx", scale, shift, Cout)
+    outputs, res = _conv_outputs("conv3d_k3_fp16mx", outputs, (N, Cout, D, H, W), dev, scl_out, pscl_out)
+    xstr = (ctypes.c_int64 * 4)(*[int(v) for v in x.stride()[:4]])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mvsdet_conv3d_k3_fp16mx_f32in(_lib.ptr(x), xstr, _lib.ptr(weight_split_mx), _lib.ptr(scale), _lib.ptr(shift),
+                                                             _lib.ptr(res.get("f32")), _lib.ptr(res["scl"].data) if "scl" in res else None,
+                                                             _lib.ptr(res["pscl"].data) if "pscl" in res else None, N, Cin, Cout, D, H, W,
+                                                             int(relu), _lib.current_stream(dev)), "conv3d_k3_fp16mx")
+    return _ret(outputs, res)
+
+
 def conv3d_k3_bf16x3_stats(x, weight_split: Tensor, pivot: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """`conv3d_k3_bf16x3(x, weight_split, None, None, False)` in front of a training-mode BatchNorm (module.py:26-37): the raw
     fp32 output and, from the kernel's epilogue, the per-channel partial sums of the outputs and of their squares -- a float64
