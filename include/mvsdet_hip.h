@@ -473,7 +473,8 @@ int mvsdet_conv3d_k3_bf16x3_io(const void* xs, const float* x, const int64_t* x_
  * place, mvs_models/mvsnet.py:76 (conv0).  x, x_strides, scale / shift / relu and the three outputs as for
  * mvsdet_conv3d_k3_bf16x3_io (no residual, no split over the input channels); weight_split_mx from mvsdet_split_conv_weight_mx
  * (mvsdet_split_conv_weight_mx_bytes).  Values within ~2^-15 relative of the exact convolution (bf16x3: 2^-16; whole-network logits
- * 1-2e-5 from float64, the bar is 1e-4).  Inputs of magnitude >= 65520 have no fp16: the block that meets one answers NaN. */
+ * 1-2e-5 from float64, the bar is 1e-4).  Inputs beyond fp16's range are cut on a
+ * block-uniform power of two (no cliff at 65504). */
 size_t mvsdet_split_conv_weight_mx_bytes(int Cout, int Cin);   /* 0 unless Cout is a positive multiple of 64 */
 int mvsdet_split_conv_weight_mx(const float* weight, void* weight_split_mx, int Cout, int Cin, mvsdet_stream_t stream);
 int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_strides /*HOST[4], NULL = contiguous*/, const void* weight_split_mx,

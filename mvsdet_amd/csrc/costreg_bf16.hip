@@ -2119,8 +2119,7 @@ extern "C" int mvsdet_convT3d_k3_s2_bf16x3_io(const void* xs, const void* weight
 // ---------------------------------------------------------------------------------------------------------------
 // conv0 on ONE fp16 and TWO block-scaled FP6 (OCP MX e2m3) products per fp32-equivalent product (costreg_mx.h): the fp32
 // (N,Cin,D,H,W) tensor read in place (x_strides as for mvsdet_conv3d_k3_bf16x3_f32in), weights from mvsdet_split_conv_weight_mx,
-// outputs as for mvsdet_conv3d_k3_bf16x3_io.  Values within ~2^-15 relative of the exact convolution (bf16x3: 2^-16); inputs of
-// magnitude >= 65520 (no fp16) make the block that meets them answer NaN.
+// outputs as for mvsdet_conv3d_k3_bf16x3_io.  Values within ~2^-15 relative of the exact convolution (bf16x3: 2^-16).
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" size_t mvsdet_split_conv_weight_mx_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cout % 64 || Cin <= 0) return 0;
@@ -2138,6 +2137,9 @@ extern "C" int mvsdet_split_conv_weight_mx(const float* weight, void* weight_spl
     return MVSDET_OK;
 }
 
+#ifndef MVS_MX_BP
+#define MVS_MX_BP 2   // column groups per batch of MX fragments (costreg_mx.h)
+#endif
 extern "C" int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_strides, const void* weight_split_mx, const float* scale,
                                              const float* shift, float* out_f32, void* out_scl, void* out_pscl, int N, int Cin, int Cout,
                                              int D, int H, int W, int relu, mvsdet_stream_t stream) {
@@ -2147,7 +2149,10 @@ extern "C" int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_st
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
     MVS_REQUIRE((((uintptr_t)weight_split_mx | (uintptr_t)out_scl | (uintptr_t)out_pscl) & 15u) == 0, "%s: SCL buffers and weights must be 16-byte aligned", name);
-    const BfPlan p = bf_plan(D, H, W);   // 4 x {12, 8} x 16 tiles
+    // 4 x 8 x 16 tiles on 8 waves: the kernel wants ~190 registers per lane, which two waves per SIMD have (256) and the three of a
+    // 4 x 12 x 16 tile do not (168: 6.2 against 5.4 ms at conv0 with the spills; option "conv_mx_th" = 12 keeps that form selectable)
+    BfPlan p = bf_plan(D, H, W);
+    if (options().conv_mx_th != 12) { p.th = 8; p.tiles_h = (H + 7) / 8; }
     const int C8 = (Cin + 7) / 8;
     const size_t vol = (size_t)D * H * W;
     MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
@@ -2161,7 +2166,7 @@ extern "C" int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_st
     hipStream_t st = (hipStream_t)stream;
 #define MVS_MX_CASE(TH_)                                                                                                     \
     {                                                                                                                        \
-        auto* k = conv3d_k3_fp16mx_kernel<4, TH_>;                                                                           \
+        auto* k = conv3d_k3_fp16mx_kernel<4, TH_>;                                                                      \
         const size_t lds = ((size_t)2 * 2 * bf_in_slots(4, TH_, kBfW) + 2 * kMxSlots * 64) * 16;                             \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
             set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                  \

@@ -1,33 +1,38 @@
 // conv0 of the cost regularisation network (mvs_models/mvsnet.py:76: Conv3d(256 -> 64, 3, padding 1) on the fp32 variance volume) with
-// ONE fp16 product and TWO block-scaled FP6 correction products per fp32-equivalent product instead of three bf16 products:
+// ONE fp16 product and ONE block-scaled FP6 product per fp32-equivalent product instead of three bf16 products:
 //
 //     x = xh + xr,  w = wh + wr          xh = fp16(x) (11 significant bits), xr = x - xh (exact in fp32); the same for w
 //     x * w ~= xh * wh                   v_mfma_f32_16x16x32_f16: the product of two 11-bit numbers is exact in fp32
-//            + Q(xh) * Q(wr)             v_mfma_scale_f32_16x16x128_f8f6f4 on e2m3 operands (OCP MX FP6: 4 significant bits, one e8m0
-//            + Q(xr) * Q(wh)             scale per 32 elements): these two terms are 2^-11 of the result, 4-5 bits of them are enough
+//            + Q(xh) * Q(wr) + Q(xr) * Q(wh)     the two correction terms (2^-11 of the result: 4-5 bits of them are enough) as ONE
+//                                        v_mfma_scale_f32_16x16x128_f8f6f4 on e2m3 operands (OCP MX FP6: 4 significant bits, one e8m0
+//                                        scale per 32 elements) whose k runs over (channel, term) pairs
 //
 // Gate and price (profiles/r06_mixed_format_gate_emulation.txt, r06_mx_mix.txt, r06_conv0_terms_whatif.txt): whole-network logits
 // 1-2e-5 from float64 (bf16x3: 2-4e-6; the bar is 1e-4); an e2m3 MX instruction of K = 128 takes 1.16 x the time of ONE 16x16x32, so a
 // group of 8 channels costs 7 + 4 x 1.16 = 11.6 units against 21.
 //
-// Included by costreg_bf16.hip inside namespace mvsdet (it shares that file's BfOut, block map and epilogue conventions).
+// Included by costreg_bf16.hip (it shares that file's BfOut, block map and epilogue conventions).
 //
-// Data flow = conv3d_k3_bf16x3_kernel<4,12,true,16,8,true,4> (the 16x16x32 form on 4 x 12 x 16 tiles, fp32 input cut in the kernel):
+// Data flow = conv3d_k3_bf16x3_kernel's 16x16x32 form with the fp32 input cut in the kernel:
 //   k-step  = 4 taps x 8 channels (lane group kg = lane >> 4 takes tap 4 ks + kg); 27 taps = 7 k-steps, the 28th slot empty
-//   stage   = 8 channels: halo tile 6 x 14 x 18 voxels in LDS as  hi[slot] = 8 fp16 (16 B),  q1[slot] = Q(xh) and q2[slot] = Q(xr), 8
-//             e2m3 codes in 6 bytes each (stored as 8: word 0 = bits 0..31, word 1 = bits 32..47 in its UPPER half)
-//   scale   : a lane's 32 elements of an MX operand are 4 taps x 8 channels, i.e. FOUR different voxels -- so the activations' scale
-//             must be one per (block, stage): E1 = floor(log2 max|x|) - 2 over the halo tile's 8 channels (every value below 8 after
-//             scaling; e2m3's largest is 7.5), found by the staging threads (wave maximum -> LDS -> barrier) before they quantise;
-//             Q(xr) uses E1 - 11 (|xr| <= 2^-11 * 2^floor(log2|x|)).  The weights' scales are per (output channel, 32 k) block.
-//   MX group: k-steps 4g .. 4g+3 (g = 0, 1; k-step 7 is empty: zero weights); the lane's 32 elements are e = 8 i + c for k-step 4g + i,
-//             channel c; the B fragment is assembled from the four 6-byte units the lane reads at its four taps (4 VALU operations)
+//   stage   = 8 channels: halo tile in LDS as  hi[slot] = 8 fp16 (16 B)  and  q[slot] = 16 e2m3 codes (12 B in a 16-B slot):
+//             element 2c = Q(xh_c * 2^-E1), element 2c + 1 = Q(xr_c * 2^-(E1 - 11)) -- what ONE v_cvt_scalef32_2xpk16_fp6_f32 makes of
+//             a thread's two voxels (it interleaves its two 16-float groups element by element: tools/micro/cvt_fp6_probe.hip)
+//   scale   : a lane's 32 elements of an MX operand are 2 taps x 8 channels x 2 terms, i.e. TWO different voxels -- so the activations'
+//             scale must be one per (block, stage): E1 = floor(log2 max|x|) - 2 over the halo tile's 8 channels (every value below 8
+//             after scaling; e2m3's largest is 7.5), found by the staging threads (wave maximum -> LDS -> barrier) before they
+//             quantise; xr rides on E1 - 11 (|xr| <= 2^-11 * 2^floor(log2|x|)).  Weights: per (output channel, 32 k) block,
+//             Ew = floor(log2 max|wh|) - 2, wr on Ew - 11: both kinds of product then carry the SAME power of two,
+//             2^(E1 + Ew - 11), which is what lets them share an instruction (scale bytes E1 + 127 and Ew - 11 + 127).
+//   MX group: k-steps 2g, 2g+1 (g = 0..3; k-step 7 is empty: zero weights); the lane's 32 elements are e = 16 i + 2 c + term for
+//             k-step 2g + i: its B fragment is the two 12-byte units it reads at its two taps -- no bit assembly
 //   weights : [Cout/64][Cin/8][sub-stage 2][slot 32][lane 64] x 16 B (mvsdet_split_conv_weight_mx):
 //             slots 0..15   hi of k-step 4s + (slot >> 2), row group slot & 3: 8 fp16 of the lane's (row m = lane & 15, tap 4 ks + kg)
-//             slots 16..31  MX group s: slot = 16 + 2 (4 term + rg) + half; term 0 = Q(wr) (multiplies Q(xh)), term 1 = Q(wh)
-//                           (multiplies Q(xr)); half 0 = fragment words 0..3, half 1 = words 4, 5, the e8m0 scale byte, padding
-//   fp16    : |x| >= 65520 has no fp16; a block that meets one answers NaN for all its outputs (the variance of backbone features is
-//             orders of magnitude below that).
+//             slots 16..31  MX group 2s + gl: slot = 16 + 2 (4 gl + rg) + half; element 16 i + 2 c = Q(wr), + 1 = Q(wh) (wr meets
+//                           Q(xh), wh meets Q(xr)); half 0 = fragment words 0..3, half 1 = words 4, 5, the e8m0 scale byte, padding
+//   fp16    : fp16 ends at 65504.  A stage whose largest magnitude reaches 2^15 is cut as x * 2^-S (S = floor(log2 max|x|) - 14, a
+//             block-uniform power of two; S = 0 for any input below 32768, i.e. always for a variance of backbone features); the
+//             accumulators carry the power of two of the stage they were last added to and are re-scaled when it changes.
 // Values: every product term is exact in fp32 and accumulated in fp32, like the bf16x3 kernel's; what is left out is the
 // quantisation of the two correction terms (2^-4 relative of a 2^-11 term each).
 
@@ -64,12 +69,6 @@ __host__ __device__ __forceinline__ int mx_block_exp(float amax) {
     const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u) - 127 - 2;       // floor(log2 amax) - 2 (subnormal amax: -129)
     return e < -116 ? -116 : (e > 120 ? 120 : e);
 }
-// 8 codes -> the unit's two words (word 1 holds bits 32..47 in its upper half)
-__host__ __device__ __forceinline__ void mx_pack_unit(const unsigned (&c)[8], unsigned& w0, unsigned& w1) {
-    w0 = c[0] | (c[1] << 6) | (c[2] << 12) | (c[3] << 18) | (c[4] << 24) | (c[5] << 30);
-    w1 = ((c[5] >> 2) | (c[6] << 4) | (c[7] << 10)) << 16;
-}
-
 // weight (Cout,Cin,27) fp32 -> the layout above; thread = one (block of 64 outputs, channel group, sub-stage, slot, lane) unit
 __global__ __launch_bounds__(kThreads) void split_conv_weight_mx_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin, int C8,
                                                                         size_t units) {
@@ -94,57 +93,55 @@ __global__ __launch_bounds__(kThreads) void split_conv_weight_mx_kernel(const fl
                              (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16));
         }
     } else {
-        const int idx = (slot - 16) >> 1, half = (slot - 16) & 1, term = idx >> 2, rg = idx & 3;
-        float v[32];
+        const int idx = (slot - 16) >> 1, half = (slot - 16) & 1, gl = idx >> 2, rg = idx & 3;
+        const int ks0 = 4 * sub + 2 * gl;                      // the group's two k-steps: ks0, ks0 + 1
+        float wh[16], wr[16];
         float amax = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float f = weight_at(rg, 4 * sub + i, c);
-                const float hi = (float)(_Float16)f;
-                v[8 * i + c] = term == 0 ? f - hi : hi;           // term 0: the remainder wr, term 1: wh
-                amax = fmaxf(amax, fabsf(v[8 * i + c]));
+                const float f = weight_at(rg, ks0 + i, c);
+                wh[8 * i + c] = (float)(_Float16)f;
+                wr[8 * i + c] = f - wh[8 * i + c];
+                amax = fmaxf(amax, fabsf(wh[8 * i + c]));
             }
-        const int e = mx_block_exp(amax);
-        unsigned words[6];
+        const int e = mx_block_exp(amax);                      // wh on 2^e, wr on 2^(e - 11)
+        unsigned words[6] = {0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned c6[8], w0, w1;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) c6[c] = mx_e2m3_code(v[8 * i + c], e);
-            mx_pack_unit(c6, w0, w1);
-            // unit i of the fragment: bits 48 i .. 48 i + 47
-            if ((i & 1) == 0) {
-                words[3 * (i >> 1)] = w0;
-                words[3 * (i >> 1) + 1] = w1 >> 16;
-            } else {
-                words[3 * (i >> 1) + 1] |= w0 << 16;
-                words[3 * (i >> 1) + 2] = (w0 >> 16) | w1;
-            }
+        for (int el = 0; el < 32; ++el) {                      // element 16 i + 2 c = Q(wr), + 1 = Q(wh)
+            const int i = el >> 4, c = (el >> 1) & 7, term = el & 1;
+            const unsigned code = term ? mx_e2m3_code(wh[8 * i + c], e) : mx_e2m3_code(wr[8 * i + c], e - 11);
+            const int bit = 6 * el;
+            words[bit >> 5] |= code << (bit & 31);
+            if ((bit & 31) > 26) words[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
         }
-        res = half == 0 ? make_uint4(words[0], words[1], words[2], words[3]) : make_uint4(words[4], words[5], (unsigned)(e + 127), 0u);
+        res = half == 0 ? make_uint4(words[0], words[1], words[2], words[3]) : make_uint4(words[4], words[5], (unsigned)(e - 11 + 127), 0u);
     }
     out[u] = res;
 }
 
-// BP: column groups whose MX fragments are assembled and held at a time (4: every weight fragment is read once per term; 2: twice,
-// 16 registers fewer -- at 12 waves a lane has 168 registers and the form with 4 spills)
-template <int TD, int TH, int BP = 2>
+typedef float mx_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned mx_u32x6 __attribute__((ext_vector_type(6)));
+typedef int mx_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int TD, int TH>
 __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
     const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
     const float* __restrict__ scale, const float* __restrict__ shift, BfOut dst, int C8, int Cout, int D, int H, int W, int tiles_w,
     int relu, int xcd_map) {
     constexpr int TW = 16, CGN = 4;
     constexpr int NW = TD * TH * TW / 64, NT = 64 * NW;
+    constexpr bool kTight = NW > 8;                        // three waves per SIMD: 168 registers per lane
     constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     constexpr int NVOX = HD * HH * HW;
     constexpr int INS = bf_in_slots(TD, TH, TW);
     static_assert(INS - NVOX >= 4, "the stage's spare slots hold the waves' maxima");
-    static_assert(NW <= 14, "one float per wave + the overflow flag in three spare slots");
+    static_assert(NW <= 14, "one float per wave in three spare slots");
     constexpr int kWSlots = kMxSlots * 64;                 // 16-byte slots of one weight buffer
-    constexpr int NV = (NVOX + NT - 1) / NT;
-    extern __shared__ uint4 s_mx[];   // [2 stages][hi INS x 16 B | q1 INS x 8 B | q2 INS x 8 B], then [2][kWSlots] weights
+    constexpr int NV = (NVOX + NT - 1) / NT;               // halo voxels per thread
+    constexpr int NVP = (NV + 1) / 2;                      // ... in pairs: one conversion instruction per pair
+    extern __shared__ uint4 s_mx[];   // [2 stages][hi INS | q INS], then [2][kWSlots] weights
     constexpr int STAGE = 2 * INS;    // uint4 per input stage
     uint4* s_in = s_mx;
     uint4* s_w = s_mx + 2 * STAGE;
@@ -159,28 +156,35 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
     const int n = bz / nob, ob64 = bz % nob;
     const int w0 = bw * TW, h0 = bh * TH, d0 = by * TD;
 
-    // ---- the fp32 input: voxel slots tid, tid + NT, .. of the halo tile; offset inside one channel's volume or -1
-    int f_off[NV];
+    // ---- the fp32 input by BUFFER loads: one descriptor for the view's Cin channel volumes; a lane's byte offset inside a channel
+    // volume, or an offset beyond the descriptor's range for a halo voxel outside the volume -- the hardware then returns 0: no
+    // branch and no 64-bit address per load
+    unsigned f_off[NV];
     float f_reg[NV][8];
     const float* xfn = xf + (size_t)n * sN;
+    const unsigned long long span = ((unsigned long long)(Cin - 1) * (unsigned long long)sC + (unsigned long long)(D - 1) * sD +
+                                     (unsigned long long)(H - 1) * sH + W) * 4ull;   // bytes of the view this kernel may touch (< 2^32: host)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xfn), 0, (int)(unsigned)span, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int slot = tid + k * NT;
         const int dz = slot / (HH * HW), r = slot - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
         const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
         const bool ok = slot < NVOX && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
-        f_off[k] = ok ? (int)((long long)d * sD + (long long)h * sH + w) : -1;
+        f_off[k] = ok ? (unsigned)(((long long)d * sD + (long long)h * sH + w) * 4) : 0xfffffff0u;
     }
+    const unsigned sC4 = (unsigned)(sC * 4);
     auto fetch_f32 = [&](int c8) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k)
+        for (int j = 0; j < 8; ++j) {
+            const int c = c8 * 8 + j;
+            const unsigned soff = (c < Cin ? (unsigned)c : (unsigned)Cin) * sC4;   // a channel beyond Cin: out of range -> 0
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = c8 * 8 + j;
-                f_reg[k][j] = (f_off[k] >= 0 && c < Cin) ? xfn[(size_t)c * sC + f_off[k]] : 0.0f;
-            }
+            for (int k = 0; k < NV; ++k)
+                f_reg[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, f_off[k], (int)soff, 0));
+        }
     };
-    // the wave's largest magnitude of the fetched values (and whether one of them has no fp16) -> the stage buffer's spare slots
+    // the wave's largest magnitude of the fetched values -> the stage buffer's spare slots
     auto publish_amax = [&](int buf) {
         float a = 0.0f;
 #pragma unroll
@@ -192,44 +196,47 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
         float* spare = reinterpret_cast<float*>(s_in + (size_t)buf * STAGE + NVOX);
         if (lane == 0) spare[wave] = a;
     };
-    auto stage_exp = [&](int buf, bool& bad) -> int {
+    auto stage_exp = [&](int buf) -> int {
         const float* spare = reinterpret_cast<const float*>(s_in + (size_t)buf * STAGE + NVOX);
         float a = 0.0f;
 #pragma unroll
         for (int i = 0; i < NW; ++i) a = fmaxf(a, spare[i]);
-        bad = bad || !(a < 65520.0f);
         return __builtin_amdgcn_readfirstlane(mx_block_exp(a));
     };
-    // registers -> LDS: hi (8 fp16), Q(xh) and Q(xr)
+    auto stage_shift = [](int e1) -> int { return e1 > 12 ? e1 - 12 : 0; };   // S: max|x| * 2^-S < 2^15
+    // registers -> LDS: hi (8 fp16) and the 16 e2m3 codes of (xh, xr * 2^11) on the stage's scale: ONE conversion per two voxels
     auto stage_cut = [&](int buf, int e1) {
         uint4* hi_s = s_in + (size_t)buf * STAGE;
-        uint2* q1_s = reinterpret_cast<uint2*>(hi_s + INS);
-        uint2* q2_s = q1_s + INS;
+        uint4* q_s = hi_s + INS;
+        const int S = stage_shift(e1);
+        const float down = __builtin_bit_cast(float, (unsigned)(127 - S) << 23);        // 2^-S (1.0 unless the stage is huge)
+        const float sdiv = __builtin_bit_cast(float, (unsigned)(e1 - S + 127) << 23);   // 2^(e1 - S) (the instruction divides by it)
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int slot = tid + k * NT;
-            unsigned hw[4], c1[8], c2[8];
+        for (int kp = 0; kp < NVP; ++kp) {
+            mx_f32x16 ga, gb;
+            unsigned hw[2][4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float f = f_reg[k][j];
-                const _Float16 h = (_Float16)f;
-                const float hf = (float)h;
-                const unsigned hb = __builtin_bit_cast(unsigned short, h);
-                if (j & 1) hw[j >> 1] |= hb << 16; else hw[j >> 1] = hb;
-#ifndef MXX_NO_CUT
-                c1[j] = mx_e2m3_code(hf, e1);
-                c2[j] = mx_e2m3_code(f - hf, e1 - 11);
-#else
-                c1[j] = hb & 63; c2[j] = (hb >> 3) & 63;
-#endif
+            for (int v = 0; v < 2; ++v) {
+                const int k = 2 * kp + v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = (k < NV ? f_reg[k < NV ? k : 0][j] : 0.0f) * down;
+                    const _Float16 h = (_Float16)f;
+                    const float hf = (float)h;
+                    const unsigned hb = __builtin_bit_cast(unsigned short, h);
+                    if (j & 1) hw[v][j >> 1] |= hb << 16; else hw[v][j >> 1] = hb;
+                    ga[8 * v + j] = hf;
+                    gb[8 * v + j] = (f - hf) * 2048.0f;          // exact: on the scale 2^(e1 - 11)
+                }
             }
-            if (slot < NVOX) {
-                unsigned a0, a1, b0, b1;
-                mx_pack_unit(c1, a0, a1);
-                mx_pack_unit(c2, b0, b1);
-                hi_s[slot] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-                q1_s[slot] = make_uint2(a0, a1);
-                q2_s[slot] = make_uint2(b0, b1);
+            const mx_u32x6 q = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ga, gb, sdiv);   // element 2 i = ga[i], 2 i + 1 = gb[i]
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int k = 2 * kp + v, slot = tid + k * NT;
+                if (k < NV && slot < NVOX) {
+                    hi_s[slot] = make_uint4(hw[v][0], hw[v][1], hw[v][2], hw[v][3]);
+                    q_s[slot] = make_uint4(q[3 * v], q[3 * v + 1], q[3 * v + 2], 0u);
+                }
             }
         }
     };
@@ -246,19 +253,34 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
     // ---- the wave's four column groups of 16 voxels (as the 16x16x32 form of conv3d_k3_bf16x3_kernel)
     constexpr int RG16 = 16 / TW > 0 ? 16 / TW : 1;
     const int col16 = lane & 15, kg = lane >> 4;
-    int vb16[CGN], toffs[8];
+    int vb16[CGN];
 #pragma unroll
     for (int cg = 0; cg < CGN; ++cg) {
         const int g = CGN * wave + cg;
         const int dz = g / (TH / RG16), hy = RG16 * (g % (TH / RG16)) + col16 / TW;
         vb16[cg] = (dz * HH + hy) * HW + col16 % TW;
     }
+    // tap offsets: lane group kg reads tap 4 ks + kg of k-step ks (k-step 7 -- taps 28..31 -- is empty: zero weights, any voxel of the
+    // tile).  Eight registers per lane; with 168 of them (12 waves) the table sits in ONE register instead -- lane i holds the offset
+    // of tap i -- and a lane fetches its entry with ds_bpermute when a k-step needs it.
+    int toffs[kTight ? 1 : 8];
+    int ttab = 0;
+    if constexpr (kTight) {
+        int t = lane & 31;
+        t = t > 26 ? 26 : t;
+        ttab = ((t / 9) * HH + (t / 3) % 3) * HW + t % 3;
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {   // k-step 7 (taps 28..31) is empty: zero weights, any voxel of the tile
-        const int k7 = ks < 7 ? ks : 6;
-        toffs[ks] = kg == 0 ? bf_tap_off<HH, HW>(4 * k7) : kg == 1 ? bf_tap_off<HH, HW>(4 * k7 + 1)
-                  : kg == 2 ? bf_tap_off<HH, HW>(4 * k7 + 2) : bf_tap_off<HH, HW>(4 * k7 + 3);
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k7 = ks < 7 ? ks : 6;
+            toffs[ks] = kg == 0 ? bf_tap_off<HH, HW>(4 * k7) : kg == 1 ? bf_tap_off<HH, HW>(4 * k7 + 1)
+                      : kg == 2 ? bf_tap_off<HH, HW>(4 * k7 + 2) : bf_tap_off<HH, HW>(4 * k7 + 3);
+        }
     }
+    auto tap_off = [&](int ks) -> int {
+        if constexpr (kTight) return __builtin_amdgcn_ds_bpermute((4 * ks + kg) << 2, ttab);
+        else return toffs[ks];
+    };
     mx_f32x4 acc[4][CGN];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -269,13 +291,14 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
         constexpr int s = decltype(sc)::value;
         constexpr int nks = s == 0 ? 4 : 3;
         const uint4* hi_s = s_in + (size_t)ibuf * STAGE;
-        const uint2* q_s = reinterpret_cast<const uint2*>(hi_s + INS);
+        const uint4* q_s = hi_s + INS;
         const uint4* ain = s_w + (size_t)wbuf * kWSlots + lane;
+        const int sb = e1 - stage_shift(e1) + 127;
         // the fp16 products, k-step by k-step
 #ifndef MXX_NO_F16
 #pragma unroll
         for (int kl = 0; kl < nks; ++kl) {
-            const int toff = toffs[4 * s + kl];
+            const int toff = tap_off(4 * s + kl);
             f16x8 A[4], B[CGN];
 #pragma unroll
             for (int a = 0; a < 4; ++a) A[a] = __builtin_bit_cast(f16x8, ain[(kl * 4 + a) * 64]);
@@ -285,73 +308,66 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < CGN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a], B[b], acc[a][b], 0, 0, 0);
-            MX_FENCE();   // a k-step's 8 fragments are dead here: the next one's loads must not be hoisted above
+            if constexpr (kTight) MX_FENCE();   // 12 waves: 168 registers -- the next k-step's fragments are not fetched ahead
         }
 #endif
-        // the two correction terms of the group's four k-steps
+        // the correction terms of the sub-stage's two pairs of k-steps
 #ifndef MXX_NO_MX
 #pragma unroll
-        for (int term = 0; term < 2; ++term) {
-            const uint2* qt = q_s + (size_t)term * INS;
-            const int sb = (term == 0 ? e1 : e1 - 11) + 127;
+        for (int gl = 0; gl < 2; ++gl) {
+            mx_i32x8 FB[CGN];
+            const int t0 = tap_off(4 * s + 2 * gl), t1 = tap_off(4 * s + 2 * gl + 1);
 #pragma unroll
-            for (int b0 = 0; b0 < CGN; b0 += BP) {
-                mx_i32x8 FB[BP];
+            for (int b = 0; b < CGN; ++b) {
+                const uint4 u0 = q_s[vb16[b] + t0], u1 = q_s[vb16[b] + t1];
+                FB[b] = (mx_i32x8){(int)u0.x, (int)u0.y, (int)u0.z, (int)u1.x, (int)u1.y, (int)u1.z, 0, 0};
+            }
 #pragma unroll
-                for (int b = 0; b < BP; ++b) {
-                    uint2 u[4];
+            for (int a = 0; a < 4; ++a) {
+                const uint4 lo = ain[(16 + 2 * (4 * gl + a)) * 64], hi = ain[(16 + 2 * (4 * gl + a) + 1) * 64];
+                const mx_i32x8 FA = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
+                const int sa = (int)hi.z;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) u[i] = qt[vb16[b0 + b] + toffs[4 * s + i]];
-                    FB[b][0] = (int)u[0].x;
-                    FB[b][1] = (int)__builtin_amdgcn_alignbit(u[1].x, u[0].y, 16);
-                    FB[b][2] = (int)__builtin_amdgcn_perm(u[1].y, u[1].x, 0x07060302u);
-                    FB[b][3] = (int)u[2].x;
-                    FB[b][4] = (int)__builtin_amdgcn_alignbit(u[3].x, u[2].y, 16);
-                    FB[b][5] = (int)__builtin_amdgcn_perm(u[3].y, u[3].x, 0x07060302u);
-                    FB[b][6] = 0;
-                    FB[b][7] = 0;
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const uint4 lo = ain[(16 + 2 * (4 * term + a)) * 64], hi = ain[(16 + 2 * (4 * term + a) + 1) * 64];
-                    const mx_i32x8 FA = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
-                    const int sa = (int)hi.z;
-#pragma unroll
-                    for (int b = 0; b < BP; ++b) {
-                        acc[a][b0 + b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(FA, FB[b], acc[a][b0 + b], 2, 2, 0, sa, 0, sb);
-                        // pinned HERE: the instruction is pure, and the compiler otherwise sinks it below the staging code that follows
-                        // the products (its 12-register operands then stay live across that code: the accumulators go to scratch)
-                        asm volatile("" : "+v"(acc[a][b0 + b]));
-                    }
-                    MX_FENCE();
-                }
+                for (int b = 0; b < CGN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(FA, FB[b], acc[a][b], 2, 2, 0, sa, 0, sb);
+            }
+            if constexpr (kTight) {
+                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                                  "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
+                                  "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
                 MX_FENCE();
             }
         }
+        // pinned HERE, once per sub-stage: the instruction is pure, and the compiler otherwise sinks the products below the staging
+        // code that follows them (their 12-register operands then stay live across that code: the accumulators go to scratch).  One
+        // statement for all sixteen accumulators: a statement per instruction makes each wait for its own result.
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                          "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
+                          "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
 #endif
     };
 
-    // ---- pipeline: per channel group two sub-stages (k-steps 0..3 + MX group 0, k-steps 4..6 + MX group 1)
-    bool bad = false;
-    int e_cur = -100;
+    // ---- pipeline: per channel group two sub-stages (k-steps 0..3 + MX groups 0, 1; k-steps 4..6 + MX groups 2, 3)
+    int e_cur = -100, s_acc = 0;      // s_acc: the accumulators hold sums of (x * 2^-s_acc) * w
     if (C8 > 0) {
         fetch_f32(0);
         dma_weights(0, 0, 0);
         publish_amax(0);
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's maximum is in LDS
         __builtin_amdgcn_s_barrier();
-        e_cur = stage_exp(0, bad);
+        e_cur = stage_exp(0);
         stage_cut(0, e_cur);
+        s_acc = stage_shift(e_cur);
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
     for (int c8 = 0; c8 < C8; ++c8) {
         const int ibuf = c8 & 1;
         const bool more = c8 + 1 < C8;
-        // the 32 sums vb16[b] + toffs[k] are loop-invariant and the compiler would keep them all in registers across the loop (with the
-        // accumulators, the prefetched input and the fragments that is more than the 168 a lane has: everything spilled): opaque to it,
-        // they are re-formed per stage -- 32 additions
+        // the sums vb16[b] + toffs[k] are loop-invariant and the compiler would keep all 32 in registers across the loop: opaque to
+        // it, they are re-formed per stage -- 32 additions
 #pragma unroll
         for (int cg = 0; cg < CGN; ++cg) asm volatile("" : "+v"(vb16[cg]));
+        if constexpr (kTight) asm volatile("" : "+v"(ttab));
         // sub-stage 0
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's weight DMAs of the sub-stage have landed
         __builtin_amdgcn_s_barrier();         // everybody's have, the stage buffer is complete, the other buffers are free
@@ -370,18 +386,26 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
         if (more) dma_weights(c8 + 1, 0, 0);
         int e_next = e_cur;
         if (more) {
-            e_next = stage_exp(ibuf ^ 1, bad);
+            e_next = stage_exp(ibuf ^ 1);
             stage_cut(ibuf ^ 1, e_next);
         }
-        MX_FENCE();   // the cut's temporaries and the products' fragments are not to be live together (168 registers)
+        MX_FENCE();   // the cut's temporaries and the products' fragments are not to be live together
         compute(std::integral_constant<int, 1>{}, ibuf, 1, e_cur);
         e_cur = e_next;
+        if (stage_shift(e_next) != s_acc) {   // block-uniform and, for inputs below 32768, never taken
+            const float f = __builtin_bit_cast(float, (unsigned)(127 + s_acc - stage_shift(e_next)) << 23);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < CGN; ++b) acc[a][b] *= f;
+            s_acc = stage_shift(e_next);
+        }
     }
 
     // ---- epilogue (the 16x16 C/D map: column = lane & 15 = voxel, register r of lane group kg = row 4 kg + r of the row group; row
     // groups 2q and 2q+1 together give a lane the eight consecutive channels 32 q + 8 kg .. + 7)
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
-    const float poison = bad ? __builtin_nanf("") : 0.0f;
+    const float up = __builtin_bit_cast(float, (unsigned)(127 + s_acc) << 23);   // 2^s_acc
 #pragma unroll
     for (int cg = 0; cg < CGN; ++cg) {
         const int g = CGN * wave + cg;
@@ -399,10 +423,9 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                v[j] = j < 4 ? acc[2 * q][cg][j & 3] : acc[2 * q + 1][cg][j & 3];
+                v[j] = (j < 4 ? acc[2 * q][cg][j & 3] : acc[2 * q + 1][cg][j & 3]) * up;
                 if (scale) v[j] = fmaf(v[j], sc[j], sh[j]);
                 if (relu) v[j] = fmaxf(v[j], 0.0f);
-                v[j] += poison;                                    // behind the ReLU, which would turn a NaN into 0
                 if (out) out[idx0 + (size_t)j * vol] = v[j];
             }
             if (dst.scl || dst.pscl) bf_store_units(dst, v, n, Cout / 8, ob64 * 8 + 4 * q + kg, d, h, w);

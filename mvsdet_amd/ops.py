@@ -1134,7 +1134,7 @@ def conv3d_k3_fp16mx(x: Tensor, weight_split_mx: Tensor, scale: Optional[Tensor]
     """Conv3d(Cin -> Cout = 64 m, kernel 3, stride 1, padding 1, no bias) [+ affine] [+ ReLU] of the fp32 (N,Cin,D,H,W) tensor read in
     place (any view with w stride 1), on ONE fp16 and TWO block-scaled FP6 products per fp32-equivalent product (csrc/costreg_mx.h:
     v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4) instead of bf16x3's three: mvsnet.py:76, the layer that reads the
-    variance volume.  weight_split_mx: `split_conv_weight_mx`.  outputs as for `conv3d_k3_bf16x3`.  |x| must stay below 65520."""
+    variance volume.  weight_split_mx: `split_conv_weight_mx`.  outputs as for `conv3d_k3_bf16x3`."""
     import ctypes
     _req(x, "x", dim=5)
     if x.stride(4) != 1 or min(x.stride()) < 0:
