@@ -632,23 +632,36 @@ def full_chain_rate(device, steps=10):
         torch.cuda.synchronize(device)
         net_ms = e0.elapsed_time(e1) / 3
         conv, bn = net.conv0.conv, net.conv0.bn
-        wq = ops.split_conv_weight(conv.weight)
         sc = torch.ones(conv.out_channels, device=device)
-        ops.conv3d_k3_bf16x3(var, wq, sc, sc, True)
-        e0.record()
-        for _ in range(3):
-            ops.conv3d_k3_bf16x3(var, wq, sc, sc, True)   # reads the fp32 variance volume itself (no packing pass)
-        e1.record()
-        torch.cuda.synchronize(device)
-        c0_ms = e0.elapsed_time(e1) / 3
+        wq, wmx = ops.split_conv_weight(conv.weight), ops.split_conv_weight_mx(conv.weight)
+        routes = {"bf16x3": lambda: ops.conv3d_k3_bf16x3(var, wq, sc, sc, True),      # both read the fp32 variance volume itself
+                  "fp16mx": lambda: ops.conv3d_k3_fp16mx(var, wmx, sc, sc, True)}
+        c0 = {}
+        for name_, fn in routes.items():
+            fn()
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            c0[name_] = e0.elapsed_time(e1) / 3
     tfl = CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12
     c0_tfl = 2.0 * 27 * wr["C"] * 64 * wr["N"] * wr["D"] * wr["H"] * wr["W"] / 1e12
-    roof = {"bound": "mfma", "achieved": round(3 * c0_tfl / c0_ms * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s",
-            "frac": round(3 * c0_tfl / c0_ms * 1e3 / 2500.0, 4),
-            "kernel": "conv3d_k3_bf16x3_kernel (conv0 256->64: 55 % of the network; bf16 MFMA, 3 terms per product)",
-            "note": "peak = dense bf16 at 2.4 GHz; by SQ_BUSY_CYCLES the kernel (16x16x32 MFMA) sustains ~1.87 GHz with the matrix pipes "
-                    "~69 % busy (profiles/r04_costreg_pmc.txt, DESIGN 4.3)",
-            "kernel_ms": round(c0_ms, 3), "useful_TFLOPs": round(c0_tfl / c0_ms * 1e3, 1),
+    shipped = net.conv0_precision
+    c0_ms = c0[shipped]
+    # matrix-pipe work per useful FLOP, in units of the dense bf16 rate: bf16x3 = 3 products; fp16mx = per 8 channels 7 fp16 k-steps + 4
+    # block-scaled FP6 instructions of K = 128, each priced as ONE 16x16x32 (MI355X_MICROARCH "MFMA" table: e2m3 at 4x the bf16 rate)
+    units = 3.0 if shipped == "bf16x3" else 11.0 / 7.0
+    roof = {"bound": "mfma", "achieved": round(units * c0_tfl / c0_ms * 1e3, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(units * c0_tfl / c0_ms * 1e3 / 2500.0, 4),
+            "kernel": ("conv3d_k3_fp16mx_kernel (conv0 256->64: one fp16 product + one block-scaled FP6 product that carries both correction "
+                       "terms per fp32-equivalent product; 11/7 matrix-pipe units per product)" if shipped == "fp16mx" else
+                       "conv3d_k3_bf16x3_kernel (conv0 256->64: bf16 MFMA, 3 terms per product)"),
+            "note": "peak = dense bf16 at 2.4 GHz; `achieved` = useful FLOP x matrix-pipe units per product / time.  The fp16 + MX kernel runs "
+                    "11.6 measured units (an e2m3 K=128 instruction takes 1.16 x a 16x16x32: profiles/r06_mx_mix.txt) and is bound by its LDS "
+                    "reads and 8-wave tile, not by the matrix pipes (profiles/r06_conv0_mx_whatif.txt)",
+            "kernel_ms": round(c0_ms, 3), "useful_TFLOPs": round(c0_tfl / c0_ms * 1e3, 1), "conv0_precision": shipped,
+            "conv0_ms_by_route": {k: round(v, 3) for k, v in c0.items()},
             "network_ms": round(net_ms, 3), "network_useful_TFLOPs": round(tfl / net_ms * 1e3, 1),
             "network_vs_fp32_mfma_peak": round(tfl / net_ms * 1e3 / 157.3, 3), "matrix_precision": net.matrix_precision,
             "view_streams": int(net.view_streams)}   # 2: the second half of the views on a stream of its own (CostRegNet3DGS.view_streams)

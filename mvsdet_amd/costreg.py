@@ -272,10 +272,11 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
         # eval route on bf16x3: "scl" = every layer hands the next one its output already cut into bf16 pieces (SCL / PSCL
         # forms: no fp32 round trip through a packing pass or a strided gather, inputs by LDS-DMA); "f32" = fp32 tensors
         # between the layers (round 3).  Same values bit for bit.
-        # conv0 (256 -> 64 on the fp32 variance volume, 41 % of a scene) in the eval chain: "bf16x3" = three bf16 products per
-        # fp32-equivalent product; "fp16mx" = one fp16 product + two block-scaled FP6 correction products (csrc/costreg_mx.h:
-        # 11.6 instead of 21 matrix-pipe units per 8 channels; logits 1-2e-5 from float64 instead of 2-4e-6, the bar is 1e-4)
-        self.conv0_precision = os.environ.get("MVSDET_CONV0_PRECISION", "bf16x3")
+        # conv0 (256 -> 64 on the fp32 variance volume, 41 % of a scene) in the eval chain: "fp16mx" (default) = one fp16 product + ONE
+        # block-scaled FP6 product that carries both correction terms (csrc/costreg_mx.h: 11.6 instead of 21 matrix-pipe units per 8
+        # channels; 3.9 against 4.3 ms; G8 logits 5e-6 from the reference's instead of 2e-6, G13 depth_coding 7e-5 instead of 5e-5:
+        # the bar is 1e-4); "bf16x3" = three bf16 products per fp32-equivalent product.  Training keeps bf16x3.
+        self.conv0_precision = os.environ.get("MVSDET_CONV0_PRECISION", "fp16mx")
         if self.conv0_precision not in ("bf16x3", "fp16mx"):
             raise ValueError(f"MVSDET_CONV0_PRECISION must be 'bf16x3' or 'fp16mx', got {self.conv0_precision!r}")
         self.skip_in_head = False   # True: conv0 + conv11(x) formed by the head while it stages its input (round 4's first form)
@@ -416,7 +417,9 @@ class CostRegNet3DGS(DerivedTensorsMixin, nn.Module):
             if self.matrix_precision == "bf16x3":
                 # the bf16 matrix cores with three-term split operands (csrc/costreg_bf16.hip): conv0 4.8 ms instead of 15.2
                 # on the fp32 MFMA; the stride-2 layers as sums over the 8 parity classes of their input
-                if conv.stride == (1, 1, 1):
+                if layer is self.conv0 and self.conv0_precision == "fp16mx":
+                    y = ops.conv3d_k3_fp16mx(x, ops.split_conv_weight_mx(conv.weight), scale, shift, True)   # as the layer-form chain
+                elif conv.stride == (1, 1, 1):
                     y = ops.conv3d_k3_bf16x3(x, ops.split_conv_weight(conv.weight), scale, shift, True)
                 else:
                     y = ops.conv3d_k3_s2_bf16x3(x, ops.split_conv_weight(conv.weight, 1), scale, shift, True)

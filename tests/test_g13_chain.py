@@ -274,18 +274,21 @@ def test_g13_composed_chain_on_the_framework_layers(oracle, monkeypatch):
 
 # --------------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("route", ["default", "one_stream_fp32"])
+@pytest.mark.parametrize("route", ["default", "conv0_bf16x3", "one_stream_fp32"])
 def test_g13_composed_chain_scene_driver_on_the_hip_kernels(gpu, oracle, record_property, route):
     """`MVSDetHotPath.forward_scene` with the package's CostRegNet3DGS, neck and head attached.  "default" is what ships and what
-    `with_cost_network` times: bf16x3 matrix route, two view streams, the detector tail on the side stream."""
+    `with_cost_network` times: conv0 on fp16 + MX FP6, the other layers on bf16x3, two view streams, the detector tail on the side
+    stream; "conv0_bf16x3": the same with conv0 on three bf16 products."""
     from mvsdet_amd.hotpath import MVSDetHotPath
     g = load_golden("g13_composed_chain")
     meta, feature = _scene(g)
     cost, neck, head = _modules(g, gpu)
     hp = MVSDetHotPath(list(g["n_voxels"]), list(g["voxel_size"]), list(g["near_far"]), 12, topk=3, cost_regularization=cost,
                        neck_3d=neck, bbox_head=head)
-    if route == "default":
-        assert cost.matrix_precision == "bf16x3" and cost.view_streams == 2
+    if route in ("default", "conv0_bf16x3"):
+        assert cost.matrix_precision == "bf16x3" and cost.view_streams == 2 and cost.conv0_precision == "fp16mx"
+        if route == "conv0_bf16x3":
+            cost.conv0_precision = "bf16x3"
         hp.overlap_detector = True
     else:
         cost.matrix_precision, cost.view_streams = "fp32", 1

@@ -108,9 +108,10 @@ def test_g8_with_conv0_on_the_mixed_format_route(gpu):
         shape = tuple(int(v) for v in g["in_shape"])
         x = torch.from_numpy(lcg_uniform(int(np.prod(shape)), int(g["input_seed"]))).reshape(shape).abs().to(gpu)
         net = net.to(gpu)
-        y3 = net(x)
-        net.conv0_precision = "fp16mx"
+        assert net.conv0_precision == "fp16mx"            # the default of the eval chain
         y = net(x)
+        net.conv0_precision = "bf16x3"
+        y3 = net(x)
     e, e3 = float(np.abs(y.cpu().numpy() - g["logits"]).max()), float(np.abs(y3.cpu().numpy() - g["logits"]).max())
     print(f"G8 logits: fp16mx conv0 {e:.2e}, bf16x3 {e3:.2e}")
     assert e <= 1e-4 and not torch.equal(y, y3)

@@ -100,21 +100,33 @@ def main():
     row(cw, "  same, detector on the side stream", c + ".detector_on_side_stream.ms_per_scene", None, None, c + ".scenes_per_sec_pipelined", "scenes/s")
     row(cw, "  CostRegNet_3DGS forward (eval)", c + ".cost_network_roofline.network_ms", c + ".cost_network_roofline.network_vs_fp32_mfma_peak",
         "fp32 MFMA peak 157 TFLOP/s, useful FLOP")
-    row(cw, "  conv0 256->64 (conv3d_k3_bf16x3_kernel)", c + ".cost_network_roofline.kernel_ms", c + ".cost_network_roofline.frac",
-        "dense bf16 2.5 PFLOP/s, 3 MFMAs per product")
+    prec = get(d, c + ".cost_network_roofline.conv0_precision") or "bf16x3"
+    row(cw, f"  conv0 256->64 ({'conv3d_k3_fp16mx_kernel' if prec == 'fp16mx' else 'conv3d_k3_bf16x3_kernel'})", c + ".cost_network_roofline.kernel_ms",
+        c + ".cost_network_roofline.frac", "dense bf16 2.5 PFLOP/s, " + ("11/7 matrix-pipe units per product" if prec == "fp16mx" else "3 MFMAs per product"))
+    by = get(d, c + ".cost_network_roofline.conv0_ms_by_route")
+    if by:
+        rows.append((cw, "  conv0 by route (the same tensor, same run)", "-", " / ".join(f"{k} {fmt(v)}" for k, v in by.items()), "-", "-",
+                     c + ".cost_network_roofline.conv0_ms_by_route"))
+    rt = get(d, c + ".detector_on_side_stream.route")
+    if rt:
+        rows.append((cw, "  route kept by overlap_detector = 'auto' (measured periods, ms)", rt, " / ".join(f"{k} {fmt(v)}" for k, v in (get(d, c + ".detector_on_side_stream.route_periods_ms") or {}).items()), "-", "-",
+                     c + ".detector_on_side_stream.route"))
     row(cw, "  IndoorImVoxelNeck forward", c + ".neck_roofline.kernel_ms", c + ".neck_roofline.frac", "dense bf16 2.5 PFLOP/s, 3 MFMAs per product")
     row(cw, "  neck + head per scene at batch 4", c + ".detector_batch4.ms_per_scene")
     for name, o in (get(d, "with_cost_network_test_shapes") or {}).items():
         rows.append((name, "chain, one stream", fmt(o.get("scenes_per_sec")) + " scenes/s", fmt(o.get("ms_per_scene")), "-", "-",
                      f"with_cost_network_test_shapes.{name}"))
-        rows.append((name, "  detector on the side stream", fmt(o.get("scenes_per_sec_pipelined")) + " scenes/s", fmt(o.get("ms_per_scene_pipelined")),
+        rows.append((name, "  detector on the side stream" + (f" (route {o['pipelined_route']})" if o.get("pipelined_route") else ""),
+                     fmt(o.get("scenes_per_sec_pipelined")) + " scenes/s", fmt(o.get("ms_per_scene_pipelined")),
                      "-", "-", f"with_cost_network_test_shapes.{name}"))
         rows.append((name, "  CostRegNet_3DGS forward", fmt(o.get("network_useful_TFLOPs")) + " useful TFLOP/s", fmt(o.get("network_ms")), "-", "-",
                      f"with_cost_network_test_shapes.{name}.network_ms"))
     t = "training"
     tw = get(d, t + ".workload")
-    row(tw, "training step, stand-in cost network", t + ".stand_in_cost_network.ms_per_step", None, None, t + ".stand_in_cost_network.scenes_per_sec", "scenes/s")
-    row(tw, "training step, real CostRegNet_3DGS", t + ".real_cost_network.ms_per_step", None, None, t + ".real_cost_network.scenes_per_sec", "scenes/s")
+    row(tw, "training step (AdamW + clip 35), stand-in cost network", t + ".stand_in_cost_network.ms_per_step", None, None, t + ".stand_in_cost_network.scenes_per_sec", "scenes/s")
+    row(tw, "  of it: clip_grad_norm_ with its host read + AdamW", t + ".stand_in_cost_network.optimizer_ms")
+    row(tw, "training step (AdamW + clip 35), real CostRegNet_3DGS (bf16x3 gradients: 1e-3 element-wise / 1e-4 in norm of the reference's)", t + ".real_cost_network.ms_per_step", None, None, t + ".real_cost_network.scenes_per_sec", "scenes/s")
+    row(tw, "  of it: clip_grad_norm_ with its host read + AdamW", t + ".real_cost_network.optimizer_ms")
     row(tw, "  plane_sweep_variance_bwd (whole operator)", t + ".roofline.backward_sweep.kernel_ms", t + ".roofline.backward_sweep.frac", "HBM 8 TB/s")
     row(tw, "  conv0 weight gradient (bf16x3)", t + ".roofline.weight_gradient_conv0.kernel_ms", t + ".roofline.weight_gradient_conv0.frac", "dense bf16 2.5 PFLOP/s")
     row(tw, "  stride-2 weight gradient (bf16x3)", t + ".roofline.weight_gradient_stride2.kernel_ms", t + ".roofline.weight_gradient_stride2.frac", "dense bf16 2.5 PFLOP/s")
