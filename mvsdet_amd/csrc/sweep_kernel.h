@@ -397,11 +397,16 @@ typedef float f2 __attribute__((ext_vector_type(2)));  // v_pk_fma_f32 / v_pk_mu
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
 
-// LDS bank swizzle of a staged box: box texel t (row-major) is kept in texel slot t ^ bit2(t).  The 8 pixel slots of a
-// wave-instruction read texels about 4 apart (each lane owns 4 consecutive pixels); unswizzled they would all start in
-// the same 128-byte half of the 64 banks (2-way conflicts on every tap), swizzled texels 4 apart alternate halves.
+// LDS bank swizzle of a staged box: box texel t (row-major) is kept in texel slot t ^ bit2(t).  A ds_read_b128 serves 16 lanes = two
+// pixel slots = two 128-byte texels per clock: conflict-free when the two lie in different halves of the 64 banks.  Pixel slots are
+// four pixels apart, their texels 3-5 apart: flipping bit 0 with bit 2 makes texels 4 apart alternate halves
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.42 -> 0.33; five other bit choices: 0.33-0.44, profiles/r06_sweep_swizzle_ab.txt).
 // An involution; the largest slot index of an n-texel box is n (hence kBoxPad).
+// The BACKWARD kernel keeps it (its LDS atomics pay for conflicts).  The FORWARD kernel does not (round 6): its LDS pipe is not what
+// bounds it, and the two vector operations per tap address cost more than the conflicts -- 1.0-1.2 % on the 32 x 4-tile shapes
+// (10.69 -> 10.59 ms at the headline, 29.9 -> 29.5 at the stress shape; no difference on the 16 x 8 tiles), the same bits.
 __device__ __forceinline__ int box_slot(int t) { return t ^ ((t >> 2) & 1); }
+__device__ __forceinline__ int fwd_box_slot(int t) { return t; }
 
 __host__ __device__ constexpr size_t sweep_lds_bytes(int K, int box_cap) { return (size_t)K * (box_cap + kBoxPad) * 128; }
 
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
         const int ntex = nc * nr;
         const float inv_nc = 1.0f / (float)nc;
         for (int q = wave; q * 8 <= ntex; q += 4) {
-            const int t = box_slot(q * 8 + ps);                 // the box texel kept in slot q*8 + ps
+            const int t = fwd_box_slot(q * 8 + ps);             // the box texel kept in slot q*8 + ps
             const int row = (int)(((float)t + 0.5f) * inv_nc);  // t / nc for t < 2^11 (never within rounding of an integer)
             const int col = t - row * nc;
             const float4* src = nb_img[j] + ((size_t)(by0 + row) * W + (bx0 + col)) * 8 + g;
@@ -751,10 +756,10 @@ __global__ __launch_bounds__(kThreads, (TW == 16 && K <= 2) ? 3 : 2) void plane_
             const int xa = clampi(tp.x0, lox, hix) - lox, xb = clampi(tp.x0 + 1, lox, hix) - lox;
             const int ya = (clampi(tp.y0, loy, hiy) - loy) * pitch, yb = (clampi(tp.y0 + 1, loy, hiy) - loy) * pitch;
             const int sbase = min(2 * p + qd, K - 1) * slot_f4 * 16;
-            const int do0 = l_staged ? box_slot(ya + xa) * 128 + sbase : (ya + xa) * 128;   // bytes: a texel of a slab is 128
-            const int do1 = l_staged ? box_slot(ya + xb) * 128 + sbase : (ya + xb) * 128;
-            const int do2 = l_staged ? box_slot(yb + xa) * 128 + sbase : (yb + xa) * 128;
-            const int do3 = l_staged ? box_slot(yb + xb) * 128 + sbase : (yb + xb) * 128;
+            const int do0 = l_staged ? fwd_box_slot(ya + xa) * 128 + sbase : (ya + xa) * 128;   // bytes: a texel of a slab is 128
+            const int do1 = l_staged ? fwd_box_slot(ya + xb) * 128 + sbase : (ya + xb) * 128;
+            const int do2 = l_staged ? fwd_box_slot(yb + xa) * 128 + sbase : (yb + xa) * 128;
+            const int do3 = l_staged ? fwd_box_slot(yb + xb) * 128 + sbase : (yb + xb) * 128;
             MVS_TAPS_OF(0)
             MVS_TAPS_OF(1)
         };
