@@ -38,7 +38,8 @@ struct Options {
     int conv_split_min_groups; // ... and a split keeps at least this many groups of 8 input channels (default 2: neck + head 2.39 -> 2.35 ms against 4)
     int bwd_groups;    // backward sweep: wave groups of a block that share its gradient images and split its planes; 0 = by the plane
                        // count (2 from 32 planes), 1 / 2 force
-    int conv_mx_th;    // fp16 + MX convolution (costreg_mx.h): tile rows; 0 / 8 = 4 x 8 x 16 on 8 waves (default), 12 = 4 x 12 x 16 on 12 waves
+    int conv_mx_th;    // fp16 + MX convolution (costreg_mx.h): 0 (default) = wave-specialised kernel (8 multiplying + 4 staging waves, 4 x 8 x 16 tiles);
+                       // 8 / 12 = every wave does everything on 4 x 8 x 16 (8 waves) / 4 x 12 x 16 (12 waves) tiles
     int conv_mfma16;   // 1 (default): the bf16x3 stride-1 convolution on v_mfma_f32_16x16x32_bf16 (conv0 of the cost network 5.37 -> 4.91 ms:
                        // the chip holds a higher clock on this shape); 0: 32x32x16.  Weights must be split under the same setting.
 };

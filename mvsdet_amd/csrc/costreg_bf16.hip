@@ -2149,10 +2149,12 @@ extern "C" int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_st
     MVS_REQUIRE(N > 0 && Cin > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N=%d Cin=%d D=%d H=%d W=%d", name, N, Cin, D, H, W);
     MVS_REQUIRE(Cout > 0 && Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", name, Cout);
     MVS_REQUIRE((((uintptr_t)weight_split_mx | (uintptr_t)out_scl | (uintptr_t)out_pscl) & 15u) == 0, "%s: SCL buffers and weights must be 16-byte aligned", name);
-    // 4 x 8 x 16 tiles on 8 waves: the kernel wants ~190 registers per lane, which two waves per SIMD have (256) and the three of a
-    // 4 x 12 x 16 tile do not (168: 6.2 against 5.4 ms at conv0 with the spills; option "conv_mx_th" = 12 keeps that form selectable)
+    // option "conv_mx_th": 0 (default) = the wave-specialised kernel (4 x 8 x 16 tiles: 8 multiplying + 4 staging waves: 3.89 ms at conv0);
+    // 8 = every wave does everything on 4 x 8 x 16 tiles (8 waves: the kernel wants ~190 registers per lane, which two waves per SIMD
+    // have: 4.02); 12 = the same on 4 x 12 x 16 tiles (12 waves, 168 registers: spills, 4.1-4.7).  Same values bit for bit.
     BfPlan p = bf_plan(D, H, W);
-    if (options().conv_mx_th != 12) { p.th = 8; p.tiles_h = (H + 7) / 8; }
+    const int mx_form = options().conv_mx_th;
+    if (mx_form != 12) { p.th = 8; p.tiles_h = (H + 7) / 8; }
     const int C8 = (Cin + 7) / 8;
     const size_t vol = (size_t)D * H * W;
     MVS_REQUIRE((long long)N * (Cout / 64) <= 65535 && p.tiles_d <= 65535, "%s: N*Cout/64 or D too large", name);
@@ -2175,7 +2177,16 @@ extern "C" int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_st
         hipLaunchKernelGGL(k, grid, dim3(4 * TH_ * 16), lds, st, x, sN, sC, sD, sH, Cin, static_cast<const uint4*>(weight_split_mx), \
                            scale, shift, dst, C8, Cout, D, H, W, p.tiles_w, relu, xcd_map);                                  \
     }
-    if (p.th == 12) MVS_MX_CASE(12) else MVS_MX_CASE(8)
+    if (mx_form == 0) {
+        auto* k = conv3d_k3_fp16mx_ws_kernel<4, 8>;
+        const size_t lds = ((size_t)2 * 2 * bf_in_slots(4, 8, kBfW) + 2 * kMxSlots * 64) * 16;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);
+            return MVSDET_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k, grid, dim3(4 * 8 * 16 + 256), lds, st, x, sN, sC, sD, sH, Cin, static_cast<const uint4*>(weight_split_mx), scale,
+                           shift, dst, C8, Cout, D, H, W, p.tiles_w, relu, xcd_map);
+    } else if (p.th == 12) MVS_MX_CASE(12) else MVS_MX_CASE(8)
 #undef MVS_MX_CASE
     MVS_LAUNCH_CHECK(name);
     return MVSDET_OK;

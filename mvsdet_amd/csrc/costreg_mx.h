@@ -229,6 +229,10 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
                     gb[8 * v + j] = (f - hf) * 2048.0f;          // exact: on the scale 2^(e1 - 11)
                 }
             }
+            // (wait states between the vector instructions that write the 32 source registers and the conversion that reads them as two
+            // 16-register tuples: without them the FIRST conversion of a thread read stale registers in the wave-specialised kernel --
+            // a hazard the compiler does not cover for this instruction)
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(ga), "+v"(gb));
             const mx_u32x6 q = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ga, gb, sdiv);   // element 2 i = ga[i], 2 i + 1 = gb[i]
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
@@ -347,8 +351,12 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
 #endif
     };
 
-    // ---- pipeline: per channel group two sub-stages (k-steps 0..3 + MX groups 0, 1; k-steps 4..6 + MX groups 2, 3)
+    // ---- pipeline: per channel group two sub-stages (k-steps 0..3 + MX groups 0, 1; k-steps 4..6 + MX groups 2, 3).  The fp32 values of
+    // stage c + 2 are requested as soon as stage c + 1 has been cut (the registers are free again) and are waited for a whole stage
+    // later: with one block of 8-12 waves per CU, all at the same point of the same stage, nothing else would cover that latency.
     int e_cur = -100, s_acc = 0;      // s_acc: the accumulators hold sums of (x * 2^-s_acc) * w
+    constexpr int kFetchLoads = NV * 8;
+    static_assert(kFetchLoads <= 48, "the counted wait below");
     if (C8 > 0) {
         fetch_f32(0);
         dma_weights(0, 0, 0);
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
         e_cur = stage_exp(0);
         stage_cut(0, e_cur);
         s_acc = stage_shift(e_cur);
+        if (C8 > 1) fetch_f32(1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
     for (int c8 = 0; c8 < C8; ++c8) {
@@ -368,16 +377,17 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
 #pragma unroll
         for (int cg = 0; cg < CGN; ++cg) asm volatile("" : "+v"(vb16[cg]));
         if constexpr (kTight) asm volatile("" : "+v"(ttab));
-        // sub-stage 0
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's weight DMAs of the sub-stage have landed
+        // sub-stage 0: this wave's weight DMAs of the sub-stage have landed -- they are OLDER than the fetch of the next stage's values
+        // (requested behind them), which stays in flight: a counted wait
+        if (more) __builtin_amdgcn_s_waitcnt(0x0f70 | (kFetchLoads & 15) | ((kFetchLoads >> 4) << 14));   // vmcnt(kFetchLoads)
+        else __builtin_amdgcn_s_waitcnt(0x0f70);                                                          // vmcnt(0)
         __builtin_amdgcn_s_barrier();         // everybody's have, the stage buffer is complete, the other buffers are free
         dma_weights(c8, 1, 1);
-        if (more) fetch_f32(c8 + 1);
         MX_FENCE();
         compute(std::integral_constant<int, 0>{}, ibuf, 0, e_cur);
         MX_FENCE();
         // sub-stage 1
-        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the sub-stage's weights and the next stage's values
         if (more) {
             publish_amax(ibuf ^ 1);
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -388,6 +398,7 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
         if (more) {
             e_next = stage_exp(ibuf ^ 1);
             stage_cut(ibuf ^ 1, e_next);
+            if (c8 + 2 < C8) fetch_f32(c8 + 2);   // behind the weight DMAs just issued (the counted wait above relies on that order)
         }
         MX_FENCE();   // the cut's temporaries and the products' fragments are not to be live together
         compute(std::integral_constant<int, 1>{}, ibuf, 1, e_cur);
@@ -406,6 +417,314 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
     // groups 2q and 2q+1 together give a lane the eight consecutive channels 32 q + 8 kg .. + 7)
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
     const float up = __builtin_bit_cast(float, (unsigned)(127 + s_acc) << 23);   // 2^s_acc
+#pragma unroll
+    for (int cg = 0; cg < CGN; ++cg) {
+        const int g = CGN * wave + cg;
+        const int d = d0 + g / (TH / RG16), h = h0 + RG16 * (g % (TH / RG16)) + col16 / TW, w = w0 + col16 % TW;
+        if (d >= D || h >= H || w >= W) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float sc[8], sh[8], v[8];
+            const int o0 = ob64 * 64 + 32 * q + 8 * kg;
+            const size_t idx0 = ((size_t)n * Cout + o0) * vol + (size_t)d * plane + (size_t)h * W + w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sc[j] = scale ? scale[o0 + j] : 1.0f;
+                sh[j] = scale ? shift[o0 + j] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = (j < 4 ? acc[2 * q][cg][j & 3] : acc[2 * q + 1][cg][j & 3]) * up;
+                if (scale) v[j] = fmaf(v[j], sc[j], sh[j]);
+                if (relu) v[j] = fmaxf(v[j], 0.0f);
+                if (out) out[idx0 + (size_t)j * vol] = v[j];
+            }
+            if (dst.scl || dst.pscl) bf_store_units(dst, v, n, Cout / 8, ob64 * 8 + 4 * q + kg, d, h, w);
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------------------------------
+// The same convolution with the waves SPECIALISED (round 6, late): 8 consumer waves multiply (a 4 x 8 x 16 tile: 64 voxels x 64
+// channels each), 4 producer waves fetch, scale, cut and stage the next channel group and issue every weight DMA.  In the kernel above
+// all waves of the one block a CU holds walk through the same phases together -- fetch / cut (vector pipe, LDS writes), products
+// (matrix pipes, LDS reads) -- so the pipes take turns instead of overlapping; here the producers' phase runs BESIDE the consumers'.
+// One block-wide barrier per sub-stage.  The consumers hold no input registers and no cut temporaries: they fit the 168 registers a
+// lane has at 12 waves.  Same LDS image, same weight image, same values bit for bit.
+//
+//   phase A of channel group c (sub-stage 0)                          phase B (sub-stage 1)
+//   consumers: products of k-steps 0..3 + MX groups 0, 1              products of k-steps 4..6 + MX groups 2, 3
+//   producers: DMA weights (c, 1); the values of c + 1 have           DMA weights (c + 1, 0); stage exponent of c + 1; cut and write
+//              arrived: wave maxima -> the spare slots                its stage buffer; request the values of c + 2
+template <int TD, int TH>
+__global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel(
+    const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
+    const float* __restrict__ scale, const float* __restrict__ shift, BfOut dst, int C8, int Cout, int D, int H, int W, int tiles_w,
+    int relu, int xcd_map) {
+    constexpr int TW = 16, CGN = 4;
+    constexpr int NCW = TD * TH * TW / 64;                 // consumer waves
+    constexpr int NPW = 4, NPT = 64 * NPW;                 // producer waves / threads
+    constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+    constexpr int NVOX = HD * HH * HW;
+    constexpr int INS = bf_in_slots(TD, TH, TW);
+    static_assert(INS - NVOX >= 2, "the stage's spare slots hold the producer waves' maxima");
+    constexpr int kWSlots = kMxSlots * 64;
+    constexpr int NV = (NVOX + NPT - 1) / NPT;             // halo voxels per producer thread
+    constexpr int NVP = (NV + 1) / 2;
+    constexpr int kFetchLoads = NV * 8;
+    static_assert(kFetchLoads <= 63, "the counted wait");
+    extern __shared__ uint4 s_mx[];
+    constexpr int STAGE = 2 * INS;
+    uint4* s_in = s_mx;
+    uint4* s_w = s_mx + 2 * STAGE;
+    float* __restrict__ out = dst.f32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= NCW;                     // wave-uniform
+    unsigned bx, by, bz;
+    xcd_block_id(xcd_map, bx, by, bz);
+    const int bw = bx % tiles_w, bh = bx / tiles_w;
+    const int nob = Cout / 64;
+    const int n = bz / nob, ob64 = bz % nob;
+    const int w0 = bw * TW, h0 = bh * TH, d0 = by * TD;
+    auto stage_shift = [](int e1) -> int { return e1 > 12 ? e1 - 12 : 0; };
+    auto stage_exp = [&](int buf) -> int {
+        const float* spare = reinterpret_cast<const float*>(s_in + (size_t)buf * STAGE + NVOX);
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) a = fmaxf(a, spare[i]);
+        return __builtin_amdgcn_readfirstlane(mx_block_exp(a));
+    };
+
+    if (producer) {
+        // =============================================================================================== producers
+        const int ptid = tid - 64 * NCW, pwave = wave - NCW;
+        unsigned f_off[NV];
+        float f_reg[NV][8];
+        const float* xfn = xf + (size_t)n * sN;
+        const unsigned long long span = ((unsigned long long)(Cin - 1) * (unsigned long long)sC + (unsigned long long)(D - 1) * sD +
+                                         (unsigned long long)(H - 1) * sH + W) * 4ull;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xfn), 0, (int)(unsigned)span, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int slot = ptid + k * NPT;
+            const int dz = slot / (HH * HW), r = slot - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
+            const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
+            const bool ok = slot < NVOX && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
+            f_off[k] = ok ? (unsigned)(((long long)d * sD + (long long)h * sH + w) * 4) : 0xfffffff0u;
+        }
+        const unsigned sC4 = (unsigned)(sC * 4);
+        auto fetch_f32 = [&](int c8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c8 * 8 + j;
+                const unsigned soff = (c < Cin ? (unsigned)c : (unsigned)Cin) * sC4;
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    f_reg[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, f_off[k], (int)soff, 0));
+            }
+        };
+        auto publish_amax = [&](int buf) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a = fmaxf(a, fabsf(f_reg[k][j]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a = fmaxf(a, __shfl_xor(a, off, 64));
+            float* spare = reinterpret_cast<float*>(s_in + (size_t)buf * STAGE + NVOX);
+            if (lane == 0) spare[pwave] = a;
+        };
+        auto stage_cut = [&](int buf, int e1) {
+            uint4* hi_s = s_in + (size_t)buf * STAGE;
+            uint4* q_s = hi_s + INS;
+            const int S = stage_shift(e1);
+            const float down = __builtin_bit_cast(float, (unsigned)(127 - S) << 23);
+            const float sdiv = __builtin_bit_cast(float, (unsigned)(e1 - S + 127) << 23);
+#pragma unroll
+            for (int kp = 0; kp < NVP; ++kp) {
+                mx_f32x16 ga, gb;
+                unsigned hw[2][4];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int k = 2 * kp + v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = (k < NV ? f_reg[k < NV ? k : 0][j] : 0.0f) * down;
+                        const _Float16 h = (_Float16)f;
+                        const float hf = (float)h;
+                        const unsigned hb = __builtin_bit_cast(unsigned short, h);
+                        if (j & 1) hw[v][j >> 1] |= hb << 16; else hw[v][j >> 1] = hb;
+                        ga[8 * v + j] = hf;
+                        gb[8 * v + j] = (f - hf) * 2048.0f;
+                    }
+                }
+                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(ga), "+v"(gb));   // (see the kernel above)
+                const mx_u32x6 q = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ga, gb, sdiv);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int k = 2 * kp + v, slot = ptid + k * NPT;
+                    if (k < NV && slot < NVOX) {
+                        hi_s[slot] = make_uint4(hw[v][0], hw[v][1], hw[v][2], hw[v][3]);
+                        q_s[slot] = make_uint4(q[3 * v], q[3 * v + 1], q[3 * v + 2], 0u);
+                    }
+                }
+            }
+        };
+        const uint4* wn = wq + (size_t)ob64 * C8 * (2 * kWSlots);
+        auto dma_weights = [&](int c8, int s, int buf) {
+            const uint4* src0 = wn + ((size_t)c8 * 2 + s) * kWSlots + lane;
+            for (int i = pwave; i < kMxSlots; i += NPW) {
+                uint4* dstp = s_w + (size_t)buf * kWSlots + i * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 64),
+                                                 (__attribute__((address_space(3))) void*)dstp, 16, 0, 0);
+            }
+        };
+        // prologue: stage 0 and the weights of its first sub-stage; the values of stage 1 requested
+        if (C8 > 0) {
+            dma_weights(0, 0, 0);
+            fetch_f32(0);
+            publish_amax(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+        __builtin_amdgcn_s_barrier();                                  // P1: the maxima of stage 0
+        if (C8 > 0) {
+            stage_cut(0, stage_exp(0));
+            if (C8 > 1) fetch_f32(1);
+            if (C8 > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (kFetchLoads & 15) | ((kFetchLoads >> 4) << 14));   // the DMAs (older) have landed
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+        __builtin_amdgcn_s_barrier();                                  // P2: stage 0 complete, weights (0, 0) in buffer 0
+        for (int c8 = 0; c8 < C8; ++c8) {
+            const int ibuf = c8 & 1;
+            const bool more = c8 + 1 < C8;
+            // phase A
+            dma_weights(c8, 1, 1);
+            if (more) {
+                __builtin_amdgcn_s_waitcnt(0x0f70 | (kMxSlots / NPW));   // vmcnt(8): this wave's 8 DMAs just issued may fly, the values of c + 1 are in
+                publish_amax(ibuf ^ 1);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);                        // the DMAs have landed
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();                              // end of A
+            // phase B
+            if (more) {
+                dma_weights(c8 + 1, 0, 0);
+                stage_cut(ibuf ^ 1, stage_exp(ibuf ^ 1));
+                if (c8 + 2 < C8) {
+                    fetch_f32(c8 + 2);
+                    __builtin_amdgcn_s_waitcnt(0x0f70 | (kFetchLoads & 15) | ((kFetchLoads >> 4) << 14));
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            }
+            __builtin_amdgcn_s_barrier();                              // end of B
+        }
+        return;
+    }
+
+    // =================================================================================================== consumers
+    constexpr int RG16 = 16 / TW > 0 ? 16 / TW : 1;
+    const int col16 = lane & 15, kg = lane >> 4;
+    int vb16[CGN], toffs[8];
+#pragma unroll
+    for (int cg = 0; cg < CGN; ++cg) {
+        const int g = CGN * wave + cg;
+        const int dz = g / (TH / RG16), hy = RG16 * (g % (TH / RG16)) + col16 / TW;
+        vb16[cg] = (dz * HH + hy) * HW + col16 % TW;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int k7 = ks < 7 ? ks : 6;
+        toffs[ks] = kg == 0 ? bf_tap_off<HH, HW>(4 * k7) : kg == 1 ? bf_tap_off<HH, HW>(4 * k7 + 1)
+                  : kg == 2 ? bf_tap_off<HH, HW>(4 * k7 + 2) : bf_tap_off<HH, HW>(4 * k7 + 3);
+    }
+    mx_f32x4 acc[4][CGN];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < CGN; ++b) acc[a][b] = (mx_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    auto compute = [&](auto sc, int ibuf, int wbuf, int e1) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int nks = s == 0 ? 4 : 3;
+        const uint4* hi_s = s_in + (size_t)ibuf * STAGE;
+        const uint4* q_s = hi_s + INS;
+        const uint4* ain = s_w + (size_t)wbuf * kWSlots + lane;
+        const int sb = e1 - stage_shift(e1) + 127;
+#pragma unroll
+        for (int kl = 0; kl < nks; ++kl) {
+            const int toff = toffs[4 * s + kl];
+            f16x8 A[4], B[CGN];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) A[a] = __builtin_bit_cast(f16x8, ain[(kl * 4 + a) * 64]);
+#pragma unroll
+            for (int b = 0; b < CGN; ++b) B[b] = __builtin_bit_cast(f16x8, hi_s[vb16[b] + toff]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < CGN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a], B[b], acc[a][b], 0, 0, 0);
+            if (kl & 1) MX_FENCE();   // 168 registers: after every second k-step nothing of the next pair has been fetched ahead
+        }
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl) {
+            mx_i32x8 FB[CGN];
+            const int t0 = toffs[4 * s + 2 * gl], t1 = toffs[4 * s + 2 * gl + 1];
+#pragma unroll
+            for (int b = 0; b < CGN; ++b) {
+                const uint4 u0 = q_s[vb16[b] + t0], u1 = q_s[vb16[b] + t1];
+                FB[b] = (mx_i32x8){(int)u0.x, (int)u0.y, (int)u0.z, (int)u1.x, (int)u1.y, (int)u1.z, 0, 0};
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const uint4 lo = ain[(16 + 2 * (4 * gl + a)) * 64], hi = ain[(16 + 2 * (4 * gl + a) + 1) * 64];
+                const mx_i32x8 FA = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
+                const int sa = (int)hi.z;
+#pragma unroll
+                for (int b = 0; b < CGN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(FA, FB[b], acc[a][b], 2, 2, 0, sa, 0, sb);
+            }
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                              "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
+                              "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+            MX_FENCE();
+        }
+        // (pinned: see the kernel above)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                          "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
+                          "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+    };
+
+    int s_acc = 0;
+    __builtin_amdgcn_s_barrier();                                      // P1
+    __builtin_amdgcn_s_barrier();                                      // P2
+    if (C8 > 0) s_acc = stage_shift(stage_exp(0));
+    for (int c8 = 0; c8 < C8; ++c8) {
+        const int ibuf = c8 & 1;
+#pragma unroll
+        for (int cg = 0; cg < CGN; ++cg) asm volatile("" : "+v"(vb16[cg]));
+        const int e_cur = stage_exp(ibuf);
+        if (stage_shift(e_cur) != s_acc) {   // block-uniform and, for inputs below 32768, never taken
+            const float f = __builtin_bit_cast(float, (unsigned)(127 + s_acc - stage_shift(e_cur)) << 23);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < CGN; ++b) acc[a][b] *= f;
+            s_acc = stage_shift(e_cur);
+        }
+        compute(std::integral_constant<int, 0>{}, ibuf, 0, e_cur);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();                                  // end of A: every consumer is done with weight buffer 0
+        compute(std::integral_constant<int, 1>{}, ibuf, 1, e_cur);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();                                  // end of B: done with weight buffer 1 and stage buffer ibuf
+    }
+
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+    const float up = __builtin_bit_cast(float, (unsigned)(127 + s_acc) << 23);
 #pragma unroll
     for (int cg = 0; cg < CGN; ++cg) {
         const int g = CGN * wave + cg;

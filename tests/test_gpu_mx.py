@@ -98,6 +98,25 @@ def test_strided_view_and_values_beyond_fp16(gpu):
         ops.conv3d_k3_fp16mx(view, wq[:, :1], None, None, False)
 
 
+def test_the_three_forms_of_the_kernel_give_the_same_bits(gpu):
+    """Library option conv_mx_th: 0 = the wave-specialised kernel (default), 8 / 12 = every wave does everything on 4 x 8 x 16 /
+    4 x 12 x 16 tiles: the same sums in the same order."""
+    from mvsdet_amd import _lib, ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand((2, 40, 5, 13, 35), generator=g).to(gpu)
+    w = (torch.randn((64, 40, 3, 3, 3), generator=g) * 0.05).to(gpu)
+    wq = ops.split_conv_weight_mx(w)
+    was = _lib.get_option("conv_mx_th")
+    try:
+        outs = []
+        for form in (0, 8, 12):
+            _lib.set_option("conv_mx_th", form)
+            outs.append(ops.conv3d_k3_fp16mx(x, wq, None, None, True))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and float(outs[0].abs().max()) > 0
+    finally:
+        _lib.set_option("conv_mx_th", was)
+
+
 def test_g8_with_conv0_on_the_mixed_format_route(gpu):
     """G8 (the REFERENCE CostRegNet_3DGS's logits, mvs_models/mvsnet.py:73-113) with conv0 on fp16 + MX FP6: 1e-4."""
     from mvsdet_amd.costreg import CostRegNet3DGS
