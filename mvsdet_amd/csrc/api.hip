@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void store_pattern_kernel(OutT* __restric
 
 using namespace mvsdet;
 
-extern "C" int mvsdet_version(void) { return 5004; }
+extern "C" int mvsdet_version(void) { return 6001; }
 
 template <typename OutT>
 static int store_pattern_probe(OutT* var, int N, int C, int D, int H, int W, int out_w_pitch, int tile_w, int planes_per_block,

@@ -49,7 +49,7 @@ def test_binding_table_matches_header():
 
 
 def test_host_only_entry_points(lib):
-    assert lib.mvsdet_version() == 5004
+    assert lib.mvsdet_version() == 6001
     # packed layout: ceil(C/32) slabs of 32 floats (128 B) per pixel
     assert lib.mvsdet_packed_bytes(40, 256, 60, 80) == 40 * 60 * 80 * 256 * 4
     assert lib.mvsdet_packed_bytes(3, 5, 4, 4) == 3 * 16 * 32 * 4
