@@ -42,6 +42,11 @@ struct Options {
                        // 8 / 12 = every wave does everything on 4 x 8 x 16 (8 waves) / 4 x 12 x 16 (12 waves) tiles
     int conv_mfma16;   // 1 (default): the bf16x3 stride-1 convolution on v_mfma_f32_16x16x32_bf16 (conv0 of the cost network 5.37 -> 4.91 ms:
                        // the chip holds a higher clock on this shape); 0: 32x32x16.  Weights must be split under the same setting.
+    int convT_persist; // transposed bf16x3 convolution, all-classes form with a skip tensor: 0 (default) = one block per (tile, 32 channels);
+                       // 1 = the persistent kernel (convt_persist.h: one block per CU, an item's stores behind the next item's
+                       // multiplications; the same bits, not faster: profiles/r06_convt_persist.txt); n >= 8: persistent on n blocks
+    int convT_whatif;  // measurement only (WRONG results): bit 0 = the persistent kernel's skip-tensor loads, bit 1 = its stores go beyond the
+                       // buffer descriptors (issued, dropped)
 };
 Options& options();
 

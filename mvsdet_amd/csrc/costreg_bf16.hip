@@ -1474,6 +1474,8 @@ __global__ __launch_bounds__(TD * TH * TW * 2) void convT3d_k3_s2_bf16x3_fused_k
     }
 }
 
+#include "convt_persist.h"   // the same layer as a persistent kernel: the stores of item i behind the multiplications of item i + 1
+
 // ONE launch for the four (PD, PH) classes: class = blockIdx.x & 3, so the four blocks that read the same input tile are
 // dispatched together (the tile's second to fourth reads hit L2) and the grid has one tail instead of four.
 template <int TD, int TH, int TW, int CG>
@@ -2066,6 +2068,34 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
                            (int)(options().conv_xcd != 0 && ((long long)fgrid.x * fgrid.y * fgrid.z) % 8 == 0 &&
                                  (long long)fgrid.x * fgrid.y * fgrid.z >= 64),
                            static_cast<double2*>(stats), stats_pivot);
+    } else
+    if (t38 && residual && options().convT_cg == 0 && options().convT_persist != 0 && C8 % 4 == 0 && C8 >= 12 && Cout <= kCtpMaxCout && !(out && out_scl) &&
+        (unsigned long long)N * Cout * 8ull * D * H * W * 4ull < 0x7ffffff0ull && (!out_scl || 2ull * dst.piece * 16ull < 0x7ffffff0ull)) {
+        // persistent form (convt_persist.h): one block per CU, the epilogue of an item behind the loop of the next
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) {
+            set_error("%s: cannot read the device's CU count", name);
+            return MVSDET_ERR_HIP;
+        }
+        const unsigned G = (unsigned)(options().convT_persist > 1 ? options().convT_persist : cus) & ~7u;
+        const size_t lds = ctp_lds_bytes();
+        const unsigned out_bytes = out_scl ? (unsigned)(2ull * dst.piece * 16ull) : (unsigned)((unsigned long long)N * Cout * 8ull * D * H * W * 4ull);
+        const unsigned res_bytes = (unsigned)((unsigned long long)N * Cout * 8ull * D * H * W * 4ull);
+#define MVS_CTP_CASE(SCL_, RES_)                                                                                             \
+    {                                                                                                                        \
+        auto* k = convT3d_k3_s2_bf16x3_persist_kernel<SCL_, RES_>;                                                           \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
+            hipSuccess) {                                                                                                    \
+            set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", name);                                   \
+            return MVSDET_ERR_HIP;                                                                                           \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(k, dim3(G), dim3(768), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split), \
+                           scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, tiles_h, tiles_d, N, relu, \
+                           out_bytes, res_bytes, (int)(options().conv_xcd != 0), options().convT_whatif);                                            \
+    }
+        if (out_scl) MVS_CTP_CASE(true, true)
+        else MVS_CTP_CASE(false, true)
+#undef MVS_CTP_CASE
     } else
     if (t38 && options().convT_cg != 1 && options().convT_cg != 2) {
         const size_t lds = ctf_lds_bytes(3, 16, 8);

@@ -455,3 +455,32 @@ def test_conv3d_k3_dw_bf16x3_needs_rows_of_whole_float4(gpu):
     x = torch.randn(1, 8, 2, 4, 18, device=gpu)
     with pytest.raises(ValueError, match="multiple of 4"):
         ops.conv3d_k3_dw(x, x.clone(), 0, 1, True)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,out", [(3, 128, 64, 6, 30, 40, "f32"), (2, 256, 128, 3, 15, 20, "scl"), (3, 128, 64, 5, 13, 21, "f32"),
+                                                   (2, 96, 128, 4, 20, 9, "scl"), (1, 96, 64, 1, 1, 1, "f32")])
+def test_transposed_persistent_kernel_same_bits(gpu, N, Cin, Cout, D, H, W, out):
+    """The transposed layer with a skip tensor as a persistent kernel (csrc/convt_persist.h, option convT_persist: one block per CU
+    walks the tiles, an item's stores and skip-tensor loads behind the next item's multiplications) against the shipped
+    one-block-per-(tile, 32 channels) kernel: every accumulator sums the same (channel group, tap pair) sequence and the epilogue
+    is the same arithmetic -- equal bits, at conv9 / conv11 of the cost network, at ragged extents (lanes and whole waves outside
+    the volume go beyond the buffer descriptors, whose sizes are the result's) and on fewer blocks than tiles and more.  The whole SCL
+    buffer is compared, zero border included."""
+    from mvsdet_amd import _lib, ops
+    g = torch.Generator().manual_seed(Cin + W)
+    x = torch.randn(N, Cin, D, H, W, generator=g).to(gpu)
+    wq = ops.split_conv_weight((torch.randn(Cin, Cout, 3, 3, 3, generator=g) / (27 * Cin / 8) ** 0.5).to(gpu), 2)
+    scale, shift = (torch.rand(Cout, generator=g) + 0.5).to(gpu), (torch.randn(Cout, generator=g) * 0.1).to(gpu)
+    res = torch.randn(N, Cout, 2 * D, 2 * H, 2 * W, generator=g).to(gpu)
+    xs = ops.scl_pack(x)
+    outs = []
+    try:
+        for persist in (0, 1, 8, 1024):
+            _lib.set_option("convT_persist", persist)
+            y = ops.convT3d_k3_s2_bf16x3(xs, wq, scale, shift, res, True, outputs=(out,))
+            outs.append(y.clone() if out == "f32" else y.data.view(torch.int16).clone())
+    finally:
+        _lib.set_option("convT_persist", 0)
+    assert float(outs[0].float().abs().max()) > 0
+    for other in outs[1:]:
+        assert torch.equal(outs[0], other)
