@@ -629,18 +629,19 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
     // =================================================================================================== consumers
     constexpr int RG16 = 16 / TW > 0 ? 16 / TW : 1;
     const int col16 = lane & 15, kg = lane >> 4;
-    int vb16[CGN], toffs[8];
+    // A wave's four column groups are four consecutive h-rows of the tile (TW = 16: one row per group; TH = 8: groups 4 wave .. + 3 never
+    // wrap into the next plane): their fragments sit HW slots apart -- ONE lane address per k-step, the group in the instruction's offset.
+    static_assert(TW == 16 && TH == 8 && CGN == 4, "the column groups of a wave are consecutive rows");
+    int badr[7];   // byte offset, inside a stage buffer, of the lane's first voxel + the tap its lane group reads at k-step ks
+    {
+        const int g = CGN * wave;
+        const int vb0 = ((g / TH) * HH + g % TH) * HW + col16;
 #pragma unroll
-    for (int cg = 0; cg < CGN; ++cg) {
-        const int g = CGN * wave + cg;
-        const int dz = g / (TH / RG16), hy = RG16 * (g % (TH / RG16)) + col16 / TW;
-        vb16[cg] = (dz * HH + hy) * HW + col16 % TW;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const int k7 = ks < 7 ? ks : 6;
-        toffs[ks] = kg == 0 ? bf_tap_off<HH, HW>(4 * k7) : kg == 1 ? bf_tap_off<HH, HW>(4 * k7 + 1)
-                  : kg == 2 ? bf_tap_off<HH, HW>(4 * k7 + 2) : bf_tap_off<HH, HW>(4 * k7 + 3);
+        for (int ks = 0; ks < 7; ++ks) {
+            const int toff = kg == 0 ? bf_tap_off<HH, HW>(4 * ks) : kg == 1 ? bf_tap_off<HH, HW>(4 * ks + 1)
+                           : kg == 2 ? bf_tap_off<HH, HW>(4 * ks + 2) : bf_tap_off<HH, HW>(4 * ks + 3);
+            badr[ks] = (vb0 + toff) * 16;
+        }
     }
     mx_f32x4 acc[4][CGN];
 #pragma unroll
@@ -648,54 +649,92 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
 #pragma unroll
         for (int b = 0; b < CGN; ++b) acc[a][b] = (mx_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+    // The products of one sub-stage, SOFTWARE-PIPELINED by hand: the fragments of step i + 1 are requested before the 16 matrix
+    // instructions of step i are issued (two fragment sets; 256 - 300 clocks of cover), so that a consumer wave waits for LDS once per
+    // sub-stage (behind the barrier) instead of before every group of four instructions -- with two such waves per SIMD the matrix
+    // pipe was 0.39 busy.  The fences keep the compiler from re-ordering the requests behind the products; the accumulation order of
+    // every accumulator is unchanged (fp16 steps, then the MX groups): the same bits.
     auto compute = [&](auto sc, int ibuf, int wbuf, int e1) {
         constexpr int s = decltype(sc)::value;
         constexpr int nks = s == 0 ? 4 : 3;
-        const uint4* hi_s = s_in + (size_t)ibuf * STAGE;
-        const uint4* q_s = hi_s + INS;
+        const char* const sbase = reinterpret_cast<const char*>(s_in + (size_t)ibuf * STAGE);
         const uint4* ain = s_w + (size_t)wbuf * kWSlots + lane;
         const int sb = e1 - stage_shift(e1) + 127;
+        f16x8 A[4], B[2][CGN];
+        mx_i32x8 FB[CGN], FA[2];
+        int sa[2];
+        auto load_a = [&](int kl, int a0) __attribute__((always_inline)) {   // weight fragments a0, a0 + 1 of k-step kl
 #pragma unroll
-        for (int kl = 0; kl < nks; ++kl) {
-            const int toff = toffs[4 * s + kl];
-            f16x8 A[4], B[CGN];
+            for (int a = a0; a < a0 + 2; ++a) A[a] = __builtin_bit_cast(f16x8, ain[(kl * 4 + a) * 64]);
+        };
+        auto load_b = [&](int kl, int set) __attribute__((always_inline)) {
+            const char* const p = sbase + badr[4 * s + kl];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) A[a] = __builtin_bit_cast(f16x8, ain[(kl * 4 + a) * 64]);
-#pragma unroll
-            for (int b = 0; b < CGN; ++b) B[b] = __builtin_bit_cast(f16x8, hi_s[vb16[b] + toff]);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < CGN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a], B[b], acc[a][b], 0, 0, 0);
-            if (kl & 1) MX_FENCE();   // 168 registers: after every second k-step nothing of the next pair has been fetched ahead
-        }
-#pragma unroll
-        for (int gl = 0; gl < 2; ++gl) {
-            mx_i32x8 FB[CGN];
-            const int t0 = toffs[4 * s + 2 * gl], t1 = toffs[4 * s + 2 * gl + 1];
+            for (int b = 0; b < CGN; ++b) B[set][b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p + b * (HW * 16)));
+        };
+        auto load_fb = [&](int gl) __attribute__((always_inline)) {
+            // (sub-stage 1 has three k-steps: its second MX group pairs taps 24 .. 27 with themselves, as the weight image does)
+            const char* const p0 = sbase + INS * 16 + badr[4 * s + 2 * gl], * const p1 = sbase + INS * 16 + badr[(4 * s + 2 * gl + 1) < 7 ? 4 * s + 2 * gl + 1 : 6];
 #pragma unroll
             for (int b = 0; b < CGN; ++b) {
-                const uint4 u0 = q_s[vb16[b] + t0], u1 = q_s[vb16[b] + t1];
+                const uint4 u0 = *reinterpret_cast<const uint4*>(p0 + b * (HW * 16)), u1 = *reinterpret_cast<const uint4*>(p1 + b * (HW * 16));
                 FB[b] = (mx_i32x8){(int)u0.x, (int)u0.y, (int)u0.z, (int)u1.x, (int)u1.y, (int)u1.z, 0, 0};
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const uint4 lo = ain[(16 + 2 * (4 * gl + a)) * 64], hi = ain[(16 + 2 * (4 * gl + a) + 1) * 64];
-                const mx_i32x8 FA = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
-                const int sa = (int)hi.z;
-#pragma unroll
-                for (int b = 0; b < CGN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(FA, FB[b], acc[a][b], 2, 2, 0, sa, 0, sb);
-            }
+        };
+        auto load_fa = [&](int m, int set) __attribute__((always_inline)) {   // m = 4 gl + a
+            const uint4 lo = ain[(16 + 2 * m) * 64], hi = ain[(16 + 2 * m + 1) * 64];
+            FA[set] = (mx_i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, 0, 0};
+            sa[set] = (int)hi.z;
+        };
+        auto pin = [&]() __attribute__((always_inline)) {   // the optimiser otherwise sinks products below the code that follows them
             asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
                               "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
                               "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+        };
+        // fp16 steps in two halves of 8 instructions (weight fragments 0, 1 | 2, 3): the voxel fragments of step i + 1 are requested
+        // before step i (two sets), a weight fragment pair of step i + 1 as soon as the half that reads its registers is issued: every
+        // request is >= 128 matrix-pipe clocks ahead of its first use, on 48 fragment registers (64 with both kinds in two sets spill)
+        load_a(0, 0);
+        load_a(0, 2);
+        load_b(0, 0);
+#pragma unroll
+        for (int kl = 0; kl < nks; ++kl) {
+            const bool last = kl + 1 == nks;
+            if (!last) load_b(kl + 1, (kl + 1) & 1);
+            else load_fb(0);
             MX_FENCE();
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < CGN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a], B[kl & 1][b], acc[a][b], 0, 0, 0);
+            pin();
+            MX_FENCE();
+            if (!last) load_a(kl + 1, 0);
+            else load_fa(0, 0);
+            MX_FENCE();
+#pragma unroll
+            for (int a = 2; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < CGN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a], B[kl & 1][b], acc[a][b], 0, 0, 0);
+            pin();
+            MX_FENCE();
+            if (!last) load_a(kl + 1, 2);
         }
-        // (pinned: see the kernel above)
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
-                          "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
-                          "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+        // MX groups: one set of voxel fragments (the second group's are requested behind the first group's last products: one exposed
+        // LDS latency per sub-stage), the weight fragment of product m + 1 requested before product m
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int gl = m >> 2, a = m & 3;
+            (void)gl;
+            if (m + 1 < 8) load_fa(m + 1, (m + 1) & 1);
+            MX_FENCE();
+#pragma unroll
+            for (int b = 0; b < CGN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(FA[m & 1], FB[b], acc[a][b], 2, 2, 0, sa[m & 1], 0, sb);
+            asm volatile("" : "+v"(acc[a][0]), "+v"(acc[a][1]), "+v"(acc[a][2]), "+v"(acc[a][3]));
+            MX_FENCE();
+            if (m == 3) load_fb(1);
+        }
     };
 
     int s_acc = 0;
@@ -704,8 +743,6 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
     if (C8 > 0) s_acc = stage_shift(stage_exp(0));
     for (int c8 = 0; c8 < C8; ++c8) {
         const int ibuf = c8 & 1;
-#pragma unroll
-        for (int cg = 0; cg < CGN; ++cg) asm volatile("" : "+v"(vb16[cg]));
         const int e_cur = stage_exp(ibuf);
         if (stage_shift(e_cur) != s_acc) {   // block-uniform and, for inputs below 32768, never taken
             const float f = __builtin_bit_cast(float, (unsigned)(127 + s_acc - stage_shift(e_cur)) << 23);
