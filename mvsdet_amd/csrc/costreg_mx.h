@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kThreads) void split_conv_weight_mx_kernel(const fl
 
 typedef float mx_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned mx_u32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned mx_u32x4 __attribute__((ext_vector_type(4)));
 typedef int mx_i32x4 __attribute__((ext_vector_type(4)));
 
 template <int TD, int TH>
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
         // =============================================================================================== producers
         const int ptid = tid - 64 * NCW, pwave = wave - NCW;
         unsigned f_off[NV];
-        float f_reg[NV][8];
+        float f_reg[2][NV][8];   // two sets: the values of channel group c + 2 are requested while those of c + 1 are still being cut
         const float* xfn = xf + (size_t)n * sN;
         const unsigned long long span = ((unsigned long long)(Cin - 1) * (unsigned long long)sC + (unsigned long long)(D - 1) * sD +
                                          (unsigned long long)(H - 1) * sH + W) * 4ull;
@@ -515,28 +516,38 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
             f_off[k] = ok ? (unsigned)(((long long)d * sD + (long long)h * sH + w) * 4) : 0xfffffff0u;
         }
         const unsigned sC4 = (unsigned)(sC * 4);
-        auto fetch_f32 = [&](int c8) {
+        auto fetch_f32 = [&](auto Ptag, int c8) __attribute__((always_inline)) {
+            constexpr int P = decltype(Ptag)::value;
+#if defined(MX_WS_WHATIF) && (MX_WS_WHATIF == 1 || MX_WS_WHATIF == 4)
+            return;
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = c8 * 8 + j;
                 const unsigned soff = (c < Cin ? (unsigned)c : (unsigned)Cin) * sC4;
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
-                    f_reg[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, f_off[k], (int)soff, 0));
+                    f_reg[P][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, f_off[k], (int)soff, 0));
             }
         };
-        auto publish_amax = [&](int buf) {
+        auto publish_amax = [&](auto Ptag, int buf) __attribute__((always_inline)) {
+            constexpr int P = decltype(Ptag)::value;
             float a = 0.0f;
 #pragma unroll
             for (int k = 0; k < NV; ++k)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a = fmaxf(a, fabsf(f_reg[k][j]));
+                for (int j = 0; j < 8; ++j) a = fmaxf(a, fabsf(f_reg[P][k][j]));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) a = fmaxf(a, __shfl_xor(a, off, 64));
             float* spare = reinterpret_cast<float*>(s_in + (size_t)buf * STAGE + NVOX);
             if (lane == 0) spare[pwave] = a;
         };
-        auto stage_cut = [&](int buf, int e1) {
+        // voxel pairs [kp0, kp1) of the thread's NVP
+        auto stage_cut = [&](auto Ptag, int buf, int e1, int kp0, int kp1) __attribute__((always_inline)) {
+            constexpr int P = decltype(Ptag)::value;
+#if defined(MX_WS_WHATIF) && MX_WS_WHATIF == 1
+            return;
+#endif
             uint4* hi_s = s_in + (size_t)buf * STAGE;
             uint4* q_s = hi_s + INS;
             const int S = stage_shift(e1);
@@ -544,6 +555,7 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
             const float sdiv = __builtin_bit_cast(float, (unsigned)(e1 - S + 127) << 23);
 #pragma unroll
             for (int kp = 0; kp < NVP; ++kp) {
+                if (kp < kp0 || kp >= kp1) continue;
                 mx_f32x16 ga, gb;
                 unsigned hw[2][4];
 #pragma unroll
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
                     const int k = 2 * kp + v;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float f = (k < NV ? f_reg[k < NV ? k : 0][j] : 0.0f) * down;
+                        const float f = (k < NV ? f_reg[P][k < NV ? k : 0][j] : 0.0f) * down;
                         const _Float16 h = (_Float16)f;
                         const float hf = (float)h;
                         const unsigned hb = __builtin_bit_cast(unsigned short, h);
@@ -566,62 +578,81 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
                 for (int v = 0; v < 2; ++v) {
                     const int k = 2 * kp + v, slot = ptid + k * NPT;
                     if (k < NV && slot < NVOX) {
-                        hi_s[slot] = make_uint4(hw[v][0], hw[v][1], hw[v][2], hw[v][3]);
-                        q_s[slot] = make_uint4(q[3 * v], q[3 * v + 1], q[3 * v + 2], 0u);
+                        // written by hand: before an LDS store it can see, the compiler waits for every LDS-DMA in flight (it cannot tell the
+                        // weight buffers from the stage buffers) and, vmcnt being in-order, for the values requested behind them
+                        const unsigned ah = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(hi_s + slot);
+                        const mx_u32x4 dh = {hw[v][0], hw[v][1], hw[v][2], hw[v][3]}, dq = {q[3 * v], q[3 * v + 1], q[3 * v + 2], 0u};
+                        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:%3" ::"v"(ah), "v"(dh), "v"(dq), "n"(INS * 16) : "memory");
                     }
                 }
             }
         };
         const uint4* wn = wq + (size_t)ob64 * C8 * (2 * kWSlots);
-        auto dma_weights = [&](int c8, int s, int buf) {
+        auto dma_weights = [&](int c8, int s, int buf) __attribute__((always_inline)) {
             const uint4* src0 = wn + ((size_t)c8 * 2 + s) * kWSlots + lane;
+#if defined(MX_WS_WHATIF) && MX_WS_WHATIF == 5
+            if (c8 > 1) return;
+#endif
             for (int i = pwave; i < kMxSlots; i += NPW) {
                 uint4* dstp = s_w + (size_t)buf * kWSlots + i * 64;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + i * 64),
                                                  (__attribute__((address_space(3))) void*)dstp, 16, 0, 0);
             }
         };
-        // prologue: stage 0 and the weights of its first sub-stage; the values of stage 1 requested
+        constexpr int KPA = NVP > 1 ? NVP - 1 : NVP;   // voxel pairs cut in phase A; the rest in phase B
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        // prologue: stage 0 complete, the maxima of stage 1 published, the weights of (0, 0) landed
         if (C8 > 0) {
             dma_weights(0, 0, 0);
-            fetch_f32(0);
-            publish_amax(0);
+            fetch_f32(P0{}, 0);
+            publish_amax(P0{}, 0);
             __builtin_amdgcn_s_waitcnt(0xc07f);
         }
         __builtin_amdgcn_s_barrier();                                  // P1: the maxima of stage 0
         if (C8 > 0) {
-            stage_cut(0, stage_exp(0));
-            if (C8 > 1) fetch_f32(1);
-            if (C8 > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (kFetchLoads & 15) | ((kFetchLoads >> 4) << 14));   // the DMAs (older) have landed
-            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            if (C8 > 1) fetch_f32(P1{}, 1);
+            stage_cut(P0{}, 0, stage_exp(0), 0, NVP);
+            if (C8 > 1) publish_amax(P1{}, 1);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
             __builtin_amdgcn_s_waitcnt(0xc07f);
         }
-        __builtin_amdgcn_s_barrier();                                  // P2: stage 0 complete, weights (0, 0) in buffer 0
-        for (int c8 = 0; c8 < C8; ++c8) {
-            const int ibuf = c8 & 1;
-            const bool more = c8 + 1 < C8;
+        __builtin_amdgcn_s_barrier();                                  // P2
+        // Channel group c (parity P): the values of c + 1 sit in set 1 - P and their maxima are published; phase A cuts most of them and
+        // requests the values of c + 2 into set P; phase B cuts the rest, then -- a whole phase after the request -- takes the maxima
+        // of c + 2.  (One set, requested at the end of B and awaited at the start of A, left the consumers waiting at barrier A for
+        // the full latency of the fetch: together 3.65 ms where the consumers alone take 2.73 and the producers alone 2.38.)
+        auto group = [&](auto Ptag, int c8) __attribute__((always_inline)) {
+            constexpr int P = decltype(Ptag)::value;
+            using Q = std::integral_constant<int, 1 - P>;
+            const int ibuf = P;
+            const bool more1 = c8 + 1 < C8, more2 = c8 + 2 < C8;
+            int e_next = 0;
             // phase A
+            if (more1) e_next = stage_exp(ibuf ^ 1);   // (an LDS read the compiler sees: before the DMAs, or it waits for them)
             dma_weights(c8, 1, 1);
-            if (more) {
-                __builtin_amdgcn_s_waitcnt(0x0f70 | (kMxSlots / NPW));   // vmcnt(8): this wave's 8 DMAs just issued may fly, the values of c + 1 are in
-                publish_amax(ibuf ^ 1);
-            }
-            __builtin_amdgcn_s_waitcnt(0x0f70);                        // the DMAs have landed
+            if (more2) fetch_f32(Ptag, c8 + 2);   // first thing: the whole group is its latency cover (without it conv0 takes 2.6 ms, with
+                                                  // the request at the end of phase A 3.6)
+            MX_FENCE();                           // (the scheduler otherwise moves the request behind the cut)
+            if (more1) stage_cut(Q{}, ibuf ^ 1, e_next, 0, KPA);
+            if (more2) __builtin_amdgcn_s_waitcnt(0x0f70 | (kFetchLoads & 15) | ((kFetchLoads >> 4) << 14));   // the DMAs (older) have landed
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();                              // end of A
             // phase B
-            if (more) {
+            if (more1) {
                 dma_weights(c8 + 1, 0, 0);
-                stage_cut(ibuf ^ 1, stage_exp(ibuf ^ 1));
-                if (c8 + 2 < C8) {
-                    fetch_f32(c8 + 2);
-                    __builtin_amdgcn_s_waitcnt(0x0f70 | (kFetchLoads & 15) | ((kFetchLoads >> 4) << 14));
-                } else {
-                    __builtin_amdgcn_s_waitcnt(0x0f70);
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
+                stage_cut(Q{}, ibuf ^ 1, e_next, KPA, NVP);
             }
+            if (more2) publish_amax(Ptag, ibuf);                       // the compiler's own wait for the values; into the spare slots of buffer
+                                                                       // ibuf, which the consumers read at the top of a group only
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();                              // end of B
+        };
+        for (int c8 = 0; c8 < C8; c8 += 2) {
+            group(P0{}, c8);
+            if (c8 + 1 < C8) group(P1{}, c8 + 1);
         }
         return;
     }
@@ -655,6 +686,9 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
     // pipe was 0.39 busy.  The fences keep the compiler from re-ordering the requests behind the products; the accumulation order of
     // every accumulator is unchanged (fp16 steps, then the MX groups): the same bits.
     auto compute = [&](auto sc, int ibuf, int wbuf, int e1) {
+#if defined(MX_WS_WHATIF) && MX_WS_WHATIF == 2
+        return;
+#endif
         constexpr int s = decltype(sc)::value;
         constexpr int nks = s == 0 ? 4 : 3;
         const char* const sbase = reinterpret_cast<const char*>(s_in + (size_t)ibuf * STAGE);
