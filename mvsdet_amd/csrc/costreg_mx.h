@@ -503,7 +503,11 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
         const int ptid = tid - 64 * NCW, pwave = wave - NCW;
         unsigned f_off[NV];
         float f_reg[2][NV][8];   // two sets: the values of channel group c + 2 are requested while those of c + 1 are still being cut
+#if defined(MX_WS_WHATIF) && MX_WS_WHATIF == 6
+        const float* xfn = xf;
+#else
         const float* xfn = xf + (size_t)n * sN;
+#endif
         const unsigned long long span = ((unsigned long long)(Cin - 1) * (unsigned long long)sC + (unsigned long long)(D - 1) * sD +
                                          (unsigned long long)(H - 1) * sH + W) * 4ull;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xfn), 0, (int)(unsigned)span, 0x00020000);
@@ -511,7 +515,11 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
         for (int k = 0; k < NV; ++k) {
             const int slot = ptid + k * NPT;
             const int dz = slot / (HH * HW), r = slot - dz * (HH * HW), hy = r / HW, wx = r - hy * HW;
+#if defined(MX_WS_WHATIF) && MX_WS_WHATIF == 6
+            const int d = dz + 1, h = hy + 1, w = wx + 1;
+#else
             const int d = d0 + dz - 1, h = h0 + hy - 1, w = w0 + wx - 1;
+#endif
             const bool ok = slot < NVOX && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
             f_off[k] = ok ? (unsigned)(((long long)d * sD + (long long)h * sH + w) * 4) : 0xfffffff0u;
         }
