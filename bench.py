@@ -503,13 +503,25 @@ def run_view_sharded(args, w, rank, world, device, dry=False):
 
 def settle_overlap_route(hp, scene, metas, device):
     """`overlap_detector = "auto"`: run scenes until the driver has measured its routes for this shape and kept one (untimed:
-    a long-running job pays these ~25 scenes once per scene shape).  -> (route, {route: ms per scene})."""
+    a long-running job pays these ~25 scenes once per scene shape), plus two watch windows of a kept side route.
+    -> (route, {route: ms per scene})."""
     hp.overlap_detector = "auto"
     need = len(hp.OVERLAP_ROUTES) * (hp._TUNE_WARM + hp._TUNE_SPAN + 1)
-    for i in range(need + 2):
-        hp.forward_scene(scene.features, metas[i % len(metas)])
+    out = None
+    for i in range(need + 2):   # as the timed loops run: the next scene's cameras announced one scene ahead (their upload and geometry
+        hp.prefetch_scene(metas[(i + 1) % len(metas)], device)   # kernel take a stream of their own -- one more hardware queue in the
+        out = hp.forward_scene(scene.features, metas[i % len(metas)])   # mix the routes are compared in), one result kept alive
     torch.cuda.synchronize(device)
-    hp.forward_scene(scene.features, metas[0])          # finds every span's events complete: decides
+    out = hp.forward_scene(scene.features, metas[0])    # finds every span's events complete: decides
+    if hp.overlap_choice(scene.features.shape, device)[0] not in (None, "one"):
+        # a kept side route stays under watch (MVSDetHotPath._watch): two windows of it here, so that a route that does not hold
+        # what its few tuning scenes promised is already given up when the timed loop starts
+        for rep in range(2):
+            for i in range(2 * (hp._WATCH_SPAN + 1)):
+                hp.prefetch_scene(metas[(i + 1) % len(metas)], device)
+                out = hp.forward_scene(scene.features, metas[i % len(metas)])
+            torch.cuda.synchronize(device)
+    del out
     torch.cuda.synchronize(device)
     return hp.overlap_choice(scene.features.shape, device)
 
@@ -547,6 +559,7 @@ def test_shape_chain_rate(device, name, steps=8):
                 out = hp.forward_scene(scene.features, metas[i])
             torch.cuda.synchronize(device)
             res[key] = round(steps / (time.perf_counter() - t0), 3)
+        res["pipelined_route_final"] = hp.overlap_choice(scene.features.shape, device)[0]   # ("one" if the watch gave the side route up)
         res["ms_per_scene"] = round(1e3 / res["scenes_per_sec"], 3)
         res["ms_per_scene_pipelined"] = round(1e3 / res["scenes_per_sec_pipelined"], 3)
         var = out.raw("variance")
@@ -614,6 +627,7 @@ def full_chain_rate(device, steps=10):
             out2 = hp.forward_scene(scene.features, metas[i])
         torch.cuda.synchronize(device)
         el_overlap = time.perf_counter() - t1
+        route_final = hp.overlap_choice(scene.features.shape, device)[0]   # ("one" if the watch gave the side route up)
         hp.overlap_detector = False
         del out2
     # the network alone on the variance volume of the last scene.  Its stride-1 layers (79 % of the FLOP) run on the bf16
@@ -712,7 +726,7 @@ def full_chain_rate(device, steps=10):
                                         "note": "depth distribution, lifting, neck and head of scene i on their own stream beside scene i+1's packing, sweep and conv0 "
                                                 "(MVSDetHotPath.overlap_detector = 'auto': the routes one / side1 / side2 are measured on the first scenes of a "
                                                 "shape and the fastest kept); the device is synchronised once, after the last scene",
-                                        "route": route, "route_periods_ms": route_periods},
+                                        "route": route, "route_periods_ms": route_periods, "route_final": route_final},
             "cost_network_tflop": round(CostRegNet3DGS.flops(wr["N"], wr["D"], wr["H"], wr["W"]) / 1e12, 3),
             "non_empty_voxels": int((out["valid"] > 0).sum().item())}
 

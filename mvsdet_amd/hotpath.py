@@ -534,7 +534,34 @@ class MVSDetHotPath:
             st["periods_ms"] = {k: round(v, 4) for k, v in per.items()}
         name = st["choice"] or names[min(st["cand"], len(names) - 1)]
         side, streams = self.OVERLAP_ROUTES[name]
-        return name, side, streams, (st if st["choice"] is None else None)
+        return name, side, streams, (st if st["choice"] is None or st["choice"] != "one" else None)
+
+    _WATCH_SPAN = 8      # scenes per check of a kept side route
+
+    def _watch(self, st: dict, device, side_done=None) -> None:
+        """A kept side route stays under watch: its period over every `_WATCH_SPAN` scenes (the slower of the two streams, from
+        events, no host wait) against the period `one` was measured at.  Two windows in a row more than 3 % behind it and the
+        shape goes back to `one` for good (`overlap_choice` then says so): the routes were compared over a few scenes, and what
+        shares the device's hardware queues with them can change afterwards."""
+        w = st.setdefault("watch", {"main": [], "side": [], "strikes": 0})
+        if side_done is not None:
+            w["side"].append(side_done)
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(device))
+        w["main"].append(ev)
+        n = self._WATCH_SPAN + 1
+        if len(w["main"]) >= 2 * n and len(w["side"]) >= 2 * n - 1:
+            # the OLDER window: its events have long completed (query() guards it; a window still in flight is looked at later)
+            m, sd = w["main"][:n], w["side"][:n]
+            if m[-1].query() and sd[-1].query():
+                period = max(m[0].elapsed_time(m[-1]), sd[0].elapsed_time(sd[-1])) / self._WATCH_SPAN
+                w["strikes"] = w["strikes"] + 1 if period > 1.03 * st["periods_ms"]["one"] else 0
+                st["watched_period_ms"] = round(period, 4)
+                if w["strikes"] >= 2:
+                    st["demoted_from"] = st["choice"]
+                    st["choice"] = "one"
+                del w["main"][:n - 1], w["side"][:n - 1]
 
     def _tune_mark(self, st: dict, name: str, device, side_done=None) -> None:
         """Timing events of a tuning scene: one behind its cost network on the caller's stream (side_done is None), one behind
@@ -585,8 +612,11 @@ class MVSDetHotPath:
         The result is a `SceneOutputs`: with `overlap_detector` a value read from it makes the reading stream wait for the side
         stream's event first."""
         route, on_side, net_streams, tuning = self._route(feature, cost_logits)
+        watching = tuning is not None and tuning["choice"] is not None   # a kept side route: `_watch`
         geo, packed, variance, cost_logits = self._front(feature, img_meta, cost_logits, geo, net_streams)
-        if tuning is not None:
+        if watching:
+            self._watch(tuning, variance.device)
+        elif tuning is not None:
             self._tune_mark(tuning, route, variance.device)
 
         def tail():
@@ -613,7 +643,9 @@ class MVSDetHotPath:
             out = tail()
             done = torch.cuda.Event(enable_timing=tuning is not None)
             done.record(side)
-        if tuning is not None:
+        if watching:
+            self._watch(tuning, dev, side_done=done)
+        elif tuning is not None:
             self._tune_mark(tuning, route, dev, side_done=done)
         # (`lift` reads geo.projection -- a view of the ONE uploaded staging buffer, which neighbor_ids, proj_rel and depth_values
         # share: recording any view records the whole block -- and geo.points, a block of its own)

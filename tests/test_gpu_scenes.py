@@ -226,6 +226,47 @@ def test_measured_overlap_route(gpu):
     assert "ready" not in out
 
 
+def test_kept_side_route_is_watched_and_given_up(gpu):
+    """`overlap_detector = "auto"` after its decision: a kept side route is re-measured every `_WATCH_SPAN` scenes from events (no
+    host wait) against the period `one` was tuned at; two windows in a row more than 3 % behind it and the shape goes back to
+    `one`.  Forced here by handing the watch a tuned period nobody can meet: the demotion happens, `overlap_choice` reports it, and
+    every scene on the way has the bits of that scene alone."""
+    from mvsdet_amd import synthetic
+    from mvsdet_amd.hotpath import MVSDetHotPath
+    C, D, hw, grid, vox = 64, 8, (24, 32), [16, 16, 8], [0.4, 0.4, 0.4]
+    net, neck, head = _modules(C, 64, gpu, seed=4)
+    f, m = synthetic.make_features(8, C, hw, seed=68).to(gpu), synthetic.make_img_meta(8, hw, seed=68)
+    solo = _solo(net, neck, head, grid, vox, D, f, m, gpu)
+    hp = _fresh_hotpath(net, neck, head, grid, vox, D)
+    hp.overlap_detector = "auto"
+    key = (tuple(f.shape), hp.num_depth, str(f.device))
+    hp._overlap_tuning[key] = {"cand": 3, "marks": [], "side_marks": [], "spans": {}, "choice": "side1",
+                               "periods_ms": {"one": 1e-6, "side1": 5e-7, "side2": 1e-6}}
+    with torch.no_grad():
+        for i in range(4 * (MVSDetHotPath._WATCH_SPAN + 1) + 2):
+            got = _keep(hp.forward_scene(f, m))
+            torch.cuda.synchronize(gpu)
+            _same(solo, got, f"scene {i} under watch")
+            if hp.overlap_choice(f.shape)[0] == "one":
+                break
+    st = hp._overlap_tuning[key]
+    assert hp.overlap_choice(f.shape)[0] == "one" and st["demoted_from"] == "side1" and st["watched_period_ms"] > 1e-6, st
+    with torch.no_grad():
+        out = hp.forward_scene(f, m)
+    assert "ready" not in out            # back on the caller's stream
+    # and a route that keeps what it promised stays: the same watch against a period it beats easily
+    hp2 = _fresh_hotpath(net, neck, head, grid, vox, D)
+    hp2.overlap_detector = "auto"
+    hp2._overlap_tuning[key] = {"cand": 3, "marks": [], "side_marks": [], "spans": {}, "choice": "side1",
+                                "periods_ms": {"one": 1e6, "side1": 1.0, "side2": 1e6}}
+    with torch.no_grad():
+        for i in range(3 * (MVSDetHotPath._WATCH_SPAN + 1)):
+            got = _keep(hp2.forward_scene(f, m))
+    torch.cuda.synchronize(gpu)
+    _same(solo, got, "last watched scene")
+    assert hp2.overlap_choice(f.shape)[0] == "side1" and hp2._overlap_tuning[key].get("watched_period_ms", 0) > 0
+
+
 def test_event_pool_orders_foreign_streams(gpu):
     """mvsdet_amd/scratch.EventPool: (1) a key at its buffer limit hands a buffer that another stream is still working on to the
     next stream, which then WAITS for that work (a long queue of adds followed by an overwrite from the other stream must not be
