@@ -2167,9 +2167,6 @@ extern "C" int mvsdet_split_conv_weight_mx(const float* weight, void* weight_spl
     return MVSDET_OK;
 }
 
-#ifndef MVS_MX_BP
-#define MVS_MX_BP 2   // column groups per batch of MX fragments (costreg_mx.h)
-#endif
 extern "C" int mvsdet_conv3d_k3_fp16mx_f32in(const float* x, const int64_t* x_strides, const void* weight_split_mx, const float* scale,
                                              const float* shift, float* out_f32, void* out_scl, void* out_pscl, int N, int Cin, int Cout,
                                              int D, int H, int W, int relu, mvsdet_stream_t stream) {

@@ -457,6 +457,8 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
 //   consumers: products of k-steps 0..3 + MX groups 0, 1              products of k-steps 4..6 + MX groups 2, 3
 //   producers: DMA weights (c, 1); the values of c + 1 have           DMA weights (c + 1, 0); stage exponent of c + 1; cut and write
 //              arrived: wave maxima -> the spare slots                its stage buffer; request the values of c + 2
+// What-if builds (-DMX_WS_WHATIF=n, WRONG results, measurement only: profiles/r06_conv0_mx_whatif.txt): 1 = producers idle (DMAs and
+// barriers only), 2 = consumers idle, 4 = no global fetch, 5 = no weight DMAs inside the loop, 6 = every block fetches one L2-resident tile.
 template <int TD, int TH>
 __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel(
     const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
