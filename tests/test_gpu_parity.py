@@ -331,7 +331,9 @@ def test_backward_stage1(gpu, oracle):
     var = ops.plane_sweep_variance(feat, dev(g["s1_neighbor_ids"], gpu), dev(g["s1_proj_rel"], gpu), dev(g["s1_depth_values"], gpu))
     np.testing.assert_allclose(var.detach().cpu().numpy(), g["s1_variance"], rtol=0, atol=TOL)
     (var * dev(g["s1_R"], gpu)).sum().backward()
-    np.testing.assert_allclose(feat.grad.cpu().numpy(), g["s1_grad_feature"], rtol=1e-4, atol=2e-4)
+    # gradients of scale 10 (max |.|; rms 1.6): the bar 1e-4 of scale would be 1e-3; measured 1.2e-6 (tools/study/r06_grad_tolerances.py: the
+    # summation order of the atomics), held to 2e-5 absolute = 2e-6 of scale
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), g["s1_grad_feature"], rtol=1e-4, atol=2e-5)
 
 
 def test_backward_stage1_shapes(gpu, oracle):
@@ -344,7 +346,8 @@ def test_backward_stage1_shapes(gpu, oracle):
         R = torch.randn(var.shape, generator=torch.Generator().manual_seed(1)).to(gpu)
         (var * R).sum().backward()
         ref = oracle.plane_sweep_variance_bwd(g["feature"], g["neighbor_ids"], g["proj_rel"], g["depth_values"], R.cpu())
-        np.testing.assert_allclose(feat.grad.cpu().numpy(), ref, rtol=1e-4, atol=5e-4)
+        # scale 15-18, measured 1.9e-6: held to 2e-5 absolute (about 1e-6 of scale; the 1e-4 bar would be 1.5e-3)
+        np.testing.assert_allclose(feat.grad.cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
 
 
 def test_backward_stage2(gpu):
