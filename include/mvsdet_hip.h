@@ -51,8 +51,7 @@ const char* mvsdet_last_error(void);
  *   "sweep_xcd"     0 | 1   XCD-aware block map for fewer than 8 channel slabs
  *   "sweep_dsplit", "sweep_groups", "conv_*", "convT_cg", "convT_persist"   schedules of the sweep's plane split, of the bf16x3
  *                   convolutions and of the fp16 + MX convolution ("conv_mx_th") (csrc/common.h: struct Options);
- *                   "probe_f16_pair" shapes mvsdet_store_pattern_probe_f16 only; "convT_whatif" is a MEASUREMENT switch of the
- *                   persistent transposed kernel (non-zero: wrong results; profiles/r06_convt_persist.txt), never set in product code
+ *                   "probe_f16_pair" shapes mvsdet_store_pattern_probe_f16 only
  * "sweep_tw" decides the layout of the sweep geometry: consume one (mvsdet_plane_sweep_variance_tabled_f32) under the
  * "sweep_tw" it was built with (mvsdet_plane_sweep_table_f32).  "sweep_boxcap" is baked into the geometry (union boxes,
  * staged / refill flags); the consuming call sizes its LDS slots for the largest capacity a geometry of that tile shape

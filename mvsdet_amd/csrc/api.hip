@@ -25,7 +25,7 @@ Options& options() {
     static Options o = {env_int("MVSDET_SWEEP_TW", 0), env_int("MVSDET_SWEEP_BOXCAP", 512), env_int("MVSDET_SWEEP_XCD", 1),
                         env_int("MVSDET_SWEEP_DSPLIT", 0), env_int("MVSDET_SWEEP_GROUPS", -1),
                         env_int("MVSDET_CONV_SUBPAIRS", 0), env_int("MVSDET_CONV_NSPLIT", 0), env_int("MVSDET_CONV_CGN", 0), env_int("MVSDET_CONV_S2_CG", 0), env_int("MVSDET_CONV_S2_OB", 0), env_int("MVSDET_CONVT_CG", 0),
-                        env_int("MVSDET_PROBE_F16_PAIR", 0), env_int("MVSDET_CONV_XCD", 1), env_int("MVSDET_CONV_SPLIT_BLOCKS", 768), env_int("MVSDET_CONV_SPLIT_MIN_GROUPS", 2), env_int("MVSDET_BWD_GROUPS", 0), env_int("MVSDET_CONV_MX_TH", 0), env_int("MVSDET_CONV_MFMA16", 1), env_int("MVSDET_CONVT_PERSIST", 0), env_int("MVSDET_CONVT_WHATIF", 0)};
+                        env_int("MVSDET_PROBE_F16_PAIR", 0), env_int("MVSDET_CONV_XCD", 1), env_int("MVSDET_CONV_SPLIT_BLOCKS", 768), env_int("MVSDET_CONV_SPLIT_MIN_GROUPS", 2), env_int("MVSDET_BWD_GROUPS", 0), env_int("MVSDET_CONV_MX_TH", 0), env_int("MVSDET_CONV_MFMA16", 1), env_int("MVSDET_CONVT_PERSIST", 0)};
     return o;
 }
 
@@ -49,7 +49,6 @@ static int* option_slot(const char* name) {
     if (!strcmp(name, "bwd_groups")) return &o.bwd_groups;
     if (!strcmp(name, "conv_mx_th")) return &o.conv_mx_th;
     if (!strcmp(name, "convT_persist")) return &o.convT_persist;
-    if (!strcmp(name, "convT_whatif")) return &o.convT_whatif;
     if (!strcmp(name, "conv_split_min_groups")) return &o.conv_split_min_groups;
     if (!strcmp(name, "conv_split_blocks")) return &o.conv_split_blocks;
     return nullptr;

@@ -45,8 +45,6 @@ struct Options {
     int convT_persist; // transposed bf16x3 convolution, all-classes form with a skip tensor: 0 (default) = one block per (tile, 32 channels);
                        // 1 = the persistent kernel (convt_persist.h: one block per CU, an item's stores behind the next item's
                        // multiplications; the same bits, not faster: profiles/r06_convt_persist.txt); n >= 8: persistent on n blocks
-    int convT_whatif;  // measurement only (WRONG results): bit 0 = the persistent kernel's skip-tensor loads, bit 1 = its stores go beyond the
-                       // buffer descriptors (issued, dropped)
 };
 Options& options();
 

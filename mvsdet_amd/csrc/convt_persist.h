@@ -46,6 +46,8 @@ __device__ __forceinline__ void ctp_wait_vm() {
     __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));
 }
 
+// whatif (what-if BUILDS only, -DMVS_CONVT_WHATIF=n; 0 in the product): bit 0 sends the skip-tensor loads, bit 1 the stores, bit 2 / 3 make every
+// block read one halo tile / one weights stage -- measurement of what bounds the kernel, wrong results.
 // OUT_SCL: the result leaves as the SCL form (bf16 pieces, conv9); else as fp32 NCDHW (conv11).  RES: a skip tensor is added.
 template <bool OUT_SCL, bool RES>
 __global__ __launch_bounds__(768) void convT3d_k3_s2_bf16x3_persist_kernel(

@@ -2081,6 +2081,9 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
         const size_t lds = ctp_lds_bytes();
         const unsigned out_bytes = out_scl ? (unsigned)(2ull * dst.piece * 16ull) : (unsigned)((unsigned long long)N * Cout * 8ull * D * H * W * 4ull);
         const unsigned res_bytes = (unsigned)((unsigned long long)N * Cout * 8ull * D * H * W * 4ull);
+#ifndef MVS_CONVT_WHATIF
+#define MVS_CONVT_WHATIF 0   // what-if BUILDS only (-DMVS_CONVT_WHATIF=n, wrong results: convt_persist.h, profiles/r06_convt_persist.txt)
+#endif
 #define MVS_CTP_CASE(SCL_, RES_)                                                                                             \
     {                                                                                                                        \
         auto* k = convT3d_k3_s2_bf16x3_persist_kernel<SCL_, RES_>;                                                           \
@@ -2091,7 +2094,7 @@ static int launch_convT(const void* xs, const void* weight_split, const float* s
         }                                                                                                                    \
         hipLaunchKernelGGL(k, dim3(G), dim3(768), lds, st, static_cast<const uint4*>(xs), static_cast<const uint4*>(weight_split), \
                            scale, shift, residual, dst, C8, Cout, D, H, W, p.Dp, p.Hp, p.Wp, piece, tiles_w, tiles_h, tiles_d, N, relu, \
-                           out_bytes, res_bytes, (int)(options().conv_xcd != 0), options().convT_whatif);                                            \
+                           out_bytes, res_bytes, (int)(options().conv_xcd != 0), MVS_CONVT_WHATIF);                                            \
     }
         if (out_scl) MVS_CTP_CASE(true, true)
         else MVS_CTP_CASE(false, true)

@@ -1,5 +1,7 @@
 """What bounds the persistent transposed kernel (csrc/convt_persist.h): conv11 / conv9 at 40 views with parts of its drain path sent
-beyond the buffer descriptors (option convT_whatif; the instructions are issued, the memory system drops them), and on fewer blocks."""
+beyond the buffer descriptors (the instructions are issued, the memory system drops them), and on fewer blocks.  The what-if forms are BUILDS
+(`-DMVS_CONVT_WHATIF=n` on costreg_bf16.hip, bit 0 loads, bit 1 stores, bit 2 one halo tile, bit 3 one weights stage; libraries under build_ab/,
+tools/ab_libs.sh): this script times whatever library MVSDET_HIP_LIB names, with the per-tile kernel, the persistent one and 128 blocks of it."""
 import os
 import sys
 
@@ -34,16 +36,11 @@ def main():
         xs, wq = ops.scl_pack(x), ops.split_conv_weight(w, 2)
         y = ops.convT3d_k3_s2_bf16x3(xs, wq, sc, sh, res, True, outputs=outputs)
         fn = lambda: ops.convT3d_k3_s2_bf16x3(xs, wq, sc, sh, res, True, outputs=outputs, scl_out=y if "scl" in outputs else None)  # noqa: E731
-        for label, persist, whatif in (("per-tile kernel", 0, 0), ("persistent", 1, 0), ("persistent, no skip loads", 1, 1), ("persistent, no stores", 1, 2),
-                                       ("persistent, neither", 1, 3), ("persistent on 128 blocks", 128, 0), ("persistent on 128 blocks, neither", 128, 3),
-                                       ("persistent, neither, one halo tile for all", 1, 7), ("persistent, neither, one stage of weights for all", 1, 11),
-                                       ("persistent, neither, both", 1, 15), ("persistent, one halo tile for all", 1, 4)):
+        for label, persist in (("per-tile kernel", 0), ("persistent", 1), ("persistent on 128 blocks", 128)):
             _lib.set_option("convT_persist", persist)
-            _lib.set_option("convT_whatif", whatif)
             lo, med = time_it(fn)
             print(f"{tag}: {label:36s} min {lo:.3f} median {med:.3f} ms", flush=True)
         _lib.set_option("convT_persist", 1)
-        _lib.set_option("convT_whatif", 0)
 
 
 if __name__ == "__main__":
