@@ -23,7 +23,9 @@
 // Counted waits: every vector-memory instruction of a wave is issued unconditionally (lanes outside the volume, and the chunks of an
 // item that does not exist, go to offsets beyond the buffer descriptors' sizes), so "all but the newest N" is exact:
 // per stage 3 DMAs; per quarter boundary S stores (8 float2 / 4 units) + R skip-tensor DMAs (16).  No spill may exist (scratch
-// traffic counts in vmcnt): the build checks.
+// traffic counts in vmcnt): the build checks.  The accounting takes vmcnt to retire loads, LDS-DMAs and stores in issue order -- the model
+// LLVM's own wait insertion uses on gfx9 (one event class for all vector memory, no separate store counter); the data of a stage is
+// requested two stages (microseconds) before the wait that guards it.  One more reason why this kernel is an option, not the default.
 constexpr int kCtpIn = 640;                                  // slots per piece per stage: 10 DMAs (612 halo voxels)
 constexpr int kCtpW = 16 * 64;                               // (local pair 8, piece 2) chunks of 64 slots
 constexpr int kCtpStage = 2 * kCtpIn + kCtpW;                // 2304 slots = 36,864 B
