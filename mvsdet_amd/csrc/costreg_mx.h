@@ -458,7 +458,8 @@ __global__ __launch_bounds__(TD * TH * 16) void conv3d_k3_fp16mx_kernel(
 //   producers: DMA weights (c, 1); the values of c + 1 have           DMA weights (c + 1, 0); stage exponent of c + 1; cut and write
 //              arrived: wave maxima -> the spare slots                its stage buffer; request the values of c + 2
 // What-if builds (-DMX_WS_WHATIF=n, WRONG results, measurement only: profiles/r06_conv0_mx_whatif.txt): 1 = producers idle (DMAs and
-// barriers only), 2 = consumers idle, 4 = no global fetch, 5 = no weight DMAs inside the loop, 6 = every block fetches one L2-resident tile.
+// barriers only), 2 = consumers idle, 4 = no global fetch, 5 = no weight DMAs inside the loop, 6 = every block fetches one L2-resident tile,
+// 7 = no epilogue.
 template <int TD, int TH>
 __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel(
     const float* __restrict__ xf, long long sN, long long sC, long long sD, long long sH, int Cin, const uint4* __restrict__ wq,
@@ -806,6 +807,9 @@ __global__ __launch_bounds__(TD * TH * 16 + 256) void conv3d_k3_fp16mx_ws_kernel
 
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
     const float up = __builtin_bit_cast(float, (unsigned)(127 + s_acc) << 23);
+#if defined(MX_WS_WHATIF) && MX_WS_WHATIF == 7
+    if (acc[0][0][0] != 12345.678f) return;   // (what-if: no epilogue)
+#endif
 #pragma unroll
     for (int cg = 0; cg < CGN; ++cg) {
         const int g = CGN * wave + cg;
